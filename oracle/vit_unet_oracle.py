@@ -1,0 +1,431 @@
+"""CPU oracle for the ViT-UNet forward/backward path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a builder-owned, functional (module-free) torch-CPU fp32 restatement of the
+arithmetic of the reference's packaged model (`/root/reference/vit_unet/torch/model.py`).
+It exists to CHECK the HIP path.  Only `tests/`, `__graft_entry__.smoke()` and the
+`cpu_baseline` leg of `bench.py` may import it; the product path never does (the product fails
+loudly when the HIP library is missing).
+
+Parity status: PINNED.  `tests/golden/make_golden.py` drives the *unmodified* reference forward
+(`HViT_UNet.forward`, model.py:372-435, assembled by a harness because the reference ctor is
+broken at model.py:309) in the build container and commits input/output/gradient vectors under
+`tests/golden/`; `tests/test_oracle_golden.py` checks this restatement against them.
+
+Each function cites the reference lines it restates.  All tensors are torch CPU tensors; all math
+is fp32 unless the caller passes fp64 tensors (the functions are dtype-agnostic, which the
+tests use for an fp64 "truth" run).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+__all__ = [
+    "Config", "retile", "patchify", "unpatchify", "downsample", "upsample",
+    "conv3x3_per_patch", "reattention", "te_block", "skip_block", "forward",
+    "param_shapes", "param_count", "make_weights", "keep_mask", "mse_loss", "psnr",
+    "dice_loss", "adamw_step", "PRESETS",
+]
+
+
+# --------------------------------------------------------------------------------------------
+# configuration (HViT_UNet ctor arguments, model.py:264-299)
+# --------------------------------------------------------------------------------------------
+@dataclass
+class Config:
+    depth: int
+    depth_te: int
+    size_bottleneck: int
+    preprocessing: str
+    im_size: int
+    patch_size: int
+    num_channels: int
+    hidden_dim: int
+    num_heads: int
+    attn_drop: float = 0.0
+    proj_drop: float = 0.0
+    linear_drop: float = 0.0
+
+    def __post_init__(self):
+        # model.py:281-283
+        assert self.patch_size % (2 ** self.depth) == 0
+        assert self.patch_size // (2 ** self.depth) >= 4
+        assert self.im_size % self.patch_size == 0
+
+    @property
+    def P(self) -> int:  # elements of the latent image
+        return self.num_channels * self.im_size * self.im_size
+
+    def level(self, l: int) -> Tuple[int, int, int, int]:
+        """(N, D, hidden, patch) at level l  (model.py:302-307)."""
+        n0 = (self.im_size // self.patch_size) ** 2
+        d0 = self.num_channels * self.patch_size ** 2
+        return n0 * 4 ** l, d0 // 4 ** l, self.hidden_dim // 2 ** l, self.patch_size // 2 ** l
+
+
+PRESETS = {  # model.py:438-485
+    "lite": dict(depth=2, depth_te=1, size_bottleneck=2, preprocessing="conv", im_size=224,
+                 patch_size=16, num_channels=3, hidden_dim=64, num_heads=4,
+                 attn_drop=0.2, proj_drop=0.2, linear_drop=0.0),
+    "base": dict(depth=2, depth_te=2, size_bottleneck=2, preprocessing="conv", im_size=224,
+                 patch_size=32, num_channels=3, hidden_dim=128, num_heads=8,
+                 attn_drop=0.2, proj_drop=0.2, linear_drop=0.0),
+    "large": dict(depth=2, depth_te=4, size_bottleneck=4, preprocessing="conv", im_size=224,
+                  patch_size=32, num_channels=3, hidden_dim=128, num_heads=8,
+                  attn_drop=0.2, proj_drop=0.2, linear_drop=0.0),
+}
+
+
+# --------------------------------------------------------------------------------------------
+# a1-a4: re-tiling (model.py:8-53).  SURVEY App. A: token n = (y//s)*e + x//s,
+# feature f = ch*s*s + (y%s)*s + x%s.  The image layout is the s = im special case.
+# --------------------------------------------------------------------------------------------
+def patchify(img: torch.Tensor, s: int) -> torch.Tensor:
+    """(B,C,H,W) -> (B,(H/s)(W/s),C*s*s)   [patch() model.py:8-18 + flatten(-3,-1)]"""
+    B, C, H, W = img.shape
+    assert H % s == 0 and W % s == 0
+    t = img.reshape(B, C, H // s, s, W // s, s).permute(0, 2, 4, 1, 3, 5)
+    return t.reshape(B, (H // s) * (W // s), C * s * s)
+
+
+def unpatchify(tok: torch.Tensor, C: int) -> torch.Tensor:
+    """(B,N,C*s*s) -> (B,C,e*s,e*s)   [unflatten+unpatch model.py:20-35]"""
+    B, N, D = tok.shape
+    s = int(round(math.sqrt(D // C)))
+    e = int(round(math.sqrt(N)))
+    assert e * e == N and C * s * s == D
+    t = tok.reshape(B, e, e, C, s, s).permute(0, 3, 1, 4, 2, 5)
+    return t.reshape(B, C, e * s, e * s)
+
+
+def retile(tok: torch.Tensor, C: int, s_out: int) -> torch.Tensor:
+    return patchify(unpatchify(tok, C), s_out)
+
+
+def downsample(tok: torch.Tensor, C: int) -> torch.Tensor:
+    """model.py:39-45: same image, patch size halved."""
+    s = int(round(math.sqrt(tok.shape[-1] // C)))
+    return retile(tok, C, s // 2)
+
+
+def upsample(tok: torch.Tensor, C: int) -> torch.Tensor:
+    """model.py:47-53: same image, patch size doubled."""
+    s = int(round(math.sqrt(tok.shape[-1] // C)))
+    return retile(tok, C, s * 2)
+
+
+# --------------------------------------------------------------------------------------------
+# dropout masks: the HIP path draws its Bernoulli masks from a counter-based integer hash
+# (csrc/vu_common.h: vu_keep).  The oracle replays exactly the same hash so train-mode outputs
+# with dropout>0 can be compared element for element.  (Bit-parity with torch's CPU RNG is
+# impossible, SURVEY §7 hard part 5.)
+# --------------------------------------------------------------------------------------------
+_M32 = np.uint64(0xFFFFFFFF)
+
+
+def _mix32(x: np.ndarray) -> np.ndarray:
+    x = x.astype(np.uint64)
+    x ^= x >> np.uint64(16)
+    x = (x * np.uint64(0x7FEB352D)) & _M32
+    x ^= x >> np.uint64(15)
+    x = (x * np.uint64(0x846CA68B)) & _M32
+    x ^= x >> np.uint64(16)
+    return x
+
+
+def _splitmix64(z: int) -> int:
+    z = (z + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return z ^ (z >> 31)
+
+
+def stream_key(seed: int, stream: int) -> Tuple[int, int]:
+    k = _splitmix64((seed & 0xFFFFFFFFFFFFFFFF) ^ _splitmix64(stream & 0xFFFFFFFFFFFFFFFF))
+    return k & 0xFFFFFFFF, (k >> 32) & 0xFFFFFFFF
+
+
+def keep_mask(numel: int, p: float, seed: int, stream: int) -> torch.Tensor:
+    """Boolean keep mask for `numel` linearly indexed elements (True = kept)."""
+    if p <= 0.0:
+        return torch.ones(numel, dtype=torch.bool)
+    thr = int(round(p * 65536.0))
+    k0, k1 = stream_key(seed, stream)
+    idx = np.arange(numel, dtype=np.uint64)
+    w = idx >> np.uint64(1)
+    lo = w & _M32
+    hi = w >> np.uint64(32)
+    x = _mix32(lo ^ np.uint64(k0))
+    x = _mix32((x + hi * np.uint64(0x9E3779B9) + np.uint64(k1)) & _M32)
+    r = np.where((idx & np.uint64(1)) == 1, x >> np.uint64(16), x & np.uint64(0xFFFF))
+    return torch.from_numpy(r >= np.uint64(thr))
+
+
+def _dropout(x: torch.Tensor, p: float, training: bool, seed: Optional[int], stream: int):
+    if (not training) or p <= 0.0:
+        return x
+    assert seed is not None, "train-mode dropout needs a seed (hash RNG shared with the HIP path)"
+    m = keep_mask(x.numel(), p, seed, stream).reshape(x.shape).to(x.dtype)
+    return x * m / (1.0 - p)
+
+
+# --------------------------------------------------------------------------------------------
+# K4: per-patch 3x3 convolution (model.py:137-139,152-154): zero halo at the PATCH border.
+# --------------------------------------------------------------------------------------------
+def conv3x3_per_patch(tok: torch.Tensor, C: int, w: torch.Tensor, b: Optional[torch.Tensor] = None):
+    B, N, D = tok.shape
+    s = int(round(math.sqrt(D // C)))
+    y = F.conv2d(tok.reshape(B * N, C, s, s), w, b, padding=1)
+    return y.reshape(B, N, D)
+
+
+# --------------------------------------------------------------------------------------------
+# a7/a9: Re-attention (model.py:150-164, 244-259).  `xq` feeds q, `xkv` feeds k and v
+# (xq is xkv inside a transformer block; the skip connection passes encoder / decoder tensors).
+# --------------------------------------------------------------------------------------------
+def reattention(xq, xkv, p: Dict[str, torch.Tensor], pre: str, h: int, C: int, *, training: bool,
+                attn_drop: float, proj_drop: float, seed: Optional[int] = None, stream: int = 0,
+                bn_momentum: float = 0.1, eps: float = 1e-5, return_map: bool = False):
+    B, N, D = xq.shape
+    d = D // h
+    q = conv3x3_per_patch(xq, C, p[pre + "qconv2d.weight"]).reshape(B, N, h, d).permute(0, 2, 1, 3)
+    k = conv3x3_per_patch(xkv, C, p[pre + "kconv2d.weight"]).reshape(B, N, h, d).permute(0, 2, 1, 3)
+    v = conv3x3_per_patch(xkv, C, p[pre + "vconv2d.weight"]).reshape(B, N, h, d).permute(0, 2, 1, 3)
+    s = torch.matmul(q, k.transpose(-2, -1)) * (d ** -0.5)           # model.py:155
+    a = torch.softmax(s, dim=-1)                                      # :156
+    a = _dropout(a, attn_drop, training, seed, 2 * stream)           # :157
+    w = p[pre + "reatten_matrix.weight"].reshape(h, h)               # 1x1 conv across heads :159
+    a = torch.einsum("gh,bhij->bgij", w, a) + p[pre + "reatten_matrix.bias"].reshape(1, h, 1, 1)
+    gam, bet = p[pre + "var_norm.weight"], p[pre + "var_norm.bias"]
+    if training:                                                      # BatchNorm2d train: batch stats
+        mean = a.mean(dim=(0, 2, 3))
+        var = a.var(dim=(0, 2, 3), unbiased=False)
+        with torch.no_grad():                                         # running stats (momentum .1, unbiased var)
+            n = a.numel() // h
+            rm, rv = p[pre + "var_norm.running_mean"], p[pre + "var_norm.running_var"]
+            rm.mul_(1 - bn_momentum).add_(bn_momentum * mean.detach().to(rm.dtype))
+            rv.mul_(1 - bn_momentum).add_(bn_momentum * (var.detach() * n / max(n - 1, 1)).to(rv.dtype))
+    else:
+        mean, var = p[pre + "var_norm.running_mean"].to(a.dtype), p[pre + "var_norm.running_var"].to(a.dtype)
+    a = (a - mean.reshape(1, h, 1, 1)) * torch.rsqrt(var.reshape(1, h, 1, 1) + eps)
+    a = a * gam.reshape(1, h, 1, 1) + bet.reshape(1, h, 1, 1)         # reatten_scale == 1.0 (:140)
+    o = torch.matmul(a, v).transpose(1, 2).reshape(B, N, D)           # :161
+    y = F.linear(o, p[pre + "proj.weight"], p[pre + "proj.bias"])     # :162
+    y = _dropout(y, proj_drop, training, seed, 2 * stream + 1)       # :163
+    return (y, a) if return_map else y
+
+
+def _layernorm_nd(x, w, b, eps=1e-5):
+    """LayerNorm(normalized_shape=(N,D)) (model.py:193-196): statistics over all N*D elements."""
+    return F.layer_norm(x, x.shape[1:], w, b, eps)
+
+
+def te_block(x, p, pre: str, cfg: Config, *, training: bool, seed=None, stream: int = 0):
+    """ReAttentionTransformerEncoder.forward (model.py:201-207), post-norm."""
+    a = reattention(x, x, p, pre + "ReAttn.", cfg.num_heads, cfg.num_channels, training=training,
+                    attn_drop=cfg.attn_drop, proj_drop=cfg.proj_drop, seed=seed, stream=stream)
+    x = _layernorm_nd(a + x, p[pre + "LN1.weight"], p[pre + "LN1.bias"])
+    hdn = F.gelu(F.linear(x, p[pre + "FeedForward.net.0.weight"], p[pre + "FeedForward.net.0.bias"]))
+    # linear_drop is 0 in every preset (model.py:451,467,483); Dropout(0) is the identity.
+    assert cfg.linear_drop == 0.0 or not training, "oracle: linear_drop>0 in train mode not restated"
+    f = F.linear(hdn, p[pre + "FeedForward.net.3.weight"], p[pre + "FeedForward.net.3.bias"])
+    return _layernorm_nd(f + x, p[pre + "LN2.weight"], p[pre + "LN2.bias"])
+
+
+def skip_block(enc, dec, p, pre: str, cfg: Config, *, training: bool, seed=None, stream: int = 0):
+    """SkipConnection.forward(q=enc, k=dec, v=dec) (model.py:244-259): replaces dec, no residual."""
+    assert enc.shape == dec.shape
+    return reattention(enc, dec, p, pre, cfg.num_heads, cfg.num_channels, training=training,
+                       attn_drop=cfg.attn_drop, proj_drop=cfg.proj_drop, seed=seed, stream=stream)
+
+
+# --------------------------------------------------------------------------------------------
+# a10: HViT_UNet.forward (model.py:372-435).  `stream` numbering of dropout sites follows
+# execution order: Encoders, BottleNeck, then Decoders interleaved with SkipConnections.
+# --------------------------------------------------------------------------------------------
+def forward(p: Dict[str, torch.Tensor], cfg: Config, X: torch.Tensor, *, training: bool = False,
+            seed: Optional[int] = None, taps: Optional[dict] = None) -> torch.Tensor:
+    B, C, H, W = X.shape
+    assert C == cfg.num_channels and H == cfg.im_size and W == cfg.im_size  # D4: Resize == identity
+    # PatchEncoder.forward (model.py:84-91): tokens + positional embedding (the unpatch/patch
+    # round trip at :88-90 is a no-op).
+    x = patchify(X, cfg.patch_size) + p["PE.position_embedding.weight"].unsqueeze(0)
+    stream = 0
+    skips: List[torch.Tensor] = []
+    for i in range(cfg.depth * cfg.depth_te):                          # :388-392
+        x = te_block(x, p, f"Encoders.{i}.", cfg, training=training, seed=seed, stream=stream)
+        stream += 1
+        if (i + 1) % cfg.depth_te == 0:
+            skips.append(x)
+            x = downsample(x, C)
+    if taps is not None:
+        taps["after_encoders"] = x
+    for i in range(cfg.size_bottleneck):                               # :400-401
+        x = te_block(x, p, f"BottleNeck.{i}.", cfg, training=training, seed=seed, stream=stream)
+        stream += 1
+    if taps is not None:
+        taps["after_bottleneck"] = x
+    for i in range(cfg.depth * cfg.depth_te):                          # :410-418
+        x = te_block(x, p, f"Decoders.{i}.", cfg, training=training, seed=seed, stream=stream)
+        stream += 1
+        if (i + 1) % cfg.depth_te == 0:
+            j = (i + 1) // cfg.depth_te
+            x = upsample(x, C)
+            enc = skips[cfg.depth - j]
+            assert enc.shape == x.shape                                # :417
+            x = skip_block(enc, x, p, f"SkipConnections.{j - 1}.", cfg, training=training,
+                           seed=seed, stream=stream)
+            stream += 1
+    if taps is not None:
+        taps["after_decoders"] = x
+    Y = unpatchify(x, C)                                               # :425
+    if cfg.preprocessing == "conv":                                    # :427-428
+        Y = F.conv2d(Y, p["conv2d.weight"], p["conv2d.bias"], padding=1)
+    elif cfg.preprocessing == "fourier":
+        raise NotImplementedError("D5: the reference 'fourier' branch (model.py:429-430) is a bug")
+    return Y
+
+
+# --------------------------------------------------------------------------------------------
+# parameters: names / shapes in reference registration order (model.py:309-370) and the
+# builder-owned deterministic weight generator used by the golden fixtures.
+# --------------------------------------------------------------------------------------------
+def _attn_shapes(pre: str, D: int, h: int, C: int) -> List[Tuple[str, Tuple[int, ...]]]:
+    return [
+        (pre + "reatten_matrix.weight", (h, h, 1, 1)), (pre + "reatten_matrix.bias", (h,)),
+        (pre + "var_norm.weight", (h,)), (pre + "var_norm.bias", (h,)),
+        (pre + "qconv2d.weight", (C, C, 3, 3)), (pre + "kconv2d.weight", (C, C, 3, 3)),
+        (pre + "vconv2d.weight", (C, C, 3, 3)),
+        (pre + "proj.weight", (D, D)), (pre + "proj.bias", (D,)),
+    ]
+
+
+def _block_shapes(pre: str, N: int, D: int, hid: int, h: int, C: int):
+    out = _attn_shapes(pre + "ReAttn.", D, h, C)
+    out += [(pre + "LN1.weight", (N, D)), (pre + "LN1.bias", (N, D)),
+            (pre + "LN2.weight", (N, D)), (pre + "LN2.bias", (N, D)),
+            (pre + "FeedForward.net.0.weight", (hid, D)), (pre + "FeedForward.net.0.bias", (hid,)),
+            (pre + "FeedForward.net.3.weight", (D, hid)), (pre + "FeedForward.net.3.bias", (D,))]
+    return out
+
+
+def param_shapes(cfg: Config) -> List[Tuple[str, Tuple[int, ...]]]:
+    h, C = cfg.num_heads, cfg.num_channels
+    N0, D0, _, _ = cfg.level(0)
+    out: List[Tuple[str, Tuple[int, ...]]] = [("PE.position_embedding.weight", (N0, D0))]
+    idx = 0
+    for lvl in range(cfg.depth):
+        N, D, hid, _ = cfg.level(lvl)
+        for _ in range(cfg.depth_te):
+            out += _block_shapes(f"Encoders.{idx}.", N, D, hid, h, C)
+            idx += 1
+    N, D, hid, _ = cfg.level(cfg.depth)
+    for i in range(cfg.size_bottleneck):
+        out += _block_shapes(f"BottleNeck.{i}.", N, D, hid, h, C)
+    dec: List[Tuple[str, Tuple[int, ...]]] = []
+    skp: List[Tuple[str, Tuple[int, ...]]] = []
+    idx = 0
+    for lvl in range(cfg.depth):
+        N, D, hid, _ = cfg.level(cfg.depth - lvl)
+        for _ in range(cfg.depth_te):
+            dec += _block_shapes(f"Decoders.{idx}.", N, D, hid, h, C)
+            idx += 1
+        _, Ds, _, _ = cfg.level(cfg.depth - lvl - 1)
+        skp += _attn_shapes(f"SkipConnections.{lvl}.", Ds, h, C)
+    out += dec + skp
+    if cfg.preprocessing == "conv":
+        out += [("conv2d.weight", (C, C, 3, 3)), ("conv2d.bias", (C,))]
+    return out
+
+
+def buffer_shapes(cfg: Config) -> List[Tuple[str, Tuple[int, ...]]]:
+    h = cfg.num_heads
+    out = []
+    for name, _ in param_shapes(cfg):
+        if name.endswith("var_norm.weight"):
+            pre = name[: -len("weight")]
+            out += [(pre + "running_mean", (h,)), (pre + "running_var", (h,)),
+                    (pre + "num_batches_tracked", ())]
+    return out
+
+
+def param_count(cfg: Config) -> int:
+    return sum(int(np.prod(s)) for _, s in param_shapes(cfg))
+
+
+def make_weights(cfg: Config, seed: int = 0, dtype=torch.float32) -> Dict[str, torch.Tensor]:
+    """Deterministic, well-conditioned weights (NumPy PCG64 -> tensors).  Not the torch default
+    initialisers: every tensor is drawn non-trivially (LN/BN affine != 1/0, biases != 0) so the
+    fixtures exercise every term."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    p: Dict[str, torch.Tensor] = {}
+    for name, shape in param_shapes(cfg):
+        n = int(np.prod(shape))
+        if name.endswith("position_embedding.weight"):
+            a = rng.standard_normal(n) * 0.5
+        elif name.endswith(("LN1.weight", "LN2.weight", "var_norm.weight")):
+            a = 1.0 + 0.2 * rng.standard_normal(n)
+        elif name.endswith(("LN1.bias", "LN2.bias", "var_norm.bias")):
+            a = 0.1 * rng.standard_normal(n)
+        elif name.endswith("reatten_matrix.weight"):
+            a = (np.eye(shape[0]).reshape(-1) + 0.3 * rng.standard_normal(n))
+        elif name.endswith("conv2d.weight"):                           # q/k/v/out 3x3 convs
+            a = rng.standard_normal(n) * (1.0 / math.sqrt(9 * shape[1]))
+        elif name.endswith(".weight"):                                 # Linear (out,in)
+            a = rng.standard_normal(n) * (1.0 / math.sqrt(shape[-1]))
+        else:                                                          # biases
+            a = 0.05 * rng.standard_normal(n)
+        p[name] = torch.from_numpy(a.reshape(shape)).to(dtype)
+    for name, shape in buffer_shapes(cfg):
+        if name.endswith("running_mean"):
+            p[name] = torch.from_numpy(0.01 * rng.standard_normal(shape)).to(dtype)
+        elif name.endswith("running_var"):
+            p[name] = torch.from_numpy(1e-4 * (1.0 + rng.random(shape))).to(dtype)
+        else:
+            p[name] = torch.zeros((), dtype=torch.int64)
+    return p
+
+
+def make_batch(cfg: Config, B: int, seed: int = 1234, dtype=torch.float32):
+    """SURVEY §8d synthetic batch: clean y ~ U[0,1), noisy x = clip(y + N(0, 0.1^2))."""
+    g = torch.Generator().manual_seed(seed)
+    y = torch.rand(B, cfg.num_channels, cfg.im_size, cfg.im_size, generator=g)
+    x = (y + 0.1 * torch.randn(y.shape, generator=g)).clamp(0.0, 1.0)
+    return x.to(dtype), y.to(dtype)
+
+
+# --------------------------------------------------------------------------------------------
+# a13 + f2: loss / optimizer / metrics
+# --------------------------------------------------------------------------------------------
+def mse_loss(out, target):
+    """torch.nn.MSELoss() (run_denoising.py:80): mean over all elements."""
+    return ((out - target) ** 2).mean()
+
+
+def dice_loss(inp, target, smooth: float = 1.0):
+    """README.md:91-101."""
+    i, t = inp.reshape(-1), target.reshape(-1)
+    return 1 - (2.0 * (i * t).sum() + smooth) / (i.sum() + t.sum() + smooth)
+
+
+def psnr(target, out, data_range: float = 1.0):
+    """functions.py:7-19 counterpart: per-image 10*log10(R^2/MSE) (skimage semantics)."""
+    B = target.shape[0]
+    mse = ((target.double() - out.double()) ** 2).reshape(B, -1).mean(dim=1)
+    return 10.0 * torch.log10(data_range ** 2 / mse)
+
+
+def adamw_step(p, g, m, v, step: int, lr=1e-4, b1=0.9, b2=0.999, eps=1e-8, wd=1e-2):
+    """torch.optim.AdamW defaults (run_denoising.py:81), one tensor, in place.  `step` >= 1."""
+    p.mul_(1 - lr * wd)
+    m.mul_(b1).add_(g, alpha=1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
+    denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+    p.addcdiv_(m, denom, value=-lr / bc1)
+    return p

@@ -1,0 +1,142 @@
+"""The CPU oracle against the golden vectors generated from the unmodified reference
+(tests/golden/make_golden.py).  This is what pins parity."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import vit_unet_oracle as O
+
+TINY = ["tiny_a", "tiny_b", "tiny_c"]
+TOL = 2e-5   # fp32 oracle vs fp32 reference: max |diff| / max |ref|
+
+
+def close(got, ref, tol=TOL):
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    err = np.abs(got - ref).max() / (np.abs(ref).max() + 1e-30)
+    assert err < tol, f"scaled max error {err:.3e} >= {tol:.1e}"
+
+
+def _load(golden_dir, name):
+    with open(os.path.join(golden_dir, "manifest.json")) as f:
+        man = json.load(f)
+    return man, dict(np.load(os.path.join(golden_dir, name + ".npz")))
+
+
+@pytest.mark.parametrize("name", TINY)
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_tiny_model_forward_backward(golden_dir, name, mode):
+    man, g = _load(golden_dir, name)
+    case = man["cases"][name]
+    cfg = O.Config(**case["config"])
+    assert O.param_count(cfg) == case["params"]
+    w = O.make_weights(cfg, seed=case["weights_seed"])
+    x, y = torch.from_numpy(g["x"]), torch.from_numpy(g["y"])
+    for k, _ in O.param_shapes(cfg):
+        w[k].requires_grad_(True)
+    out = O.forward(w, cfg, x, training=(mode == "train"))
+    loss = O.mse_loss(out, y)
+    loss.backward()
+    close(out.detach().numpy(), g[f"{mode}.out"])
+    np.testing.assert_allclose(loss.item(), g[f"{mode}.loss"], rtol=1e-5)
+    for k in g:
+        if k.startswith(f"{mode}.grad."):
+            pname = k[len(f"{mode}.grad."):]
+            if mode == "train" and pname.endswith("reatten_matrix.bias"):
+                continue   # exactly 0 in exact arithmetic (train-mode BN removes the mean): noise
+            ref = g[k]
+            got = w[pname].grad.numpy()
+            scale = np.abs(ref).max() + 1e-12
+            assert np.abs(got - ref).max() / scale < 2e-3, pname   # fp32-vs-fp32 gradient noise
+    gabs = np.array([float(w[k].grad.double().abs().sum()) for k, _ in O.param_shapes(cfg)])
+    sel = np.array([not (mode == "train" and k.endswith("reatten_matrix.bias"))
+                    for k, _ in O.param_shapes(cfg)])
+    np.testing.assert_allclose(gabs[sel], g[f"{mode}.gradabs"][sel], rtol=1e-2)  # per-parameter L1 summary
+    if mode == "train":
+        for k in g:
+            if k.startswith("train.buf."):
+                np.testing.assert_allclose(w[k[len("train.buf."):]].numpy(), g[k], rtol=1e-4, atol=1e-9)
+
+
+def test_retile_ops(golden_dir):
+    _, g = _load(golden_dir, "ops")
+    X = torch.from_numpy(g["patch.in"])
+    t = O.patchify(X, 8)
+    assert np.array_equal(t.numpy(), g["patch.out_s8"])          # permutations are bit-exact
+    assert np.array_equal(O.unpatchify(t, 3).numpy(), g["unpatch.out"])
+    assert np.array_equal(O.downsample(t, 3).numpy(), g["down.out"])
+    assert np.array_equal(O.upsample(t, 3).numpy(), g["up.out"])
+    assert np.array_equal(O.upsample(O.downsample(t, 3), 3).numpy(), t.numpy())
+
+
+@pytest.mark.parametrize("tag,N,C,s,h,hid", [("n49", 49, 3, 8, 4, 16), ("d12", 16, 3, 4, 4, 8)])
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_block_ops(golden_dir, tag, N, C, s, h, hid, mode):
+    _, g = _load(golden_dir, "ops")
+    training = mode == "train"
+    cfg = O.Config(depth=0, depth_te=1, size_bottleneck=1, preprocessing="conv", im_size=int(N ** 0.5) * s,
+                   patch_size=s, num_channels=C, hidden_dim=hid, num_heads=h)
+    x, enc = torch.from_numpy(g[f"{tag}.x"]), torch.from_numpy(g[f"{tag}.enc"])
+
+    def params(prefix):
+        return {k[len(f"{tag}.{prefix}."):]: torch.from_numpy(v.copy()) for k, v in g.items()
+                if k.startswith(f"{tag}.{prefix}.")}
+    p = params("blk")
+    y, amap = O.reattention(x, x, p, "ReAttn.", h, C, training=training, attn_drop=0., proj_drop=0.,
+                            return_map=True)
+    close(amap.numpy(), g[f"{tag}.{mode}.attn.map"])
+    close(y.numpy(), g[f"{tag}.{mode}.attn.out"])
+    p = params("blk")
+    close(O.te_block(x, p, "", cfg, training=training).numpy(), g[f"{tag}.{mode}.block.out"])
+    p = params("skp")
+    close(O.skip_block(enc, x, p, "", cfg, training=training).numpy(), g[f"{tag}.{mode}.skip.out"])
+
+
+@pytest.mark.parametrize("name", ["base", "large"])
+def test_full_config_checksums(golden_dir, name):
+    """Full-size eval forward: weights regenerated from the seed, compared with the reference's
+    sampled outputs / checksums.  (lite and seg512 take ~5 s each on the reference; they are
+    covered by the GPU tests against the same manifest.)"""
+    man, _ = _load(golden_dir, "ops")
+    ref = man["full"][name]
+    kw = dict(O.PRESETS[name], attn_drop=0.0, proj_drop=0.0)
+    cfg = O.Config(**kw)
+    assert O.param_count(cfg) == ref["params"] == man["kat"]["packaged_counts"][name]
+    w = O.make_weights(cfg, seed=0)
+    x, _ = O.make_batch(cfg, B=ref["B"], seed=1234)
+    with torch.no_grad():
+        out = O.forward(w, cfg, x, training=False)
+    flat = out.reshape(-1)
+    got = flat[torch.tensor(ref["sample_idx"])].double().numpy()
+    close(got, np.array(ref["sample"]), 1e-4)
+    assert abs(float(out.double().mean()) - ref["mean"]) < 1e-4 * max(1.0, abs(ref["mean"]))
+    assert abs(float(out.abs().max()) - ref["absmax"]) < 1e-3 * ref["absmax"]
+
+
+def test_parameter_count_kats(golden_dir):
+    """README.md:16,34,52 counts via the derivation of SURVEY §4 / App. B, and packaged counts."""
+    man, _ = _load(golden_dir, "ops")
+    for name in ("lite", "base", "large"):
+        cfg = O.Config(**O.PRESETS[name])
+        total = O.param_count(cfg)
+        assert total == man["kat"]["packaged_counts"][name]
+        n_te = 2 * cfg.depth * cfg.depth_te + cfg.size_bottleneck
+        C = cfg.num_channels
+        readme = total - n_te * 2 * cfg.P + (9 * C * C + C)
+        assert readme == man["kat"]["readme_counts"][name]
+    seg = O.Config(**dict(O.PRESETS["base"], im_size=512, num_channels=1))
+    assert O.param_count(seg) == man["kat"]["packaged_counts"]["seg512"]
+
+
+def test_keep_mask_statistics():
+    m = O.keep_mask(1 << 20, 0.2, seed=123, stream=5)
+    rate = m.float().mean().item()
+    assert abs(rate - 0.8) < 2e-3
+    m2 = O.keep_mask(1 << 20, 0.2, seed=123, stream=6)
+    assert (m != m2).float().mean().item() > 0.25      # different streams decorrelate
+    assert torch.equal(m, O.keep_mask(1 << 20, 0.2, seed=123, stream=5))
+    # neighbouring pairs are not correlated
+    a, b = m[0::2].float(), m[1::2].float()
+    assert abs(((a - a.mean()) * (b - b.mean())).mean().item()) < 2e-3
