@@ -1,0 +1,147 @@
+/* vit_unet_amd.h - C ABI of libvitunet_amd.so, the MI355X (gfx950) ViT-UNet forward/backward path.
+ *
+ * This is the drop-in boundary for the hot path of benayas1/vit-unet.  The
+ * reference has no native code: every entry point below replaces a run of PyTorch ATen calls
+ * made by /root/reference/vit_unet/torch/model.py (cited per function as model.py:LINES).  The
+ * Python package vit-unet_amd/vit_unet binds these symbols with ctypes (INTEGRATION.md shows the
+ * stub) and mirrors the reference's nn.Module surface on top of them.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer is DEVICE memory unless stated otherwise;
+ *  - all work is enqueued on the caller's `stream` (a hipStream_t passed as void*); no hidden
+ *    synchronisation, no allocation, no global mutable state (thread-local last-error text only);
+ *  - return 0 (VU_OK) on success, negative VU_E* otherwise; vu_last_error() gives the text;
+ *  - `dtype` selects the STORAGE type of activations / GEMM weights: 0 = fp32, 1 = bf16.
+ *    Arithmetic is always fp32 (fp32 MFMA accumulators).  Parameters that are not GEMM operands
+ *    (conv taps, head-mix matrix, BatchNorm / LayerNorm affine, biases, positional embedding)
+ *    are always read from the fp32 master arena.
+ */
+#ifndef VIT_UNET_AMD_H
+#define VIT_UNET_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VU_OK 0
+#define VU_EINVAL (-1)
+#define VU_EUNSUPPORTED (-2)
+#define VU_EWORKSPACE (-3)
+#define VU_ELAUNCH (-4)
+
+int vu_version(void);
+const char* vu_last_error(void);
+
+/* HViT_UNet constructor arguments (model.py:264-299). */
+typedef struct vu_config {
+  int depth, depth_te, size_bottleneck;
+  int im_size, patch_size, num_channels, hidden_dim, num_heads;
+  float attn_drop, proj_drop, linear_drop;
+  int out_conv; /* preprocessing == 'conv' (model.py:369-370, 427-428) */
+  int dtype;    /* 0 fp32, 1 bf16 */
+} vu_config;
+
+/* One parameter of the flat arena, in the reference's registration order (model.py:309-370);
+ * `name` is the reference state_dict key.  Offsets are in elements and 8-element aligned. */
+typedef struct vu_param_entry {
+  char name[96];
+  long long offset;
+  int ndim;
+  int shape[4];
+  int bn_index; /* >= 0 for var_norm.weight: index of this module's running stats */
+} vu_param_entry;
+
+int vu_model_validate(const vu_config* cfg);                    /* asserts of model.py:281-283 */
+long long vu_model_param_elems(const vu_config* cfg);           /* arena length (padded)       */
+int vu_model_num_params(const vu_config* cfg);
+int vu_model_param_table(const vu_config* cfg, vu_param_entry* out, int capacity);
+int vu_model_num_attn(const vu_config* cfg);                    /* BatchNorm modules           */
+size_t vu_model_workspace_bytes(const vu_config* cfg, int B);
+
+/* HViT_UNet.forward (model.py:372-435).
+ *  params      fp32 master arena            shadow   bf16 copy of the arena (dtype 1) or NULL
+ *  bn_state    fp32 [num_attn][2][heads] running_mean / running_var (updated when training)
+ *  x, y        fp32 (B, C, im, im)          ws       workspace of vu_model_workspace_bytes()
+ *  training    1: BatchNorm batch statistics + dropout (seed); 0: running statistics
+ *  rng_salt    optional device uint32 mixed into the dropout keys (hipGraph replay), or NULL */
+int vu_model_forward(const vu_config* cfg, const float* params, const void* shadow, float* bn_state,
+                     const float* x, float* y, void* ws, size_t ws_bytes, int B, int training,
+                     uint64_t seed, const uint32_t* rng_salt, void* stream);
+/* Backward of the forward that last filled `ws`.  Parameter gradients are ACCUMULATED into the
+ * fp32 arena `grads`; dx (fp32 (B,C,im,im)) may be NULL.  stage: 0 = all, 1 = output conv +
+ * decoders + skips, 2 = bottleneck, 3 = encoders + positional embedding (for bucketed
+ * all-reduce overlap; stages must be run in order 1,2,3). */
+int vu_model_backward(const vu_config* cfg, const float* params, const void* shadow,
+                      const float* bn_state, float* grads, const float* dy, float* dx, void* ws,
+                      size_t ws_bytes, int B, int training, uint64_t seed, const uint32_t* rng_salt,
+                      int stage, void* stream);
+
+/* ---- per-op entry points (used by the parity tests and by the stand-alone sub-modules) ---- */
+
+/* patch / unpatch / downsampling / upsampling (model.py:8-53): one latent image re-tiled from
+ * patch size s_in to s_out (the (B,C,im,im) image is the s = im case).  pos (fp32, output
+ * layout, one sample) is added when non-NULL (PatchEncoder, model.py:84-91). */
+int vu_retile(int dtype, int in_f32, int out_f32, const void* in, void* out, const float* pos,
+              int B, int C, int im, int s_in, int s_out, void* stream);
+
+/* Conv2d(C,C,3,padding='same') applied per patch (model.py:137-139,152-154) or on the whole
+ * image (model.py:370,428: npatch = B, s = im). */
+int vu_conv3x3_fwd(int dtype, int out_f32, const void* in, const float* w, const float* bias,
+                   void* out, long long npatch, int C, int s, void* stream);
+int vu_conv3x3_bwd(int dtype, int dout_f32, const void* dout, const void* in, const float* w,
+                   const void* add, void* din, float* dw, float* dbias, long long npatch, int C,
+                   int s, void* stream);
+
+/* ReAttention.forward / SkipConnection.forward (model.py:150-164, 244-259) on token maps
+ * xq, xkv (B,N,D); prm = pointers into the arenas.  ws from vu_attn_workspace_bytes. */
+typedef struct vu_attn_params {
+  const float* mix_w; const float* mix_b; const float* bn_w; const float* bn_b;
+  const float* wq; const float* wk; const float* wv;
+  const void* proj_w;  /* storage dtype */
+  const float* proj_b;
+  float* run_mean; float* run_var;
+} vu_attn_params;
+typedef struct vu_attn_grads {
+  float* mix_w; float* mix_b; float* bn_w; float* bn_b; float* wq; float* wk; float* wv;
+  float* proj_w; float* proj_b;
+} vu_attn_grads;
+size_t vu_attn_workspace_bytes(int dtype, int B, int N, int D, int H);
+int vu_attn_forward(int dtype, const vu_attn_params* prm, const void* xq, const void* xkv, void* y,
+                    void* map_out, void* ws, size_t ws_bytes, int B, int N, int D, int H, int C,
+                    float attn_drop, float proj_drop, int training, uint64_t seed, uint64_t stream_id,
+                    void* stream);
+int vu_attn_backward(int dtype, const vu_attn_params* prm, const vu_attn_grads* grd, const void* xq,
+                     const void* xkv, const void* dy, void* dxq, void* dxkv, void* ws, size_t ws_bytes,
+                     int B, int N, int D, int H, int C, float attn_drop, float proj_drop, int training,
+                     uint64_t seed, uint64_t stream_id, void* stream);
+
+/* residual add + LayerNorm((N,D)) (model.py:193-196, 203-206); x may be NULL. */
+size_t vu_layernorm_workspace_floats(int B, long long P);
+int vu_add_layernorm_fwd(int dtype, const void* a, const void* x, void* z, const float* w,
+                         const float* b, void* y, float* ws, float* stats, int B, long long P,
+                         void* stream);
+int vu_layernorm_bwd(int dtype, const void* dy, const void* z, const float* w, const float* stats,
+                     float* dw, float* db, float* ws, void* dz, int B, long long P, void* stream);
+
+/* strided batched GEMM C = alpha * A * B (+bias) used for every contraction on the path;
+ * strides in elements; exactly one of (sAm,sAk) and one of (sBk,sBn) must be 1. */
+int vu_gemm(int dtype, int c_float, const void* A, const void* Bm, void* C, int M, int N, int K,
+            long long sAm, long long sAk, long long sBk, long long sBn, long long ldc, int Z1, int Z2,
+            long long sA1, long long sA2, long long sB1, long long sB2, long long sC1, long long sC2,
+            float alpha, const float* bias, int accumulate, void* stream);
+
+/* MSELoss + its gradient (run_denoising.py:80); partials: >= 1024 floats. */
+int vu_mse_loss(const float* out, const float* target, float* dout, float* loss, float* partials,
+                long long n, float grad_scale, void* stream);
+/* AdamW over the flat arena (run_denoising.py:81); hyper = {lr,beta1,beta2,eps,weight_decay}
+ * and the int step counter live in device memory. */
+int vu_adamw(float* params, const float* grads, float* m, float* v, void* shadow_bf16, long long n,
+             const float* hyper, int* step, float grad_scale, void* stream);
+int vu_cast_bf16(const float* in, void* out, long long n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

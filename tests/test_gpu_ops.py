@@ -1,0 +1,302 @@
+"""GPU parity tests, per op, through the C ABI (ctypes) against the CPU oracle / plain torch CPU.
+
+Tolerances (scaled max error = max|got-ref| / max|ref|):
+  fp32 storage : 2e-5 forward, 2e-4 backward (fp32 MFMA, fp32 reductions in a different order)
+  bf16 storage : 3e-2 (inputs, weights and every intermediate rounded to 8 significant bits)
+Re-tiling is a permutation: bit-exact.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import vit_unet_oracle as O
+from vit_unet.torch import _lib
+from vit_unet.torch._lib import check, lib, ptr
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+TOL = {torch.float32: (2e-5, 2e-4), torch.bfloat16: (3e-2, 5e-2)}
+
+
+def serr(got, ref):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    return ((got - ref).abs().max() / (ref.abs().max() + 1e-30)).item()
+
+
+def st():
+    return _lib.stream_ptr()
+
+
+def dev(t, dt=None):
+    t = t.to(DEV)
+    return t.to(dt).contiguous() if dt is not None else t.contiguous()
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C_,im,s_in,s_out", [(3, 32, 32, 8), (3, 32, 8, 4), (3, 32, 4, 16), (1, 64, 16, 64),
+                                              (3, 224, 224, 32), (3, 224, 32, 16), (3, 224, 8, 16)])
+def test_retile_bit_exact(dt, C_, im, s_in, s_out):
+    B = 2
+    img = torch.rand(B, C_, im, im)
+    tin = O.patchify(img, s_in).to(dt)
+    ref = O.retile(tin.float(), C_, s_out).to(dt)
+    x = dev(tin)
+    out = torch.empty(ref.shape, dtype=dt, device=DEV)
+    check(lib().vu_retile(_lib.DTYPE_CODE[dt], 0, 0, ptr(x), ptr(out), None, B, C_, im, s_in, s_out, st()))
+    assert torch.equal(out.cpu(), ref)
+
+
+def test_retile_patch_encoder_posemb():
+    B, C_, im, s = 3, 3, 56, 8
+    img = torch.rand(B, C_, im, im)
+    pos = torch.randn((im // s) ** 2, C_ * s * s)
+    ref = O.patchify(img, s) + pos
+    out = torch.empty(ref.shape, device=DEV)
+    check(lib().vu_retile(0, 1, 1, ptr(dev(img)), ptr(out), ptr(dev(pos)), B, C_, im, im, s, st()))
+    assert torch.equal(out.cpu(), ref)
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C_,s,npatch", [(3, 8, 98), (1, 16, 10), (3, 4, 1000), (3, 32, 5)])
+def test_conv3x3_fwd_bwd(dt, C_, s, npatch):
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(npatch, C_, s, s, generator=g).to(dt)
+    w = torch.randn(C_, C_, 3, 3, generator=g) * 0.3
+    b = torch.randn(C_, generator=g)
+    dy = torch.randn(npatch, C_, s, s, generator=g).to(dt)
+    add = torch.randn(npatch, C_, s, s, generator=g).to(dt)
+    xr = x.float().requires_grad_(True)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = torch.nn.functional.conv2d(xr, wr, br, padding=1)
+    yr.backward(dy.float())
+    code = _lib.DTYPE_CODE[dt]
+    xd, wd, bd, dyd, addd = dev(x), dev(w), dev(b), dev(dy), dev(add)
+    y = torch.empty_like(xd)
+    check(lib().vu_conv3x3_fwd(code, 0, ptr(xd), ptr(wd), ptr(bd), ptr(y), npatch, C_, s, st()))
+    ft, bt = TOL[dt]
+    assert serr(y, yr) < ft
+    din = torch.empty_like(xd)
+    dw = torch.zeros(C_, C_, 3, 3, device=DEV)
+    db = torch.zeros(C_, device=DEV)
+    check(lib().vu_conv3x3_bwd(code, 0, ptr(dyd), ptr(xd), ptr(wd), ptr(addd), ptr(din), ptr(dw), ptr(db), npatch, C_, s, st()))
+    assert serr(din, xr.grad + add.float()) < bt
+    assert serr(dw, wr.grad) < bt
+    assert serr(db, br.grad) < bt
+
+
+# ------------------------------------------------------------------------------------------------
+def _gemm(dt, A, Bm, M, N, K, sAm, sAk, sBk, sBn, Z1=1, Z2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), ldc=None, alpha=1.0,
+          bias=None, c_float=0, accumulate=0, out=None):
+    ldc = ldc or N
+    if out is None:
+        odt = torch.float32 if c_float else dt
+        out = torch.zeros(M * ldc, dtype=odt, device=DEV)
+    check(lib().vu_gemm(_lib.DTYPE_CODE[dt], c_float, ptr(A), ptr(Bm), ptr(out), M, N, K, sAm, sAk, sBk, sBn, ldc, Z1, Z2,
+                        sA[0], sA[1], sB[0], sB[1], sC[0], sC[1], alpha, ptr(bias), accumulate, st()))
+    return out
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(49, 49, 24), (200, 130, 70), (128, 128, 32), (130, 24, 196), (64, 16, 3072),
+                                   (784, 784, 24), (300, 3072 // 8, 392)])
+def test_gemm_forms(dt, M, N, K):
+    g = torch.Generator().manual_seed(M * 7 + N)
+    ft, _ = TOL[dt]
+    a = torch.randn(M, K, generator=g).to(dt)
+    b = torch.randn(K, N, generator=g).to(dt)
+    ref = a.double() @ b.double()
+    bias = torch.randn(N, generator=g)
+    # NT: A (M,K) k-contiguous ; B given as (N,K) k-contiguous
+    out = _gemm(dt, dev(a), dev(b.t().contiguous()), M, N, K, K, 1, 1, K, bias=dev(bias), alpha=0.5)
+    assert serr(out.view(M, N), 0.5 * ref + bias.double()) < ft * (4 if dt == torch.bfloat16 else 40)
+    # NN: B (K,N) n-contiguous
+    out = _gemm(dt, dev(a), dev(b), M, N, K, K, 1, N, 1)
+    assert serr(out.view(M, N), ref) < ft * (4 if dt == torch.bfloat16 else 40)
+    # TT: A stored (K,M) m-contiguous, B (K,N) n-contiguous, float accumulate output
+    base = torch.randn(M, N, generator=g)
+    out = dev(base.clone())
+    _gemm(dt, dev(a.t().contiguous()), dev(b), M, N, K, 1, M, N, 1, c_float=1, accumulate=1, out=out)
+    assert serr(out.view(M, N), ref + base.double()) < ft * (4 if dt == torch.bfloat16 else 40)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_gemm_batched_heads(dt):
+    """the per-head attention products: q k^T and A v on column slices of (B,N,D)."""
+    B, N, D, H = 2, 49, 96, 4
+    d = D // H
+    ld = 56
+    g = torch.Generator().manual_seed(5)
+    q = torch.randn(B, N, D, generator=g).to(dt)
+    k = torch.randn(B, N, D, generator=g).to(dt)
+    ft, _ = TOL[dt]
+    S = torch.zeros(B, H, N, ld, dtype=dt, device=DEV)
+    _gemm(dt, dev(q), dev(k), N, N, d, D, 1, 1, D, Z1=B, Z2=H, sA=(N * D, d), sB=(N * D, d), sC=(H * N * ld, N * ld), ldc=ld,
+          alpha=d ** -0.5, out=S)
+    qh = q.double().view(B, N, H, d).permute(0, 2, 1, 3)
+    kh = k.double().view(B, N, H, d).permute(0, 2, 1, 3)
+    ref = qh @ kh.transpose(-1, -2) * d ** -0.5
+    assert serr(S[..., :N], ref) < ft * 40
+    A = torch.randn(B, H, N, ld, generator=g).to(dt)
+    out = torch.zeros(B, N, D, dtype=dt, device=DEV)
+    _gemm(dt, dev(A), dev(k), N, d, N, ld, 1, D, 1, Z1=B, Z2=H, sA=(H * N * ld, N * ld), sB=(N * D, d), sC=(N * D, d), ldc=D, out=out)
+    ref = (A.double()[..., :N] @ kh).permute(0, 2, 1, 3).reshape(B, N, D)
+    assert serr(out, ref) < ft * 40
+
+
+# ------------------------------------------------------------------------------------------------
+def _attn_case(N, Cn, s, H, B=2, seed=11):
+    D = Cn * s * s
+    g = torch.Generator().manual_seed(seed)
+    p = {"reatten_matrix.weight": (torch.eye(H) + 0.3 * torch.randn(H, H, generator=g)).reshape(H, H, 1, 1),
+         "reatten_matrix.bias": 0.05 * torch.randn(H, generator=g),
+         "var_norm.weight": 1 + 0.2 * torch.randn(H, generator=g), "var_norm.bias": 0.1 * torch.randn(H, generator=g),
+         "var_norm.running_mean": 0.01 * torch.randn(H, generator=g),
+         "var_norm.running_var": 1e-4 * (1 + torch.rand(H, generator=g)),
+         "qconv2d.weight": torch.randn(Cn, Cn, 3, 3, generator=g) / (9 * Cn) ** 0.5,
+         "kconv2d.weight": torch.randn(Cn, Cn, 3, 3, generator=g) / (9 * Cn) ** 0.5,
+         "vconv2d.weight": torch.randn(Cn, Cn, 3, 3, generator=g) / (9 * Cn) ** 0.5,
+         "proj.weight": torch.randn(D, D, generator=g) / D ** 0.5, "proj.bias": 0.05 * torch.randn(D, generator=g)}
+    xq = torch.randn(B, N, D, generator=g)
+    xkv = torch.randn(B, N, D, generator=g)
+    dy = torch.randn(B, N, D, generator=g)
+    return p, xq, xkv, dy, D
+
+
+GRAD_KEYS = ["reatten_matrix.weight", "reatten_matrix.bias", "var_norm.weight", "var_norm.bias", "qconv2d.weight",
+             "kconv2d.weight", "vconv2d.weight", "proj.weight", "proj.bias"]
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,Cn,s,H", [(49, 3, 8, 4), (16, 3, 4, 4), (196, 1, 8, 2), (64, 3, 8, 8)])
+@pytest.mark.parametrize("mode", ["eval", "train", "train_drop"])
+@pytest.mark.parametrize("cross", [False, True])
+def test_attention_fwd_bwd(dt, N, Cn, s, H, mode, cross):
+    if dt == torch.bfloat16 and mode == "eval":
+        pytest.skip("eval with tiny running_var amplifies bf16 rounding by 100x; covered in fp32")
+    p, xq, xkv, dy, D = _attn_case(N, Cn, s, H)
+    B = xq.shape[0]
+    training = mode != "eval"
+    ad, pd = (0.2, 0.2) if mode == "train_drop" else (0.0, 0.0)
+    seed, sid = 1234, 3
+    if not cross:
+        xkv = xq
+    # bf16 storage: the oracle sees the same rounded inputs / GEMM weights
+    xq_r, xkv_r, dy_r = xq.to(dt).float(), xkv.to(dt).float(), dy.to(dt).float()
+    pr = {k: v.clone() for k, v in p.items()}
+    pr["proj.weight"] = p["proj.weight"].to(dt).float()
+    xq_r.requires_grad_(True)
+    if cross:
+        xkv_r.requires_grad_(True)
+    for k in GRAD_KEYS:
+        pr[k].requires_grad_(True)
+    yr, mapr = O.reattention(xq_r, xkv_r if cross else xq_r, pr, "", H, Cn, training=training, attn_drop=ad, proj_drop=pd,
+                             seed=seed, stream=sid, return_map=True)
+    yr.backward(dy_r)
+    # ---- HIP ----
+    code = _lib.DTYPE_CODE[dt]
+    L = lib()
+    d = {k: dev(v) for k, v in p.items()}
+    pw = dev(p["proj.weight"], dt)
+    prm = _lib.vu_attn_params(*[d[k].data_ptr() for k in GRAD_KEYS[:7]], pw.data_ptr(), d["proj.bias"].data_ptr(),
+                              d["var_norm.running_mean"].data_ptr(), d["var_norm.running_var"].data_ptr())
+    xqd, xkvd, dyd = dev(xq, dt), dev(xkv, dt), dev(dy, dt)
+    if not cross:
+        xkvd = xqd
+    nbytes = L.vu_attn_workspace_bytes(code, B, N, D, H)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    y = torch.empty_like(xqd)
+    amap = torch.empty(B, H, N, N, dtype=dt, device=DEV)
+    check(L.vu_attn_forward(code, C.byref(prm), ptr(xqd), ptr(xkvd), ptr(y), ptr(amap), ptr(ws), nbytes, B, N, D, H, Cn,
+                            ad, pd, int(training), seed, sid, st()))
+    ft, bt = TOL[dt]
+    if dt == torch.float32:
+        ft, bt = 1e-4, 1e-3      # softmax/BN chains: fp32 noise amplified by 1/sqrt(var) ~ 100
+    assert serr(amap, mapr) < ft, "attention map"
+    assert serr(y, yr) < ft, "attention output"
+    if training:    # running statistics updated in place (momentum 0.1, unbiased variance)
+        assert serr(d["var_norm.running_mean"], pr["var_norm.running_mean"]) < 1e-4
+        assert serr(d["var_norm.running_var"], pr["var_norm.running_var"]) < 1e-3
+    grads = [torch.zeros_like(d[k]) for k in GRAD_KEYS]
+    gs = _lib.vu_attn_grads(*[g.data_ptr() for g in grads])
+    dxq = torch.empty_like(xqd)
+    dxkv = torch.empty_like(xqd) if cross else None
+    check(L.vu_attn_backward(code, C.byref(prm), C.byref(gs), ptr(xqd), ptr(xkvd), ptr(dyd), ptr(dxq), ptr(dxkv), ptr(ws),
+                             nbytes, B, N, D, H, Cn, ad, pd, int(training), seed, sid, st()))
+    assert serr(dxq, xq_r.grad) < bt, "dxq"
+    if cross:
+        assert serr(dxkv, xkv_r.grad) < bt, "dxkv"
+    for k, g in zip(GRAD_KEYS, grads):
+        if training and k == "reatten_matrix.bias":
+            # exactly zero in exact arithmetic (train-mode BN removes the mean)
+            assert g.abs().max().item() < 1e-2 * grads[0].abs().max().item() + 1e-6
+            continue
+        assert serr(g, pr[k].grad) < bt, k
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,P", [(3, 49 * 192), (2, 150528), (1, 4096), (5, 1028)])
+def test_add_layernorm_fwd_bwd(dt, B, P):
+    g = torch.Generator().manual_seed(P)
+    a = torch.randn(B, P, generator=g).to(dt)
+    x = (3 + torch.randn(B, P, generator=g)).to(dt)
+    w = 1 + 0.2 * torch.randn(P, generator=g)
+    b = 0.1 * torch.randn(P, generator=g)
+    dy = torch.randn(B, P, generator=g).to(dt)
+    code = _lib.DTYPE_CODE[dt]
+    L = lib()
+    ad, xd, wd, bd, dyd = dev(a), dev(x), dev(w), dev(b), dev(dy)
+    ws = torch.empty(L.vu_layernorm_workspace_floats(B, P), device=DEV)
+    z, y = torch.empty_like(ad), torch.empty_like(ad)
+    stats = torch.empty(B, 2, device=DEV)
+    check(L.vu_add_layernorm_fwd(code, ptr(ad), ptr(xd), ptr(z), ptr(wd), ptr(bd), ptr(y), ptr(ws), ptr(stats), B, P, st()))
+    zr = (a.float() + x.float()).to(dt).float().requires_grad_(True)      # statistics are taken on the stored sum
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(zr, (P,), wr, br, 1e-5)
+    yr.backward(dy.float())
+    ft, bt = TOL[dt]
+    assert serr(z, zr) < 1e-6
+    assert serr(y, yr) < ft
+    dw, db = torch.zeros_like(wd), torch.zeros_like(wd)
+    dz = torch.empty_like(ad)
+    check(L.vu_layernorm_bwd(code, ptr(dyd), ptr(z), ptr(wd), ptr(stats), ptr(dw), ptr(db), ptr(ws), ptr(dz), B, P, st()))
+    assert serr(dz, zr.grad) < bt
+    assert serr(dw, wr.grad) < bt
+    assert serr(db, br.grad) < bt
+
+
+# ------------------------------------------------------------------------------------------------
+def test_mse_and_adamw_and_cast():
+    L = lib()
+    n = 3 * 150528
+    g = torch.Generator().manual_seed(1)
+    o, t = torch.rand(n, generator=g), torch.rand(n, generator=g)
+    od, td = dev(o), dev(t)
+    do = torch.empty_like(od)
+    loss = torch.zeros(1, device=DEV)
+    part = torch.zeros(2048, device=DEV)
+    check(L.vu_mse_loss(ptr(od), ptr(td), ptr(do), ptr(loss), ptr(part), n, 1.0, st()))
+    assert abs(loss.item() - O.mse_loss(o.double(), t.double()).item()) < 1e-6
+    assert serr(do, 2 * (o - t) / n) < 1e-6
+    # AdamW, 3 steps, against the oracle's restatement of torch.optim.AdamW
+    m = 4096 * 3 + 8
+    p = torch.randn(m, generator=g)
+    pr, mr, vr = p.clone().double(), torch.zeros(m).double(), torch.zeros(m).double()
+    pd, md, vd = dev(p), torch.zeros(m, device=DEV), torch.zeros(m, device=DEV)
+    sh = torch.empty(m, dtype=torch.bfloat16, device=DEV)
+    hyper = dev(torch.tensor([1e-2, 0.9, 0.999, 1e-8, 1e-2]))
+    step = torch.zeros(1, dtype=torch.int32, device=DEV)
+    for s in range(1, 4):
+        gr = torch.randn(m, generator=g)
+        O.adamw_step(pr, gr.double() * 0.5, mr, vr, s, lr=1e-2)
+        check(L.vu_adamw(ptr(pd), ptr(dev(gr)), ptr(md), ptr(vd), ptr(sh), m, ptr(hyper), ptr(step), 0.5, st()))
+    assert step.item() == 3
+    assert serr(pd, pr) < 1e-5
+    assert torch.equal(sh.float().cpu(), pd.cpu().to(torch.bfloat16).float())
+    c = torch.empty(m, dtype=torch.bfloat16, device=DEV)
+    check(L.vu_cast_bf16(ptr(pd), ptr(c), m, st()))
+    assert torch.equal(c, sh)

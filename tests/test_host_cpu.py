@@ -1,0 +1,107 @@
+"""CPU-side checks of the boundary: the C-ABI library loads and exports every declared symbol,
+the C parameter table equals the reference state_dict layout (via the oracle's table), workspace
+sizing, error conventions.  No kernel is launched (no GPU here)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+import vit_unet_oracle as O
+from vit_unet.torch import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_exported():
+    hdr = open(os.path.join(ROOT, "include", "vit_unet_amd.h")).read()
+    names = set(re.findall(r"\b(vu_[a-z0-9_]+)\s*\(", hdr))
+    names -= {"vu_config", "vu_param_entry", "vu_attn_params", "vu_attn_grads"}
+    assert len(names) >= 20
+    L = C.CDLL(_lib.LIB_PATH)
+    for n in sorted(names):
+        assert hasattr(L, n), f"{n} declared in include/vit_unet_amd.h but not exported"
+    assert set(_lib.SIGNATURES) == names, set(_lib.SIGNATURES) ^ names
+
+
+@pytest.mark.parametrize("name", ["lite", "base", "large"])
+def test_param_table_matches_reference_layout(name):
+    kw = O.PRESETS[name]
+    ocfg = O.Config(**kw)
+    cfg = _lib.make_config(dtype=torch.float32, **kw)
+    table = _lib.param_table(cfg)
+    assert [(n, s) for n, _, s, _ in table] == [(n, tuple(s)) for n, s in O.param_shapes(ocfg)]
+    # offsets: increasing, 8-element aligned, non-overlapping
+    end = 0
+    for n, off, shape, _ in table:
+        assert off % 8 == 0 and off >= end
+        numel = 1
+        for d in shape:
+            numel *= d
+        end = off + numel
+    assert _lib.lib().vu_model_param_elems(C.byref(cfg)) >= end
+    assert sum(torch.Size(s).numel() for _, _, s, _ in table) == O.param_count(ocfg)
+    n_attn = sum(1 for n, *_ in table if n.endswith("var_norm.weight"))
+    assert _lib.lib().vu_model_num_attn(C.byref(cfg)) == n_attn
+    assert sorted(b for *_, b in table if b >= 0) == list(range(n_attn))
+
+
+def test_constructor_asserts_match_reference():
+    L = _lib.lib()
+    bad = [dict(depth=2, patch_size=6), dict(depth=3, patch_size=16), dict(im_size=100, patch_size=16)]
+    for b in bad:
+        kw = dict(O.PRESETS["lite"]); kw.update(b)
+        cfg = _lib.make_config(dtype=torch.float32, **kw)
+        with pytest.raises(AssertionError):
+            _lib.check(L.vu_model_validate(C.byref(cfg)))
+    from vit_unet.torch import model as M
+    with pytest.raises(AssertionError):
+        M.HViT_UNet(2, 1, 1, "conv", 224, 6, 3, 16, 2, 0., 0., 0.)
+    with pytest.raises(ValueError):
+        M.get_vit_unet("huge")
+    with pytest.raises(NotImplementedError):
+        M.HViT_UNet(1, 1, 1, "fourier", 32, 8, 3, 16, 2, 0., 0., 0.)
+
+
+def test_workspace_grows_with_batch():
+    L = _lib.lib()
+    cfg = _lib.make_config(dtype=torch.bfloat16, **O.PRESETS["base"])
+    w8, w64 = L.vu_model_workspace_bytes(C.byref(cfg), 8), L.vu_model_workspace_bytes(C.byref(cfg), 64)
+    assert 0 < w8 < w64 < 16 * 2 ** 30
+    cfg32 = _lib.make_config(dtype=torch.float32, **O.PRESETS["base"])
+    assert L.vu_model_workspace_bytes(C.byref(cfg32), 8) > w8
+
+
+def test_module_surface_and_state_dict_keys():
+    from vit_unet.torch import model as M
+    m = M.get_vit_unet("lite")
+    ocfg = O.Config(**O.PRESETS["lite"])
+    assert [k for k, _ in m.named_parameters()] == [k for k, _ in O.param_shapes(ocfg)]
+    sd = m.state_dict()
+    want = [k for k, _ in O.param_shapes(ocfg)] + [k for k, _ in O.buffer_shapes(ocfg)]
+    assert sorted(sd.keys()) == sorted(want)
+    assert sum(p.numel() for p in m.parameters()) == 5193820
+    for attr in ("PE", "Encoders", "BottleNeck", "Decoders", "SkipConnections", "conv2d"):
+        assert hasattr(m, attr)
+    # README ctor surface
+    r = M.ViT_UNet(depth=2, depth_te=2, size_bottleneck=2, preprocessing="conv", num_patches=49, patch_size=32,
+                   num_channels=3, hidden_dim=128, num_heads=8, attn_drop=.2, proj_drop=.2, linear_drop=0,
+                   dtype=torch.float32)
+    assert r.im_size == 224 and sum(p.numel() for p in r.parameters()) == 39623512
+
+
+def test_product_path_refuses_cpu_tensors():
+    from vit_unet.torch import model as M
+    m = M.HViT_UNet(1, 1, 1, "conv", 32, 8, 3, 16, 2, 0., 0., 0.)
+    with pytest.raises(_lib.VuError):
+        m(torch.rand(1, 3, 32, 32))
+
+
+def test_no_oracle_import_in_product():
+    pkg = os.path.join(ROOT, "vit-unet_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "vit_unet_oracle" not in txt or f == "vu_common.h" and "import" not in txt, f

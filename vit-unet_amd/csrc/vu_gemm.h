@@ -1,0 +1,249 @@
+// Strided / batched MFMA GEMM for gfx950 with fused epilogues.
+//
+//   C[z](m,n) (+)= epilogue( alpha * sum_k A[z](m,k) * B[z](k,n) )
+//
+// Operands are addressed with element strides so the same kernel serves the projection /
+// feed-forward linears, the per-head attention products (heads are column slices of the
+// token-major (B,N,D) activations) and every backward product.  Each operand is either
+// K-contiguous ("N" form: LDS image [row][k], fragments by ds_read_b128) or row-contiguous
+// ("T" form: LDS image [k][row], fragments by ds_read_b64_tr_b16 - the gfx950 transposing LDS
+// read - so no scattered LDS writes are needed).  T = __bf16 uses v_mfma_f32_16x16x32_bf16,
+// T = float uses the exact-fp32 v_mfma_f32_16x16x4_f32 (parity mode).
+//
+// 256 threads = 4 waves in a 2x2 arrangement; wave tile (BM/2)x(BN/2) of 16x16 MFMA tiles;
+// BK = 32; register-prefetched global loads (tile t+1 in flight while tile t is multiplied).
+#pragma once
+#include "vu_common.h"
+
+enum { VU_ACT_NONE = 0, VU_ACT_GELU = 1, VU_ACT_DGELU = 2 };
+
+struct vu_gemm_args {
+  const void* A; const void* B; void* C;
+  int M, N, K;
+  long long sAm, sAk, sBk, sBn, ldc;
+  int Z1, Z2;  // batch count = Z1*Z2, z = z1*Z2 + z2
+  long long sA1, sA2, sB1, sB2, sC1, sC2;
+  float alpha;
+  const float* bias;   // [N] fp32, or null
+  int act;             // VU_ACT_*: GELU stores act(x) in C and x in aux; DGELU multiplies by gelu'(aux)
+  void* aux;           // T, C layout
+  const void* addend;  // T, C layout: C = result + addend
+  int accumulate;      // C += result   (float C only)
+  int dropout;         // apply dropout(rng) to result; element index = (z*M + m)*N + n
+  vu_rng rng;
+  int vecA, vecB;      // 16-byte vector loads legal for A / B
+};
+
+template <typename T> struct vu_vec { static constexpr int N = 16 / sizeof(T); };
+
+template <typename T, typename TC, bool TA, bool TB, int BM, int BN>
+__global__ __launch_bounds__(256) void vu_gemm_kernel(const vu_gemm_args g) {
+  constexpr int BK = 32;
+  constexpr int VEC = vu_vec<T>::N;            // elements per 16 B
+  constexpr bool IS_BF16 = sizeof(T) == 2;
+  constexpr int PADK = IS_BF16 ? 8 : 4;        // [row][k] images: row stride 80 B / 144 B
+  constexpr int PADR = IS_BF16 ? 16 : 4;       // [k][row] images
+  constexpr int LDA = TA ? (BM + PADR) : (BK + PADK);
+  constexpr int LDB = TB ? (BN + PADR) : (BK + PADK);
+  constexpr int A_ELEMS = TA ? BK * LDA : BM * LDA;
+  constexpr int B_ELEMS = TB ? BK * LDB : BN * LDB;
+  constexpr int TM = BM / 32, TN = BN / 32;    // 16x16 tiles per wave
+  constexpr int NCA = BM * BK / VEC / 256;     // 16-B chunks per thread per k-tile
+  constexpr int NCB = (BN * BK / VEC + 255) / 256;
+  static_assert(NCA >= 1, "tile too small");
+
+  __shared__ __attribute__((aligned(16))) T smem[A_ELEMS + B_ELEMS];
+  T* As = smem;
+  T* Bs = smem + A_ELEMS;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_n = (g.N + BN - 1) / BN;
+  const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+  const int z = blockIdx.y, z1 = z / g.Z2, z2 = z % g.Z2;
+  const int m_base = tile_m * BM, n_base = tile_n * BN;
+
+  const T* Ab = (const T*)g.A + z1 * g.sA1 + z2 * g.sA2;
+  const T* Bb = (const T*)g.B + z1 * g.sB1 + z2 * g.sB2;
+
+  // ---- global -> register staging ---------------------------------------------------------
+  uint4 ra[NCA], rb[NCB];
+
+  auto load_tile = [&](int k0) {
+#pragma unroll
+    for (int c = 0; c < NCA; ++c) {
+      const int ch = tid + c * 256;
+      int row, kk;  // row = m index in tile, kk = k index in tile of the chunk's first element
+      if (TA) { kk = ch / (BM / VEC); row = (ch % (BM / VEC)) * VEC; }
+      else    { row = ch / (BK / VEC); kk = (ch % (BK / VEC)) * VEC; }
+      const int m = m_base + row, k = k0 + kk;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      const bool full = TA ? (k < g.K && m + VEC <= g.M) : (m < g.M && k + VEC <= g.K);
+      if (full && g.vecA) {
+        v = *reinterpret_cast<const uint4*>(Ab + (long long)m * g.sAm + (long long)k * g.sAk);
+      } else {
+        alignas(16) T tmp[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const int mm = TA ? m + e : m, kx = TA ? k : k + e;
+          tmp[e] = (mm < g.M && kx < g.K) ? Ab[(long long)mm * g.sAm + (long long)kx * g.sAk] : (T)0.f;
+        }
+        v = *reinterpret_cast<uint4*>(tmp);
+      }
+      ra[c] = v;
+    }
+#pragma unroll
+    for (int c = 0; c < NCB; ++c) {
+      const int ch = tid + c * 256;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (ch < BN * BK / VEC) {
+        int col, kk;
+        if (TB) { kk = ch / (BN / VEC); col = (ch % (BN / VEC)) * VEC; }
+        else    { col = ch / (BK / VEC); kk = (ch % (BK / VEC)) * VEC; }
+        const int n = n_base + col, k = k0 + kk;
+        const bool full = TB ? (k < g.K && n + VEC <= g.N) : (n < g.N && k + VEC <= g.K);
+        if (full && g.vecB) {
+          v = *reinterpret_cast<const uint4*>(Bb + (long long)k * g.sBk + (long long)n * g.sBn);
+        } else {
+          alignas(16) T tmp[VEC];
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            const int nn = TB ? n + e : n, kx = TB ? k : k + e;
+            tmp[e] = (nn < g.N && kx < g.K) ? Bb[(long long)kx * g.sBk + (long long)nn * g.sBn] : (T)0.f;
+          }
+          v = *reinterpret_cast<uint4*>(tmp);
+        }
+      }
+      rb[c] = v;
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int c = 0; c < NCA; ++c) {
+      const int ch = tid + c * 256;
+      int row, kk;
+      if (TA) { kk = ch / (BM / VEC); row = (ch % (BM / VEC)) * VEC; *reinterpret_cast<uint4*>(&As[kk * LDA + row]) = ra[c]; }
+      else    { row = ch / (BK / VEC); kk = (ch % (BK / VEC)) * VEC; *reinterpret_cast<uint4*>(&As[row * LDA + kk]) = ra[c]; }
+    }
+#pragma unroll
+    for (int c = 0; c < NCB; ++c) {
+      const int ch = tid + c * 256;
+      if (ch < BN * BK / VEC) {
+        int col, kk;
+        if (TB) { kk = ch / (BN / VEC); col = (ch % (BN / VEC)) * VEC; *reinterpret_cast<uint4*>(&Bs[kk * LDB + col]) = rb[c]; }
+        else    { col = ch / (BK / VEC); kk = (ch % (BK / VEC)) * VEC; *reinterpret_cast<uint4*>(&Bs[col * LDB + kk]) = rb[c]; }
+      }
+    }
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int nk = (g.K + BK - 1) / BK;
+  load_tile(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    store_tile();
+    __syncthreads();
+    if (kt + 1 < nk) load_tile((kt + 1) * BK);
+    if constexpr (IS_BF16) {
+      typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+      bf16x8 af[TM], bfr[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int r0 = wm * (BM / 2) + i * 16;
+        if constexpr (TA) {
+          const int q = l15 >> 2, p = l15 & 3;
+          const bf16_t* a0 = (const bf16_t*)&As[(8 * lg + q) * LDA + r0 + 4 * p];
+          s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)a0);
+          s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(a0 + 4 * LDA));
+          typedef __attribute__((ext_vector_type(8))) short s16x8;
+          s16x8 t = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          af[i] = __builtin_bit_cast(bf16x8, t);
+        } else {
+          af[i] = *reinterpret_cast<const bf16x8*>(&As[(r0 + l15) * LDA + 8 * lg]);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int c0 = wn * (BN / 2) + j * 16;
+        if constexpr (TB) {
+          const int q = l15 >> 2, p = l15 & 3;
+          const bf16_t* b0 = (const bf16_t*)&Bs[(8 * lg + q) * LDB + c0 + 4 * p];
+          s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)b0);
+          s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(b0 + 4 * LDB));
+          typedef __attribute__((ext_vector_type(8))) short s16x8;
+          s16x8 t = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          bfr[j] = __builtin_bit_cast(bf16x8, t);
+        } else {
+          bfr[j] = *reinterpret_cast<const bf16x8*>(&Bs[(c0 + l15) * LDB + 8 * lg]);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < BK / 4; ++ks) {
+        float af[TM], bfr[TN];
+        const int kq = ks * 4 + lg;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int r = wm * (BM / 2) + i * 16 + l15;
+          af[i] = TA ? (float)As[kq * LDA + r] : (float)As[r * LDA + kq];
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int c = wn * (BN / 2) + j * 16 + l15;
+          bfr[j] = TB ? (float)Bs[kq * LDB + c] : (float)Bs[c * LDB + kq];
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue -----------------------------------------------------------------------------
+  const vu_rng rng = g.dropout ? vu_rng_resolve(g.rng) : g.rng;
+  const long long coff = z1 * g.sC1 + z2 * g.sC2;
+  TC* Cb = (TC*)g.C + coff;
+  T* auxb = g.aux ? (T*)g.aux + coff : nullptr;
+  const T* addb = g.addend ? (const T*)g.addend + coff : nullptr;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n_base + wn * (BN / 2) + j * 16 + l15;
+      if (n >= g.N) continue;
+      const float bv = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m_base + wm * (BM / 2) + i * 16 + lg * 4 + r;
+        if (m >= g.M) continue;
+        float v = acc[i][j][r] * g.alpha + bv;
+        const long long o = (long long)m * g.ldc + n;
+        if (g.act == VU_ACT_GELU) { vu_st(auxb + o, v); v = vu_gelu(v); }
+        else if (g.act == VU_ACT_DGELU) { v *= vu_gelu_grad(vu_ld(auxb + o)); }
+        if (g.dropout) {
+          const uint64_t idx = ((uint64_t)z * g.M + m) * (uint64_t)g.N + n;
+          v = vu_keep(rng, idx) ? v * rng.inv_keep : 0.f;
+        }
+        if (addb) v += vu_ld(addb + o);
+        if constexpr (sizeof(TC) == 4) {
+          float* cp = (float*)Cb + o;
+          if (g.accumulate) *cp += v; else *cp = v;
+        } else {
+          vu_st((T*)Cb + o, v);
+        }
+      }
+    }
+}

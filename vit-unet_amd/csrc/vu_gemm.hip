@@ -1,0 +1,53 @@
+// GEMM instantiations + host launcher.
+#include "vu_gemm.h"
+
+template <typename T, typename TC, bool TA, bool TB, int BM, int BN>
+static int launch_one(const vu_gemm_args& g, hipStream_t st) {
+  dim3 grid((unsigned)(vu_cdiv(g.M, BM) * vu_cdiv(g.N, BN)), (unsigned)(g.Z1 * g.Z2));
+  hipLaunchKernelGGL((vu_gemm_kernel<T, TC, TA, TB, BM, BN>), grid, dim3(256), 0, st, g);
+  return vu_check_launch("vu_gemm");
+}
+
+template <typename T, typename TC, bool TA, bool TB>
+static int launch_tiles(const vu_gemm_args& g, hipStream_t st) {
+  if (g.N <= 32) return launch_one<T, TC, TA, TB, 128, 32>(g, st);
+  if (g.M <= 64) return launch_one<T, TC, TA, TB, 64, 64>(g, st);
+  if (g.N <= 64) return launch_one<T, TC, TA, TB, 128, 64>(g, st);
+  return launch_one<T, TC, TA, TB, 128, 128>(g, st);
+}
+
+template <typename T>
+static int launch_layout(vu_gemm_args& g, int c_float, hipStream_t st) {
+  const bool TA = g.sAk != 1, TB = g.sBk != 1;
+  if (TA && g.sAm != 1) { vu_set_error("vu_gemm: A must have a unit stride"); return VU_EINVAL; }
+  if (TB && g.sBn != 1) { vu_set_error("vu_gemm: B must have a unit stride"); return VU_EINVAL; }
+  constexpr long long VEC = 16 / sizeof(T);
+  auto al = [&](const void* p, long long s1, long long s2, long long big) {
+    return ((uintptr_t)p % 16 == 0) && (s1 % VEC == 0) && (s2 % VEC == 0) && (big % VEC == 0);
+  };
+  g.vecA = al(g.A, g.sA1, g.sA2, TA ? g.sAk : g.sAm) ? 1 : 0;
+  g.vecB = al(g.B, g.sB1, g.sB2, TB ? g.sBk : g.sBn) ? 1 : 0;
+  if (sizeof(T) == 2 && c_float) {
+    if (TA && TB) return launch_tiles<T, float, true, true>(g, st);
+    if (!TA && !TB) return launch_tiles<T, float, false, false>(g, st);
+    vu_set_error("vu_gemm: float output only for NT / TT operand forms");
+    return VU_EUNSUPPORTED;
+  }
+  if (sizeof(T) == 2 && g.accumulate) { vu_set_error("vu_gemm: accumulate needs float C"); return VU_EINVAL; }
+  if (!TA && !TB) return launch_tiles<T, T, false, false>(g, st);
+  if (!TA && TB) return launch_tiles<T, T, false, true>(g, st);
+  if (TA && TB) return launch_tiles<T, T, true, true>(g, st);
+  vu_set_error("vu_gemm: (A row-contiguous, B k-contiguous) form is not instantiated");
+  return VU_EUNSUPPORTED;
+}
+
+// dtype: 0 = fp32 storage, 1 = bf16 storage.
+int vu_gemm_launch(int dtype, int c_float, vu_gemm_args g, hipStream_t st) {
+  if (g.M <= 0 || g.N <= 0 || g.Z1 * g.Z2 <= 0) return VU_OK;
+  if (g.K <= 0) { vu_set_error("vu_gemm: K must be positive"); return VU_EINVAL; }
+  if (dtype == 0) {
+    // for fp32 storage every C is float; c_float only selects accumulate-capable paths
+    return launch_layout<float>(g, 0, st);
+  }
+  return launch_layout<bf16_t>(g, c_float, st);
+}

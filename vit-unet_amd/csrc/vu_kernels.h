@@ -1,0 +1,76 @@
+// Host-side launchers for the non-GEMM kernels (all HBM-bound; see DESIGN.md for the byte model).
+// dtype: 0 = fp32 storage, 1 = bf16 storage.  Every launcher enqueues on `st` and returns VU_*.
+#pragma once
+#include "vu_common.h"
+#include "vu_gemm.h"
+
+int vu_gemm_launch(int dtype, int c_float, vu_gemm_args g, hipStream_t st);
+
+// a1-a4: token re-tiling of one latent image between patch sizes (image layout = patch size im).
+// in_f32 / out_f32: the tensor is fp32 regardless of dtype (model input / output side).
+int vu_k_retile(int dtype, int in_f32, int out_f32, const void* in, void* out, const float* pos,
+                int B, int C, int im, int s_in, int s_out, hipStream_t st);
+// out[r] += sum_b in[b*P + r]   (positional-embedding gradient)
+int vu_k_batch_sum(int dtype, const void* in, float* out, int B, long long P, hipStream_t st);
+
+// K4 / K15: 3x3 convolution with zero halo at the patch border; tensors are (npatch, C, s, s).
+int vu_k_conv3x3_fwd(int dtype, int out_f32, const void* in, const float* w, const float* bias,
+                     void* out, long long npatch, int C, int s, hipStream_t st);
+int vu_k_conv3x3_dgrad(int dtype, int dout_f32, const void* dout, const float* w, const void* add,
+                       void* din, long long npatch, int C, int s, hipStream_t st);
+int vu_k_conv3x3_wgrad(int dtype, int dout_f32, const void* dout, const void* in, float* dw,
+                       float* dbias, long long npatch, int C, int s, hipStream_t st);
+
+// K7+K8: row softmax + dropout on (rows, ld) logits, N valid columns; writes sign-tagged
+// probabilities (negative = dropped) in place.
+int vu_k_softmax_dropout(int dtype, void* S, long long rows, int N, int ld, vu_rng rng,
+                         hipStream_t st);
+
+// K9+K10: head mixing + BatchNorm on sign-tagged maps (B,H,N,ld).
+// stats buffer layout (floats): Wf[H*H] cf[H] mean[H] rstd[H] m1[H] m2[H]
+#define VU_BN_STATS_FLOATS(H) ((H) * (H) + 5 * (H))
+int vu_k_mix_stats(int dtype, const void* Ps, const float* W, const float* c, float* partials,
+                   int nblocks, int B, int H, int N, int ld, float inv_keep, hipStream_t st);
+int vu_k_bn_finalize(const float* partials, int nblocks, const float* W, const float* c,
+                     const float* gamma, const float* beta, float* run_mean, float* run_var,
+                     float* stats, int H, int N, double count, int training, float momentum,
+                     float eps, hipStream_t st);
+int vu_k_mix_apply(int dtype, const void* Ps, void* Ahat, const float* stats, int B, int H, int N,
+                   int ld, float inv_keep, hipStream_t st);
+int vu_k_bn_bwd_stats(int dtype, const void* Ps, const void* dAhat, const float* W, const float* c,
+                      const float* stats, float* partials, int nblocks, int B, int H, int N, int ld,
+                      float inv_keep, hipStream_t st);
+int vu_k_bn_bwd_finalize(const float* partials, int nblocks, float* stats, float* dgamma,
+                         float* dbeta, int H, double count, int training, hipStream_t st);
+// dS written over dAhat.  dW (H*H) and dc (H) are accumulated with atomics.
+int vu_k_map_bwd(int dtype, const void* Ps, void* dAhat_dS, const float* W, const float* c,
+                 const float* gamma, const float* stats, float* dW, float* dc, int B, int H, int N,
+                 int ld, float inv_keep, float scale, hipStream_t st);
+
+// K13: residual add + LayerNorm over all P elements of a sample.
+#define VU_LN_CHUNK 4096
+#define VU_LN_BCHUNK 1024
+static inline int vu_ln_nchunks(long long P) { return (int)((P + VU_LN_CHUNK - 1) / VU_LN_CHUNK); }
+static inline int vu_ln_nbchunks(long long P) { return (int)((P + VU_LN_BCHUNK - 1) / VU_LN_BCHUNK); }
+// partials: B*nchunks*3 floats ; stats: B*2 floats (mean, rstd)
+int vu_k_add_ln_fwd(int dtype, const void* a, const void* x, void* z, const float* w,
+                    const float* bias, void* y, float* partials, float* stats, int B, long long P,
+                    float eps, hipStream_t st);
+// partials2: B*nbchunks*2 floats.  dz_drop (optional): dropout(dz) with rng (proj dropout bwd).
+int vu_k_ln_bwd(int dtype, const void* dy, const void* z, const float* w, const float* stats,
+                float* dw, float* db, float* partials2, void* dz, void* dz_drop, vu_rng rng,
+                int B, long long P, hipStream_t st);
+
+// column sums: out[n] += sum_m in[m*ld + n]
+int vu_k_colsum(int dtype, const void* in, float* out, long long rows, int ncols, long long ld,
+                hipStream_t st);
+int vu_k_add(int dtype, const void* a, const void* b, void* out, long long n, hipStream_t st);
+int vu_k_dropout(int dtype, const void* in, void* out, long long n, vu_rng rng, hipStream_t st);
+
+// a13: loss / optimizer
+int vu_k_mse(const float* out, const float* target, float* dout, float* loss, float* partials,
+             long long n, float gscale, hipStream_t st);
+int vu_k_adamw(float* p, const float* g, float* m, float* v, void* shadow_bf16, long long n,
+               const float* hyper, int* step, float gscale, hipStream_t st);
+int vu_k_cast_bf16(const float* in, void* out, long long n, hipStream_t st);
+int vu_k_fill(float* p, float v, long long n, hipStream_t st);

@@ -1,0 +1,1005 @@
+// HBM-bound kernels of the ViT-UNet path for gfx950: re-tiling, per-patch 3x3 convolutions,
+// row softmax + dropout, head mixing + BatchNorm on attention maps, (N,D) LayerNorm, loss,
+// AdamW.  Storage T in {float, __bf16}; arithmetic fp32.  Reference call sites are cited per
+// kernel (file:line into /root/reference/vit_unet/torch/model.py unless noted).
+#include "vu_kernels.h"
+
+#define VU_DISPATCH_T(dtype, ...)                  \
+  if ((dtype) == 0) { typedef float T; __VA_ARGS__ } \
+  else { typedef bf16_t T; __VA_ARGS__ }
+
+static inline int grid_for(long long work_items, int block = 256, int cap = 256 * 16) {
+  long long g = (work_items + block - 1) / block;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// =============================================================================================
+// a1-a4 retile (model.py:8-53).  SURVEY App. A index maps.  4 consecutive x per thread.
+// =============================================================================================
+template <typename TI, typename TO>
+__global__ void retile_kernel(const TI* __restrict__ in, TO* __restrict__ out,
+                              const float* __restrict__ pos, long long total4, int P, int C, int im,
+                              int s_in, int s_out) {
+  const int e_in = im / s_in, e_out = im / s_out;
+  const int ss_in = s_in * s_in, ss_out = s_out * s_out;
+  const int D_in = C * ss_in, D_out = C * ss_out;
+  const int P4 = P >> 2;
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total4;
+       t += (long long)gridDim.x * blockDim.x) {
+    const long long b = t / P4;
+    const int r = (int)(t - b * P4) << 2;
+    const int n_out = r / D_out, f = r - n_out * D_out;
+    const int ch = f / ss_out, rem = f - ch * ss_out;
+    const int i = rem / s_out, j = rem - i * s_out;
+    const int y = (n_out / e_out) * s_out + i, x = (n_out % e_out) * s_out + j;
+    const int n_in = (y / s_in) * e_in + x / s_in;
+    const int f_in = ch * ss_in + (y % s_in) * s_in + (x % s_in);
+    vu_f4 v = vu_ld4(in + b * P + (long long)n_in * D_in + f_in);
+    if (pos) {
+      const float4 pp = *reinterpret_cast<const float4*>(pos + r);
+      v.v[0] += pp.x; v.v[1] += pp.y; v.v[2] += pp.z; v.v[3] += pp.w;
+    }
+    vu_st4(out + b * P + r, v);
+  }
+}
+
+int vu_k_retile(int dtype, int in_f32, int out_f32, const void* in, void* out, const float* pos,
+                int B, int C, int im, int s_in, int s_out, hipStream_t st) {
+  VU_REQUIRE(s_in % 4 == 0 && s_out % 4 == 0 && im % s_in == 0 && im % s_out == 0,
+             "vu_retile: patch sizes must be multiples of 4 that divide im (im=%d s_in=%d s_out=%d)", im, s_in, s_out);
+  const int P = C * im * im;
+  const long long total4 = (long long)B * (P / 4);
+  if (total4 == 0) return VU_OK;
+  const int grid = grid_for(total4);
+  const bool fi = in_f32 || dtype == 0, fo = out_f32 || dtype == 0;
+  if (fi && fo) hipLaunchKernelGGL((retile_kernel<float, float>), dim3(grid), dim3(256), 0, st, (const float*)in, (float*)out, pos, total4, P, C, im, s_in, s_out);
+  else if (fi) hipLaunchKernelGGL((retile_kernel<float, bf16_t>), dim3(grid), dim3(256), 0, st, (const float*)in, (bf16_t*)out, pos, total4, P, C, im, s_in, s_out);
+  else if (fo) hipLaunchKernelGGL((retile_kernel<bf16_t, float>), dim3(grid), dim3(256), 0, st, (const bf16_t*)in, (float*)out, pos, total4, P, C, im, s_in, s_out);
+  else hipLaunchKernelGGL((retile_kernel<bf16_t, bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)in, (bf16_t*)out, pos, total4, P, C, im, s_in, s_out);
+  return vu_check_launch("vu_retile");
+}
+
+template <typename T>
+__global__ void batch_sum_kernel(const T* __restrict__ in, float* __restrict__ out, int B, long long P) {
+  const long long r = (blockIdx.x * (long long)blockDim.x + threadIdx.x) * 4;
+  if (r >= P) return;
+  float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  for (int b = 0; b < B; ++b) {
+    vu_f4 v = vu_ld4(in + b * P + r);
+    a0 += v.v[0]; a1 += v.v[1]; a2 += v.v[2]; a3 += v.v[3];
+  }
+  float4* o = reinterpret_cast<float4*>(out + r);
+  float4 c = *o;
+  c.x += a0; c.y += a1; c.z += a2; c.w += a3;
+  *o = c;
+}
+int vu_k_batch_sum(int dtype, const void* in, float* out, int B, long long P, hipStream_t st) {
+  VU_REQUIRE(P % 4 == 0, "vu_batch_sum: P %% 4 != 0");
+  const int grid = vu_cdiv(P / 4, 256);
+  VU_DISPATCH_T(dtype, hipLaunchKernelGGL((batch_sum_kernel<T>), dim3(grid), dim3(256), 0, st, (const T*)in, out, B, P);)
+  return vu_check_launch("vu_batch_sum");
+}
+
+// =============================================================================================
+// K4/K15: 3x3 conv, zero halo at the patch border (model.py:137-139,152-154; :370,:428).
+// One thread per pixel, all channels.  Taps come through L1 (9x re-use inside a patch row).
+// =============================================================================================
+template <typename TI, typename TO, int C>
+__global__ void conv3x3_fwd_kernel(const TI* __restrict__ in, const float* __restrict__ w,
+                                   const float* __restrict__ bias, TO* __restrict__ out,
+                                   long long npix, int s) {
+  __shared__ float ws[C * C * 9 + C];
+  for (int i = threadIdx.x; i < C * C * 9; i += blockDim.x) ws[i] = w[i];
+  for (int i = threadIdx.x; i < C; i += blockDim.x) ws[C * C * 9 + i] = bias ? bias[i] : 0.f;
+  __syncthreads();
+  const int ss = s * s;
+  for (long long pix = blockIdx.x * (long long)blockDim.x + threadIdx.x; pix < npix;
+       pix += (long long)gridDim.x * blockDim.x) {
+    const long long patch = pix / ss;
+    const int rem = (int)(pix - patch * ss), y = rem / s, x = rem - y * s;
+    const TI* base = in + patch * (long long)(C * ss);
+    float a[C][9];
+#pragma unroll
+    for (int ci = 0; ci < C; ++ci)
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int yy = y + ky - 1, xx = x + kx - 1;
+          a[ci][ky * 3 + kx] = (yy >= 0 && yy < s && xx >= 0 && xx < s) ? vu_ld(base + ci * ss + yy * s + xx) : 0.f;
+        }
+    TO* ob = out + patch * (long long)(C * ss) + rem;
+#pragma unroll
+    for (int co = 0; co < C; ++co) {
+      float acc = ws[C * C * 9 + co];
+#pragma unroll
+      for (int ci = 0; ci < C; ++ci)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc += ws[(co * C + ci) * 9 + t] * a[ci][t];
+      vu_st(ob + co * ss, acc);
+    }
+  }
+}
+
+// dIn[ci,Y,X] = sum_co sum_ky,kx w[co][ci][ky][kx] * dOut[co, Y-ky+1, X-kx+1]  (+ add)
+template <typename TDO, typename T, int C>
+__global__ void conv3x3_dgrad_kernel(const TDO* __restrict__ dout, const float* __restrict__ w,
+                                     const T* add, T* din, long long npix, int s) {
+  __shared__ float ws[C * C * 9];
+  for (int i = threadIdx.x; i < C * C * 9; i += blockDim.x) ws[i] = w[i];
+  __syncthreads();
+  const int ss = s * s;
+  for (long long pix = blockIdx.x * (long long)blockDim.x + threadIdx.x; pix < npix;
+       pix += (long long)gridDim.x * blockDim.x) {
+    const long long patch = pix / ss;
+    const int rem = (int)(pix - patch * ss), y = rem / s, x = rem - y * s;
+    const TDO* base = dout + patch * (long long)(C * ss);
+    float g[C][9];
+#pragma unroll
+    for (int co = 0; co < C; ++co)
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int yy = y - ky + 1, xx = x - kx + 1;
+          g[co][ky * 3 + kx] = (yy >= 0 && yy < s && xx >= 0 && xx < s) ? vu_ld(base + co * ss + yy * s + xx) : 0.f;
+        }
+    const long long o = patch * (long long)(C * ss) + rem;
+#pragma unroll
+    for (int ci = 0; ci < C; ++ci) {
+      float acc = add ? vu_ld(add + o + ci * ss) : 0.f;
+#pragma unroll
+      for (int co = 0; co < C; ++co)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc += ws[(co * C + ci) * 9 + t] * g[co][t];
+      vu_st(din + o + ci * ss, acc);
+    }
+  }
+}
+
+// dW[co][ci][ky][kx] += sum_pix dOut[co,y,x] * in[ci,y+ky-1,x+kx-1] ; dbias[co] += sum dOut
+template <typename TDO, typename TI, int C>
+__global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const TDO* __restrict__ dout,
+                                                            const TI* __restrict__ in,
+                                                            float* dw, float* dbias,
+                                                            long long npix, int s) {
+  constexpr int NW = C * C * 9;
+  __shared__ float red[4][NW + C];
+  const int ss = s * s;
+  float acc[NW];
+  float accb[C];
+#pragma unroll
+  for (int i = 0; i < NW; ++i) acc[i] = 0.f;
+#pragma unroll
+  for (int i = 0; i < C; ++i) accb[i] = 0.f;
+  for (long long pix = blockIdx.x * (long long)blockDim.x + threadIdx.x; pix < npix;
+       pix += (long long)gridDim.x * blockDim.x) {
+    const long long patch = pix / ss;
+    const int rem = (int)(pix - patch * ss), y = rem / s, x = rem - y * s;
+    const TI* ib = in + patch * (long long)(C * ss);
+    const TDO* db = dout + patch * (long long)(C * ss) + rem;
+    float a[C][9];
+#pragma unroll
+    for (int ci = 0; ci < C; ++ci)
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int yy = y + ky - 1, xx = x + kx - 1;
+          a[ci][ky * 3 + kx] = (yy >= 0 && yy < s && xx >= 0 && xx < s) ? vu_ld(ib + ci * ss + yy * s + xx) : 0.f;
+        }
+#pragma unroll
+    for (int co = 0; co < C; ++co) {
+      const float d = vu_ld(db + co * ss);
+      accb[co] += d;
+#pragma unroll
+      for (int ci = 0; ci < C; ++ci)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[(co * C + ci) * 9 + t] += d * a[ci][t];
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) {
+    const float v = vu_wave_sum(acc[i]);
+    if (lane == 0) red[wave][i] = v;
+  }
+#pragma unroll
+  for (int i = 0; i < C; ++i) {
+    const float v = vu_wave_sum(accb[i]);
+    if (lane == 0) red[wave][NW + i] = v;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < NW + C; i += blockDim.x) {
+    const float v = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+    if (i < NW) atomicAdd(dw + i, v);
+    else if (dbias) atomicAdd(dbias + (i - NW), v);
+  }
+}
+
+#define VU_CONV_C(Cv, ...) \
+  switch (Cv) { case 1: { constexpr int CC = 1; __VA_ARGS__ } break; case 2: { constexpr int CC = 2; __VA_ARGS__ } break; \
+                case 3: { constexpr int CC = 3; __VA_ARGS__ } break; case 4: { constexpr int CC = 4; __VA_ARGS__ } break; \
+                default: vu_set_error("conv3x3: num_channels %d not supported (1..4)", Cv); return VU_EUNSUPPORTED; }
+
+int vu_k_conv3x3_fwd(int dtype, int out_f32, const void* in, const float* w, const float* bias,
+                     void* out, long long npatch, int C, int s, hipStream_t st) {
+  const long long npix = npatch * s * s;
+  if (npix == 0) return VU_OK;
+  const int grid = grid_for(npix, 256, 256 * 32);
+  const bool fo = out_f32 || dtype == 0;
+  VU_CONV_C(C,
+    if (dtype == 0) hipLaunchKernelGGL((conv3x3_fwd_kernel<float, float, CC>), dim3(grid), dim3(256), 0, st, (const float*)in, w, bias, (float*)out, npix, s);
+    else if (fo) hipLaunchKernelGGL((conv3x3_fwd_kernel<bf16_t, float, CC>), dim3(grid), dim3(256), 0, st, (const bf16_t*)in, w, bias, (float*)out, npix, s);
+    else hipLaunchKernelGGL((conv3x3_fwd_kernel<bf16_t, bf16_t, CC>), dim3(grid), dim3(256), 0, st, (const bf16_t*)in, w, bias, (bf16_t*)out, npix, s);)
+  return vu_check_launch("vu_conv3x3_fwd");
+}
+int vu_k_conv3x3_dgrad(int dtype, int dout_f32, const void* dout, const float* w, const void* add,
+                       void* din, long long npatch, int C, int s, hipStream_t st) {
+  const long long npix = npatch * s * s;
+  if (npix == 0) return VU_OK;
+  const int grid = grid_for(npix, 256, 256 * 32);
+  VU_CONV_C(C,
+    if (dtype == 0) hipLaunchKernelGGL((conv3x3_dgrad_kernel<float, float, CC>), dim3(grid), dim3(256), 0, st, (const float*)dout, w, (const float*)add, (float*)din, npix, s);
+    else if (dout_f32) hipLaunchKernelGGL((conv3x3_dgrad_kernel<float, bf16_t, CC>), dim3(grid), dim3(256), 0, st, (const float*)dout, w, (const bf16_t*)add, (bf16_t*)din, npix, s);
+    else hipLaunchKernelGGL((conv3x3_dgrad_kernel<bf16_t, bf16_t, CC>), dim3(grid), dim3(256), 0, st, (const bf16_t*)dout, w, (const bf16_t*)add, (bf16_t*)din, npix, s);)
+  return vu_check_launch("vu_conv3x3_dgrad");
+}
+int vu_k_conv3x3_wgrad(int dtype, int dout_f32, const void* dout, const void* in, float* dw,
+                       float* dbias, long long npatch, int C, int s, hipStream_t st) {
+  const long long npix = npatch * s * s;
+  if (npix == 0) return VU_OK;
+  const int grid = grid_for(npix, 256, 1024);
+  VU_CONV_C(C,
+    if (dtype == 0) hipLaunchKernelGGL((conv3x3_wgrad_kernel<float, float, CC>), dim3(grid), dim3(256), 0, st, (const float*)dout, (const float*)in, dw, dbias, npix, s);
+    else if (dout_f32) hipLaunchKernelGGL((conv3x3_wgrad_kernel<float, bf16_t, CC>), dim3(grid), dim3(256), 0, st, (const float*)dout, (const bf16_t*)in, dw, dbias, npix, s);
+    else hipLaunchKernelGGL((conv3x3_wgrad_kernel<bf16_t, bf16_t, CC>), dim3(grid), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)in, dw, dbias, npix, s);)
+  return vu_check_launch("vu_conv3x3_wgrad");
+}
+
+// =============================================================================================
+// K7+K8 softmax + dropout (model.py:156-157).  One wave per row; probabilities are stored
+// sign-tagged: +p kept, -p dropped (p > 0 always), so every later pass recovers both the
+// pre-dropout probability |p| and the mask without re-running the RNG.
+// =============================================================================================
+template <typename T>
+__global__ void softmax_dropout_kernel(T* S, long long rows, int N, int ld, vu_rng rng_in) {
+  const vu_rng rng = vu_rng_resolve(rng_in);
+  const int lane = threadIdx.x & 63;
+  const long long row = blockIdx.x * (long long)(blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  T* p = S + row * ld;
+  float mx = -INFINITY;
+  for (int j = lane; j < N; j += 64) mx = fmaxf(mx, vu_ld(p + j));
+  mx = vu_wave_max(mx);
+  float sum = 0.f;
+  for (int j = lane; j < N; j += 64) sum += __expf(vu_ld(p + j) - mx);
+  sum = vu_wave_sum(sum);
+  const float inv = 1.0f / sum;
+  const uint64_t base = (uint64_t)row * (uint64_t)N;
+  for (int j = lane; j < N; j += 64) {
+    float v = __expf(vu_ld(p + j) - mx) * inv;
+    if (rng.thr && !vu_keep(rng, base + j)) v = -v;
+    vu_st(p + j, v);
+  }
+  for (int j = N + lane; j < ld; j += 64) vu_st(p + j, 0.f);
+}
+int vu_k_softmax_dropout(int dtype, void* S, long long rows, int N, int ld, vu_rng rng, hipStream_t st) {
+  if (rows == 0) return VU_OK;
+  const long long grid = (rows + 3) / 4;
+  VU_REQUIRE(grid < 2147483647LL, "vu_softmax_dropout: too many rows");
+  VU_DISPATCH_T(dtype, hipLaunchKernelGGL((softmax_dropout_kernel<T>), dim3((unsigned)grid), dim3(256), 0, st, (T*)S, rows, N, ld, rng);)
+  return vu_check_launch("vu_softmax_dropout");
+}
+
+// =============================================================================================
+// K9+K10 head mixing (1x1 conv across heads, model.py:135,159) + BatchNorm2d(h) (:136,159).
+// Train: pass 1 accumulates per-channel shifted moments of A_g = sum_h W[g,h] P~_h + c_g, the
+// finalize kernel folds mean / rstd / gamma / beta into Wf, cf so that pass 2 is a plain mix.
+// =============================================================================================
+template <typename T, int H>
+__device__ __forceinline__ void load_heads4(const T* base, long long head_stride, float inv_keep,
+                                            float (&pt)[H][4], float (&pa)[H][4]) {
+  // pt = post-dropout probability (0 if dropped, |p|/keep otherwise) ; pa = |p|
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    const vu_f4 v = vu_ld4(base + h * head_stride);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      pa[h][e] = fabsf(v.v[e]);
+      pt[h][e] = v.v[e] > 0.f ? v.v[e] * inv_keep : 0.f;
+    }
+  }
+}
+
+template <typename T, int H>
+__global__ __launch_bounds__(256) void mix_stats_kernel(const T* __restrict__ Ps, const float* __restrict__ W,
+                                                        const float* __restrict__ c, float* partials,
+                                                        int B, int N, int ld, float inv_keep) {
+  __shared__ float sW[H * H + H];
+  __shared__ float red[4][2 * H];
+  for (int i = threadIdx.x; i < H * H; i += blockDim.x) sW[i] = W[i];
+  __syncthreads();
+  if (threadIdx.x < H) {  // shift_g = c_g + sum_h W[g,h] / N  (the exact mean without dropout)
+    float s = 0.f;
+    for (int h = 0; h < H; ++h) s += sW[threadIdx.x * H + h];
+    sW[H * H + threadIdx.x] = s / (float)N;   // bias cancels in (A - shift)
+  }
+  __syncthreads();
+  const int ld4 = ld >> 2;
+  const long long total = (long long)B * N * ld4;
+  const long long hs = (long long)N * ld;
+  float s1[H], s2[H];
+#pragma unroll
+  for (int g = 0; g < H; ++g) { s1[g] = 0.f; s2[g] = 0.f; }
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    const long long row = t / ld4;
+    const int jc = (int)(t - row * ld4) << 2;
+    const long long b = row / N;
+    const int i = (int)(row - b * N);
+    float pt[H][4], pa[H][4];
+    load_heads4<T, H>(Ps + (b * H * N + i) * (long long)ld + jc, hs, inv_keep, pt, pa);
+#pragma unroll
+    for (int g = 0; g < H; ++g) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float a = -sW[H * H + g];
+#pragma unroll
+        for (int h = 0; h < H; ++h) a += sW[g * H + h] * pt[h][e];
+        if (jc + e < N) { s1[g] += a; s2[g] += a * a; }
+      }
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int g = 0; g < H; ++g) {
+    const float a = vu_wave_sum(s1[g]), b2 = vu_wave_sum(s2[g]);
+    if (lane == 0) { red[wave][g] = a; red[wave][H + g] = b2; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * H)
+    partials[blockIdx.x * 2 * H + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// single block; H <= 16.  stats layout: Wf[H*H] cf[H] mean[H] rstd[H] m1[H] m2[H]
+__global__ void bn_finalize_kernel(const float* partials, int nblocks, const float* W, const float* c,
+                                   const float* gamma, const float* beta, float* run_mean, float* run_var,
+                                   float* stats, int H, int N, double count, int training, float momentum, float eps) {
+  __shared__ double sd[256];
+  __shared__ float smean[16], srstd[16];
+  for (int q = 0; q < 2 * H; ++q) {   // q < H: first moment, else second
+    double a = 0.0;
+    if (training) for (int i = threadIdx.x; i < nblocks; i += blockDim.x) a += (double)partials[i * 2 * H + q];
+    sd[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) sd[threadIdx.x] += sd[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) { if (q < H) smean[q] = (float)(sd[0] / count); else srstd[q - H] = (float)(sd[0] / count); }
+    __syncthreads();
+  }
+  if (threadIdx.x < H) {
+    const int g = threadIdx.x;
+    float mean, var;
+    if (training) {
+      float sw = 0.f;
+      for (int h = 0; h < H; ++h) sw += W[g * H + h];
+      const float shift = c[g] + sw / (float)N;
+      const float d1 = smean[g], d2 = srstd[g];
+      mean = shift + d1;
+      var = fmaxf(d2 - d1 * d1, 0.f);
+      const float unb = count > 1.0 ? (float)(count / (count - 1.0)) : 1.f;
+      run_mean[g] = (1.f - momentum) * run_mean[g] + momentum * mean;
+      run_var[g] = (1.f - momentum) * run_var[g] + momentum * var * unb;
+    } else {
+      mean = run_mean[g];
+      var = run_var[g];
+    }
+    const float rstd = rsqrtf(var + eps);
+    const float sc = gamma[g] * rstd;
+    for (int h = 0; h < H; ++h) stats[g * H + h] = W[g * H + h] * sc;
+    stats[H * H + g] = (c[g] - mean) * sc + beta[g];
+    stats[H * H + H + g] = mean;
+    stats[H * H + 2 * H + g] = rstd;
+    stats[H * H + 3 * H + g] = 0.f;
+    stats[H * H + 4 * H + g] = 0.f;
+  }
+}
+
+template <typename T, int H>
+__global__ __launch_bounds__(256) void mix_apply_kernel(const T* __restrict__ Ps, T* __restrict__ Ah,
+                                                        const float* __restrict__ stats, int B, int N, int ld,
+                                                        float inv_keep) {
+  __shared__ float sW[H * H + H];
+  for (int i = threadIdx.x; i < H * H + H; i += blockDim.x) sW[i] = stats[i];
+  __syncthreads();
+  const int ld4 = ld >> 2;
+  const long long total = (long long)B * N * ld4;
+  const long long hs = (long long)N * ld;
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    const long long row = t / ld4;
+    const int jc = (int)(t - row * ld4) << 2;
+    const long long b = row / N;
+    const int i = (int)(row - b * N);
+    const long long off = (b * H * N + i) * (long long)ld + jc;
+    float pt[H][4], pa[H][4];
+    load_heads4<T, H>(Ps + off, hs, inv_keep, pt, pa);
+#pragma unroll
+    for (int g = 0; g < H; ++g) {
+      vu_f4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float a = sW[H * H + g];
+#pragma unroll
+        for (int h = 0; h < H; ++h) a += sW[g * H + h] * pt[h][e];
+        o.v[e] = (jc + e < N) ? a : 0.f;
+      }
+      vu_st4(Ah + off + g * hs, o);
+    }
+  }
+}
+
+// backward pass 1: s1_g = sum dAhat_g ; s2_g = sum dAhat_g * xhat_g
+template <typename T, int H>
+__global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const T* __restrict__ Ps, const T* __restrict__ dA,
+                                                           const float* __restrict__ W, const float* __restrict__ c,
+                                                           const float* __restrict__ stats, float* partials,
+                                                           int B, int N, int ld, float inv_keep) {
+  __shared__ float sW[H * H + H];   // W * rstd_g ; (c - mean) * rstd
+  __shared__ float red[4][2 * H];
+  for (int i = threadIdx.x; i < H * H; i += blockDim.x) sW[i] = W[i] * stats[H * H + 2 * H + i / H];
+  for (int i = threadIdx.x; i < H; i += blockDim.x) sW[H * H + i] = (c[i] - stats[H * H + H + i]) * stats[H * H + 2 * H + i];
+  __syncthreads();
+  const int ld4 = ld >> 2;
+  const long long total = (long long)B * N * ld4;
+  const long long hs = (long long)N * ld;
+  float s1[H], s2[H];
+#pragma unroll
+  for (int g = 0; g < H; ++g) { s1[g] = 0.f; s2[g] = 0.f; }
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    const long long row = t / ld4;
+    const int jc = (int)(t - row * ld4) << 2;
+    const long long b = row / N;
+    const int i = (int)(row - b * N);
+    const long long off = (b * H * N + i) * (long long)ld + jc;
+    float pt[H][4], pa[H][4];
+    load_heads4<T, H>(Ps + off, hs, inv_keep, pt, pa);
+#pragma unroll
+    for (int g = 0; g < H; ++g) {
+      const vu_f4 d = vu_ld4(dA + off + g * hs);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float xh = sW[H * H + g];
+#pragma unroll
+        for (int h = 0; h < H; ++h) xh += sW[g * H + h] * pt[h][e];
+        if (jc + e < N) { s1[g] += d.v[e]; s2[g] += d.v[e] * xh; }
+      }
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int g = 0; g < H; ++g) {
+    const float a = vu_wave_sum(s1[g]), b2 = vu_wave_sum(s2[g]);
+    if (lane == 0) { red[wave][g] = a; red[wave][H + g] = b2; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * H)
+    partials[blockIdx.x * 2 * H + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* partials, int nblocks, float* stats, float* dgamma,
+                                       float* dbeta, int H, double count, int training) {
+  __shared__ double sd[256];
+  for (int q = 0; q < 2 * H; ++q) {
+    double a = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += blockDim.x) a += (double)partials[i * 2 * H + q];
+    sd[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) sd[threadIdx.x] += sd[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) {
+      const int g = q < H ? q : q - H;
+      if (q < H) { dbeta[g] += (float)sd[0]; stats[H * H + 3 * H + g] = training ? (float)(sd[0] / count) : 0.f; }
+      else { dgamma[g] += (float)sd[0]; stats[H * H + 4 * H + g] = training ? (float)(sd[0] / count) : 0.f; }
+    }
+    __syncthreads();
+  }
+}
+
+// backward pass 2 (one wave per (b,i) row, all heads): dAhat -> dA -> dP~ -> dP -> dS, in place.
+template <typename T, int H>
+__global__ __launch_bounds__(256) void map_bwd_kernel(const T* __restrict__ Ps, T* dA, const float* __restrict__ W,
+                                                      const float* __restrict__ c, const float* __restrict__ gamma,
+                                                      const float* __restrict__ stats, float* dW, float* dc,
+                                                      long long rows, int N, int ld, float inv_keep, float scale) {
+  __shared__ float sW[H * H];      // W
+  __shared__ float sX[H * H + H];  // W*rstd, (c-mean)*rstd   -> xhat
+  __shared__ float sG[3 * H];      // gamma*rstd, m1, m2
+  __shared__ float red[4][H * H + H];
+  for (int i = threadIdx.x; i < H * H; i += blockDim.x) { sW[i] = W[i]; sX[i] = W[i] * stats[H * H + 2 * H + i / H]; }
+  for (int i = threadIdx.x; i < H; i += blockDim.x) {
+    sX[H * H + i] = (c[i] - stats[H * H + H + i]) * stats[H * H + 2 * H + i];
+    sG[i] = gamma[i] * stats[H * H + 2 * H + i];
+    sG[H + i] = stats[H * H + 3 * H + i];
+    sG[2 * H + i] = stats[H * H + 4 * H + i];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long hs = (long long)N * ld;
+  float aW[H * H], ac[H];
+#pragma unroll
+  for (int i = 0; i < H * H; ++i) aW[i] = 0.f;
+#pragma unroll
+  for (int i = 0; i < H; ++i) ac[i] = 0.f;
+  const long long wstride = (long long)gridDim.x * 4;
+  for (long long row = blockIdx.x * 4LL + wave; row < rows; row += wstride) {
+    const long long b = row / N;
+    const int i = (int)(row - b * N);
+    const long long off = (b * H * N + i) * (long long)ld;
+    float delta[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) delta[h] = 0.f;
+    for (int pass = 0; pass < 2; ++pass) {
+      for (int j = lane; j < N; j += 64) {
+        float pt[H], pa[H], dAg[H];
+        bool kept[H];
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+          const float v = vu_ld(Ps + off + h * hs + j);
+          pa[h] = fabsf(v); kept[h] = v > 0.f; pt[h] = kept[h] ? v * inv_keep : 0.f;
+        }
+#pragma unroll
+        for (int g = 0; g < H; ++g) {
+          float xh = sX[H * H + g];
+#pragma unroll
+          for (int h = 0; h < H; ++h) xh += sX[g * H + h] * pt[h];
+          const float d = vu_ld(dA + off + g * hs + j);
+          dAg[g] = sG[g] * (d - sG[H + g] - xh * sG[2 * H + g]);
+        }
+        if (pass == 0) {
+#pragma unroll
+          for (int g = 0; g < H; ++g) {
+            ac[g] += dAg[g];
+#pragma unroll
+            for (int h = 0; h < H; ++h) aW[g * H + h] += dAg[g] * pt[h];
+          }
+        }
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+          float dp = 0.f;
+#pragma unroll
+          for (int g = 0; g < H; ++g) dp += sW[g * H + h] * dAg[g];
+          dp = kept[h] ? dp * inv_keep : 0.f;
+          if (pass == 0) delta[h] += dp * pa[h];
+          else vu_st(dA + off + h * hs + j, pa[h] * (dp - delta[h]) * scale);
+        }
+      }
+      if (pass == 0) {
+#pragma unroll
+        for (int h = 0; h < H; ++h) delta[h] = vu_wave_sum(delta[h]);
+      }
+    }
+    for (int j = N + lane; j < ld; j += 64)
+#pragma unroll
+      for (int h = 0; h < H; ++h) vu_st(dA + off + h * hs + j, 0.f);
+  }
+#pragma unroll
+  for (int i = 0; i < H * H; ++i) { const float v = vu_wave_sum(aW[i]); if (lane == 0) red[wave][i] = v; }
+#pragma unroll
+  for (int i = 0; i < H; ++i) { const float v = vu_wave_sum(ac[i]); if (lane == 0) red[wave][H * H + i] = v; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < H * H + H; i += blockDim.x) {
+    const float v = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+    if (i < H * H) atomicAdd(dW + i, v); else atomicAdd(dc + (i - H * H), v);
+  }
+}
+
+#define VU_HEADS(Hv, ...) \
+  switch (Hv) { case 1: { constexpr int HH = 1; __VA_ARGS__ } break; case 2: { constexpr int HH = 2; __VA_ARGS__ } break; \
+                case 4: { constexpr int HH = 4; __VA_ARGS__ } break; case 8: { constexpr int HH = 8; __VA_ARGS__ } break; \
+                default: vu_set_error("num_heads %d not supported by the map kernels (1,2,4,8)", Hv); return VU_EUNSUPPORTED; }
+
+int vu_k_mix_stats(int dtype, const void* Ps, const float* W, const float* c, float* partials, int nblocks,
+                   int B, int H, int N, int ld, float inv_keep, hipStream_t st) {
+  VU_REQUIRE(ld % 4 == 0, "mix_stats: ld %% 4");
+  VU_HEADS(H, VU_DISPATCH_T(dtype, hipLaunchKernelGGL((mix_stats_kernel<T, HH>), dim3(nblocks), dim3(256), 0, st, (const T*)Ps, W, c, partials, B, N, ld, inv_keep);))
+  return vu_check_launch("vu_mix_stats");
+}
+int vu_k_bn_finalize(const float* partials, int nblocks, const float* W, const float* c, const float* gamma,
+                     const float* beta, float* run_mean, float* run_var, float* stats, int H, int N, double count,
+                     int training, float momentum, float eps, hipStream_t st) {
+  VU_REQUIRE(H <= 16, "bn_finalize: H > 16");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, st, partials, nblocks, W, c, gamma, beta, run_mean, run_var, stats, H, N, count, training, momentum, eps);
+  return vu_check_launch("vu_bn_finalize");
+}
+int vu_k_mix_apply(int dtype, const void* Ps, void* Ahat, const float* stats, int B, int H, int N, int ld,
+                   float inv_keep, hipStream_t st) {
+  const long long total = (long long)B * N * (ld / 4);
+  const int grid = grid_for(total, 256, 256 * 32);
+  VU_HEADS(H, VU_DISPATCH_T(dtype, hipLaunchKernelGGL((mix_apply_kernel<T, HH>), dim3(grid), dim3(256), 0, st, (const T*)Ps, (T*)Ahat, stats, B, N, ld, inv_keep);))
+  return vu_check_launch("vu_mix_apply");
+}
+int vu_k_bn_bwd_stats(int dtype, const void* Ps, const void* dAhat, const float* W, const float* c,
+                      const float* stats, float* partials, int nblocks, int B, int H, int N, int ld,
+                      float inv_keep, hipStream_t st) {
+  VU_HEADS(H, VU_DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_stats_kernel<T, HH>), dim3(nblocks), dim3(256), 0, st, (const T*)Ps, (const T*)dAhat, W, c, stats, partials, B, N, ld, inv_keep);))
+  return vu_check_launch("vu_bn_bwd_stats");
+}
+int vu_k_bn_bwd_finalize(const float* partials, int nblocks, float* stats, float* dgamma, float* dbeta, int H,
+                         double count, int training, hipStream_t st) {
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, partials, nblocks, stats, dgamma, dbeta, H, count, training);
+  return vu_check_launch("vu_bn_bwd_finalize");
+}
+int vu_k_map_bwd(int dtype, const void* Ps, void* dAhat_dS, const float* W, const float* c, const float* gamma,
+                 const float* stats, float* dW, float* dc, int B, int H, int N, int ld, float inv_keep,
+                 float scale, hipStream_t st) {
+  const long long rows = (long long)B * N;
+  long long grid = (rows + 3) / 4;
+  if (grid > 256 * 8) grid = 256 * 8;
+  VU_HEADS(H, VU_DISPATCH_T(dtype, hipLaunchKernelGGL((map_bwd_kernel<T, HH>), dim3((unsigned)grid), dim3(256), 0, st, (const T*)Ps, (T*)dAhat_dS, W, c, gamma, stats, dW, dc, rows, N, ld, inv_keep, scale);))
+  return vu_check_launch("vu_map_bwd");
+}
+
+// =============================================================================================
+// K13 residual + LayerNorm((N,D)) (model.py:193-196,203-206): statistics over all P = N*D
+// elements of a sample; affine weight/bias of shape (N,D).  Two launches forward (chunk stats
+// with Chan merge, apply), two backward.
+// =============================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void add_ln_stats_kernel(const T* __restrict__ a, const T* __restrict__ x,
+                                                           T* __restrict__ z, float* partials, long long P) {
+  __shared__ float sm[16];
+  const int c = blockIdx.x, b = blockIdx.y, nch = gridDim.x;
+  const long long base = (long long)c * VU_LN_CHUNK;
+  const long long sb = (long long)b * P;
+  float v[16];
+  int cnt = 0;
+  float sum = 0.f;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const long long e = base + (it * 256 + threadIdx.x) * 4;
+    if (e < P) {
+      vu_f4 t = vu_ld4(a + sb + e);
+      if (x) { const vu_f4 u = vu_ld4(x + sb + e); t.v[0] += u.v[0]; t.v[1] += u.v[1]; t.v[2] += u.v[2]; t.v[3] += u.v[3]; }
+      vu_st4(z + sb + e, t);
+      // statistics are taken on the values as stored (so forward and backward agree bit for bit)
+      t = vu_ld4(z + sb + e);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { v[it * 4 + q] = t.v[q]; sum += t.v[q]; }
+      cnt += 4;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[it * 4 + q] = 0.f;
+    }
+  }
+  const float tot = vu_block_sum(sum, sm);
+  long long n = P - base; if (n > VU_LN_CHUNK) n = VU_LN_CHUNK;
+  const float mean = tot / (float)n;
+  float m2 = 0.f;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const long long e = base + (it * 256 + threadIdx.x) * 4;
+    if (e < P) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const float d = v[it * 4 + q] - mean; m2 += d * d; }
+    }
+  }
+  const float M2 = vu_block_sum(m2, sm);
+  if (threadIdx.x == 0) {
+    float* o = partials + ((long long)b * nch + c) * 3;
+    o[0] = (float)n; o[1] = mean; o[2] = M2;
+  }
+}
+
+__device__ __forceinline__ void ln_merge_stats(const float* partials, int b, int nch, float eps, float* sm2,
+                                               float& mean, float& rstd) {
+  if (threadIdx.x == 0) {
+    double n = 0.0, mu = 0.0, M2 = 0.0;
+    for (int c = 0; c < nch; ++c) {
+      const float* o = partials + ((long long)b * nch + c) * 3;
+      const double nb = o[0], mb = o[1], Mb = o[2];
+      const double d = mb - mu, nn = n + nb;
+      mu += d * nb / nn;
+      M2 += Mb + d * d * n * nb / nn;
+      n = nn;
+    }
+    sm2[0] = (float)mu;
+    sm2[1] = (float)(1.0 / sqrt(M2 / n + (double)eps));
+  }
+  __syncthreads();
+  mean = sm2[0]; rstd = sm2[1];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ln_apply_kernel(const T* __restrict__ z, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, T* __restrict__ y,
+                                                       const float* partials, float* stats, long long P, float eps) {
+  __shared__ float sm2[2];
+  const int c = blockIdx.x, b = blockIdx.y, nch = gridDim.x;
+  float mean, rstd;
+  ln_merge_stats(partials, b, nch, eps, sm2, mean, rstd);
+  if (c == 0 && threadIdx.x == 0) { stats[2 * b] = mean; stats[2 * b + 1] = rstd; }
+  const long long base = (long long)c * VU_LN_CHUNK, sb = (long long)b * P;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const long long e = base + (it * 256 + threadIdx.x) * 4;
+    if (e < P) {
+      vu_f4 t = vu_ld4(z + sb + e);
+      const float4 ww = *reinterpret_cast<const float4*>(w + e), bb = *reinterpret_cast<const float4*>(bias + e);
+      t.v[0] = (t.v[0] - mean) * rstd * ww.x + bb.x;
+      t.v[1] = (t.v[1] - mean) * rstd * ww.y + bb.y;
+      t.v[2] = (t.v[2] - mean) * rstd * ww.z + bb.z;
+      t.v[3] = (t.v[3] - mean) * rstd * ww.w + bb.w;
+      vu_st4(y + sb + e, t);
+    }
+  }
+}
+
+int vu_k_add_ln_fwd(int dtype, const void* a, const void* x, void* z, const float* w, const float* bias,
+                    void* y, float* partials, float* stats, int B, long long P, float eps, hipStream_t st) {
+  VU_REQUIRE(P % 4 == 0, "layernorm: P %% 4");
+  const int nch = vu_ln_nchunks(P);
+  VU_DISPATCH_T(dtype,
+    hipLaunchKernelGGL((add_ln_stats_kernel<T>), dim3(nch, B), dim3(256), 0, st, (const T*)a, (const T*)x, (T*)z, partials, P);
+    hipLaunchKernelGGL((ln_apply_kernel<T>), dim3(nch, B), dim3(256), 0, st, (const T*)z, w, bias, (T*)y, partials, stats, P, eps);)
+  return vu_check_launch("vu_add_ln_fwd");
+}
+
+// backward A: per chunk of P (1024 elements), loop over samples: parameter gradients for the
+// chunk's elements and per-(sample,chunk) partial sums c1 = sum dy*w, c2 = sum dy*w*xhat.
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_stats_kernel(const T* __restrict__ dy, const T* __restrict__ z,
+                                                           const float* __restrict__ w, const float* __restrict__ stats,
+                                                           float* dw, float* db, float* partials2, int B, long long P) {
+  __shared__ float red[2][4];
+  const int c = blockIdx.x, nch = gridDim.x;
+  const long long e = (long long)c * VU_LN_BCHUNK + threadIdx.x * 4;
+  const bool ok = e < P;
+  float4 ww = make_float4(0, 0, 0, 0);
+  if (ok) ww = *reinterpret_cast<const float4*>(w + e);
+  float gw[4] = {0, 0, 0, 0}, gb[4] = {0, 0, 0, 0};
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int b = 0; b < B; ++b) {
+    const float mean = stats[2 * b], rstd = stats[2 * b + 1];
+    float c1 = 0.f, c2 = 0.f;
+    if (ok) {
+      const vu_f4 d = vu_ld4(dy + (long long)b * P + e), zz = vu_ld4(z + (long long)b * P + e);
+      const float wv[4] = {ww.x, ww.y, ww.z, ww.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float xh = (zz.v[q] - mean) * rstd, g = d.v[q] * wv[q];
+        gw[q] += d.v[q] * xh; gb[q] += d.v[q];
+        c1 += g; c2 += g * xh;
+      }
+    }
+    c1 = vu_wave_sum(c1); c2 = vu_wave_sum(c2);
+    if (lane == 0) { red[0][wave] = c1; red[1][wave] = c2; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+      float* o = partials2 + ((long long)b * nch + c) * 2;
+      o[threadIdx.x] = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+    }
+    __syncthreads();
+  }
+  if (ok) {
+    float4* pw = reinterpret_cast<float4*>(dw + e); float4* pb = reinterpret_cast<float4*>(db + e);
+    float4 a = *pw, bq = *pb;
+    a.x += gw[0]; a.y += gw[1]; a.z += gw[2]; a.w += gw[3];
+    bq.x += gb[0]; bq.y += gb[1]; bq.z += gb[2]; bq.w += gb[3];
+    *pw = a; *pb = bq;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ z,
+                                                           const float* __restrict__ w, const float* __restrict__ stats,
+                                                           const float* partials2, int nbch, T* __restrict__ dz,
+                                                           T* __restrict__ dzd, vu_rng rng_in, long long P) {
+  const vu_rng rng = vu_rng_resolve(rng_in);
+  __shared__ float sm[16];
+  const int c = blockIdx.x, b = blockIdx.y;
+  float a1 = 0.f, a2 = 0.f;
+  for (int i = threadIdx.x; i < nbch; i += blockDim.x) {
+    const float* o = partials2 + ((long long)b * nbch + i) * 2;
+    a1 += o[0]; a2 += o[1];
+  }
+  const float c1 = vu_block_sum(a1, sm) / (float)P;
+  const float c2 = vu_block_sum(a2, sm) / (float)P;
+  const float mean = stats[2 * b], rstd = stats[2 * b + 1];
+  const long long base = (long long)c * VU_LN_CHUNK, sb = (long long)b * P;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const long long e = base + (it * 256 + threadIdx.x) * 4;
+    if (e < P) {
+      const vu_f4 d = vu_ld4(dy + sb + e), zz = vu_ld4(z + sb + e);
+      const float4 ww = *reinterpret_cast<const float4*>(w + e);
+      const float wv[4] = {ww.x, ww.y, ww.z, ww.w};
+      vu_f4 o, od;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float xh = (zz.v[q] - mean) * rstd;
+        o.v[q] = rstd * (d.v[q] * wv[q] - c1 - xh * c2);
+      }
+      vu_st4(dz + sb + e, o);
+      if (dzd) {
+        // dropout backward acts on the gradient as the next consumer sees it (rounded to T)
+        const vu_f4 r = vu_ld4(dz + sb + e);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) od.v[q] = (rng.thr == 0 || vu_keep(rng, (uint64_t)(sb + e + q))) ? r.v[q] * rng.inv_keep : 0.f;
+        vu_st4(dzd + sb + e, od);
+      }
+    }
+  }
+}
+
+int vu_k_ln_bwd(int dtype, const void* dy, const void* z, const float* w, const float* stats, float* dw,
+                float* db, float* partials2, void* dz, void* dz_drop, vu_rng rng, int B, long long P,
+                hipStream_t st) {
+  VU_REQUIRE(P % 4 == 0, "layernorm: P %% 4");
+  const int nbch = vu_ln_nbchunks(P), nch = vu_ln_nchunks(P);
+  VU_DISPATCH_T(dtype,
+    hipLaunchKernelGGL((ln_bwd_stats_kernel<T>), dim3(nbch), dim3(256), 0, st, (const T*)dy, (const T*)z, w, stats, dw, db, partials2, B, P);
+    hipLaunchKernelGGL((ln_bwd_apply_kernel<T>), dim3(nch, B), dim3(256), 0, st, (const T*)dy, (const T*)z, w, stats, partials2, nbch, (T*)dz, (T*)dz_drop, rng, P);)
+  return vu_check_launch("vu_ln_bwd");
+}
+
+// =============================================================================================
+// small helpers: column sums (bias gradients), dropout, loss, optimizer
+// =============================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ in, float* out, long long rows,
+                                                     int ncols, long long ld, long long rows_per_block) {
+  __shared__ float red[4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cx;
+  const long long r0 = blockIdx.y * rows_per_block;
+  long long r1 = r0 + rows_per_block; if (r1 > rows) r1 = rows;
+  float a = 0.f;
+  if (col < ncols)
+    for (long long r = r0 + ry; r < r1; r += 4) a += vu_ld(in + r * ld + col);
+  red[ry][cx] = a;
+  __syncthreads();
+  if (ry == 0 && col < ncols) atomicAdd(out + col, red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx]);
+}
+int vu_k_colsum(int dtype, const void* in, float* out, long long rows, int ncols, long long ld, hipStream_t st) {
+  if (rows == 0 || ncols == 0) return VU_OK;
+  const int gx = vu_cdiv(ncols, 64);
+  int gy = 512 / gx; if (gy < 1) gy = 1;
+  long long rpb = vu_cdiv64(rows, gy); if (rpb < 16) rpb = 16;
+  gy = (int)vu_cdiv64(rows, rpb);
+  VU_DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_kernel<T>), dim3(gx, gy), dim3(256), 0, st, (const T*)in, out, rows, ncols, ld, rpb);)
+  return vu_check_launch("vu_colsum");
+}
+
+template <typename T>
+__global__ void dropout_kernel(const T* __restrict__ in, T* __restrict__ out, long long n4, vu_rng rng_in) {
+  const vu_rng rng = vu_rng_resolve(rng_in);
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n4; t += (long long)gridDim.x * blockDim.x) {
+    vu_f4 v = vu_ld4(in + t * 4);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v.v[q] = (rng.thr == 0 || vu_keep(rng, (uint64_t)(t * 4 + q))) ? v.v[q] * rng.inv_keep : 0.f;
+    vu_st4(out + t * 4, v);
+  }
+}
+int vu_k_dropout(int dtype, const void* in, void* out, long long n, vu_rng rng, hipStream_t st) {
+  VU_REQUIRE(n % 4 == 0, "dropout: n %% 4");
+  if (n == 0) return VU_OK;
+  VU_DISPATCH_T(dtype, hipLaunchKernelGGL((dropout_kernel<T>), dim3(grid_for(n / 4)), dim3(256), 0, st, (const T*)in, (T*)out, n / 4, rng);)
+  return vu_check_launch("vu_dropout");
+}
+
+template <typename T>
+__global__ void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, long long n4) {
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n4; t += (long long)gridDim.x * blockDim.x) {
+    vu_f4 x = vu_ld4(a + t * 4);
+    const vu_f4 y = vu_ld4(b + t * 4);
+    x.v[0] += y.v[0]; x.v[1] += y.v[1]; x.v[2] += y.v[2]; x.v[3] += y.v[3];
+    vu_st4(out + t * 4, x);
+  }
+}
+int vu_k_add(int dtype, const void* a, const void* b, void* out, long long n, hipStream_t st) {
+  VU_REQUIRE(n % 4 == 0, "add: n %% 4");
+  if (n == 0) return VU_OK;
+  VU_DISPATCH_T(dtype, hipLaunchKernelGGL((add_kernel<T>), dim3(grid_for(n / 4)), dim3(256), 0, st, (const T*)a, (const T*)b, (T*)out, n / 4);)
+  return vu_check_launch("vu_add");
+}
+
+// MSELoss (run_denoising.py:80): loss = mean((out-target)^2) ; dout = 2 (out-target) / n * gscale
+__global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ o, const float* __restrict__ t,
+                                                  float* __restrict__ d, float* partials, long long n, float k) {
+  __shared__ float sm[16];
+  float acc = 0.f;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float e = o[i] - t[i];
+    acc += e * e;
+    if (d) d[i] = e * k;
+  }
+  const float tot = vu_block_sum(acc, sm);
+  if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+}
+__global__ void mse_finalize_kernel(const float* partials, int nb, float* loss, double inv_n) {
+  __shared__ double sd[256];
+  double a = 0.0;
+  for (int i = threadIdx.x; i < nb; i += blockDim.x) a += (double)partials[i];
+  sd[threadIdx.x] = a;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) sd[threadIdx.x] += sd[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) *loss = (float)(sd[0] * inv_n);
+}
+int vu_k_mse(const float* out, const float* target, float* dout, float* loss, float* partials, long long n,
+             float gscale, hipStream_t st) {
+  VU_REQUIRE(n > 0, "mse: empty");
+  const int nb = grid_for(n, 256, 1024);
+  hipLaunchKernelGGL(mse_kernel, dim3(nb), dim3(256), 0, st, out, target, dout, partials, n, 2.0f * gscale / (float)n);
+  hipLaunchKernelGGL(mse_finalize_kernel, dim3(1), dim3(256), 0, st, partials, nb, loss, 1.0 / (double)n);
+  return vu_check_launch("vu_mse");
+}
+
+// AdamW (torch.optim.AdamW semantics, run_denoising.py:81) over the flat parameter arena.
+// hyper = {lr, beta1, beta2, eps, weight_decay} in device memory, step counter in device memory
+// (incremented by the kernel's block 0 AFTER use via a separate tiny launch) so a captured
+// hipGraph replays with the right bias correction and a host-updated learning rate.
+__global__ void adamw_step_kernel(int* step) { *step += 1; }
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v,
+                                                    bf16_t* __restrict__ shadow, long long n4,
+                                                    const float* __restrict__ hyper, const int* __restrict__ step,
+                                                    float gscale) {
+  const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4];
+  const float t = (float)(*step);
+  const float bc1 = 1.f - powf(b1, t), bc2 = 1.f - powf(b2, t);
+  const float step_size = lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    float4 pp = reinterpret_cast<float4*>(p)[i];
+    const float4 gg = reinterpret_cast<const float4*>(g)[i];
+    float4 mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+    float pa[4] = {pp.x, pp.y, pp.z, pp.w}, ga[4] = {gg.x, gg.y, gg.z, gg.w};
+    float ma[4] = {mm.x, mm.y, mm.z, mm.w}, va[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float gr = ga[q] * gscale;
+      pa[q] *= (1.f - lr * wd);
+      ma[q] = b1 * ma[q] + (1.f - b1) * gr;
+      va[q] = b2 * va[q] + (1.f - b2) * gr * gr;
+      pa[q] -= step_size * ma[q] / (sqrtf(va[q]) * inv_sqrt_bc2 + eps);
+    }
+    reinterpret_cast<float4*>(p)[i] = make_float4(pa[0], pa[1], pa[2], pa[3]);
+    reinterpret_cast<float4*>(m)[i] = make_float4(ma[0], ma[1], ma[2], ma[3]);
+    reinterpret_cast<float4*>(v)[i] = make_float4(va[0], va[1], va[2], va[3]);
+    if (shadow) {
+      bf16x4 s = {(bf16_t)pa[0], (bf16_t)pa[1], (bf16_t)pa[2], (bf16_t)pa[3]};
+      reinterpret_cast<bf16x4*>(shadow)[i] = s;
+    }
+  }
+}
+int vu_k_adamw(float* p, const float* g, float* m, float* v, void* shadow_bf16, long long n, const float* hyper,
+               int* step, float gscale, hipStream_t st) {
+  VU_REQUIRE(n % 4 == 0, "adamw: arena length must be a multiple of 4 (pad the arena)");
+  hipLaunchKernelGGL(adamw_step_kernel, dim3(1), dim3(1), 0, st, step);
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4, 256, 256 * 8)), dim3(256), 0, st, p, g, m, v, (bf16_t*)shadow_bf16, n / 4, hyper, step, gscale);
+  return vu_check_launch("vu_adamw");
+}
+
+__global__ void cast_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, long long n4) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const float4 a = reinterpret_cast<const float4*>(in)[i];
+    bf16x4 s = {(bf16_t)a.x, (bf16_t)a.y, (bf16_t)a.z, (bf16_t)a.w};
+    reinterpret_cast<bf16x4*>(out)[i] = s;
+  }
+}
+int vu_k_cast_bf16(const float* in, void* out, long long n, hipStream_t st) {
+  VU_REQUIRE(n % 4 == 0, "cast: n %% 4");
+  if (n == 0) return VU_OK;
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for(n / 4, 256, 256 * 8)), dim3(256), 0, st, in, (bf16_t*)out, n / 4);
+  return vu_check_launch("vu_cast_bf16");
+}
+__global__ void fill_kernel(float* p, float v, long long n) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = v;
+}
+int vu_k_fill(float* p, float v, long long n, hipStream_t st) {
+  if (n == 0) return VU_OK;
+  hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n, 256, 256 * 8)), dim3(256), 0, st, p, v, n);
+  return vu_check_launch("vu_fill");
+}

@@ -1,0 +1,799 @@
+// Host-side executor: parameter table, workspace layout, and the forward / backward launch
+// sequences of ReAttention (model.py:150-164), SkipConnection (:244-259),
+// ReAttentionTransformerEncoder (:201-207) and HViT_UNet.forward (:372-435), plus the
+// extern "C" boundary declared in include/vit_unet_amd.h.  No device allocation happens here:
+// every buffer is carved from the caller's workspace by a deterministic bump layout that the
+// forward and the backward both recompute from (config, B).
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include <vector>
+#include <string>
+
+#include "../../include/vit_unet_amd.h"
+#include "vu_kernels.h"
+
+const char* vu_get_error();
+
+#define VU_TRY(expr)            \
+  do {                          \
+    int _rc = (expr);           \
+    if (_rc != VU_OK) return _rc; \
+  } while (0)
+
+namespace {
+
+inline size_t esize(int dtype) { return dtype == 0 ? 4 : 2; }
+inline int round_up(int x, int a) { return (x + a - 1) / a * a; }
+
+struct Bump {
+  char* base; size_t off;
+  void* take(size_t bytes) {
+    off = vu_align_up(off, 256);
+    void* p = base ? base + off : nullptr;
+    off += bytes;
+    return p;
+  }
+  float* takef(size_t n) { return (float*)take(n * sizeof(float)); }
+};
+
+// ---------------------------------------------------------------------------------------------
+// parameter plan
+// ---------------------------------------------------------------------------------------------
+struct AttnP { long long mixw, mixb, bng, bnb, wq, wk, wv, projw, projb; int bn; };
+struct BlockP { AttnP at; long long ln1w, ln1b, ln2w, ln2b, w1, b1, w2, b2; int level; };
+struct Level { int N, D, hid, s, ld; };
+struct Plan {
+  vu_config cfg;
+  std::vector<Level> lv;
+  long long pos = -1, outw = -1, outb = -1, total = 0;
+  std::vector<BlockP> enc, bot, dec;
+  std::vector<AttnP> skip;           // skip[j] merges at level depth-j-1
+  std::vector<vu_param_entry> table;
+  int nattn = 0;
+};
+
+int validate(const vu_config& c) {
+  VU_REQUIRE(c.depth >= 0 && c.depth <= 6 && c.depth_te >= 1 && c.size_bottleneck >= 0, "config: bad depth / depth_te / size_bottleneck");
+  VU_REQUIRE(c.patch_size > 0 && c.patch_size % (1 << c.depth) == 0, "Depth must be adjusted, final patch size is incompatible.");
+  VU_REQUIRE(c.patch_size / (1 << c.depth) >= 4, "Depth must be adjusted, final patch size is too small (lower than 4).");
+  VU_REQUIRE(c.im_size > 0 && c.im_size % c.patch_size == 0, "Patch size is not compatible with image size.");
+  VU_REQUIRE((c.patch_size / (1 << c.depth)) % 4 == 0, "final patch size must be a multiple of 4 for the HIP path");
+  VU_REQUIRE(c.num_channels >= 1 && c.num_channels <= 4, "num_channels must be 1..4");
+  VU_REQUIRE(c.num_heads == 1 || c.num_heads == 2 || c.num_heads == 4 || c.num_heads == 8, "num_heads must be 1, 2, 4 or 8");
+  const int dl = c.num_channels * (c.patch_size >> c.depth) * (c.patch_size >> c.depth);
+  VU_REQUIRE(dl % c.num_heads == 0, "num_heads must divide the projection size at every level");
+  VU_REQUIRE((c.hidden_dim >> c.depth) >= 1, "hidden_dim too small for depth");
+  VU_REQUIRE(c.linear_drop == 0.f, "linear_drop > 0 is not implemented (0 in every reference preset)");
+  VU_REQUIRE(c.attn_drop >= 0.f && c.attn_drop < 1.f && c.proj_drop >= 0.f && c.proj_drop < 1.f, "dropout must be in [0,1)");
+  VU_REQUIRE(c.dtype == 0 || c.dtype == 1, "dtype must be 0 (fp32) or 1 (bf16)");
+  return VU_OK;
+}
+
+int build_plan(const vu_config& c, Plan& pl) {
+  VU_TRY(validate(c));
+  pl.cfg = c;
+  const int n0 = (c.im_size / c.patch_size) * (c.im_size / c.patch_size);
+  const int d0 = c.num_channels * c.patch_size * c.patch_size;
+  for (int l = 0; l <= c.depth; ++l) {
+    Level L;
+    L.N = n0 << (2 * l); L.D = d0 >> (2 * l); L.hid = c.hidden_dim >> l; L.s = c.patch_size >> l;
+    L.ld = round_up(L.N, 8);
+    pl.lv.push_back(L);
+  }
+  long long off = 0;
+  const int H = c.num_heads, C = c.num_channels;
+  auto add = [&](const std::string& name, int ndim, int s0, int s1, int s2, int s3, int bn = -1) {
+    vu_param_entry e;
+    memset(&e, 0, sizeof(e));
+    snprintf(e.name, sizeof(e.name), "%s", name.c_str());
+    e.offset = off; e.ndim = ndim; e.shape[0] = s0; e.shape[1] = s1; e.shape[2] = s2; e.shape[3] = s3;
+    e.bn_index = bn;
+    long long n = 1;
+    for (int i = 0; i < ndim; ++i) n *= e.shape[i];
+    pl.table.push_back(e);
+    const long long o = off;
+    off += (n + 7) / 8 * 8;
+    return o;
+  };
+  auto add_attn = [&](const std::string& pre, int D) {
+    AttnP a;
+    a.bn = pl.nattn++;
+    a.mixw = add(pre + "reatten_matrix.weight", 4, H, H, 1, 1);
+    a.mixb = add(pre + "reatten_matrix.bias", 1, H, 0, 0, 0);
+    a.bng = add(pre + "var_norm.weight", 1, H, 0, 0, 0, a.bn);
+    a.bnb = add(pre + "var_norm.bias", 1, H, 0, 0, 0);
+    a.wq = add(pre + "qconv2d.weight", 4, C, C, 3, 3);
+    a.wk = add(pre + "kconv2d.weight", 4, C, C, 3, 3);
+    a.wv = add(pre + "vconv2d.weight", 4, C, C, 3, 3);
+    a.projw = add(pre + "proj.weight", 2, D, D, 0, 0);
+    a.projb = add(pre + "proj.bias", 1, D, 0, 0, 0);
+    return a;
+  };
+  auto add_block = [&](const std::string& pre, int level) {
+    const Level& L = pl.lv[level];
+    BlockP b;
+    b.level = level;
+    b.at = add_attn(pre + "ReAttn.", L.D);
+    b.ln1w = add(pre + "LN1.weight", 2, L.N, L.D, 0, 0);
+    b.ln1b = add(pre + "LN1.bias", 2, L.N, L.D, 0, 0);
+    b.ln2w = add(pre + "LN2.weight", 2, L.N, L.D, 0, 0);
+    b.ln2b = add(pre + "LN2.bias", 2, L.N, L.D, 0, 0);
+    b.w1 = add(pre + "FeedForward.net.0.weight", 2, L.hid, L.D, 0, 0);
+    b.b1 = add(pre + "FeedForward.net.0.bias", 1, L.hid, 0, 0, 0);
+    b.w2 = add(pre + "FeedForward.net.3.weight", 2, L.D, L.hid, 0, 0);
+    b.b2 = add(pre + "FeedForward.net.3.bias", 1, L.D, 0, 0, 0);
+    return b;
+  };
+  pl.pos = add("PE.position_embedding.weight", 2, pl.lv[0].N, pl.lv[0].D, 0, 0);
+  int idx = 0;
+  for (int l = 0; l < c.depth; ++l)
+    for (int t = 0; t < c.depth_te; ++t) pl.enc.push_back(add_block("Encoders." + std::to_string(idx++) + ".", l));
+  for (int t = 0; t < c.size_bottleneck; ++t) pl.bot.push_back(add_block("BottleNeck." + std::to_string(t) + ".", c.depth));
+  idx = 0;
+  for (int l = 0; l < c.depth; ++l)
+    for (int t = 0; t < c.depth_te; ++t) pl.dec.push_back(add_block("Decoders." + std::to_string(idx++) + ".", c.depth - l));
+  for (int l = 0; l < c.depth; ++l) pl.skip.push_back(add_attn("SkipConnections." + std::to_string(l) + ".", pl.lv[c.depth - l - 1].D));
+  if (c.out_conv) {
+    pl.outw = add("conv2d.weight", 4, C, C, 3, 3);
+    pl.outb = add("conv2d.bias", 1, C, 0, 0, 0);
+  }
+  pl.total = off;
+  return VU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ReAttention / SkipConnection
+// ---------------------------------------------------------------------------------------------
+struct AttnBuf { void *q, *k, *v, *Ps, *Ah, *O; float* stats; };
+struct AttnScratch { void *dO, *dq, *dk, *dv, *dA; float* partials; int nblocks; };
+
+struct AttnDims { int dtype, B, N, D, H, C, s, ld; };
+
+inline int stats_blocks(const AttnDims& d) {
+  long long t = (long long)d.B * d.N * (d.ld / 4);
+  long long g = (t + 255) / 256;
+  return (int)(g > 1024 ? 1024 : (g < 1 ? 1 : g));
+}
+void carve_attn(Bump& bp, const AttnDims& d, AttnBuf& a) {
+  const size_t act = (size_t)d.B * d.N * d.D * esize(d.dtype);
+  const size_t map = (size_t)d.B * d.H * d.N * d.ld * esize(d.dtype);
+  a.q = bp.take(act); a.k = bp.take(act); a.v = bp.take(act); a.O = bp.take(act);
+  a.Ps = bp.take(map); a.Ah = bp.take(map);
+  a.stats = bp.takef(VU_BN_STATS_FLOATS(d.H));
+}
+
+int attn_forward(const AttnDims& d, const vu_attn_params& p, const void* xq, const void* xkv, void* y,
+                 AttnBuf& a, float* partials, float attn_drop, float proj_drop, int training, uint64_t seed,
+                 uint64_t stream_id, const uint32_t* salt, hipStream_t st) {
+  const int dt = d.dtype, B = d.B, N = d.N, D = d.D, H = d.H, ld = d.ld;
+  const int dh = D / H;
+  const long long npatch = (long long)B * N;
+  VU_TRY(vu_k_conv3x3_fwd(dt, 0, xq, p.wq, nullptr, a.q, npatch, d.C, d.s, st));
+  VU_TRY(vu_k_conv3x3_fwd(dt, 0, xkv, p.wk, nullptr, a.k, npatch, d.C, d.s, st));
+  VU_TRY(vu_k_conv3x3_fwd(dt, 0, xkv, p.wv, nullptr, a.v, npatch, d.C, d.s, st));
+  {  // S = scale * q k^T  (model.py:155)
+    vu_gemm_args g;
+    memset(&g, 0, sizeof(g));
+    g.A = a.q; g.B = a.k; g.C = a.Ps; g.M = N; g.N = N; g.K = dh;
+    g.sAm = D; g.sAk = 1; g.sBk = 1; g.sBn = D; g.ldc = ld;
+    g.Z1 = B; g.Z2 = H; g.sA1 = (long long)N * D; g.sA2 = dh; g.sB1 = (long long)N * D; g.sB2 = dh;
+    g.sC1 = (long long)H * N * ld; g.sC2 = (long long)N * ld;
+    g.alpha = 1.0f / sqrtf((float)dh);
+    VU_TRY(vu_gemm_launch(dt, 0, g, st));
+  }
+  vu_rng ra = vu_make_rng(seed, 2 * stream_id, training ? attn_drop : 0.f);
+  ra.salt = salt;
+  VU_TRY(vu_k_softmax_dropout(dt, a.Ps, (long long)B * H * N, N, ld, ra, st));
+  const double count = (double)B * N * N;
+  if (training) VU_TRY(vu_k_mix_stats(dt, a.Ps, p.mix_w, p.mix_b, partials, stats_blocks(d), B, H, N, ld, ra.inv_keep, st));
+  VU_TRY(vu_k_bn_finalize(partials, stats_blocks(d), p.mix_w, p.mix_b, p.bn_w, p.bn_b, p.run_mean, p.run_var,
+                          a.stats, H, N, count, training, 0.1f, 1e-5f, st));
+  VU_TRY(vu_k_mix_apply(dt, a.Ps, a.Ah, a.stats, B, H, N, ld, ra.inv_keep, st));
+  {  // O = Ahat v  (model.py:161)
+    vu_gemm_args g;
+    memset(&g, 0, sizeof(g));
+    g.A = a.Ah; g.B = a.v; g.C = a.O; g.M = N; g.N = dh; g.K = N;
+    g.sAm = ld; g.sAk = 1; g.sBk = D; g.sBn = 1; g.ldc = D;
+    g.Z1 = B; g.Z2 = H; g.sA1 = (long long)H * N * ld; g.sA2 = (long long)N * ld;
+    g.sB1 = (long long)N * D; g.sB2 = dh; g.sC1 = (long long)N * D; g.sC2 = dh;
+    g.alpha = 1.f;
+    VU_TRY(vu_gemm_launch(dt, 0, g, st));
+  }
+  {  // y = dropout(O Wp^T + bp)  (model.py:162-163)
+    vu_gemm_args g;
+    memset(&g, 0, sizeof(g));
+    g.A = a.O; g.B = p.proj_w; g.C = y; g.M = B * N; g.N = D; g.K = D;
+    g.sAm = D; g.sAk = 1; g.sBk = 1; g.sBn = D; g.ldc = D; g.Z1 = 1; g.Z2 = 1;
+    g.alpha = 1.f; g.bias = p.proj_b;
+    g.rng = vu_make_rng(seed, 2 * stream_id + 1, training ? proj_drop : 0.f);
+    g.rng.salt = salt;
+    g.dropout = g.rng.thr != 0;
+    VU_TRY(vu_gemm_launch(dt, 0, g, st));
+  }
+  return VU_OK;
+}
+
+// dz: gradient wrt the module output AFTER the projection dropout mask has been applied
+// (i.e. gradient wrt O Wp^T + bp).  add_q / add_kv: tensors added to dxq / dxkv (residuals).
+// If dxkv == nullptr the module is self-attention (xq == xkv) and everything lands in dxq.
+int attn_backward(const AttnDims& d, const vu_attn_params& p, const vu_attn_grads& gr, const void* xq,
+                  const void* xkv, const void* dz, const void* add_q, const void* add_kv, void* dxq, void* dxkv,
+                  AttnBuf& a, AttnScratch& sc, float attn_drop, int training, hipStream_t st) {
+  const int dt = d.dtype, B = d.B, N = d.N, D = d.D, H = d.H, ld = d.ld;
+  const int dh = D / H;
+  const long long npatch = (long long)B * N, rows = (long long)B * N;
+  const float inv_keep = (training && attn_drop > 0.f) ? 1.f / (1.f - attn_drop) : 1.f;
+  VU_TRY(vu_k_colsum(dt, dz, gr.proj_b, rows, D, D, st));
+  {  // dWp += dz^T O
+    vu_gemm_args g;
+    memset(&g, 0, sizeof(g));
+    g.A = dz; g.B = a.O; g.C = gr.proj_w; g.M = D; g.N = D; g.K = (int)rows;
+    g.sAm = 1; g.sAk = D; g.sBk = D; g.sBn = 1; g.ldc = D; g.Z1 = 1; g.Z2 = 1; g.alpha = 1.f; g.accumulate = 1;
+    VU_TRY(vu_gemm_launch(dt, 1, g, st));
+  }
+  {  // dO = dz Wp
+    vu_gemm_args g;
+    memset(&g, 0, sizeof(g));
+    g.A = dz; g.B = p.proj_w; g.C = sc.dO; g.M = (int)rows; g.N = D; g.K = D;
+    g.sAm = D; g.sAk = 1; g.sBk = D; g.sBn = 1; g.ldc = D; g.Z1 = 1; g.Z2 = 1; g.alpha = 1.f;
+    VU_TRY(vu_gemm_launch(dt, 0, g, st));
+  }
+  {  // dAhat = dO v^T
+    vu_gemm_args g;
+    memset(&g, 0, sizeof(g));
+    g.A = sc.dO; g.B = a.v; g.C = sc.dA; g.M = N; g.N = N; g.K = dh;
+    g.sAm = D; g.sAk = 1; g.sBk = 1; g.sBn = D; g.ldc = ld;
+    g.Z1 = B; g.Z2 = H; g.sA1 = (long long)N * D; g.sA2 = dh; g.sB1 = (long long)N * D; g.sB2 = dh;
+    g.sC1 = (long long)H * N * ld; g.sC2 = (long long)N * ld; g.alpha = 1.f;
+    VU_TRY(vu_gemm_launch(dt, 0, g, st));
+  }
+  {  // dv = Ahat^T dO
+    vu_gemm_args g;
+    memset(&g, 0, sizeof(g));
+    g.A = a.Ah; g.B = sc.dO; g.C = sc.dv; g.M = N; g.N = dh; g.K = N;
+    g.sAm = 1; g.sAk = ld; g.sBk = D; g.sBn = 1; g.ldc = D;
+    g.Z1 = B; g.Z2 = H; g.sA1 = (long long)H * N * ld; g.sA2 = (long long)N * ld;
+    g.sB1 = (long long)N * D; g.sB2 = dh; g.sC1 = (long long)N * D; g.sC2 = dh; g.alpha = 1.f;
+    VU_TRY(vu_gemm_launch(dt, 0, g, st));
+  }
+  const double count = (double)B * N * N;
+  VU_TRY(vu_k_bn_bwd_stats(dt, a.Ps, sc.dA, p.mix_w, p.mix_b, a.stats, sc.partials, sc.nblocks, B, H, N, ld, inv_keep, st));
+  VU_TRY(vu_k_bn_bwd_finalize(sc.partials, sc.nblocks, a.stats, gr.bn_w, gr.bn_b, H, count, training, st));
+  VU_TRY(vu_k_map_bwd(dt, a.Ps, sc.dA, p.mix_w, p.mix_b, p.bn_w, a.stats, gr.mix_w, gr.mix_b, B, H, N, ld, inv_keep,
+                      1.0f / sqrtf((float)dh), st));
+  {  // dq = dS k
+    vu_gemm_args g;
+    memset(&g, 0, sizeof(g));
+    g.A = sc.dA; g.B = a.k; g.C = sc.dq; g.M = N; g.N = dh; g.K = N;
+    g.sAm = ld; g.sAk = 1; g.sBk = D; g.sBn = 1; g.ldc = D;
+    g.Z1 = B; g.Z2 = H; g.sA1 = (long long)H * N * ld; g.sA2 = (long long)N * ld;
+    g.sB1 = (long long)N * D; g.sB2 = dh; g.sC1 = (long long)N * D; g.sC2 = dh; g.alpha = 1.f;
+    VU_TRY(vu_gemm_launch(dt, 0, g, st));
+  }
+  {  // dk = dS^T q
+    vu_gemm_args g;
+    memset(&g, 0, sizeof(g));
+    g.A = sc.dA; g.B = a.q; g.C = sc.dk; g.M = N; g.N = dh; g.K = N;
+    g.sAm = 1; g.sAk = ld; g.sBk = D; g.sBn = 1; g.ldc = D;
+    g.Z1 = B; g.Z2 = H; g.sA1 = (long long)H * N * ld; g.sA2 = (long long)N * ld;
+    g.sB1 = (long long)N * D; g.sB2 = dh; g.sC1 = (long long)N * D; g.sC2 = dh; g.alpha = 1.f;
+    VU_TRY(vu_gemm_launch(dt, 0, g, st));
+  }
+  VU_TRY(vu_k_conv3x3_wgrad(dt, 0, sc.dq, xq, gr.wq, nullptr, npatch, d.C, d.s, st));
+  VU_TRY(vu_k_conv3x3_wgrad(dt, 0, sc.dk, xkv, gr.wk, nullptr, npatch, d.C, d.s, st));
+  VU_TRY(vu_k_conv3x3_wgrad(dt, 0, sc.dv, xkv, gr.wv, nullptr, npatch, d.C, d.s, st));
+  if (dxkv == nullptr) {
+    VU_TRY(vu_k_conv3x3_dgrad(dt, 0, sc.dq, p.wq, add_q, dxq, npatch, d.C, d.s, st));
+    VU_TRY(vu_k_conv3x3_dgrad(dt, 0, sc.dk, p.wk, dxq, dxq, npatch, d.C, d.s, st));
+    VU_TRY(vu_k_conv3x3_dgrad(dt, 0, sc.dv, p.wv, dxq, dxq, npatch, d.C, d.s, st));
+  } else {
+    VU_TRY(vu_k_conv3x3_dgrad(dt, 0, sc.dq, p.wq, add_q, dxq, npatch, d.C, d.s, st));
+    VU_TRY(vu_k_conv3x3_dgrad(dt, 0, sc.dk, p.wk, add_kv, dxkv, npatch, d.C, d.s, st));
+    VU_TRY(vu_k_conv3x3_dgrad(dt, 0, sc.dv, p.wv, dxkv, dxkv, npatch, d.C, d.s, st));
+  }
+  return VU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// model workspace
+// ---------------------------------------------------------------------------------------------
+struct BlockBuf { AttnBuf at; void *z1, *x1, *hpre, *hact, *z2, *out; float *ln1s, *ln2s; };
+struct ModelWS {
+  void* tok0;
+  std::vector<BlockBuf> enc, bot, dec;
+  std::vector<AttnBuf> skip;
+  std::vector<void*> skip_out, down_out, up_out;
+  void* img;
+  // forward scratch
+  void *y_attn, *f_ff;
+  // backward scratch
+  void *gx0, *gx1, *ga, *gb, *gc, *gh;
+  AttnScratch asc;
+  std::vector<void*> dskip;
+  float *partials, *lnp, *lnp2;
+  size_t bytes;
+};
+
+void carve_block(Bump& bp, const Plan& pl, int B, int level, BlockBuf& b) {
+  const Level& L = pl.lv[level];
+  const int dt = pl.cfg.dtype;
+  AttnDims d{dt, B, L.N, L.D, pl.cfg.num_heads, pl.cfg.num_channels, L.s, L.ld};
+  carve_attn(bp, d, b.at);
+  const size_t act = (size_t)B * L.N * L.D * esize(dt), hh = (size_t)B * L.N * L.hid * esize(dt);
+  b.z1 = bp.take(act); b.x1 = bp.take(act); b.hpre = bp.take(hh); b.hact = bp.take(hh);
+  b.z2 = bp.take(act); b.out = bp.take(act);
+  b.ln1s = bp.takef(2 * B); b.ln2s = bp.takef(2 * B);
+}
+
+void carve_model(const Plan& pl, int B, char* base, ModelWS& w) {
+  Bump bp{base, 0};
+  const vu_config& c = pl.cfg;
+  const int dt = c.dtype, H = c.num_heads;
+  const long long P = (long long)c.num_channels * c.im_size * c.im_size;
+  const size_t act = (size_t)B * P * esize(dt);
+  w.tok0 = bp.take(act);
+  w.enc.resize(pl.enc.size()); w.bot.resize(pl.bot.size()); w.dec.resize(pl.dec.size()); w.skip.resize(pl.skip.size());
+  for (size_t i = 0; i < pl.enc.size(); ++i) carve_block(bp, pl, B, pl.enc[i].level, w.enc[i]);
+  for (size_t i = 0; i < pl.bot.size(); ++i) carve_block(bp, pl, B, pl.bot[i].level, w.bot[i]);
+  for (size_t i = 0; i < pl.dec.size(); ++i) carve_block(bp, pl, B, pl.dec[i].level, w.dec[i]);
+  for (int j = 0; j < c.depth; ++j) {
+    const Level& L = pl.lv[c.depth - j - 1];
+    AttnDims d{dt, B, L.N, L.D, H, c.num_channels, L.s, L.ld};
+    carve_attn(bp, d, w.skip[j]);
+  }
+  w.skip_out.resize(c.depth); w.down_out.resize(c.depth); w.up_out.resize(c.depth); w.dskip.resize(c.depth);
+  for (int j = 0; j < c.depth; ++j) { w.skip_out[j] = bp.take(act); w.down_out[j] = bp.take(act); w.up_out[j] = bp.take(act); }
+  w.img = bp.take(act);
+  w.y_attn = bp.take(act); w.f_ff = bp.take(act);
+  w.gx0 = bp.take(act); w.gx1 = bp.take(act); w.ga = bp.take(act); w.gb = bp.take(act); w.gc = bp.take(act);
+  size_t hh = 0, map = 0;
+  int nb = 1;
+  for (const Level& L : pl.lv) {
+    hh = std::max(hh, (size_t)B * L.N * L.hid * esize(dt));
+    map = std::max(map, (size_t)B * H * L.N * L.ld * esize(dt));
+    AttnDims d{dt, B, L.N, L.D, H, c.num_channels, L.s, L.ld};
+    nb = std::max(nb, stats_blocks(d));
+  }
+  w.gh = bp.take(hh);
+  w.asc.dO = bp.take(act); w.asc.dq = bp.take(act); w.asc.dk = bp.take(act); w.asc.dv = bp.take(act);
+  w.asc.dA = bp.take(map);
+  w.asc.nblocks = nb;
+  for (int j = 0; j < c.depth; ++j) w.dskip[j] = bp.take(act);
+  w.partials = bp.takef((size_t)nb * 2 * H + 1024);
+  w.asc.partials = w.partials;
+  w.lnp = bp.takef((size_t)B * vu_ln_nchunks(P) * 3);
+  w.lnp2 = bp.takef((size_t)B * vu_ln_nbchunks(P) * 2);
+  w.bytes = vu_align_up(bp.off, 256);
+}
+
+vu_attn_params attn_params(const AttnP& a, const vu_config& c, const float* prm, const void* shadow, float* bn) {
+  vu_attn_params p;
+  p.mix_w = prm + a.mixw; p.mix_b = prm + a.mixb; p.bn_w = prm + a.bng; p.bn_b = prm + a.bnb;
+  p.wq = prm + a.wq; p.wk = prm + a.wk; p.wv = prm + a.wv;
+  p.proj_w = c.dtype == 0 ? (const void*)(prm + a.projw) : (const void*)((const bf16_t*)shadow + a.projw);
+  p.proj_b = prm + a.projb;
+  p.run_mean = bn ? bn + (long long)a.bn * 2 * c.num_heads : nullptr;
+  p.run_var = bn ? bn + (long long)a.bn * 2 * c.num_heads + c.num_heads : nullptr;
+  return p;
+}
+vu_attn_grads attn_grads(const AttnP& a, float* g) {
+  vu_attn_grads r;
+  r.mix_w = g + a.mixw; r.mix_b = g + a.mixb; r.bn_w = g + a.bng; r.bn_b = g + a.bnb;
+  r.wq = g + a.wq; r.wk = g + a.wk; r.wv = g + a.wv; r.proj_w = g + a.projw; r.proj_b = g + a.projb;
+  return r;
+}
+inline const void* wptr(const vu_config& c, const float* prm, const void* shadow, long long off) {
+  return c.dtype == 0 ? (const void*)(prm + off) : (const void*)((const bf16_t*)shadow + off);
+}
+
+struct Ctx {
+  const Plan* pl; int B; const float* prm; const void* shadow; float* bn; float* grads;
+  int training; uint64_t seed; const uint32_t* salt; hipStream_t st; ModelWS* w;
+};
+
+int block_forward(Ctx& cx, const BlockP& bp, BlockBuf& bb, const void* x, uint64_t stream_id) {
+  const vu_config& c = cx.pl->cfg;
+  const Level& L = cx.pl->lv[bp.level];
+  const int dt = c.dtype, B = cx.B;
+  const long long P = (long long)L.N * L.D;
+  AttnDims d{dt, B, L.N, L.D, c.num_heads, c.num_channels, L.s, L.ld};
+  vu_attn_params ap = attn_params(bp.at, c, cx.prm, cx.shadow, cx.bn);
+  VU_TRY(attn_forward(d, ap, x, x, cx.w->y_attn, bb.at, cx.w->partials, c.attn_drop, c.proj_drop, cx.training,
+                      cx.seed, stream_id, cx.salt, cx.st));
+  VU_TRY(vu_k_add_ln_fwd(dt, cx.w->y_attn, x, bb.z1, cx.prm + bp.ln1w, cx.prm + bp.ln1b, bb.x1, cx.w->lnp, bb.ln1s,
+                         B, P, 1e-5f, cx.st));
+  {  // hact = gelu(x1 W1^T + b1)  (model.py:102-104)
+    vu_gemm_args g;
+    memset(&g, 0, sizeof(g));
+    g.A = bb.x1; g.B = wptr(c, cx.prm, cx.shadow, bp.w1); g.C = bb.hact; g.aux = bb.hpre;
+    g.M = B * L.N; g.N = L.hid; g.K = L.D; g.sAm = L.D; g.sAk = 1; g.sBk = 1; g.sBn = L.D; g.ldc = L.hid;
+    g.Z1 = 1; g.Z2 = 1; g.alpha = 1.f; g.bias = cx.prm + bp.b1; g.act = VU_ACT_GELU;
+    VU_TRY(vu_gemm_launch(dt, 0, g, cx.st));
+  }
+  {  // f = hact W2^T + b2  (model.py:106)
+    vu_gemm_args g;
+    memset(&g, 0, sizeof(g));
+    g.A = bb.hact; g.B = wptr(c, cx.prm, cx.shadow, bp.w2); g.C = cx.w->f_ff;
+    g.M = B * L.N; g.N = L.D; g.K = L.hid; g.sAm = L.hid; g.sAk = 1; g.sBk = 1; g.sBn = L.hid; g.ldc = L.D;
+    g.Z1 = 1; g.Z2 = 1; g.alpha = 1.f; g.bias = cx.prm + bp.b2;
+    VU_TRY(vu_gemm_launch(dt, 0, g, cx.st));
+  }
+  VU_TRY(vu_k_add_ln_fwd(dt, cx.w->f_ff, bb.x1, bb.z2, cx.prm + bp.ln2w, cx.prm + bp.ln2b, bb.out, cx.w->lnp, bb.ln2s,
+                         B, P, 1e-5f, cx.st));
+  return VU_OK;
+}
+
+// dout -> dx (both B*P T).  dout is clobbered.
+int block_backward(Ctx& cx, const BlockP& bp, BlockBuf& bb, const void* x, void* dout, void* dx, uint64_t stream_id) {
+  const vu_config& c = cx.pl->cfg;
+  const Level& L = cx.pl->lv[bp.level];
+  const int dt = c.dtype, B = cx.B;
+  const long long P = (long long)L.N * L.D, rows = (long long)B * L.N;
+  ModelWS& w = *cx.w;
+  float* G = cx.grads;
+  vu_rng none = vu_make_rng(0, 0, 0.f);
+  // LN2 backward: dz2 -> ga
+  VU_TRY(vu_k_ln_bwd(dt, dout, bb.z2, cx.prm + bp.ln2w, bb.ln2s, G + bp.ln2w, G + bp.ln2b, w.lnp2, w.ga, nullptr, none, B, P, cx.st));
+  // FeedForward backward
+  VU_TRY(vu_k_colsum(dt, w.ga, G + bp.b2, rows, L.D, L.D, cx.st));
+  {  // dW2 += dz2^T hact
+    vu_gemm_args g;
+    memset(&g, 0, sizeof(g));
+    g.A = w.ga; g.B = bb.hact; g.C = G + bp.w2; g.M = L.D; g.N = L.hid; g.K = (int)rows;
+    g.sAm = 1; g.sAk = L.D; g.sBk = L.hid; g.sBn = 1; g.ldc = L.hid; g.Z1 = 1; g.Z2 = 1; g.alpha = 1.f; g.accumulate = 1;
+    VU_TRY(vu_gemm_launch(dt, 1, g, cx.st));
+  }
+  {  // dh = (dz2 W2) * gelu'(hpre)
+    vu_gemm_args g;
+    memset(&g, 0, sizeof(g));
+    g.A = w.ga; g.B = wptr(c, cx.prm, cx.shadow, bp.w2); g.C = w.gh; g.aux = bb.hpre;
+    g.M = (int)rows; g.N = L.hid; g.K = L.D; g.sAm = L.D; g.sAk = 1; g.sBk = L.hid; g.sBn = 1; g.ldc = L.hid;
+    g.Z1 = 1; g.Z2 = 1; g.alpha = 1.f; g.act = VU_ACT_DGELU;
+    VU_TRY(vu_gemm_launch(dt, 0, g, cx.st));
+  }
+  VU_TRY(vu_k_colsum(dt, w.gh, G + bp.b1, rows, L.hid, L.hid, cx.st));
+  {  // dW1 += dh^T x1
+    vu_gemm_args g;
+    memset(&g, 0, sizeof(g));
+    g.A = w.gh; g.B = bb.x1; g.C = G + bp.w1; g.M = L.hid; g.N = L.D; g.K = (int)rows;
+    g.sAm = 1; g.sAk = L.hid; g.sBk = L.D; g.sBn = 1; g.ldc = L.D; g.Z1 = 1; g.Z2 = 1; g.alpha = 1.f; g.accumulate = 1;
+    VU_TRY(vu_gemm_launch(dt, 1, g, cx.st));
+  }
+  {  // dx1 = dh W1 + dz2  -> gb
+    vu_gemm_args g;
+    memset(&g, 0, sizeof(g));
+    g.A = w.gh; g.B = wptr(c, cx.prm, cx.shadow, bp.w1); g.C = w.gb; g.addend = w.ga;
+    g.M = (int)rows; g.N = L.D; g.K = L.hid; g.sAm = L.hid; g.sAk = 1; g.sBk = L.D; g.sBn = 1; g.ldc = L.D;
+    g.Z1 = 1; g.Z2 = 1; g.alpha = 1.f;
+    VU_TRY(vu_gemm_launch(dt, 0, g, cx.st));
+  }
+  // LN1 backward: dz1 -> ga ; masked copy (projection dropout backward) -> gc
+  vu_rng rp = vu_make_rng(cx.seed, 2 * stream_id + 1, cx.training ? c.proj_drop : 0.f);
+  rp.salt = cx.salt;
+  const bool masked = rp.thr != 0;
+  VU_TRY(vu_k_ln_bwd(dt, w.gb, bb.z1, cx.prm + bp.ln1w, bb.ln1s, G + bp.ln1w, G + bp.ln1b, w.lnp2, w.ga,
+                     masked ? w.gc : nullptr, rp, B, P, cx.st));
+  AttnDims d{dt, B, L.N, L.D, c.num_heads, c.num_channels, L.s, L.ld};
+  vu_attn_params ap = attn_params(bp.at, c, cx.prm, cx.shadow, cx.bn);
+  vu_attn_grads ag = attn_grads(bp.at, G);
+  VU_TRY(attn_backward(d, ap, ag, x, x, masked ? w.gc : w.ga, w.ga, nullptr, dx, nullptr, bb.at, w.asc, c.attn_drop,
+                       cx.training, cx.st));
+  return VU_OK;
+}
+
+int model_forward(Ctx& cx, const float* x, float* y) {
+  const Plan& pl = *cx.pl;
+  const vu_config& c = pl.cfg;
+  ModelWS& w = *cx.w;
+  const int dt = c.dtype, B = cx.B, C = c.num_channels, im = c.im_size;
+  // PatchEncoder (model.py:84-91): tokens + positional embedding
+  VU_TRY(vu_k_retile(dt, 1, 0, x, w.tok0, cx.prm + pl.pos, B, C, im, im, c.patch_size, cx.st));
+  const void* cur = w.tok0;
+  uint64_t sid = 0;
+  std::vector<const void*> skips(c.depth, nullptr);
+  for (size_t i = 0; i < pl.enc.size(); ++i) {  // model.py:388-392
+    VU_TRY(block_forward(cx, pl.enc[i], w.enc[i], cur, sid++));
+    cur = w.enc[i].out;
+    if ((i + 1) % c.depth_te == 0) {
+      const int l = pl.enc[i].level;
+      skips[l] = cur;
+      VU_TRY(vu_k_retile(dt, 0, 0, cur, w.down_out[l], nullptr, B, C, im, pl.lv[l].s, pl.lv[l + 1].s, cx.st));
+      cur = w.down_out[l];
+    }
+  }
+  for (size_t i = 0; i < pl.bot.size(); ++i) {  // model.py:400-401
+    VU_TRY(block_forward(cx, pl.bot[i], w.bot[i], cur, sid++));
+    cur = w.bot[i].out;
+  }
+  for (size_t i = 0; i < pl.dec.size(); ++i) {  // model.py:410-418
+    VU_TRY(block_forward(cx, pl.dec[i], w.dec[i], cur, sid++));
+    cur = w.dec[i].out;
+    if ((i + 1) % c.depth_te == 0) {
+      const int j = (int)(i + 1) / c.depth_te - 1;  // SkipConnections[j]
+      const int lfrom = pl.dec[i].level, lto = lfrom - 1;
+      VU_TRY(vu_k_retile(dt, 0, 0, cur, w.up_out[j], nullptr, B, C, im, pl.lv[lfrom].s, pl.lv[lto].s, cx.st));
+      const Level& L = pl.lv[lto];
+      AttnDims d{dt, B, L.N, L.D, c.num_heads, C, L.s, L.ld};
+      vu_attn_params ap = attn_params(pl.skip[j], c, cx.prm, cx.shadow, cx.bn);
+      VU_TRY(attn_forward(d, ap, skips[lto], w.up_out[j], w.skip_out[j], w.skip[j], w.partials, c.attn_drop, c.proj_drop,
+                          cx.training, cx.seed, sid++, cx.salt, cx.st));
+      cur = w.skip_out[j];
+    }
+  }
+  // model.py:425-428
+  if (c.out_conv) {
+    VU_TRY(vu_k_retile(dt, 0, 0, cur, w.img, nullptr, B, C, im, pl.lv[0].s, im, cx.st));
+    VU_TRY(vu_k_conv3x3_fwd(dt, 1, w.img, cx.prm + pl.outw, cx.prm + pl.outb, y, B, C, im, cx.st));
+  } else {
+    VU_TRY(vu_k_retile(dt, 0, 1, cur, y, nullptr, B, C, im, pl.lv[0].s, im, cx.st));
+  }
+  return VU_OK;
+}
+
+// number of attention modules executed before decoder block i / skip j etc. follows forward order
+int model_backward(Ctx& cx, const float* dy, float* dx, int stage) {
+  const Plan& pl = *cx.pl;
+  const vu_config& c = pl.cfg;
+  ModelWS& w = *cx.w;
+  const int dt = c.dtype, B = cx.B, C = c.num_channels, im = c.im_size;
+  const long long P = (long long)C * im * im;
+  float* G = cx.grads;
+  // forward-order stream ids
+  const uint64_t sid_enc0 = 0, sid_bot0 = pl.enc.size(), sid_dec0 = sid_bot0 + pl.bot.size();
+  // which buffer currently holds the running gradient is kept in ws (gx0/gx1 ping-pong); between
+  // stages the running gradient always sits in gx0.
+  void* cur = w.gx0;
+  void* oth = w.gx1;
+  auto swap = [&]() { void* t = cur; cur = oth; oth = t; };
+
+  if (stage == 0 || stage == 1) {
+    if (c.out_conv) {
+      VU_TRY(vu_k_conv3x3_wgrad(dt, 1, dy, w.img, G + pl.outw, G + pl.outb, B, C, im, cx.st));
+      VU_TRY(vu_k_conv3x3_dgrad(dt, 1, dy, cx.prm + pl.outw, nullptr, w.ga, B, C, im, cx.st));
+      VU_TRY(vu_k_retile(dt, 0, 0, w.ga, cur, nullptr, B, C, im, im, pl.lv[0].s, cx.st));
+    } else {
+      VU_TRY(vu_k_retile(dt, 1, 0, dy, cur, nullptr, B, C, im, im, pl.lv[0].s, cx.st));
+    }
+    // decoders in reverse; skip j follows decoder block (j+1)*depth_te-1
+    for (int i = (int)pl.dec.size() - 1; i >= 0; --i) {
+      // stream id of decoder block i in forward order: dec blocks and skips interleave
+      const uint64_t sid_blk = sid_dec0 + i + (uint64_t)(i / c.depth_te);
+      if ((i + 1) % c.depth_te == 0) {
+        const int j = (i + 1) / c.depth_te - 1;
+        const uint64_t sid_skip = sid_blk + 1;
+        const int lfrom = pl.dec[i].level, lto = lfrom - 1;
+        const Level& L = pl.lv[lto];
+        AttnDims d{dt, B, L.N, L.D, c.num_heads, C, L.s, L.ld};
+        vu_attn_params ap = attn_params(pl.skip[j], c, cx.prm, cx.shadow, cx.bn);
+        vu_attn_grads ag = attn_grads(pl.skip[j], G);
+        const void* dz = cur;
+        vu_rng rp = vu_make_rng(cx.seed, 2 * sid_skip + 1, cx.training ? c.proj_drop : 0.f);
+        rp.salt = cx.salt;
+        if (rp.thr != 0) { VU_TRY(vu_k_dropout(dt, cur, w.gc, (long long)B * P, rp, cx.st)); dz = w.gc; }
+        // encoder skip tensor at level lto is the output of the last encoder block of that level
+        const void* enc_x = w.enc[(lto + 1) * c.depth_te - 1].out;
+        VU_TRY(attn_backward(d, ap, ag, enc_x, w.up_out[j], dz, nullptr, nullptr, w.dskip[lto], w.ga, w.skip[j], w.asc,
+                             c.attn_drop, cx.training, cx.st));
+        // gradient of upsampling = retile back to the finer level
+        VU_TRY(vu_k_retile(dt, 0, 0, w.ga, cur, nullptr, B, C, im, pl.lv[lto].s, pl.lv[lfrom].s, cx.st));
+      }
+      const void* xin = (i == 0) ? (pl.bot.empty() ? (c.depth > 0 ? w.down_out[c.depth - 1] : w.tok0) : w.bot.back().out)
+                                 : (((i) % c.depth_te == 0) ? w.skip_out[i / c.depth_te - 1] : w.dec[i - 1].out);
+      VU_TRY(block_backward(cx, pl.dec[i], w.dec[i], xin, cur, oth, sid_blk));
+      swap();
+    }
+    if (cur != w.gx0) { VU_TRY(hipMemcpyAsync(w.gx0, cur, (size_t)B * P * esize(dt), hipMemcpyDeviceToDevice, cx.st) == hipSuccess ? VU_OK : VU_ELAUNCH); cur = w.gx0; oth = w.gx1; }
+  }
+  if (stage == 0 || stage == 2) {
+    cur = w.gx0; oth = w.gx1;
+    for (int i = (int)pl.bot.size() - 1; i >= 0; --i) {
+      const void* xin = (i == 0) ? (c.depth > 0 ? w.down_out[c.depth - 1] : w.tok0) : w.bot[i - 1].out;
+      VU_TRY(block_backward(cx, pl.bot[i], w.bot[i], xin, cur, oth, sid_bot0 + i));
+      swap();
+    }
+    if (cur != w.gx0) { VU_TRY(hipMemcpyAsync(w.gx0, cur, (size_t)B * P * esize(dt), hipMemcpyDeviceToDevice, cx.st) == hipSuccess ? VU_OK : VU_ELAUNCH); cur = w.gx0; oth = w.gx1; }
+  }
+  if (stage == 0 || stage == 3) {
+    cur = w.gx0; oth = w.gx1;
+    for (int i = (int)pl.enc.size() - 1; i >= 0; --i) {
+      if ((i + 1) % c.depth_te == 0) {
+        const int l = pl.enc[i].level;
+        // gradient of downsampling (retile back) + gradient arriving through the skip connection
+        VU_TRY(vu_k_retile(dt, 0, 0, cur, oth, nullptr, B, C, im, pl.lv[l + 1].s, pl.lv[l].s, cx.st));
+        VU_TRY(vu_k_add(dt, oth, w.dskip[l], oth, (long long)B * P, cx.st));
+        swap();
+      }
+      const void* xin = (i == 0) ? w.tok0 : ((i % c.depth_te == 0) ? w.down_out[pl.enc[i].level - 1] : w.enc[i - 1].out);
+      VU_TRY(block_backward(cx, pl.enc[i], w.enc[i], xin, cur, oth, sid_enc0 + i));
+      swap();
+    }
+    VU_TRY(vu_k_batch_sum(dt, cur, G + pl.pos, B, P, cx.st));
+    if (dx) VU_TRY(vu_k_retile(dt, 0, 1, cur, dx, nullptr, B, C, im, c.patch_size, im, cx.st));
+  }
+  return VU_OK;
+}
+
+}  // namespace
+
+// =============================================================================================
+// extern "C" boundary
+// =============================================================================================
+extern "C" {
+
+int vu_version(void) { return 100; }
+const char* vu_last_error(void) { return vu_get_error(); }
+
+int vu_model_validate(const vu_config* cfg) { return cfg ? validate(*cfg) : VU_EINVAL; }
+long long vu_model_param_elems(const vu_config* cfg) {
+  Plan pl;
+  if (!cfg || build_plan(*cfg, pl) != VU_OK) return -1;
+  return pl.total;
+}
+int vu_model_num_params(const vu_config* cfg) {
+  Plan pl;
+  if (!cfg || build_plan(*cfg, pl) != VU_OK) return -1;
+  return (int)pl.table.size();
+}
+int vu_model_param_table(const vu_config* cfg, vu_param_entry* out, int capacity) {
+  Plan pl;
+  if (!cfg) return VU_EINVAL;
+  VU_TRY(build_plan(*cfg, pl));
+  VU_REQUIRE((int)pl.table.size() <= capacity, "param table: capacity %d < %d", capacity, (int)pl.table.size());
+  memcpy(out, pl.table.data(), pl.table.size() * sizeof(vu_param_entry));
+  return (int)pl.table.size();
+}
+int vu_model_num_attn(const vu_config* cfg) {
+  Plan pl;
+  if (!cfg || build_plan(*cfg, pl) != VU_OK) return -1;
+  return pl.nattn;
+}
+size_t vu_model_workspace_bytes(const vu_config* cfg, int B) {
+  Plan pl;
+  if (!cfg || B <= 0 || build_plan(*cfg, pl) != VU_OK) return 0;
+  ModelWS w;
+  carve_model(pl, B, nullptr, w);
+  return w.bytes;
+}
+
+int vu_model_forward(const vu_config* cfg, const float* params, const void* shadow, float* bn_state, const float* x,
+                     float* y, void* ws, size_t ws_bytes, int B, int training, uint64_t seed, const uint32_t* rng_salt,
+                     void* stream) {
+  VU_REQUIRE(cfg && params && bn_state && x && y && ws && B > 0, "vu_model_forward: null argument");
+  Plan pl;
+  VU_TRY(build_plan(*cfg, pl));
+  VU_REQUIRE(cfg->dtype == 0 || shadow, "vu_model_forward: bf16 mode needs the bf16 shadow arena");
+  ModelWS w;
+  carve_model(pl, B, (char*)ws, w);
+  if (w.bytes > ws_bytes) { vu_set_error("workspace too small: need %zu, have %zu", w.bytes, ws_bytes); return VU_EWORKSPACE; }
+  Ctx cx{&pl, B, params, shadow, bn_state, nullptr, training, seed, rng_salt, (hipStream_t)stream, &w};
+  return model_forward(cx, x, y);
+}
+
+int vu_model_backward(const vu_config* cfg, const float* params, const void* shadow, const float* bn_state, float* grads,
+                      const float* dy, float* dx, void* ws, size_t ws_bytes, int B, int training, uint64_t seed,
+                      const uint32_t* rng_salt, int stage, void* stream) {
+  VU_REQUIRE(cfg && params && grads && dy && ws && B > 0, "vu_model_backward: null argument");
+  VU_REQUIRE(stage >= 0 && stage <= 3, "vu_model_backward: stage must be 0..3");
+  Plan pl;
+  VU_TRY(build_plan(*cfg, pl));
+  VU_REQUIRE(cfg->dtype == 0 || shadow, "vu_model_backward: bf16 mode needs the bf16 shadow arena");
+  ModelWS w;
+  carve_model(pl, B, (char*)ws, w);
+  if (w.bytes > ws_bytes) { vu_set_error("workspace too small: need %zu, have %zu", w.bytes, ws_bytes); return VU_EWORKSPACE; }
+  Ctx cx{&pl, B, params, shadow, (float*)bn_state, grads, training, seed, rng_salt, (hipStream_t)stream, &w};
+  return model_backward(cx, dy, dx, stage);
+}
+
+// ---- per-op ----
+int vu_retile(int dtype, int in_f32, int out_f32, const void* in, void* out, const float* pos, int B, int C, int im,
+              int s_in, int s_out, void* stream) {
+  return vu_k_retile(dtype, in_f32, out_f32, in, out, pos, B, C, im, s_in, s_out, (hipStream_t)stream);
+}
+int vu_conv3x3_fwd(int dtype, int out_f32, const void* in, const float* w, const float* bias, void* out, long long npatch,
+                   int C, int s, void* stream) {
+  return vu_k_conv3x3_fwd(dtype, out_f32, in, w, bias, out, npatch, C, s, (hipStream_t)stream);
+}
+int vu_conv3x3_bwd(int dtype, int dout_f32, const void* dout, const void* in, const float* w, const void* add, void* din,
+                   float* dw, float* dbias, long long npatch, int C, int s, void* stream) {
+  if (dw) VU_TRY(vu_k_conv3x3_wgrad(dtype, dout_f32, dout, in, dw, dbias, npatch, C, s, (hipStream_t)stream));
+  if (din) VU_TRY(vu_k_conv3x3_dgrad(dtype, dout_f32, dout, w, add, din, npatch, C, s, (hipStream_t)stream));
+  return VU_OK;
+}
+
+static void carve_attn_ws(Bump& bp, const AttnDims& d, AttnBuf& a, AttnScratch& sc, void** dzbuf) {
+  carve_attn(bp, d, a);
+  const size_t act = (size_t)d.B * d.N * d.D * esize(d.dtype);
+  const size_t map = (size_t)d.B * d.H * d.N * d.ld * esize(d.dtype);
+  sc.dO = bp.take(act); sc.dq = bp.take(act); sc.dk = bp.take(act); sc.dv = bp.take(act); sc.dA = bp.take(map);
+  *dzbuf = bp.take(act);
+  sc.nblocks = stats_blocks(d);
+  sc.partials = bp.takef((size_t)sc.nblocks * 2 * d.H);
+}
+size_t vu_attn_workspace_bytes(int dtype, int B, int N, int D, int H) {
+  AttnDims d{dtype, B, N, D, H, 1, 4, round_up(N, 8)};
+  Bump bp{nullptr, 0};
+  AttnBuf a; AttnScratch sc; void* dz;
+  carve_attn_ws(bp, d, a, sc, &dz);
+  return vu_align_up(bp.off, 256);
+}
+static int attn_dims(int dtype, int B, int N, int D, int H, int C, AttnDims& d) {
+  VU_REQUIRE(B > 0 && N > 0 && D > 0 && H > 0 && C > 0 && D % H == 0 && D % C == 0, "attention: bad dims");
+  int s = 1;
+  while ((long long)s * s * C < D) ++s;
+  VU_REQUIRE((long long)s * s * C == D && s % 4 == 0, "attention: D must be C*s*s with s a multiple of 4");
+  d = AttnDims{dtype, B, N, D, H, C, s, round_up(N, 8)};
+  return VU_OK;
+}
+int vu_attn_forward(int dtype, const vu_attn_params* prm, const void* xq, const void* xkv, void* y, void* map_out,
+                    void* ws, size_t ws_bytes, int B, int N, int D, int H, int C, float attn_drop, float proj_drop,
+                    int training, uint64_t seed, uint64_t stream_id, void* stream) {
+  AttnDims d;
+  VU_TRY(attn_dims(dtype, B, N, D, H, C, d));
+  Bump bp{(char*)ws, 0};
+  AttnBuf a; AttnScratch sc; void* dz;
+  carve_attn_ws(bp, d, a, sc, &dz);
+  if (bp.off > ws_bytes) { vu_set_error("attention workspace too small"); return VU_EWORKSPACE; }
+  VU_TRY(attn_forward(d, *prm, xq, xkv, y, a, sc.partials, attn_drop, proj_drop, training, seed, stream_id, nullptr,
+                      (hipStream_t)stream));
+  if (map_out) {  // the attn_next tensor of model.py:160 as (B,H,N,N) without row padding
+    const size_t es = esize(dtype);
+    hipError_t e = hipMemcpy2DAsync(map_out, (size_t)N * es, a.Ah, (size_t)d.ld * es, (size_t)N * es, (size_t)B * H * N,
+                                    hipMemcpyDeviceToDevice, (hipStream_t)stream);
+    if (e != hipSuccess) { vu_set_error("map copy: %s", hipGetErrorString(e)); return VU_ELAUNCH; }
+  }
+  return VU_OK;
+}
+int vu_attn_backward(int dtype, const vu_attn_params* prm, const vu_attn_grads* grd, const void* xq, const void* xkv,
+                     const void* dy, void* dxq, void* dxkv, void* ws, size_t ws_bytes, int B, int N, int D, int H, int C,
+                     float attn_drop, float proj_drop, int training, uint64_t seed, uint64_t stream_id, void* stream) {
+  AttnDims d;
+  VU_TRY(attn_dims(dtype, B, N, D, H, C, d));
+  Bump bp{(char*)ws, 0};
+  AttnBuf a; AttnScratch sc; void* dzb;
+  carve_attn_ws(bp, d, a, sc, &dzb);
+  if (bp.off > ws_bytes) { vu_set_error("attention workspace too small"); return VU_EWORKSPACE; }
+  const void* dz = dy;
+  vu_rng rp = vu_make_rng(seed, 2 * stream_id + 1, training ? proj_drop : 0.f);
+  if (rp.thr != 0) { VU_TRY(vu_k_dropout(dtype, dy, dzb, (long long)B * N * D, rp, (hipStream_t)stream)); dz = dzb; }
+  return attn_backward(d, *prm, *grd, xq, xkv, dz, nullptr, nullptr, dxq, dxkv, a, sc, attn_drop, training, (hipStream_t)stream);
+}
+
+size_t vu_layernorm_workspace_floats(int B, long long P) {
+  return (size_t)B * vu_ln_nchunks(P) * 3 + (size_t)B * vu_ln_nbchunks(P) * 2 + 64;
+}
+int vu_add_layernorm_fwd(int dtype, const void* a, const void* x, void* z, const float* w, const float* b, void* y,
+                         float* ws, float* stats, int B, long long P, void* stream) {
+  return vu_k_add_ln_fwd(dtype, a, x, z, w, b, y, ws, stats, B, P, 1e-5f, (hipStream_t)stream);
+}
+int vu_layernorm_bwd(int dtype, const void* dy, const void* z, const float* w, const float* stats, float* dw, float* db,
+                     float* ws, void* dz, int B, long long P, void* stream) {
+  vu_rng none = vu_make_rng(0, 0, 0.f);
+  return vu_k_ln_bwd(dtype, dy, z, w, stats, dw, db, ws, dz, nullptr, none, B, P, (hipStream_t)stream);
+}
+
+int vu_gemm(int dtype, int c_float, const void* A, const void* Bm, void* C, int M, int N, int K, long long sAm,
+            long long sAk, long long sBk, long long sBn, long long ldc, int Z1, int Z2, long long sA1, long long sA2,
+            long long sB1, long long sB2, long long sC1, long long sC2, float alpha, const float* bias, int accumulate,
+            void* stream) {
+  vu_gemm_args g;
+  memset(&g, 0, sizeof(g));
+  g.A = A; g.B = Bm; g.C = C; g.M = M; g.N = N; g.K = K; g.sAm = sAm; g.sAk = sAk; g.sBk = sBk; g.sBn = sBn; g.ldc = ldc;
+  g.Z1 = Z1; g.Z2 = Z2; g.sA1 = sA1; g.sA2 = sA2; g.sB1 = sB1; g.sB2 = sB2; g.sC1 = sC1; g.sC2 = sC2;
+  g.alpha = alpha; g.bias = bias; g.accumulate = accumulate;
+  return vu_gemm_launch(dtype, c_float, g, (hipStream_t)stream);
+}
+
+int vu_mse_loss(const float* out, const float* target, float* dout, float* loss, float* partials, long long n,
+                float grad_scale, void* stream) {
+  return vu_k_mse(out, target, dout, loss, partials, n, grad_scale, (hipStream_t)stream);
+}
+int vu_adamw(float* params, const float* grads, float* m, float* v, void* shadow_bf16, long long n, const float* hyper,
+             int* step, float grad_scale, void* stream) {
+  return vu_k_adamw(params, grads, m, v, shadow_bf16, n, hyper, step, grad_scale, (hipStream_t)stream);
+}
+int vu_cast_bf16(const float* in, void* out, long long n, void* stream) {
+  return vu_k_cast_bf16(in, out, n, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,143 @@
+"""ctypes binding of libvitunet_amd.so (the C ABI declared in include/vit_unet_amd.h).
+
+The product path has no CPU fallback: if the shared library is missing, or a kernel is asked to
+run on a non-GPU tensor, this module raises.  `__graft_entry__.build()` (or `make -C
+vit-unet_amd/csrc`) produces the library next to this file.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvitunet_amd.so")
+
+VU_OK = 0
+
+
+class VuError(RuntimeError):
+    pass
+
+
+class vu_config(C.Structure):
+    _fields_ = [("depth", C.c_int), ("depth_te", C.c_int), ("size_bottleneck", C.c_int),
+                ("im_size", C.c_int), ("patch_size", C.c_int), ("num_channels", C.c_int),
+                ("hidden_dim", C.c_int), ("num_heads", C.c_int),
+                ("attn_drop", C.c_float), ("proj_drop", C.c_float), ("linear_drop", C.c_float),
+                ("out_conv", C.c_int), ("dtype", C.c_int)]
+
+
+class vu_param_entry(C.Structure):
+    _fields_ = [("name", C.c_char * 96), ("offset", C.c_longlong), ("ndim", C.c_int),
+                ("shape", C.c_int * 4), ("bn_index", C.c_int)]
+
+
+class vu_attn_params(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("mix_w", "mix_b", "bn_w", "bn_b", "wq", "wk", "wv",
+                                          "proj_w", "proj_b", "run_mean", "run_var")]
+
+
+class vu_attn_grads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("mix_w", "mix_b", "bn_w", "bn_b", "wq", "wk", "wv",
+                                          "proj_w", "proj_b")]
+
+
+_vp, _i, _ll, _f, _u64, _sz = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_uint64, C.c_size_t
+_cfgp = C.POINTER(vu_config)
+
+# name -> (restype, argtypes); mirrors include/vit_unet_amd.h one to one
+SIGNATURES = {
+    "vu_version": (_i, []),
+    "vu_last_error": (C.c_char_p, []),
+    "vu_model_validate": (_i, [_cfgp]),
+    "vu_model_param_elems": (_ll, [_cfgp]),
+    "vu_model_num_params": (_i, [_cfgp]),
+    "vu_model_param_table": (_i, [_cfgp, C.POINTER(vu_param_entry), _i]),
+    "vu_model_num_attn": (_i, [_cfgp]),
+    "vu_model_workspace_bytes": (_sz, [_cfgp, _i]),
+    "vu_model_forward": (_i, [_cfgp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _u64, _vp, _vp]),
+    "vu_model_backward": (_i, [_cfgp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _u64, _vp, _i, _vp]),
+    "vu_retile": (_i, [_i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "vu_conv3x3_fwd": (_i, [_i, _i, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp]),
+    "vu_conv3x3_bwd": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp]),
+    "vu_attn_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "vu_attn_forward": (_i, [_i, C.POINTER(vu_attn_params), _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i,
+                             _f, _f, _i, _u64, _u64, _vp]),
+    "vu_attn_backward": (_i, [_i, C.POINTER(vu_attn_params), C.POINTER(vu_attn_grads), _vp, _vp, _vp, _vp, _vp,
+                              _vp, _sz, _i, _i, _i, _i, _i, _f, _f, _i, _u64, _u64, _vp]),
+    "vu_layernorm_workspace_floats": (_sz, [_i, _ll]),
+    "vu_add_layernorm_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _ll, _vp]),
+    "vu_layernorm_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _ll, _vp]),
+    "vu_gemm": (_i, [_i, _i, _vp, _vp, _vp, _i, _i, _i, _ll, _ll, _ll, _ll, _ll, _i, _i,
+                     _ll, _ll, _ll, _ll, _ll, _ll, _f, _vp, _i, _vp]),
+    "vu_mse_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _f, _vp]),
+    "vu_adamw": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _vp, _vp, _f, _vp]),
+    "vu_cast_bf16": (_i, [_vp, _vp, _ll, _vp]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    """Load the HIP library (once).  Raises if it has not been built - there is no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VuError(f"{LIB_PATH} is missing: build it with `make -C vit-unet_amd/csrc` "
+                          "(or __graft_entry__.build()); the ViT-UNet path has no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)     # AttributeError if the symbol is not exported
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str = "") -> int:
+    if rc < 0:
+        msg = lib().vu_last_error().decode("utf-8", "replace")
+        if rc == -1 and msg and ("Depth must" in msg or "Patch size" in msg):
+            raise AssertionError(msg)               # reference error convention (model.py:281-283)
+        raise VuError(f"{what or 'vit_unet_amd'} failed (rc={rc}): {msg}")
+    return rc
+
+
+def ptr(t: Optional[torch.Tensor]):
+    """Device pointer of a contiguous GPU tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise VuError("the ViT-UNet HIP path needs GPU tensors (got a CPU tensor); there is no CPU fallback")
+    if not t.is_contiguous():
+        raise VuError("non-contiguous tensor passed to the HIP path")
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device=None):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1}
+
+
+def make_config(depth, depth_te, size_bottleneck, preprocessing, im_size, patch_size, num_channels,
+                hidden_dim, num_heads, attn_drop, proj_drop, linear_drop, dtype) -> vu_config:
+    if dtype not in DTYPE_CODE:
+        raise ValueError(f"dtype must be torch.float32 or torch.bfloat16, got {dtype}")
+    return vu_config(int(depth), int(depth_te), int(size_bottleneck), int(im_size), int(patch_size),
+                     int(num_channels), int(hidden_dim), int(num_heads), float(attn_drop), float(proj_drop),
+                     float(linear_drop), 1 if preprocessing == "conv" else 0, DTYPE_CODE[dtype])
+
+
+def param_table(cfg: vu_config):
+    L = lib()
+    n = check(L.vu_model_num_params(C.byref(cfg)), "vu_model_num_params")
+    arr = (vu_param_entry * n)()
+    check(L.vu_model_param_table(C.byref(cfg), arr, n), "vu_model_param_table")
+    out = []
+    for e in arr:
+        out.append((e.name.decode(), int(e.offset), tuple(e.shape[i] for i in range(e.ndim)), int(e.bn_index)))
+    return out

@@ -1,0 +1,138 @@
+"""Fused train step: forward + MSE + backward + (bucketed RCCL all-reduce) + AdamW, all on HIP
+kernels over the flat arenas, with optional hipGraph capture.
+
+This is the counterpart of what `benatools.TorchFitterBase.fit` does per batch for
+run_denoising.py:78-98 (`out = model(x); loss = MSELoss()(out, y); loss.backward();
+AdamW.step()`), minus Python-side autograd: one C call for the forward, one per backward stage,
+one for the loss and one for the optimizer.  Data parallelism: one process per GPU, gradients of
+the flat arena are all-reduced (sum) in three buckets - decoder side, bottleneck, encoder side -
+each launched on a side stream as soon as its backward stage has been enqueued, so the
+collective overlaps the remaining backward; the 1/world average is folded into AdamW.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import check, lib, ptr, stream_ptr
+
+
+class TrainStep:
+    def __init__(self, model, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
+                 process_group=None, seed: int = 0, overlap: bool = True):
+        model._ensure_flat()
+        self.model = model
+        dev = model._arena.device
+        self.dev = dev
+        n = model._arena.numel()
+        self.m = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.hyper = torch.tensor([lr, betas[0], betas[1], eps, weight_decay], dtype=torch.float32, device=dev)
+        self.step_count = torch.zeros(1, dtype=torch.int32, device=dev)      # device-side (graph replay safe)
+        self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.partials = torch.zeros(2048, dtype=torch.float32, device=dev)
+        self.seed = seed
+        self.pg = process_group
+        self.world = 1
+        if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            self.world = torch.distributed.get_world_size(process_group)
+        self.overlap = overlap and self.world > 1
+        self.comm_stream = torch.cuda.Stream(device=dev) if self.world > 1 else None
+        self._graph = None
+        self._gx = self._gy = self._gout = self._dout = None
+        self._buckets = self._make_buckets()
+        model.refresh_shadow()
+        model._shadow_clean = True      # from now on AdamW keeps the bf16 shadow in sync
+
+    def set_lr(self, lr: float):
+        self.hyper[0] = lr
+
+    def _make_buckets(self):
+        """Three contiguous arena ranges in backward order: [Decoders..end], [BottleNeck], [start..Encoders]."""
+        names = [t[0] for t in self.model._table]
+        offs = [t[1] for t in self.model._table]
+        total = self.model._arena.numel()
+
+        def first(prefix):
+            for n, o in zip(names, offs):
+                if n.startswith(prefix):
+                    return o
+            return None
+        o_bot, o_dec = first("BottleNeck."), first("Decoders.")
+        if o_dec is None:
+            o_dec = first("conv2d.") or total
+        if o_bot is None:
+            o_bot = o_dec
+        return [(o_dec, total), (o_bot, o_dec), (0, o_bot)]
+
+    # ---- the step ----------------------------------------------------------------------------
+    def _enqueue(self, x, y, out, dout):
+        m = self.model
+        L = lib()
+        B = x.shape[0]
+        st = stream_ptr(self.dev)
+        cfg = C.byref(m._cfg)
+        ws = m._workspace(B)
+        salt = self.step_count.view(torch.int32)
+        m._garena.zero_()
+        check(L.vu_model_forward(cfg, ptr(m._arena), ptr(m._shadow), ptr(m._bn), ptr(x), ptr(out), ptr(ws), ws.numel(),
+                                 B, 1, self.seed, ptr(salt), st), "vu_model_forward")
+        check(L.vu_mse_loss(ptr(out), ptr(y), ptr(dout), ptr(self.loss), ptr(self.partials), out.numel(), 1.0, st),
+              "vu_mse_loss")
+        cur = torch.cuda.current_stream(self.dev)
+        for stage, (lo, hi) in zip((1, 2, 3), self._buckets):
+            check(L.vu_model_backward(cfg, ptr(m._arena), ptr(m._shadow), ptr(m._bn), ptr(m._garena), ptr(dout), None,
+                                      ptr(ws), ws.numel(), B, 1, self.seed, ptr(salt), stage, st), "vu_model_backward")
+            if self.world > 1 and hi > lo:
+                if self.overlap:
+                    self.comm_stream.wait_stream(cur)
+                    with torch.cuda.stream(self.comm_stream):
+                        torch.distributed.all_reduce(m._garena[lo:hi], group=self.pg)
+                else:
+                    torch.distributed.all_reduce(m._garena[lo:hi], group=self.pg)
+        if self.world > 1 and self.overlap:
+            cur.wait_stream(self.comm_stream)
+        check(L.vu_adamw(ptr(m._arena), ptr(m._garena), ptr(self.m), ptr(self.v), ptr(m._shadow), m._arena.numel(),
+                         ptr(self.hyper), ptr(self.step_count), 1.0 / self.world, st), "vu_adamw")
+
+    def step(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+        """One optimisation step on a float32 (B,C,im,im) batch already resident on the GPU.
+        Returns the (device) loss scalar of this step."""
+        x = x.float().contiguous()
+        y = y.float().contiguous()
+        if self._gout is None or self._gout.shape != x.shape:
+            self._gout = torch.empty_like(x)
+            self._dout = torch.empty_like(x)
+        self._enqueue(x, y, self._gout, self._dout)
+        self.model._gen += 1
+        return self.loss
+
+    # ---- hipGraph capture ----------------------------------------------------------------------
+    def capture(self, x: torch.Tensor, y: torch.Tensor):
+        """Capture one step into a hipGraph (static input buffers); `replay(x, y)` then copies the
+        batch into the static buffers and launches the graph.  Single-GPU only: the collective is
+        launched eagerly in DP runs."""
+        assert self.world == 1, "graph capture is used for the single-GPU path"
+        self._gx, self._gy = x.float().contiguous().clone(), y.float().contiguous().clone()
+        self._gout, self._dout = torch.empty_like(self._gx), torch.empty_like(self._gx)
+        self.model._workspace(x.shape[0])
+        s = torch.cuda.Stream(device=self.dev)
+        s.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(s):
+            self._enqueue(self._gx, self._gy, self._gout, self._dout)     # warm-up (also a real step)
+        torch.cuda.current_stream(self.dev).wait_stream(s)
+        torch.cuda.synchronize(self.dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._enqueue(self._gx, self._gy, self._gout, self._dout)
+        self._graph = g
+
+    def replay(self, x: Optional[torch.Tensor] = None, y: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if x is not None:
+            self._gx.copy_(x)
+            self._gy.copy_(y)
+        self._graph.replay()
+        return self.loss
