@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""bench.py - images/sec of one ViT_UNet train step (forward + MSE + backward + gradient all-reduce +
+AdamW) on N MI355X GPUs of one node, the metric BASELINE.json names.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One process per GPU (RANK / LOCAL_RANK / WORLD_SIZE from the environment), data parallel over
+RCCL: every rank holds `--batch` images (weak scaling), gradients of the flat arena are summed in
+three buckets overlapped with the backward.  Inputs are synthetic and resident in HBM before the
+timed region.  Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline     - the dominant kernel of the step, timed live with HIP events behind every launch
+                 (vu_prof_enable) over extra instrumented steps; achieved = algorithmic flops (or
+                 bytes) / launch time, against the MI355X dense bf16 MFMA peak (or HBM peak)
+  cpu_baseline - the CPU oracle (torch CPU fp32 restatement of the reference) timed on this
+                 host's cores on a bounded sample (B=8, a few iterations), N=1 only
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "vit-unet_amd"))
+
+import torch  # noqa: E402
+
+TRAIN_GFLOP_PER_IMG = {"lite": 27.93, "base": 23.27, "large": 42.43}
+MFMA_PEAK_TFLOPS = 2500.0      # dense bf16, MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--model", default="base", choices=["lite", "base", "large"])
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-graph", action="store_true", help="N=1: launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=2)
+    return ap.parse_args()
+
+
+def cpu_baseline(model_name: str, threads: int):
+    """The oracle's train step on the host cores: B=8, 1 warm-up + 2 timed iterations."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import vit_unet_oracle as O
+    torch.set_num_threads(threads)
+    cfg = O.Config(**O.PRESETS[model_name])
+    w = O.make_weights(cfg, seed=0)
+    names = [k for k, _ in O.param_shapes(cfg)]
+    for k in names:
+        w[k].requires_grad_(True)
+    m = {k: torch.zeros_like(w[k]) for k in names}
+    v = {k: torch.zeros_like(w[k]) for k in names}
+    B = 8
+    x, y = O.make_batch(cfg, B=B, seed=1234)
+    times = []
+    for it in range(3):
+        t0 = time.perf_counter()
+        out = O.forward(w, cfg, x, training=True, seed=None)      # torch-native dropout, as the reference
+        loss = O.mse_loss(out, y)
+        loss.backward()
+        with torch.no_grad():
+            for k in names:
+                O.adamw_step(w[k], w[k].grad, m[k], v[k], it + 1)
+                w[k].grad = None
+        times.append(time.perf_counter() - t0)
+    best = min(times[1:])
+    return {"value": B / best, "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"oracle (torch CPU fp32) train step, {model_name}, B={B}, best of 2 after 1 warm-up",
+            "s_per_step": best}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus > 1 and world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} needs torchrun with {a.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.distributed.init_process_group("nccl", device_id=dev)
+
+    from vit_unet.torch import model as M
+    from vit_unet.torch import _lib
+    from vit_unet.torch.engine import TrainStep
+
+    dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    torch.manual_seed(0)                                   # identical initial weights on every rank
+    model = M.get_vit_unet(a.model, dtype=dt).to(dev).train()
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    y = torch.rand(a.batch, 3, 224, 224, generator=g)
+    x = (y + 0.1 * torch.randn(y.shape, generator=g)).clamp(0, 1)
+    x, y = x.to(dev), y.to(dev)
+    ts = TrainStep(model, lr=1e-4, seed=1234 + rank)
+    use_graph = world == 1 and not a.no_graph
+    if use_graph:
+        ts.capture(x, y)
+        step = lambda: ts.replay()                          # noqa: E731  (inputs stay resident)
+    else:
+        step = lambda: ts.step(x, y)                        # noqa: E731
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    fence()
+    dt_s = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt_s], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt_s = t.item()
+    loss = float(ts.loss.item())
+    images = a.batch * world * a.steps
+    value = images / dt_s
+
+    roof = None
+    if rank == 0 and not a.no_roofline:
+        L = _lib.lib()
+        st = torch.cuda.current_stream(dev)
+        torch.cuda.synchronize(dev)
+        if world == 1:
+            L.vu_prof_enable(_lib.C.c_void_p(st.cuda_stream))
+            for _ in range(a.profile_steps):
+                ts.step(x, y)
+            rep = json.loads(L.vu_prof_report().decode())
+            tot_ms = sum(v["ms"] for v in rep.values())
+            top = sorted(rep.items(), key=lambda kv: -kv[1]["ms"])
+            name, d = top[0]
+            avg_s = d["ms"] / d["count"] * 1e-3
+            if d["flops"] > 0:
+                ach = d["flops"] / d["count"] / avg_s / 1e12
+                roof = {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": ach / MFMA_PEAK_TFLOPS}
+            else:
+                ach = d["bytes"] / d["count"] / avg_s / 1e9
+                roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
+            roof.update({"traffic": None, "kernel": name, "avg_launch_us": avg_s * 1e6,
+                         "launches_per_step": d["count"] / a.profile_steps,
+                         "share_of_step": d["ms"] / tot_ms,
+                         "step_mfma_frac": value * TRAIN_GFLOP_PER_IMG[a.model] / 1e3 / MFMA_PEAK_TFLOPS,
+                         "top": [{"kernel": k, "ms_per_step": v["ms"] / a.profile_steps,
+                                  "launches_per_step": v["count"] / a.profile_steps,
+                                  "TFLOPs": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["flops"] else None,
+                                  "GBs": (v["bytes"] / (v["ms"] * 1e-3) / 1e9) if v["bytes"] else None}
+                                 for k, v in top[:8]]})
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(a.model, os.cpu_count() or 1)
+
+    if rank == 0:
+        out = {"metric": f"images/sec (224x224x3) ViT_UNet-{a.model.capitalize()} train step",
+               "value": value, "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": dt_s / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+               "config": {"workload": f"ViT_UNet-{a.model.capitalize()} train step: forward + MSELoss + backward + "
+                                      f"AdamW on synthetic SIDD-style 224x224x3 noisy/clean pairs, random-init weights",
+                          "per_gpu_batch": a.batch, "global_batch": a.batch * world, "parallelism": f"dp{world}",
+                          "hip_graph": use_graph, "final_loss": loss},
+               "roofline": roof, "cpu_baseline": cpu}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

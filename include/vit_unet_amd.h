@@ -141,6 +141,12 @@ int vu_adamw(float* params, const float* grads, float* m, float* v, void* shadow
              const float* hyper, int* step, float grad_scale, void* stream);
 int vu_cast_bf16(const float* in, void* out, long long n, void* stream);
 
+/* In-process launch profiler (bench.py's roofline leg): after vu_prof_enable(stream) an event is
+ * recorded behind every launch; vu_prof_report() stops, waits, and returns a JSON object
+ * {"<kernel tag>": {"count","ms","flops","bytes"}} with ALGORITHMIC flops / bytes per tag. */
+int vu_prof_enable(void* stream);
+const char* vu_prof_report(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -169,9 +169,21 @@ def keep_mask(numel: int, p: float, seed: int, stream: int) -> torch.Tensor:
 def _dropout(x: torch.Tensor, p: float, training: bool, seed: Optional[int], stream: int):
     if (not training) or p <= 0.0:
         return x
-    assert seed is not None, "train-mode dropout needs a seed (hash RNG shared with the HIP path)"
+    if seed is None:   # timing-only path (bench.py cpu_baseline): torch's own Bernoulli, as the reference
+        return F.dropout(x, p, True)
     m = keep_mask(x.numel(), p, seed, stream).reshape(x.shape).to(x.dtype)
     return x * m / (1.0 - p)
+
+
+# --------------------------------------------------------------------------------------------
+# bf16-storage emulation: the HIP path in bf16 mode computes in fp32 and rounds to bf16 exactly
+# where a tensor is written to HBM.  `_r(t, st)` rounds at those points (straight-through in
+# autograd) so a bf16 run can be checked against an oracle that follows the same rounding.
+# --------------------------------------------------------------------------------------------
+def _r(t: torch.Tensor, st) -> torch.Tensor:
+    if st is None or st == torch.float32:
+        return t
+    return t + (t.detach().to(st).to(t.dtype) - t.detach())
 
 
 # --------------------------------------------------------------------------------------------
@@ -190,14 +202,15 @@ def conv3x3_per_patch(tok: torch.Tensor, C: int, w: torch.Tensor, b: Optional[to
 # --------------------------------------------------------------------------------------------
 def reattention(xq, xkv, p: Dict[str, torch.Tensor], pre: str, h: int, C: int, *, training: bool,
                 attn_drop: float, proj_drop: float, seed: Optional[int] = None, stream: int = 0,
-                bn_momentum: float = 0.1, eps: float = 1e-5, return_map: bool = False):
+                bn_momentum: float = 0.1, eps: float = 1e-5, return_map: bool = False, storage=None):
     B, N, D = xq.shape
     d = D // h
-    q = conv3x3_per_patch(xq, C, p[pre + "qconv2d.weight"]).reshape(B, N, h, d).permute(0, 2, 1, 3)
-    k = conv3x3_per_patch(xkv, C, p[pre + "kconv2d.weight"]).reshape(B, N, h, d).permute(0, 2, 1, 3)
-    v = conv3x3_per_patch(xkv, C, p[pre + "vconv2d.weight"]).reshape(B, N, h, d).permute(0, 2, 1, 3)
-    s = torch.matmul(q, k.transpose(-2, -1)) * (d ** -0.5)           # model.py:155
-    a = torch.softmax(s, dim=-1)                                      # :156
+    st = storage
+    q = _r(conv3x3_per_patch(xq, C, p[pre + "qconv2d.weight"]), st).reshape(B, N, h, d).permute(0, 2, 1, 3)
+    k = _r(conv3x3_per_patch(xkv, C, p[pre + "kconv2d.weight"]), st).reshape(B, N, h, d).permute(0, 2, 1, 3)
+    v = _r(conv3x3_per_patch(xkv, C, p[pre + "vconv2d.weight"]), st).reshape(B, N, h, d).permute(0, 2, 1, 3)
+    s = _r(torch.matmul(q, k.transpose(-2, -1)) * (d ** -0.5), st)    # model.py:155
+    a = _r(torch.softmax(s, dim=-1), st)                              # :156
     a = _dropout(a, attn_drop, training, seed, 2 * stream)           # :157
     w = p[pre + "reatten_matrix.weight"].reshape(h, h)               # 1x1 conv across heads :159
     a = torch.einsum("gh,bhij->bgij", w, a) + p[pre + "reatten_matrix.bias"].reshape(1, h, 1, 1)
@@ -213,10 +226,10 @@ def reattention(xq, xkv, p: Dict[str, torch.Tensor], pre: str, h: int, C: int, *
     else:
         mean, var = p[pre + "var_norm.running_mean"].to(a.dtype), p[pre + "var_norm.running_var"].to(a.dtype)
     a = (a - mean.reshape(1, h, 1, 1)) * torch.rsqrt(var.reshape(1, h, 1, 1) + eps)
-    a = a * gam.reshape(1, h, 1, 1) + bet.reshape(1, h, 1, 1)         # reatten_scale == 1.0 (:140)
-    o = torch.matmul(a, v).transpose(1, 2).reshape(B, N, D)           # :161
-    y = F.linear(o, p[pre + "proj.weight"], p[pre + "proj.bias"])     # :162
-    y = _dropout(y, proj_drop, training, seed, 2 * stream + 1)       # :163
+    a = _r(a * gam.reshape(1, h, 1, 1) + bet.reshape(1, h, 1, 1), st)  # reatten_scale == 1.0 (:140)
+    o = _r(torch.matmul(a, v).transpose(1, 2).reshape(B, N, D), st)   # :161
+    y = F.linear(o, _r(p[pre + "proj.weight"], st), p[pre + "proj.bias"])     # :162
+    y = _r(_dropout(y, proj_drop, training, seed, 2 * stream + 1), st)        # :163
     return (y, a) if return_map else y
 
 
@@ -225,23 +238,24 @@ def _layernorm_nd(x, w, b, eps=1e-5):
     return F.layer_norm(x, x.shape[1:], w, b, eps)
 
 
-def te_block(x, p, pre: str, cfg: Config, *, training: bool, seed=None, stream: int = 0):
+def te_block(x, p, pre: str, cfg: Config, *, training: bool, seed=None, stream: int = 0, storage=None):
     """ReAttentionTransformerEncoder.forward (model.py:201-207), post-norm."""
+    st = storage
     a = reattention(x, x, p, pre + "ReAttn.", cfg.num_heads, cfg.num_channels, training=training,
-                    attn_drop=cfg.attn_drop, proj_drop=cfg.proj_drop, seed=seed, stream=stream)
-    x = _layernorm_nd(a + x, p[pre + "LN1.weight"], p[pre + "LN1.bias"])
-    hdn = F.gelu(F.linear(x, p[pre + "FeedForward.net.0.weight"], p[pre + "FeedForward.net.0.bias"]))
+                    attn_drop=cfg.attn_drop, proj_drop=cfg.proj_drop, seed=seed, stream=stream, storage=st)
+    x = _r(_layernorm_nd(_r(a + x, st), p[pre + "LN1.weight"], p[pre + "LN1.bias"]), st)
+    hdn = _r(F.gelu(F.linear(x, _r(p[pre + "FeedForward.net.0.weight"], st), p[pre + "FeedForward.net.0.bias"])), st)
     # linear_drop is 0 in every preset (model.py:451,467,483); Dropout(0) is the identity.
     assert cfg.linear_drop == 0.0 or not training, "oracle: linear_drop>0 in train mode not restated"
-    f = F.linear(hdn, p[pre + "FeedForward.net.3.weight"], p[pre + "FeedForward.net.3.bias"])
-    return _layernorm_nd(f + x, p[pre + "LN2.weight"], p[pre + "LN2.bias"])
+    f = _r(F.linear(hdn, _r(p[pre + "FeedForward.net.3.weight"], st), p[pre + "FeedForward.net.3.bias"]), st)
+    return _r(_layernorm_nd(_r(f + x, st), p[pre + "LN2.weight"], p[pre + "LN2.bias"]), st)
 
 
-def skip_block(enc, dec, p, pre: str, cfg: Config, *, training: bool, seed=None, stream: int = 0):
+def skip_block(enc, dec, p, pre: str, cfg: Config, *, training: bool, seed=None, stream: int = 0, storage=None):
     """SkipConnection.forward(q=enc, k=dec, v=dec) (model.py:244-259): replaces dec, no residual."""
     assert enc.shape == dec.shape
     return reattention(enc, dec, p, pre, cfg.num_heads, cfg.num_channels, training=training,
-                       attn_drop=cfg.attn_drop, proj_drop=cfg.proj_drop, seed=seed, stream=stream)
+                       attn_drop=cfg.attn_drop, proj_drop=cfg.proj_drop, seed=seed, stream=stream, storage=storage)
 
 
 # --------------------------------------------------------------------------------------------
@@ -249,16 +263,16 @@ def skip_block(enc, dec, p, pre: str, cfg: Config, *, training: bool, seed=None,
 # execution order: Encoders, BottleNeck, then Decoders interleaved with SkipConnections.
 # --------------------------------------------------------------------------------------------
 def forward(p: Dict[str, torch.Tensor], cfg: Config, X: torch.Tensor, *, training: bool = False,
-            seed: Optional[int] = None, taps: Optional[dict] = None) -> torch.Tensor:
+            seed: Optional[int] = None, taps: Optional[dict] = None, storage=None) -> torch.Tensor:
     B, C, H, W = X.shape
     assert C == cfg.num_channels and H == cfg.im_size and W == cfg.im_size  # D4: Resize == identity
     # PatchEncoder.forward (model.py:84-91): tokens + positional embedding (the unpatch/patch
     # round trip at :88-90 is a no-op).
-    x = patchify(X, cfg.patch_size) + p["PE.position_embedding.weight"].unsqueeze(0)
+    x = _r(patchify(X, cfg.patch_size) + p["PE.position_embedding.weight"].unsqueeze(0), storage)
     stream = 0
     skips: List[torch.Tensor] = []
     for i in range(cfg.depth * cfg.depth_te):                          # :388-392
-        x = te_block(x, p, f"Encoders.{i}.", cfg, training=training, seed=seed, stream=stream)
+        x = te_block(x, p, f"Encoders.{i}.", cfg, training=training, seed=seed, stream=stream, storage=storage)
         stream += 1
         if (i + 1) % cfg.depth_te == 0:
             skips.append(x)
@@ -266,12 +280,12 @@ def forward(p: Dict[str, torch.Tensor], cfg: Config, X: torch.Tensor, *, trainin
     if taps is not None:
         taps["after_encoders"] = x
     for i in range(cfg.size_bottleneck):                               # :400-401
-        x = te_block(x, p, f"BottleNeck.{i}.", cfg, training=training, seed=seed, stream=stream)
+        x = te_block(x, p, f"BottleNeck.{i}.", cfg, training=training, seed=seed, stream=stream, storage=storage)
         stream += 1
     if taps is not None:
         taps["after_bottleneck"] = x
     for i in range(cfg.depth * cfg.depth_te):                          # :410-418
-        x = te_block(x, p, f"Decoders.{i}.", cfg, training=training, seed=seed, stream=stream)
+        x = te_block(x, p, f"Decoders.{i}.", cfg, training=training, seed=seed, stream=stream, storage=storage)
         stream += 1
         if (i + 1) % cfg.depth_te == 0:
             j = (i + 1) // cfg.depth_te
@@ -279,7 +293,7 @@ def forward(p: Dict[str, torch.Tensor], cfg: Config, X: torch.Tensor, *, trainin
             enc = skips[cfg.depth - j]
             assert enc.shape == x.shape                                # :417
             x = skip_block(enc, x, p, f"SkipConnections.{j - 1}.", cfg, training=training,
-                           seed=seed, stream=stream)
+                           seed=seed, stream=stream, storage=storage)
             stream += 1
     if taps is not None:
         taps["after_decoders"] = x

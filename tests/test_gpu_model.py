@@ -81,7 +81,7 @@ def test_tiny_train_dropout_vs_oracle(golden_dir, name):
     """train mode WITH dropout: the oracle replays the device hash RNG, so outputs and gradients
     are compared element for element."""
     man, g = load_case(golden_dir, name)
-    kw = dict(man["cases"][name]["config"], attn_drop=0.2, proj_drop=0.2)
+    kw = dict(man["cases"][name]["config"], attn_drop=0.2, proj_drop=0.2, linear_drop=0.0)
     cfg = O.Config(**kw)
     w = O.make_weights(cfg, seed=7)
     m = build(kw, w).train()
@@ -105,25 +105,39 @@ def test_tiny_train_dropout_vs_oracle(golden_dir, name):
 
 
 @pytest.mark.parametrize("name", ["tiny_a", "tiny_b", "tiny_c"])
-def test_tiny_bf16_train(golden_dir, name):
+@pytest.mark.parametrize("drop", [0.0, 0.2])
+def test_tiny_bf16_train(golden_dir, name, drop):
+    """bf16 storage / fp32 arithmetic against the oracle run with bf16-storage emulation (the
+    oracle rounds to bf16 exactly where the HIP path writes a tensor to HBM).  Tolerance 2e-2 of
+    the output scale: both sides follow the same rounding, what is left is fp32 summation order
+    amplified through the softmax / BatchNorm chain (a plain fp32 oracle differs by 6e-2..4e-1
+    from either of them on these models: that is bf16 rounding, not a kernel error)."""
     man, g = load_case(golden_dir, name)
     case = man["cases"][name]
-    cfg = O.Config(**case["config"])
+    kw = dict(case["config"], attn_drop=drop, proj_drop=drop, linear_drop=0.0)
+    cfg = O.Config(**kw)
     w = O.make_weights(cfg, seed=case["weights_seed"])
-    m = build(case["config"], w, dtype=torch.bfloat16, attn_drop=0.0, proj_drop=0.0, linear_drop=0.0).train()
+    m = build(kw, w, dtype=torch.bfloat16).train()
     x, y = torch.from_numpy(g["x"]).to(DEV), torch.from_numpy(g["y"]).to(DEV)
+    m._step_seed = 31337
     out = m(x)
     assert out.dtype == torch.float32
-    assert serr(out, g["train.out"]) < 6e-2
+    wr = {k: v.clone() for k, v in w.items()}
+    for k, _ in O.param_shapes(cfg):
+        wr[k].requires_grad_(True)
+    ref = O.forward(wr, cfg, x.cpu(), training=True, seed=31337, storage=torch.bfloat16)
+    assert serr(out, ref) < 2e-2
     loss = torch.nn.MSELoss()(out, y)
     loss.backward()
+    O.mse_loss(ref, y.cpu()).backward()
     sd = dict(m.named_parameters())
-    # gradient direction agrees with the fp32 reference (cosine) for the big tensors
-    for k in ("PE.position_embedding.weight", "Encoders.0.ReAttn.proj.weight", "Encoders.0.LN1.weight"):
+    # gradients: bf16 gradient tensors are rounded too (not emulated): direction must agree
+    for k in ("PE.position_embedding.weight", "Encoders.0.ReAttn.proj.weight", "Encoders.0.LN1.weight",
+              "BottleNeck.0.FeedForward.net.0.weight", "SkipConnections.0.proj.weight", "conv2d.weight"):
         a = sd[k].grad.double().cpu().reshape(-1)
-        b = torch.from_numpy(g[f"train.grad.{k}"]).double().reshape(-1)
+        b = wr[k].grad.double().reshape(-1)
         cos = (a @ b / (a.norm() * b.norm())).item()
-        assert cos > 0.98, (k, cos)
+        assert cos > 0.97, (k, cos)
 
 
 @pytest.mark.parametrize("name", ["base", "lite", "large", "seg512"])
@@ -173,7 +187,7 @@ def test_train_step_fused_matches_autograd_path(golden_dir):
     torch.optim.AdamW path it replaces (run_denoising.py:78-98), and a hipGraph replay equals the
     eager step."""
     man, g = load_case(golden_dir, "tiny_c")
-    kw = dict(man["cases"]["tiny_c"]["config"], attn_drop=0.2, proj_drop=0.2)
+    kw = dict(man["cases"]["tiny_c"]["config"], attn_drop=0.2, proj_drop=0.2, linear_drop=0.0)
     cfg = O.Config(**kw)
     w = O.make_weights(cfg, seed=7)
     x, y = torch.from_numpy(g["x"]).to(DEV), torch.from_numpy(g["y"]).to(DEV)

@@ -55,7 +55,8 @@ def test_retile_patch_encoder_posemb():
     pos = torch.randn((im // s) ** 2, C_ * s * s)
     ref = O.patchify(img, s) + pos
     out = torch.empty(ref.shape, device=DEV)
-    check(lib().vu_retile(0, 1, 1, ptr(dev(img)), ptr(out), ptr(dev(pos)), B, C_, im, im, s, st()))
+    imgd, posd = dev(img), dev(pos)
+    check(lib().vu_retile(0, 1, 1, ptr(imgd), ptr(out), ptr(posd), B, C_, im, im, s, st()))
     assert torch.equal(out.cpu(), ref)
 
 

@@ -21,6 +21,9 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 void vu_set_error(const char* fmt, ...);
 int vu_check_launch(const char* what);
+// profiler annotation for the NEXT vu_check_launch: kernel tag + algorithmic flops / bytes
+void vu_prof_note(const char* tag, double flops, double bytes);
+bool vu_prof_on();
 
 #define VU_REQUIRE(cond, ...)                  \
   do {                                         \

@@ -1,10 +1,19 @@
 // GEMM instantiations + host launcher.
+#include <stdio.h>
 #include "vu_gemm.h"
 
 template <typename T, typename TC, bool TA, bool TB, int BM, int BN>
 static int launch_one(const vu_gemm_args& g, hipStream_t st) {
   dim3 grid((unsigned)(vu_cdiv(g.M, BM) * vu_cdiv(g.N, BN)), (unsigned)(g.Z1 * g.Z2));
   hipLaunchKernelGGL((vu_gemm_kernel<T, TC, TA, TB, BM, BN>), grid, dim3(256), 0, st, g);
+  if (vu_prof_on()) {
+    char tag[96];
+    snprintf(tag, sizeof(tag), "vu_gemm_kernel<%s,%s,%c%c,%dx%d>", sizeof(T) == 2 ? "bf16" : "f32",
+             sizeof(TC) == 2 ? "bf16" : "f32", TA ? 'T' : 'N', TB ? 'T' : 'N', BM, BN);
+    const double Z = (double)g.Z1 * g.Z2;
+    vu_prof_note(tag, 2.0 * g.M * (double)g.N * g.K * Z,
+                 Z * (((double)g.M * g.K + (double)g.K * g.N) * sizeof(T) + (double)g.M * g.N * sizeof(TC)));
+  }
   return vu_check_launch("vu_gemm");
 }
 

@@ -58,6 +58,7 @@ int vu_k_retile(int dtype, int in_f32, int out_f32, const void* in, void* out, c
   else if (fi) hipLaunchKernelGGL((retile_kernel<float, bf16_t>), dim3(grid), dim3(256), 0, st, (const float*)in, (bf16_t*)out, pos, total4, P, C, im, s_in, s_out);
   else if (fo) hipLaunchKernelGGL((retile_kernel<bf16_t, float>), dim3(grid), dim3(256), 0, st, (const bf16_t*)in, (float*)out, pos, total4, P, C, im, s_in, s_out);
   else hipLaunchKernelGGL((retile_kernel<bf16_t, bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)in, (bf16_t*)out, pos, total4, P, C, im, s_in, s_out);
+  if (vu_prof_on()) vu_prof_note("retile_kernel", 0.0, (double)total4 * 4 * 2 * (dtype == 0 ? 4.0 : 2.0));
   return vu_check_launch("vu_retile");
 }
 
@@ -234,6 +235,7 @@ int vu_k_conv3x3_fwd(int dtype, int out_f32, const void* in, const float* w, con
     if (dtype == 0) hipLaunchKernelGGL((conv3x3_fwd_kernel<float, float, CC>), dim3(grid), dim3(256), 0, st, (const float*)in, w, bias, (float*)out, npix, s);
     else if (fo) hipLaunchKernelGGL((conv3x3_fwd_kernel<bf16_t, float, CC>), dim3(grid), dim3(256), 0, st, (const bf16_t*)in, w, bias, (float*)out, npix, s);
     else hipLaunchKernelGGL((conv3x3_fwd_kernel<bf16_t, bf16_t, CC>), dim3(grid), dim3(256), 0, st, (const bf16_t*)in, w, bias, (bf16_t*)out, npix, s);)
+  if (vu_prof_on()) vu_prof_note("conv3x3_fwd_kernel", 0.0, (double)npix * C * 2 * (dtype == 0 ? 4.0 : 2.0));
   return vu_check_launch("vu_conv3x3_fwd");
 }
 int vu_k_conv3x3_dgrad(int dtype, int dout_f32, const void* dout, const float* w, const void* add,
@@ -245,6 +247,7 @@ int vu_k_conv3x3_dgrad(int dtype, int dout_f32, const void* dout, const float* w
     if (dtype == 0) hipLaunchKernelGGL((conv3x3_dgrad_kernel<float, float, CC>), dim3(grid), dim3(256), 0, st, (const float*)dout, w, (const float*)add, (float*)din, npix, s);
     else if (dout_f32) hipLaunchKernelGGL((conv3x3_dgrad_kernel<float, bf16_t, CC>), dim3(grid), dim3(256), 0, st, (const float*)dout, w, (const bf16_t*)add, (bf16_t*)din, npix, s);
     else hipLaunchKernelGGL((conv3x3_dgrad_kernel<bf16_t, bf16_t, CC>), dim3(grid), dim3(256), 0, st, (const bf16_t*)dout, w, (const bf16_t*)add, (bf16_t*)din, npix, s);)
+  if (vu_prof_on()) vu_prof_note("conv3x3_dgrad_kernel", 0.0, (double)npix * C * 3 * (dtype == 0 ? 4.0 : 2.0));
   return vu_check_launch("vu_conv3x3_dgrad");
 }
 int vu_k_conv3x3_wgrad(int dtype, int dout_f32, const void* dout, const void* in, float* dw,
@@ -256,6 +259,7 @@ int vu_k_conv3x3_wgrad(int dtype, int dout_f32, const void* dout, const void* in
     if (dtype == 0) hipLaunchKernelGGL((conv3x3_wgrad_kernel<float, float, CC>), dim3(grid), dim3(256), 0, st, (const float*)dout, (const float*)in, dw, dbias, npix, s);
     else if (dout_f32) hipLaunchKernelGGL((conv3x3_wgrad_kernel<float, bf16_t, CC>), dim3(grid), dim3(256), 0, st, (const float*)dout, (const bf16_t*)in, dw, dbias, npix, s);
     else hipLaunchKernelGGL((conv3x3_wgrad_kernel<bf16_t, bf16_t, CC>), dim3(grid), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)in, dw, dbias, npix, s);)
+  if (vu_prof_on()) vu_prof_note("conv3x3_wgrad_kernel", 0.0, (double)npix * C * 2 * (dtype == 0 ? 4.0 : 2.0));
   return vu_check_launch("vu_conv3x3_wgrad");
 }
 
@@ -291,6 +295,7 @@ int vu_k_softmax_dropout(int dtype, void* S, long long rows, int N, int ld, vu_r
   const long long grid = (rows + 3) / 4;
   VU_REQUIRE(grid < 2147483647LL, "vu_softmax_dropout: too many rows");
   VU_DISPATCH_T(dtype, hipLaunchKernelGGL((softmax_dropout_kernel<T>), dim3((unsigned)grid), dim3(256), 0, st, (T*)S, rows, N, ld, rng);)
+  if (vu_prof_on()) vu_prof_note("softmax_dropout_kernel", 0.0, (double)rows * N * 2 * (dtype == 0 ? 4.0 : 2.0));
   return vu_check_launch("vu_softmax_dropout");
 }
 
@@ -605,6 +610,7 @@ int vu_k_mix_stats(int dtype, const void* Ps, const float* W, const float* c, fl
                    int B, int H, int N, int ld, float inv_keep, hipStream_t st) {
   VU_REQUIRE(ld % 4 == 0, "mix_stats: ld %% 4");
   VU_HEADS(H, VU_DISPATCH_T(dtype, hipLaunchKernelGGL((mix_stats_kernel<T, HH>), dim3(nblocks), dim3(256), 0, st, (const T*)Ps, W, c, partials, B, N, ld, inv_keep);))
+  if (vu_prof_on()) vu_prof_note("mix_stats_kernel", 0.0, (double)B * H * N * N * (dtype == 0 ? 4.0 : 2.0));
   return vu_check_launch("vu_mix_stats");
 }
 int vu_k_bn_finalize(const float* partials, int nblocks, const float* W, const float* c, const float* gamma,
@@ -619,12 +625,14 @@ int vu_k_mix_apply(int dtype, const void* Ps, void* Ahat, const float* stats, in
   const long long total = (long long)B * N * (ld / 4);
   const int grid = grid_for(total, 256, 256 * 32);
   VU_HEADS(H, VU_DISPATCH_T(dtype, hipLaunchKernelGGL((mix_apply_kernel<T, HH>), dim3(grid), dim3(256), 0, st, (const T*)Ps, (T*)Ahat, stats, B, N, ld, inv_keep);))
+  if (vu_prof_on()) vu_prof_note("mix_apply_kernel", 0.0, (double)B * H * N * N * 2 * (dtype == 0 ? 4.0 : 2.0));
   return vu_check_launch("vu_mix_apply");
 }
 int vu_k_bn_bwd_stats(int dtype, const void* Ps, const void* dAhat, const float* W, const float* c,
                       const float* stats, float* partials, int nblocks, int B, int H, int N, int ld,
                       float inv_keep, hipStream_t st) {
   VU_HEADS(H, VU_DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_stats_kernel<T, HH>), dim3(nblocks), dim3(256), 0, st, (const T*)Ps, (const T*)dAhat, W, c, stats, partials, B, N, ld, inv_keep);))
+  if (vu_prof_on()) vu_prof_note("bn_bwd_stats_kernel", 0.0, (double)B * H * N * N * 2 * (dtype == 0 ? 4.0 : 2.0));
   return vu_check_launch("vu_bn_bwd_stats");
 }
 int vu_k_bn_bwd_finalize(const float* partials, int nblocks, float* stats, float* dgamma, float* dbeta, int H,
@@ -639,6 +647,7 @@ int vu_k_map_bwd(int dtype, const void* Ps, void* dAhat_dS, const float* W, cons
   long long grid = (rows + 3) / 4;
   if (grid > 256 * 8) grid = 256 * 8;
   VU_HEADS(H, VU_DISPATCH_T(dtype, hipLaunchKernelGGL((map_bwd_kernel<T, HH>), dim3((unsigned)grid), dim3(256), 0, st, (const T*)Ps, (T*)dAhat_dS, W, c, gamma, stats, dW, dc, rows, N, ld, inv_keep, scale);))
+  if (vu_prof_on()) vu_prof_note("map_bwd_kernel", 0.0, (double)B * H * N * N * 3 * (dtype == 0 ? 4.0 : 2.0));
   return vu_check_launch("vu_map_bwd");
 }
 
@@ -744,6 +753,7 @@ int vu_k_add_ln_fwd(int dtype, const void* a, const void* x, void* z, const floa
   VU_DISPATCH_T(dtype,
     hipLaunchKernelGGL((add_ln_stats_kernel<T>), dim3(nch, B), dim3(256), 0, st, (const T*)a, (const T*)x, (T*)z, partials, P);
     hipLaunchKernelGGL((ln_apply_kernel<T>), dim3(nch, B), dim3(256), 0, st, (const T*)z, w, bias, (T*)y, partials, stats, P, eps);)
+  if (vu_prof_on()) vu_prof_note("add_ln_fwd(2 kernels)", 0.0, (double)B * P * 5 * (dtype == 0 ? 4.0 : 2.0) + (double)P * 8);
   return vu_check_launch("vu_add_ln_fwd");
 }
 
@@ -842,6 +852,7 @@ int vu_k_ln_bwd(int dtype, const void* dy, const void* z, const float* w, const 
   VU_DISPATCH_T(dtype,
     hipLaunchKernelGGL((ln_bwd_stats_kernel<T>), dim3(nbch), dim3(256), 0, st, (const T*)dy, (const T*)z, w, stats, dw, db, partials2, B, P);
     hipLaunchKernelGGL((ln_bwd_apply_kernel<T>), dim3(nch, B), dim3(256), 0, st, (const T*)dy, (const T*)z, w, stats, partials2, nbch, (T*)dz, (T*)dz_drop, rng, P);)
+  if (vu_prof_on()) vu_prof_note("ln_bwd(2 kernels)", 0.0, (double)B * P * 5 * (dtype == 0 ? 4.0 : 2.0) + (double)P * 24);
   return vu_check_launch("vu_ln_bwd");
 }
 
@@ -870,6 +881,7 @@ int vu_k_colsum(int dtype, const void* in, float* out, long long rows, int ncols
   long long rpb = vu_cdiv64(rows, gy); if (rpb < 16) rpb = 16;
   gy = (int)vu_cdiv64(rows, rpb);
   VU_DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_kernel<T>), dim3(gx, gy), dim3(256), 0, st, (const T*)in, out, rows, ncols, ld, rpb);)
+  if (vu_prof_on()) vu_prof_note("colsum_kernel", 0.0, (double)rows * ncols * (dtype == 0 ? 4.0 : 2.0));
   return vu_check_launch("vu_colsum");
 }
 
@@ -887,6 +899,7 @@ int vu_k_dropout(int dtype, const void* in, void* out, long long n, vu_rng rng, 
   VU_REQUIRE(n % 4 == 0, "dropout: n %% 4");
   if (n == 0) return VU_OK;
   VU_DISPATCH_T(dtype, hipLaunchKernelGGL((dropout_kernel<T>), dim3(grid_for(n / 4)), dim3(256), 0, st, (const T*)in, (T*)out, n / 4, rng);)
+  if (vu_prof_on()) vu_prof_note("dropout_kernel", 0.0, (double)n * 2 * (dtype == 0 ? 4.0 : 2.0));
   return vu_check_launch("vu_dropout");
 }
 
@@ -903,6 +916,7 @@ int vu_k_add(int dtype, const void* a, const void* b, void* out, long long n, hi
   VU_REQUIRE(n % 4 == 0, "add: n %% 4");
   if (n == 0) return VU_OK;
   VU_DISPATCH_T(dtype, hipLaunchKernelGGL((add_kernel<T>), dim3(grid_for(n / 4)), dim3(256), 0, st, (const T*)a, (const T*)b, (T*)out, n / 4);)
+  if (vu_prof_on()) vu_prof_note("add_kernel", 0.0, (double)n * 3 * (dtype == 0 ? 4.0 : 2.0));
   return vu_check_launch("vu_add");
 }
 
@@ -979,6 +993,7 @@ int vu_k_adamw(float* p, const float* g, float* m, float* v, void* shadow_bf16, 
   VU_REQUIRE(n % 4 == 0, "adamw: arena length must be a multiple of 4 (pad the arena)");
   hipLaunchKernelGGL(adamw_step_kernel, dim3(1), dim3(1), 0, st, step);
   hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4, 256, 256 * 8)), dim3(256), 0, st, p, g, m, v, (bf16_t*)shadow_bf16, n / 4, hyper, step, gscale);
+  if (vu_prof_on()) vu_prof_note("adamw_kernel", 0.0, (double)n * 30);
   return vu_check_launch("vu_adamw");
 }
 

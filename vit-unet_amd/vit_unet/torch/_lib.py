@@ -76,6 +76,8 @@ SIGNATURES = {
     "vu_mse_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _f, _vp]),
     "vu_adamw": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _vp, _vp, _f, _vp]),
     "vu_cast_bf16": (_i, [_vp, _vp, _ll, _vp]),
+    "vu_prof_enable": (_i, [_vp]),
+    "vu_prof_report": (C.c_char_p, []),
 }
 
 _lib: Optional[C.CDLL] = None
