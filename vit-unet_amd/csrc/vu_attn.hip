@@ -1,0 +1,229 @@
+// Fused re-attention kernels for gfx950.
+//
+// attn_scores_kernel (K6+K7+K8, model.py:155-157): one workgroup = 64 query rows of one (batch,
+// head); the head's whole K (N x d, always 2*P/h bytes = 37.6 KB in bf16 for 224x224x3) is staged
+// in LDS once, each wave computes its 16 x N logits tile with MFMA into registers (N <= 784:
+// 49 accumulator tiles), does the row softmax with 16-lane shuffles, draws the dropout mask from
+// the counter hash and writes the sign-tagged probabilities - the (B,h,N,N) logits never touch
+// HBM.  Algorithmic traffic: one write of the map (E*|T|) + q, k reads.
+#include "vu_kernels.h"
+
+namespace {
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+  static constexpr int KS = 32;          // k per MFMA
+  static constexpr int FE = 8;           // elements per lane fragment
+  typedef bf16x8 Frag;
+  static __device__ __forceinline__ Frag zero() { return Frag{0, 0, 0, 0, 0, 0, 0, 0}; }
+  static __device__ __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  static constexpr int KS = 4;
+  static constexpr int FE = 1;
+  typedef float Frag;
+  static __device__ __forceinline__ Frag zero() { return 0.f; }
+  static __device__ __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+};
+
+// fragment of a k-contiguous row: FE consecutive elements starting at p (k bounds handled by caller)
+template <typename T>
+__device__ __forceinline__ typename Mma<T>::Frag load_frag(const T* p, int kvalid, bool vec) {
+  typedef typename Mma<T>::Frag Frag;
+  constexpr int FE = Mma<T>::FE;
+  if constexpr (FE == 1) {
+    return kvalid > 0 ? (float)p[0] : 0.f;
+  } else {
+    if (vec && kvalid >= FE) return *reinterpret_cast<const Frag*>(p);
+    Frag f = Mma<T>::zero();
+#pragma unroll
+    for (int e = 0; e < FE; ++e)
+      if (e < kvalid) f[e] = p[e];
+    return f;
+  }
+}
+
+// DP = head dim padded to a multiple of 32 ; NT = max 16-column tiles (N <= 16*NT)
+template <typename T, int NT, int DP, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void attn_scores_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                          T* __restrict__ Ps, int N, int D, int H, int d, int ld,
+                                                          float scale, vu_rng rng_in) {
+  typedef Mma<T> MM;
+  typedef typename MM::Frag Frag;
+  constexpr int KSTEPS = DP / MM::KS;
+  constexpr int LDK = DP + (sizeof(T) == 2 ? 8 : 4);   // LDS row stride (elements)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* Ks = reinterpret_cast<T*>(smem_raw);
+  const vu_rng rng = vu_rng_resolve(rng_in);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int bz = blockIdx.y, b = bz / H, g = bz % H;
+  const T* qb = q + (long long)b * N * D + g * d;
+  const T* kb = k + (long long)b * N * D + g * d;
+  const bool vec = (d % (16 / (int)sizeof(T)) == 0);   // head slices 16-byte aligned
+
+  // ---- stage K_g (N x d, zero-padded to DP columns) in LDS ---------------------------------
+  {
+    constexpr int VE = 16 / sizeof(T);
+    const int chunks_per_row = DP / VE;
+    const int total = N * chunks_per_row;
+    for (int c = tid; c < total; c += WAVES * 64) {
+      const int row = c / chunks_per_row, kc = (c % chunks_per_row) * VE;
+      alignas(16) T tmp[VE];
+      if (vec && kc + VE <= d) {
+        *reinterpret_cast<uint4*>(tmp) = *reinterpret_cast<const uint4*>(kb + (long long)row * D + kc);
+      } else {
+#pragma unroll
+        for (int e = 0; e < VE; ++e) tmp[e] = (kc + e < d) ? kb[(long long)row * D + kc + e] : (T)0.f;
+      }
+      *reinterpret_cast<uint4*>(&Ks[row * LDK + kc]) = *reinterpret_cast<uint4*>(tmp);
+    }
+  }
+  // ---- this wave's q fragments (16 rows x DP) ------------------------------------------------
+  const int i0 = blockIdx.x * (WAVES * 16) + wave * 16;
+  Frag qf[KSTEPS];
+  {
+    const int row = i0 + l15;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      const int k0 = ks * MM::KS + lg * MM::FE;
+      qf[ks] = (row < N) ? load_frag<T>(qb + (long long)row * D + k0, d - k0, vec) : MM::zero();
+    }
+  }
+  __syncthreads();
+
+  const int ntiles = (N + 15) >> 4;
+  f32x4 acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (nt < ntiles) {
+      const int key = nt * 16 + l15;
+      const bool kv = key < N;
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+        Frag kf;
+        if constexpr (MM::FE == 1) kf = kv ? (float)Ks[key * LDK + ks * MM::KS + lg] : 0.f;
+        else kf = kv ? *reinterpret_cast<const Frag*>(&Ks[key * LDK + ks * MM::KS + lg * MM::FE]) : MM::zero();
+        acc[nt] = MM::mma(qf[ks], kf, acc[nt]);
+      }
+    }
+  }
+  // ---- row softmax: lane holds rows lg*4+r (r=0..3), column nt*16+l15 ---------------------------
+  // logits are rounded to the storage type first so that fused and unfused paths agree bit for bit
+  float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    if (nt < ntiles) {
+      const bool cv = nt * 16 + l15 < N;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s = acc[nt][r] * scale;
+        if constexpr (sizeof(T) == 2) s = (float)(bf16_t)s;
+        s = cv ? s : -INFINITY;
+        acc[nt][r] = s;
+        mx[r] = fmaxf(mx[r], s);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) mx[r] = fmaxf(mx[r], __shfl_xor(mx[r], o, 64));
+  }
+  float sum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    if (nt < ntiles) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = __expf(acc[nt][r] - mx[r]);   // exp(-inf) = 0 for masked columns
+        acc[nt][r] = e;
+        sum[r] += e;
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) sum[r] += __shfl_xor(sum[r], o, 64);
+    sum[r] = 1.0f / sum[r];
+  }
+  // ---- dropout + sign-tagged store -------------------------------------------------------------
+  T* pb = Ps + (long long)bz * N * ld;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    if (nt < ntiles) {
+      const int j = nt * 16 + l15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = i0 + lg * 4 + r;
+        if (i < N && j < ld) {
+          float v = 0.f;
+          if (j < N) {
+            v = acc[nt][r] * sum[r];
+            if (rng.thr && !vu_keep(rng, ((uint64_t)bz * N + i) * (uint64_t)N + j)) v = -v;
+          }
+          vu_st(pb + (long long)i * ld + j, v);
+        }
+      }
+    }
+  }
+}
+
+template <typename T, int NT, int DP>
+int launch_scores(const T* q, const T* k, T* Ps, int B, int N, int D, int H, int ld, float scale, vu_rng rng,
+                  hipStream_t st) {
+  const int d = D / H;
+  constexpr int LDK = DP + (sizeof(T) == 2 ? 8 : 4);
+  const size_t lds = (size_t)N * LDK * sizeof(T);
+  constexpr int WAVES = NT > 13 ? 8 : 4;
+  auto kern = attn_scores_kernel<T, NT, DP, WAVES>;
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { vu_set_error("attn_scores: cannot reserve %zu bytes of LDS", lds); return VU_ELAUNCH; }
+  }
+  dim3 grid((unsigned)((N + WAVES * 16 - 1) / (WAVES * 16)), (unsigned)(B * H));
+  hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, st, q, k, Ps, N, D, H, d, ld, scale, rng);
+  if (vu_prof_on()) vu_prof_note("attn_scores_kernel", 2.0 * B * H * (double)N * N * d,
+                                 ((double)B * H * N * N + 2.0 * B * N * D) * sizeof(T));
+  return vu_check_launch("vu_attn_scores");
+}
+
+template <typename T>
+int dispatch_scores(const void* q, const void* k, void* Ps, int B, int N, int D, int H, int ld, float scale, vu_rng rng,
+                    hipStream_t st) {
+  const int d = D / H;
+  const int dp = (d + 31) / 32 * 32;
+  const int nt = (N + 15) / 16;
+#define VU_SC(NTv, DPv) return launch_scores<T, NTv, DPv>((const T*)q, (const T*)k, (T*)Ps, B, N, D, H, ld, scale, rng, st)
+  if (nt <= 4) {
+    if (dp == 32) VU_SC(4, 32); if (dp == 64) VU_SC(4, 64); if (dp == 96) VU_SC(4, 96); if (dp == 128) VU_SC(4, 128);
+    if (dp == 192) VU_SC(4, 192); if (dp == 384) VU_SC(4, 384);
+  } else if (nt <= 13) {
+    if (dp == 32) VU_SC(13, 32); if (dp == 64) VU_SC(13, 64); if (dp == 96) VU_SC(13, 96); if (dp == 128) VU_SC(13, 128);
+  } else if (nt <= 49) {
+    if (dp == 32) VU_SC(49, 32); if (dp == 64) VU_SC(49, 64);
+  }
+#undef VU_SC
+  return 1;   // shape not covered: the caller falls back to GEMM + softmax kernels
+}
+
+}  // namespace
+
+// returns VU_OK, a negative error, or 1 when the shape is not covered by the fused kernel
+int vu_k_attn_scores(int dtype, const void* q, const void* k, void* Ps, int B, int N, int D, int H, int ld, float scale,
+                     vu_rng rng, hipStream_t st) {
+  const int d = D / H;
+  const int dp = (d + 31) / 32 * 32;
+  const size_t es = dtype == 0 ? 4 : 2;
+  const size_t lds = (size_t)N * (dp + (es == 2 ? 8 : 4)) * es;
+  if (lds > 150 * 1024) return 1;
+  if (dtype == 0) return dispatch_scores<float>(q, k, Ps, B, N, D, H, ld, scale, rng, st);
+  return dispatch_scores<bf16_t>(q, k, Ps, B, N, D, H, ld, scale, rng, st);
+}

@@ -32,6 +32,7 @@ struct vu_gemm_args {
   int dropout;         // apply dropout(rng) to result; element index = (z*M + m)*N + n
   vu_rng rng;
   int vecA, vecB;      // 16-byte vector loads legal for A / B
+  int ksplit;          // >1: K is split over blockIdx.z and C is accumulated with float atomics
 };
 
 template <typename T> struct vu_vec { static constexpr int N = 16 / sizeof(T); };
@@ -143,9 +144,15 @@ __global__ __launch_bounds__(256) void vu_gemm_kernel(const vu_gemm_args g) {
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int l15 = lane & 15, lg = lane >> 4;
-  const int nk = (g.K + BK - 1) / BK;
-  load_tile(0);
-  for (int kt = 0; kt < nk; ++kt) {
+  const int nk_all = (g.K + BK - 1) / BK;
+  int kt0 = 0, nk = nk_all;
+  if (g.ksplit > 1) {   // split-K: this block owns k-tiles [kt0, nk)
+    const int per = (nk_all + g.ksplit - 1) / g.ksplit;
+    kt0 = blockIdx.z * per;
+    nk = kt0 + per < nk_all ? kt0 + per : nk_all;
+  }
+  if (kt0 < nk) load_tile(kt0 * BK);
+  for (int kt = kt0; kt < nk; ++kt) {
     store_tile();
     __syncthreads();
     if (kt + 1 < nk) load_tile((kt + 1) * BK);
@@ -224,7 +231,7 @@ __global__ __launch_bounds__(256) void vu_gemm_kernel(const vu_gemm_args g) {
     for (int j = 0; j < TN; ++j) {
       const int n = n_base + wn * (BN / 2) + j * 16 + l15;
       if (n >= g.N) continue;
-      const float bv = g.bias ? g.bias[n] : 0.f;
+      const float bv = (g.bias && blockIdx.z == 0) ? g.bias[n] : 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int m = m_base + wm * (BM / 2) + i * 16 + lg * 4 + r;
@@ -240,7 +247,7 @@ __global__ __launch_bounds__(256) void vu_gemm_kernel(const vu_gemm_args g) {
         if (addb) v += vu_ld(addb + o);
         if constexpr (sizeof(TC) == 4) {
           float* cp = (float*)Cb + o;
-          if (g.accumulate) *cp += v; else *cp = v;
+          if (g.ksplit > 1) atomicAdd(cp, v); else if (g.accumulate) *cp += v; else *cp = v;
         } else {
           vu_st((T*)Cb + o, v);
         }

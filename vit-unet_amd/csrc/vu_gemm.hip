@@ -1,15 +1,31 @@
 // GEMM instantiations + host launcher.
 #include <stdio.h>
+#include <stdlib.h>
 #include "vu_gemm.h"
 
 template <typename T, typename TC, bool TA, bool TB, int BM, int BN>
 static int launch_one(const vu_gemm_args& g, hipStream_t st) {
-  dim3 grid((unsigned)(vu_cdiv(g.M, BM) * vu_cdiv(g.N, BN)), (unsigned)(g.Z1 * g.Z2));
-  hipLaunchKernelGGL((vu_gemm_kernel<T, TC, TA, TB, BM, BN>), grid, dim3(256), 0, st, g);
+  vu_gemm_args ga = g;
+  const long long blocks = (long long)vu_cdiv(g.M, BM) * vu_cdiv(g.N, BN) * g.Z1 * g.Z2;
+  ga.ksplit = 1;
+  if (sizeof(TC) == 4 && g.accumulate && !g.act && !g.dropout && !g.addend && blocks < 512) {
+    // small output, long K (weight gradients over B*N rows): split K so the chip is filled
+    int want = (int)((1024 + blocks - 1) / blocks);
+    const int maxs = vu_cdiv(g.K, 256);
+    ga.ksplit = want < maxs ? want : maxs;
+    if (ga.ksplit < 1) ga.ksplit = 1;
+  }
+  dim3 grid((unsigned)(vu_cdiv(g.M, BM) * vu_cdiv(g.N, BN)), (unsigned)(g.Z1 * g.Z2), (unsigned)ga.ksplit);
+  hipLaunchKernelGGL((vu_gemm_kernel<T, TC, TA, TB, BM, BN>), grid, dim3(256), 0, st, ga);
   if (vu_prof_on()) {
     char tag[96];
-    snprintf(tag, sizeof(tag), "vu_gemm_kernel<%s,%s,%c%c,%dx%d>", sizeof(T) == 2 ? "bf16" : "f32",
-             sizeof(TC) == 2 ? "bf16" : "f32", TA ? 'T' : 'N', TB ? 'T' : 'N', BM, BN);
+    static const bool shapes = getenv("VU_PROF_SHAPES") != nullptr;
+    if (shapes)
+      snprintf(tag, sizeof(tag), "gemm<%s,%s,%c%c,%dx%d> M%d N%d K%d Z%d s%d", sizeof(T) == 2 ? "bf16" : "f32",
+               sizeof(TC) == 2 ? "bf16" : "f32", TA ? 'T' : 'N', TB ? 'T' : 'N', BM, BN, g.M, g.N, g.K, g.Z1 * g.Z2, ga.ksplit);
+    else
+      snprintf(tag, sizeof(tag), "vu_gemm_kernel<%s,%s,%c%c,%dx%d>", sizeof(T) == 2 ? "bf16" : "f32",
+               sizeof(TC) == 2 ? "bf16" : "f32", TA ? 'T' : 'N', TB ? 'T' : 'N', BM, BN);
     const double Z = (double)g.Z1 * g.Z2;
     vu_prof_note(tag, 2.0 * g.M * (double)g.N * g.K * Z,
                  Z * (((double)g.M * g.K + (double)g.K * g.N) * sizeof(T) + (double)g.M * g.N * sizeof(TC)));

@@ -26,6 +26,11 @@ int vu_k_conv3x3_wgrad(int dtype, int dout_f32, const void* dout, const void* in
 int vu_k_softmax_dropout(int dtype, void* S, long long rows, int N, int ld, vu_rng rng,
                          hipStream_t st);
 
+// fused K6+K7+K8 (vu_attn.hip): logits by MFMA, row softmax, dropout, sign-tagged store; the
+// logits never reach HBM.  Returns 1 when the shape is not covered (caller falls back).
+int vu_k_attn_scores(int dtype, const void* q, const void* k, void* Ps, int B, int N, int D, int H, int ld,
+                     float scale, vu_rng rng, hipStream_t st);
+
 // K9+K10: head mixing + BatchNorm on sign-tagged maps (B,H,N,ld).
 // stats buffer layout (floats): Wf[H*H] cf[H] mean[H] rstd[H] m1[H] m2[H]
 #define VU_BN_STATS_FLOATS(H) ((H) * (H) + 5 * (H))

@@ -172,7 +172,11 @@ int attn_forward(const AttnDims& d, const vu_attn_params& p, const void* xq, con
   VU_TRY(vu_k_conv3x3_fwd(dt, 0, xq, p.wq, nullptr, a.q, npatch, d.C, d.s, st));
   VU_TRY(vu_k_conv3x3_fwd(dt, 0, xkv, p.wk, nullptr, a.k, npatch, d.C, d.s, st));
   VU_TRY(vu_k_conv3x3_fwd(dt, 0, xkv, p.wv, nullptr, a.v, npatch, d.C, d.s, st));
-  {  // S = scale * q k^T  (model.py:155)
+  vu_rng ra = vu_make_rng(seed, 2 * stream_id, training ? attn_drop : 0.f);
+  ra.salt = salt;
+  int fused = vu_k_attn_scores(dt, a.q, a.k, a.Ps, B, N, D, H, ld, 1.0f / sqrtf((float)dh), ra, st);
+  if (fused < 0) return fused;
+  if (fused == 1) {  // shape outside the fused kernel: S = scale * q k^T (model.py:155), then softmax + dropout
     vu_gemm_args g;
     memset(&g, 0, sizeof(g));
     g.A = a.q; g.B = a.k; g.C = a.Ps; g.M = N; g.N = N; g.K = dh;
@@ -181,10 +185,8 @@ int attn_forward(const AttnDims& d, const vu_attn_params& p, const void* xq, con
     g.sC1 = (long long)H * N * ld; g.sC2 = (long long)N * ld;
     g.alpha = 1.0f / sqrtf((float)dh);
     VU_TRY(vu_gemm_launch(dt, 0, g, st));
+    VU_TRY(vu_k_softmax_dropout(dt, a.Ps, (long long)B * H * N, N, ld, ra, st));
   }
-  vu_rng ra = vu_make_rng(seed, 2 * stream_id, training ? attn_drop : 0.f);
-  ra.salt = salt;
-  VU_TRY(vu_k_softmax_dropout(dt, a.Ps, (long long)B * H * N, N, ld, ra, st));
   const double count = (double)B * N * N;
   if (training) VU_TRY(vu_k_mix_stats(dt, a.Ps, p.mix_w, p.mix_b, partials, stats_blocks(d), B, H, N, ld, ra.inv_keep, st));
   VU_TRY(vu_k_bn_finalize(partials, stats_blocks(d), p.mix_w, p.mix_b, p.bn_w, p.bn_b, p.run_mean, p.run_var,

@@ -20,6 +20,32 @@ from . import _lib
 from ._lib import check, lib, ptr, stream_ptr
 
 
+def dp_buckets(table, total: int):
+    """Three contiguous arena ranges in backward order: [Decoders..end], [BottleNeck], [start..Encoders].
+    `table` = [(name, offset, shape, bn_index)] from vu_model_param_table."""
+    def first(prefix):
+        for n, o, *_ in table:
+            if n.startswith(prefix):
+                return o
+        return None
+    o_dec = first("Decoders.")
+    if o_dec is None:
+        o_dec = first("conv2d.")
+    if o_dec is None:
+        o_dec = total
+    o_bot = first("BottleNeck.")
+    if o_bot is None:
+        o_bot = o_dec
+    return [(o_dec, total), (o_bot, o_dec), (0, o_bot)]
+
+
+def allreduce_bucket(flat: torch.Tensor, lo: int, hi: int, group=None):
+    """Sum one bucket of the flat gradient arena over the data-parallel group (RCCL on GPU
+    tensors, gloo on CPU tensors in the tests).  The 1/world average is applied by AdamW."""
+    if hi > lo:
+        torch.distributed.all_reduce(flat[lo:hi], group=group)
+
+
 class TrainStep:
     def __init__(self, model, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
                  process_group=None, seed: int = 0, overlap: bool = True):
@@ -51,22 +77,7 @@ class TrainStep:
         self.hyper[0] = lr
 
     def _make_buckets(self):
-        """Three contiguous arena ranges in backward order: [Decoders..end], [BottleNeck], [start..Encoders]."""
-        names = [t[0] for t in self.model._table]
-        offs = [t[1] for t in self.model._table]
-        total = self.model._arena.numel()
-
-        def first(prefix):
-            for n, o in zip(names, offs):
-                if n.startswith(prefix):
-                    return o
-            return None
-        o_bot, o_dec = first("BottleNeck."), first("Decoders.")
-        if o_dec is None:
-            o_dec = first("conv2d.") or total
-        if o_bot is None:
-            o_bot = o_dec
-        return [(o_dec, total), (o_bot, o_dec), (0, o_bot)]
+        return dp_buckets(self.model._table, self.model._arena.numel())
 
     # ---- the step ----------------------------------------------------------------------------
     def _enqueue(self, x, y, out, dout):
@@ -90,9 +101,9 @@ class TrainStep:
                 if self.overlap:
                     self.comm_stream.wait_stream(cur)
                     with torch.cuda.stream(self.comm_stream):
-                        torch.distributed.all_reduce(m._garena[lo:hi], group=self.pg)
+                        allreduce_bucket(m._garena, lo, hi, self.pg)
                 else:
-                    torch.distributed.all_reduce(m._garena[lo:hi], group=self.pg)
+                    allreduce_bucket(m._garena, lo, hi, self.pg)
         if self.world > 1 and self.overlap:
             cur.wait_stream(self.comm_stream)
         check(L.vu_adamw(ptr(m._arena), ptr(m._garena), ptr(self.m), ptr(self.v), ptr(m._shadow), m._arena.numel(),
