@@ -227,3 +227,154 @@ int vu_k_attn_scores(int dtype, const void* q, const void* k, void* Ps, int B, i
   if (dtype == 0) return dispatch_scores<float>(q, k, Ps, B, N, D, H, ld, scale, rng, st);
   return dispatch_scores<bf16_t>(q, k, Ps, B, N, D, H, ld, scale, rng, st);
 }
+
+// =============================================================================================
+// map_bwd_row_kernel: backward of BatchNorm -> head mix -> dropout -> softmax on one map row for
+// ALL heads, with the row held in registers (one read of the tagged probabilities and of dAhat,
+// one write of dS over dAhat).  TPR threads per row, each owning 4 consecutive columns; a block
+// of 256 threads handles 256/TPR rows per iteration and walks the rows persistently so that the
+// head-mix weight gradient (h x h) stays in registers until one final reduction.
+// =============================================================================================
+namespace {
+
+template <typename T, int H, int TPR>
+__global__ __launch_bounds__(256) void map_bwd_row_kernel(const T* __restrict__ Ps, T* dA, const float* __restrict__ W,
+                                                          const float* __restrict__ c, const float* __restrict__ gamma,
+                                                          const float* __restrict__ stats, float* dW, float* dc,
+                                                          long long rows, int N, int ld, float inv_keep, float scale) {
+  constexpr int RPB = 256 / TPR;
+  __shared__ float sW[H * H];
+  __shared__ float sX[H * H + H];
+  __shared__ float sG[3 * H];
+  __shared__ float redd[4][H];
+  __shared__ float red[4][H * H + H];
+  for (int i = threadIdx.x; i < H * H; i += blockDim.x) { sW[i] = W[i]; sX[i] = W[i] * stats[H * H + 2 * H + i / H]; }
+  for (int i = threadIdx.x; i < H; i += blockDim.x) {
+    sX[H * H + i] = (c[i] - stats[H * H + H + i]) * stats[H * H + 2 * H + i];
+    sG[i] = gamma[i] * stats[H * H + 2 * H + i];
+    sG[H + i] = stats[H * H + 3 * H + i];
+    sG[2 * H + i] = stats[H * H + 4 * H + i];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int rsub = threadIdx.x / TPR, t = threadIdx.x % TPR;
+  const int jc = t * 4;
+  const long long hs = (long long)N * ld;
+  float aW[H * H], ac[H];
+#pragma unroll
+  for (int i = 0; i < H * H; ++i) aW[i] = 0.f;
+#pragma unroll
+  for (int i = 0; i < H; ++i) ac[i] = 0.f;
+  const long long nrow_iters = (rows + RPB - 1) / RPB;
+  for (long long it = blockIdx.x; it < nrow_iters; it += gridDim.x) {
+    const long long row = it * RPB + rsub;
+    const bool live = row < rows && jc < ld;
+    const long long b = live ? row / N : 0;
+    const int i = live ? (int)(row - b * N) : 0;
+    const long long off = (b * H * N + i) * (long long)ld + jc;
+    float pv[H][4], dP[H][4];
+    float delta[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) delta[h] = 0.f;
+    if (live) {
+      float dAh[H][4];
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        const vu_f4 v = vu_ld4(Ps + off + h * hs);
+        const vu_f4 d = vu_ld4(dA + off + h * hs);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { pv[h][e] = v.v[e]; dAh[h][e] = d.v[e]; }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool cv = jc + e < N;
+        float pt[H], dAg[H];
+#pragma unroll
+        for (int h = 0; h < H; ++h) pt[h] = pv[h][e] > 0.f ? pv[h][e] * inv_keep : 0.f;
+#pragma unroll
+        for (int g = 0; g < H; ++g) {
+          float xh = sX[H * H + g];
+#pragma unroll
+          for (int h = 0; h < H; ++h) xh += sX[g * H + h] * pt[h];
+          dAg[g] = cv ? sG[g] * (dAh[g][e] - sG[H + g] - xh * sG[2 * H + g]) : 0.f;
+          ac[g] += dAg[g];
+#pragma unroll
+          for (int h = 0; h < H; ++h) aW[g * H + h] += dAg[g] * pt[h];
+        }
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+          float dp = 0.f;
+#pragma unroll
+          for (int g = 0; g < H; ++g) dp += sW[g * H + h] * dAg[g];
+          dp = pv[h][e] > 0.f ? dp * inv_keep : 0.f;
+          dP[h][e] = dp;
+          delta[h] += dp * fabsf(pv[h][e]);
+        }
+      }
+    }
+    // delta[h] = sum over the row
+    if constexpr (TPR == 64) {
+#pragma unroll
+      for (int h = 0; h < H; ++h) delta[h] = vu_wave_sum(delta[h]);
+    } else {
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        const float v = vu_wave_sum(delta[h]);
+        if (lane == 0) redd[wave][h] = v;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int h = 0; h < H; ++h) delta[h] = redd[0][h] + redd[1][h] + redd[2][h] + redd[3][h];
+      __syncthreads();
+    }
+    if (live) {
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        vu_f4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o.v[e] = (jc + e < N) ? fabsf(pv[h][e]) * (dP[h][e] - delta[h]) * scale : 0.f;
+        vu_st4(dA + off + h * hs, o);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < H * H; ++i) { const float v = vu_wave_sum(aW[i]); if (lane == 0) red[wave][i] = v; }
+#pragma unroll
+  for (int i = 0; i < H; ++i) { const float v = vu_wave_sum(ac[i]); if (lane == 0) red[wave][H * H + i] = v; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < H * H + H; i += blockDim.x) {
+    const float v = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+    if (i < H * H) atomicAdd(dW + i, v); else atomicAdd(dc + (i - H * H), v);
+  }
+}
+
+template <typename T, int H>
+int launch_map_bwd_row(const void* Ps, void* dA, const float* W, const float* c, const float* gamma, const float* stats,
+                       float* dW, float* dc, int B, int N, int ld, float inv_keep, float scale, hipStream_t st) {
+  const long long rows = (long long)B * N;
+  if (ld <= 256) {
+    long long grid = (rows + 3) / 4; if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL((map_bwd_row_kernel<T, H, 64>), dim3((unsigned)grid), dim3(256), 0, st, (const T*)Ps, (T*)dA, W, c, gamma,
+                       stats, dW, dc, rows, N, ld, inv_keep, scale);
+  } else {
+    long long grid = rows; if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL((map_bwd_row_kernel<T, H, 256>), dim3((unsigned)grid), dim3(256), 0, st, (const T*)Ps, (T*)dA, W, c, gamma,
+                       stats, dW, dc, rows, N, ld, inv_keep, scale);
+  }
+  if (vu_prof_on()) vu_prof_note("map_bwd_row_kernel", 0.0, (double)B * H * N * N * 3 * sizeof(T));
+  return vu_check_launch("vu_map_bwd");
+}
+
+}  // namespace
+
+int vu_k_map_bwd(int dtype, const void* Ps, void* dAhat_dS, const float* W, const float* c, const float* gamma,
+                 const float* stats, float* dW, float* dc, int B, int H, int N, int ld, float inv_keep, float scale,
+                 hipStream_t st) {
+  if (ld > 1024) return vu_k_map_bwd_2sweep(dtype, Ps, dAhat_dS, W, c, gamma, stats, dW, dc, B, H, N, ld, inv_keep, scale, st);
+#define VU_MB(Tt, Hh) return launch_map_bwd_row<Tt, Hh>(Ps, dAhat_dS, W, c, gamma, stats, dW, dc, B, N, ld, inv_keep, scale, st)
+  if (dtype == 0) { switch (H) { case 1: VU_MB(float, 1); case 2: VU_MB(float, 2); case 4: VU_MB(float, 4); case 8: VU_MB(float, 8); } }
+  else { switch (H) { case 1: VU_MB(bf16_t, 1); case 2: VU_MB(bf16_t, 2); case 4: VU_MB(bf16_t, 4); case 8: VU_MB(bf16_t, 8); } }
+#undef VU_MB
+  vu_set_error("map_bwd: num_heads %d not supported", H);
+  return VU_EUNSUPPORTED;
+}

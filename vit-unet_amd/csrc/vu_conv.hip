@@ -1,0 +1,339 @@
+// K4 / K15: 3x3 convolutions with zero halo at the PATCH border (model.py:137-139,152-154 per
+// patch; :370,:428 whole image = one patch of size im).  HBM-bound stencils (K = 9C <= 27 taps,
+// C <= 4 outputs: not GEMM-shaped).  One thread owns 4 consecutive pixels of a patch row and
+// loads each channel's 3x6 window with three unconditional loads per row (one 4-vector + two
+// clamped halo scalars) so all loads of a thread are in flight together; q, k and v are produced
+// from one read of x; their data gradients are summed in one kernel.
+#include "vu_kernels.h"
+
+namespace {
+
+// window of rows y-1..y+1, columns x0-1..x0+4 of one s x s channel plane; zero outside.
+template <typename T>
+__device__ __forceinline__ void load_win(const T* __restrict__ plane, int s, int y, int x0, float (&w)[3][6]) {
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy) {
+    const int yy = y + dy - 1;
+    const bool rv = (yy >= 0) && (yy < s);
+    const int yc = yy < 0 ? 0 : (yy >= s ? s - 1 : yy);
+    const T* rp = plane + yc * s + x0;
+    const vu_f4 c = vu_ld4(rp);
+    const bool lv = x0 > 0, rr = x0 + 4 < s;
+    const float l = vu_ld(rp - (lv ? 1 : 0));
+    const float r = vu_ld(rp + (rr ? 4 : 3));
+    w[dy][0] = (rv && lv) ? l : 0.f;
+    w[dy][1] = rv ? c.v[0] : 0.f;
+    w[dy][2] = rv ? c.v[1] : 0.f;
+    w[dy][3] = rv ? c.v[2] : 0.f;
+    w[dy][4] = rv ? c.v[3] : 0.f;
+    w[dy][5] = (rv && rr) ? r : 0.f;
+  }
+}
+
+__device__ __forceinline__ void quad_coords(long long qid, int s, long long& patch, int& y, int& x0) {
+  const int qpp = (s * s) >> 2;   // quads per channel plane
+  patch = qid / qpp;
+  const int rem = (int)(qid - patch * qpp) << 2;
+  y = rem / s;
+  x0 = rem - y * s;
+}
+
+// ---- forward ---------------------------------------------------------------------------------
+// NOUT = 1: out0 = conv(in0, w0) (+bias)      NOUT = 3: q = conv(in0,w0), k = conv(in1,w1), v = conv(in1,w2)
+template <typename TI, typename TO, int C, int NOUT>
+__global__ __launch_bounds__(256) void conv_fwd_kernel(const TI* __restrict__ in0, const TI* __restrict__ in1,
+                                                       const float* __restrict__ w0, const float* __restrict__ w1,
+                                                       const float* __restrict__ w2, const float* __restrict__ bias,
+                                                       TO* __restrict__ o0, TO* __restrict__ o1, TO* __restrict__ o2,
+                                                       long long nquads, int s) {
+  __shared__ float ws[NOUT][C * C * 9];
+  __shared__ float bs[C];
+  for (int i = threadIdx.x; i < C * C * 9; i += blockDim.x) {
+    ws[0][i] = w0[i];
+    if (NOUT == 3) { ws[1][i] = w1[i]; ws[2][i] = w2[i]; }
+  }
+  if (threadIdx.x < C) bs[threadIdx.x] = bias ? bias[threadIdx.x] : 0.f;
+  __syncthreads();
+  const int ss = s * s;
+  const bool same = (in0 == in1);
+  for (long long qid = blockIdx.x * (long long)blockDim.x + threadIdx.x; qid < nquads;
+       qid += (long long)gridDim.x * blockDim.x) {
+    long long patch; int y, x0;
+    quad_coords(qid, s, patch, y, x0);
+    const long long pbase = patch * (long long)(C * ss);
+    const long long obase = pbase + y * s + x0;
+    float win[C][3][6];
+#pragma unroll
+    for (int ci = 0; ci < C; ++ci) load_win(in0 + pbase + ci * ss, s, y, x0, win[ci]);
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+      if (NOUT == 3 && o == 1 && !same) {
+#pragma unroll
+        for (int ci = 0; ci < C; ++ci) load_win(in1 + pbase + ci * ss, s, y, x0, win[ci]);
+      }
+      TO* op = o == 0 ? o0 : (o == 1 ? o1 : o2);
+#pragma unroll
+      for (int co = 0; co < C; ++co) {
+        vu_f4 acc;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc.v[i] = bs[co];
+#pragma unroll
+        for (int ci = 0; ci < C; ++ci)
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+              const float wv = ws[o][(co * C + ci) * 9 + ky * 3 + kx];
+#pragma unroll
+              for (int i = 0; i < 4; ++i) acc.v[i] += wv * win[ci][ky][i + kx];
+            }
+        vu_st4(op + obase + co * ss, acc);
+      }
+    }
+  }
+}
+
+// ---- data gradient -----------------------------------------------------------------------------
+// dIn[ci,y,x] = sum_co,ky,kx w[co][ci][ky][kx] * dOut[co, y-ky+1, x-kx+1]
+// NIN = 1: din0 = convT(d0,w0) + add0
+// NIN = 3: same input:  din0 = convT(d0,w0)+convT(d1,w1)+convT(d2,w2) + add0
+//          cross:       din0 = convT(d0,w0) + add0 ; din1 = convT(d1,w1)+convT(d2,w2) + add1
+template <typename TDO, typename T, int C, int NIN>
+__global__ __launch_bounds__(256) void conv_dgrad_kernel(const TDO* __restrict__ d0, const TDO* __restrict__ d1,
+                                                         const TDO* __restrict__ d2, const float* __restrict__ w0,
+                                                         const float* __restrict__ w1, const float* __restrict__ w2,
+                                                         const T* add0, const T* add1, T* din0, T* din1,
+                                                         long long nquads, int s) {
+  __shared__ float ws[NIN][C * C * 9];
+  for (int i = threadIdx.x; i < C * C * 9; i += blockDim.x) {
+    ws[0][i] = w0[i];
+    if (NIN == 3) { ws[1][i] = w1[i]; ws[2][i] = w2[i]; }
+  }
+  __syncthreads();
+  const int ss = s * s;
+  const bool cross = (NIN == 3) && (din1 != nullptr);
+  for (long long qid = blockIdx.x * (long long)blockDim.x + threadIdx.x; qid < nquads;
+       qid += (long long)gridDim.x * blockDim.x) {
+    long long patch; int y, x0;
+    quad_coords(qid, s, patch, y, x0);
+    const long long pbase = patch * (long long)(C * ss);
+    const long long obase = pbase + y * s + x0;
+    float acc0[C][4], acc1[C][4];
+#pragma unroll
+    for (int ci = 0; ci < C; ++ci) {
+      vu_f4 a0 = {{0.f, 0.f, 0.f, 0.f}}, a1 = {{0.f, 0.f, 0.f, 0.f}};
+      if (add0) a0 = vu_ld4(add0 + obase + ci * ss);
+      if (cross && add1) a1 = vu_ld4(add1 + obase + ci * ss);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { acc0[ci][i] = a0.v[i]; acc1[ci][i] = a1.v[i]; }
+    }
+#pragma unroll
+    for (int t = 0; t < NIN; ++t) {
+      const TDO* dp = t == 0 ? d0 : (t == 1 ? d1 : d2);
+      float win[C][3][6];
+#pragma unroll
+      for (int co = 0; co < C; ++co) load_win(dp + pbase + co * ss, s, y, x0, win[co]);
+      const bool to1 = cross && t > 0;
+      float tmp[C][4];
+#pragma unroll
+      for (int ci = 0; ci < C; ++ci) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tmp[ci][i] = 0.f;
+#pragma unroll
+        for (int co = 0; co < C; ++co)
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+              const float wv = ws[t][(co * C + ci) * 9 + ky * 3 + kx];
+#pragma unroll
+              for (int i = 0; i < 4; ++i) tmp[ci][i] += wv * win[co][2 - ky][i + 2 - kx];
+            }
+      }
+#pragma unroll
+      for (int ci = 0; ci < C; ++ci)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (to1) acc1[ci][i] += tmp[ci][i]; else acc0[ci][i] += tmp[ci][i];
+        }
+    }
+#pragma unroll
+    for (int ci = 0; ci < C; ++ci) {
+      vu_f4 o;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o.v[i] = acc0[ci][i];
+      vu_st4(din0 + obase + ci * ss, o);
+      if (cross) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o.v[i] = acc1[ci][i];
+        vu_st4(din1 + obase + ci * ss, o);
+      }
+    }
+  }
+}
+
+// ---- weight gradient ---------------------------------------------------------------------------
+// dW[co][ci][ky][kx] += sum_pix dOut[co,y,x] * in[ci,y+ky-1,x+kx-1] ; blockIdx.y selects the conv
+struct WgradSet { const void* dout[3]; const void* in[3]; float* dw[3]; float* dbias[3]; };
+
+template <typename TDO, typename TI, int C>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradSet set, long long nquads, int s) {
+  constexpr int NW = C * C * 9;
+  __shared__ float red[4][NW + C];
+  const TDO* dout = (const TDO*)set.dout[blockIdx.y];
+  const TI* in = (const TI*)set.in[blockIdx.y];
+  float* dw = set.dw[blockIdx.y];
+  float* dbias = set.dbias[blockIdx.y];
+  const int ss = s * s;
+  float acc[NW], accb[C];
+#pragma unroll
+  for (int i = 0; i < NW; ++i) acc[i] = 0.f;
+#pragma unroll
+  for (int i = 0; i < C; ++i) accb[i] = 0.f;
+  for (long long qid = blockIdx.x * (long long)blockDim.x + threadIdx.x; qid < nquads;
+       qid += (long long)gridDim.x * blockDim.x) {
+    long long patch; int y, x0;
+    quad_coords(qid, s, patch, y, x0);
+    const long long pbase = patch * (long long)(C * ss);
+    const long long obase = pbase + y * s + x0;
+    float win[C][3][6];
+#pragma unroll
+    for (int ci = 0; ci < C; ++ci) load_win(in + pbase + ci * ss, s, y, x0, win[ci]);
+#pragma unroll
+    for (int co = 0; co < C; ++co) {
+      const vu_f4 d = vu_ld4(dout + obase + co * ss);
+      accb[co] += d.v[0] + d.v[1] + d.v[2] + d.v[3];
+#pragma unroll
+      for (int ci = 0; ci < C; ++ci)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            float a = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a += d.v[i] * win[ci][ky][i + kx];
+            acc[(co * C + ci) * 9 + ky * 3 + kx] += a;
+          }
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) {
+    const float v = vu_wave_sum(acc[i]);
+    if (lane == 0) red[wave][i] = v;
+  }
+#pragma unroll
+  for (int i = 0; i < C; ++i) {
+    const float v = vu_wave_sum(accb[i]);
+    if (lane == 0) red[wave][NW + i] = v;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < NW + C; i += blockDim.x) {
+    const float v = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+    if (i < NW) atomicAdd(dw + i, v);
+    else if (dbias) atomicAdd(dbias + (i - NW), v);
+  }
+}
+
+inline int grid_for(long long items, int cap) {
+  long long g = (items + 255) / 256;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+#define VU_CONV_C(Cv, ...) \
+  switch (Cv) { case 1: { constexpr int CC = 1; __VA_ARGS__ } break; case 2: { constexpr int CC = 2; __VA_ARGS__ } break; \
+                case 3: { constexpr int CC = 3; __VA_ARGS__ } break; case 4: { constexpr int CC = 4; __VA_ARGS__ } break; \
+                default: vu_set_error("conv3x3: num_channels %d not supported (1..4)", Cv); return VU_EUNSUPPORTED; }
+
+int vu_k_conv3x3_fwd(int dtype, int out_f32, const void* in, const float* w, const float* bias, void* out,
+                     long long npatch, int C, int s, hipStream_t st) {
+  VU_REQUIRE(s % 4 == 0, "conv3x3: patch size must be a multiple of 4");
+  const long long nq = npatch * s * s / 4;
+  if (nq == 0) return VU_OK;
+  const int grid = grid_for(nq, 256 * 16);
+  const bool fo = out_f32 || dtype == 0;
+  VU_CONV_C(C,
+    if (dtype == 0) hipLaunchKernelGGL((conv_fwd_kernel<float, float, CC, 1>), dim3(grid), dim3(256), 0, st, (const float*)in, (const float*)in, w, w, w, bias, (float*)out, (float*)out, (float*)out, nq, s);
+    else if (fo) hipLaunchKernelGGL((conv_fwd_kernel<bf16_t, float, CC, 1>), dim3(grid), dim3(256), 0, st, (const bf16_t*)in, (const bf16_t*)in, w, w, w, bias, (float*)out, (float*)out, (float*)out, nq, s);
+    else hipLaunchKernelGGL((conv_fwd_kernel<bf16_t, bf16_t, CC, 1>), dim3(grid), dim3(256), 0, st, (const bf16_t*)in, (const bf16_t*)in, w, w, w, bias, (bf16_t*)out, (bf16_t*)out, (bf16_t*)out, nq, s);)
+  if (vu_prof_on()) vu_prof_note("conv_fwd_kernel<1>", 0.0, (double)nq * 4 * C * ((dtype == 0 ? 4.0 : 2.0) + (fo ? 4.0 : 2.0)));
+  return vu_check_launch("vu_conv3x3_fwd");
+}
+
+int vu_k_conv3x3_qkv_fwd(int dtype, const void* xq, const void* xkv, const float* wq, const float* wk, const float* wv,
+                         void* q, void* k, void* v, long long npatch, int C, int s, hipStream_t st) {
+  VU_REQUIRE(s % 4 == 0, "conv3x3: patch size must be a multiple of 4");
+  const long long nq = npatch * s * s / 4;
+  if (nq == 0) return VU_OK;
+  const int grid = grid_for(nq, 256 * 16);
+  VU_CONV_C(C,
+    if (dtype == 0) hipLaunchKernelGGL((conv_fwd_kernel<float, float, CC, 3>), dim3(grid), dim3(256), 0, st, (const float*)xq, (const float*)xkv, wq, wk, wv, (const float*)nullptr, (float*)q, (float*)k, (float*)v, nq, s);
+    else hipLaunchKernelGGL((conv_fwd_kernel<bf16_t, bf16_t, CC, 3>), dim3(grid), dim3(256), 0, st, (const bf16_t*)xq, (const bf16_t*)xkv, wq, wk, wv, (const float*)nullptr, (bf16_t*)q, (bf16_t*)k, (bf16_t*)v, nq, s);)
+  if (vu_prof_on()) vu_prof_note("conv_fwd_kernel<3>", 0.0, (double)nq * 4 * C * (dtype == 0 ? 4.0 : 2.0) * (xq == xkv ? 4 : 5));
+  return vu_check_launch("vu_conv3x3_qkv_fwd");
+}
+
+int vu_k_conv3x3_dgrad(int dtype, int dout_f32, const void* dout, const float* w, const void* add, void* din,
+                       long long npatch, int C, int s, hipStream_t st) {
+  VU_REQUIRE(s % 4 == 0, "conv3x3: patch size must be a multiple of 4");
+  const long long nq = npatch * s * s / 4;
+  if (nq == 0) return VU_OK;
+  const int grid = grid_for(nq, 256 * 16);
+  VU_CONV_C(C,
+    if (dtype == 0) hipLaunchKernelGGL((conv_dgrad_kernel<float, float, CC, 1>), dim3(grid), dim3(256), 0, st, (const float*)dout, (const float*)dout, (const float*)dout, w, w, w, (const float*)add, (const float*)nullptr, (float*)din, (float*)nullptr, nq, s);
+    else if (dout_f32) hipLaunchKernelGGL((conv_dgrad_kernel<float, bf16_t, CC, 1>), dim3(grid), dim3(256), 0, st, (const float*)dout, (const float*)dout, (const float*)dout, w, w, w, (const bf16_t*)add, (const bf16_t*)nullptr, (bf16_t*)din, (bf16_t*)nullptr, nq, s);
+    else hipLaunchKernelGGL((conv_dgrad_kernel<bf16_t, bf16_t, CC, 1>), dim3(grid), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)dout, (const bf16_t*)dout, w, w, w, (const bf16_t*)add, (const bf16_t*)nullptr, (bf16_t*)din, (bf16_t*)nullptr, nq, s);)
+  if (vu_prof_on()) vu_prof_note("conv_dgrad_kernel<1>", 0.0, (double)nq * 4 * C * ((dout_f32 || dtype == 0 ? 4.0 : 2.0) + (dtype == 0 ? 4.0 : 2.0) * (add ? 2 : 1)));
+  return vu_check_launch("vu_conv3x3_dgrad");
+}
+
+// dxq (and dxkv when non-null) from dq, dk, dv; add_q / add_kv are added (residual gradients).
+int vu_k_conv3x3_qkv_dgrad(int dtype, const void* dq, const void* dk, const void* dv, const float* wq, const float* wk,
+                           const float* wv, const void* add_q, const void* add_kv, void* dxq, void* dxkv,
+                           long long npatch, int C, int s, hipStream_t st) {
+  VU_REQUIRE(s % 4 == 0, "conv3x3: patch size must be a multiple of 4");
+  const long long nq = npatch * s * s / 4;
+  if (nq == 0) return VU_OK;
+  const int grid = grid_for(nq, 256 * 16);
+  VU_CONV_C(C,
+    if (dtype == 0) hipLaunchKernelGGL((conv_dgrad_kernel<float, float, CC, 3>), dim3(grid), dim3(256), 0, st, (const float*)dq, (const float*)dk, (const float*)dv, wq, wk, wv, (const float*)add_q, (const float*)add_kv, (float*)dxq, (float*)dxkv, nq, s);
+    else hipLaunchKernelGGL((conv_dgrad_kernel<bf16_t, bf16_t, CC, 3>), dim3(grid), dim3(256), 0, st, (const bf16_t*)dq, (const bf16_t*)dk, (const bf16_t*)dv, wq, wk, wv, (const bf16_t*)add_q, (const bf16_t*)add_kv, (bf16_t*)dxq, (bf16_t*)dxkv, nq, s);)
+  if (vu_prof_on()) vu_prof_note("conv_dgrad_kernel<3>", 0.0, (double)nq * 4 * C * (dtype == 0 ? 4.0 : 2.0) * (dxkv ? 5 + (add_q ? 1 : 0) + (add_kv ? 1 : 0) : 4 + (add_q ? 1 : 0)));
+  return vu_check_launch("vu_conv3x3_qkv_dgrad");
+}
+
+static int wgrad_launch(int dtype, int dout_f32, const WgradSet& set, int nconv, long long npatch, int C, int s,
+                        hipStream_t st) {
+  VU_REQUIRE(s % 4 == 0, "conv3x3: patch size must be a multiple of 4");
+  const long long nq = npatch * s * s / 4;
+  if (nq == 0) return VU_OK;
+  const int gx = grid_for(nq, nconv == 1 ? 1024 : 512);
+  VU_CONV_C(C,
+    if (dtype == 0) hipLaunchKernelGGL((conv_wgrad_kernel<float, float, CC>), dim3(gx, nconv), dim3(256), 0, st, set, nq, s);
+    else if (dout_f32) hipLaunchKernelGGL((conv_wgrad_kernel<float, bf16_t, CC>), dim3(gx, nconv), dim3(256), 0, st, set, nq, s);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, bf16_t, CC>), dim3(gx, nconv), dim3(256), 0, st, set, nq, s);)
+  if (vu_prof_on()) vu_prof_note(nconv == 1 ? "conv_wgrad_kernel<1>" : "conv_wgrad_kernel<3>", 0.0,
+                                 (double)nq * 4 * C * nconv * ((dout_f32 || dtype == 0 ? 4.0 : 2.0) + (dtype == 0 ? 4.0 : 2.0)));
+  return vu_check_launch("vu_conv3x3_wgrad");
+}
+
+int vu_k_conv3x3_wgrad(int dtype, int dout_f32, const void* dout, const void* in, float* dw, float* dbias,
+                       long long npatch, int C, int s, hipStream_t st) {
+  WgradSet set;
+  for (int i = 0; i < 3; ++i) { set.dout[i] = dout; set.in[i] = in; set.dw[i] = dw; set.dbias[i] = dbias; }
+  return wgrad_launch(dtype, dout_f32, set, 1, npatch, C, s, st);
+}
+
+int vu_k_conv3x3_qkv_wgrad(int dtype, const void* dq, const void* dk, const void* dv, const void* xq, const void* xkv,
+                           float* dwq, float* dwk, float* dwv, long long npatch, int C, int s, hipStream_t st) {
+  WgradSet set;
+  set.dout[0] = dq; set.dout[1] = dk; set.dout[2] = dv;
+  set.in[0] = xq; set.in[1] = xkv; set.in[2] = xkv;
+  set.dw[0] = dwq; set.dw[1] = dwk; set.dw[2] = dwv;
+  set.dbias[0] = set.dbias[1] = set.dbias[2] = nullptr;
+  return wgrad_launch(dtype, 0, set, 3, npatch, C, s, st);
+}

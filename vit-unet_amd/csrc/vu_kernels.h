@@ -21,6 +21,15 @@ int vu_k_conv3x3_dgrad(int dtype, int dout_f32, const void* dout, const float* w
 int vu_k_conv3x3_wgrad(int dtype, int dout_f32, const void* dout, const void* in, float* dw,
                        float* dbias, long long npatch, int C, int s, hipStream_t st);
 
+// fused q/k/v forms (vu_conv.hip): one read of x gives q,k,v; the three data gradients are summed
+int vu_k_conv3x3_qkv_fwd(int dtype, const void* xq, const void* xkv, const float* wq, const float* wk, const float* wv,
+                         void* q, void* k, void* v, long long npatch, int C, int s, hipStream_t st);
+int vu_k_conv3x3_qkv_dgrad(int dtype, const void* dq, const void* dk, const void* dv, const float* wq, const float* wk,
+                           const float* wv, const void* add_q, const void* add_kv, void* dxq, void* dxkv,
+                           long long npatch, int C, int s, hipStream_t st);
+int vu_k_conv3x3_qkv_wgrad(int dtype, const void* dq, const void* dk, const void* dv, const void* xq, const void* xkv,
+                           float* dwq, float* dwk, float* dwv, long long npatch, int C, int s, hipStream_t st);
+
 // K7+K8: row softmax + dropout on (rows, ld) logits, N valid columns; writes sign-tagged
 // probabilities (negative = dropped) in place.
 int vu_k_softmax_dropout(int dtype, void* S, long long rows, int N, int ld, vu_rng rng,
@@ -51,6 +60,9 @@ int vu_k_bn_bwd_finalize(const float* partials, int nblocks, float* stats, float
 int vu_k_map_bwd(int dtype, const void* Ps, void* dAhat_dS, const float* W, const float* c,
                  const float* gamma, const float* stats, float* dW, float* dc, int B, int H, int N,
                  int ld, float inv_keep, float scale, hipStream_t st);
+int vu_k_map_bwd_2sweep(int dtype, const void* Ps, void* dAhat_dS, const float* W, const float* c,
+                        const float* gamma, const float* stats, float* dW, float* dc, int B, int H, int N,
+                        int ld, float inv_keep, float scale, hipStream_t st);
 
 // K13: residual add + LayerNorm over all P elements of a sample.
 #define VU_LN_CHUNK 4096

@@ -84,186 +84,6 @@ int vu_k_batch_sum(int dtype, const void* in, float* out, int B, long long P, hi
 }
 
 // =============================================================================================
-// K4/K15: 3x3 conv, zero halo at the patch border (model.py:137-139,152-154; :370,:428).
-// One thread per pixel, all channels.  Taps come through L1 (9x re-use inside a patch row).
-// =============================================================================================
-template <typename TI, typename TO, int C>
-__global__ void conv3x3_fwd_kernel(const TI* __restrict__ in, const float* __restrict__ w,
-                                   const float* __restrict__ bias, TO* __restrict__ out,
-                                   long long npix, int s) {
-  __shared__ float ws[C * C * 9 + C];
-  for (int i = threadIdx.x; i < C * C * 9; i += blockDim.x) ws[i] = w[i];
-  for (int i = threadIdx.x; i < C; i += blockDim.x) ws[C * C * 9 + i] = bias ? bias[i] : 0.f;
-  __syncthreads();
-  const int ss = s * s;
-  for (long long pix = blockIdx.x * (long long)blockDim.x + threadIdx.x; pix < npix;
-       pix += (long long)gridDim.x * blockDim.x) {
-    const long long patch = pix / ss;
-    const int rem = (int)(pix - patch * ss), y = rem / s, x = rem - y * s;
-    const TI* base = in + patch * (long long)(C * ss);
-    float a[C][9];
-#pragma unroll
-    for (int ci = 0; ci < C; ++ci)
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const int yy = y + ky - 1, xx = x + kx - 1;
-          a[ci][ky * 3 + kx] = (yy >= 0 && yy < s && xx >= 0 && xx < s) ? vu_ld(base + ci * ss + yy * s + xx) : 0.f;
-        }
-    TO* ob = out + patch * (long long)(C * ss) + rem;
-#pragma unroll
-    for (int co = 0; co < C; ++co) {
-      float acc = ws[C * C * 9 + co];
-#pragma unroll
-      for (int ci = 0; ci < C; ++ci)
-#pragma unroll
-        for (int t = 0; t < 9; ++t) acc += ws[(co * C + ci) * 9 + t] * a[ci][t];
-      vu_st(ob + co * ss, acc);
-    }
-  }
-}
-
-// dIn[ci,Y,X] = sum_co sum_ky,kx w[co][ci][ky][kx] * dOut[co, Y-ky+1, X-kx+1]  (+ add)
-template <typename TDO, typename T, int C>
-__global__ void conv3x3_dgrad_kernel(const TDO* __restrict__ dout, const float* __restrict__ w,
-                                     const T* add, T* din, long long npix, int s) {
-  __shared__ float ws[C * C * 9];
-  for (int i = threadIdx.x; i < C * C * 9; i += blockDim.x) ws[i] = w[i];
-  __syncthreads();
-  const int ss = s * s;
-  for (long long pix = blockIdx.x * (long long)blockDim.x + threadIdx.x; pix < npix;
-       pix += (long long)gridDim.x * blockDim.x) {
-    const long long patch = pix / ss;
-    const int rem = (int)(pix - patch * ss), y = rem / s, x = rem - y * s;
-    const TDO* base = dout + patch * (long long)(C * ss);
-    float g[C][9];
-#pragma unroll
-    for (int co = 0; co < C; ++co)
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const int yy = y - ky + 1, xx = x - kx + 1;
-          g[co][ky * 3 + kx] = (yy >= 0 && yy < s && xx >= 0 && xx < s) ? vu_ld(base + co * ss + yy * s + xx) : 0.f;
-        }
-    const long long o = patch * (long long)(C * ss) + rem;
-#pragma unroll
-    for (int ci = 0; ci < C; ++ci) {
-      float acc = add ? vu_ld(add + o + ci * ss) : 0.f;
-#pragma unroll
-      for (int co = 0; co < C; ++co)
-#pragma unroll
-        for (int t = 0; t < 9; ++t) acc += ws[(co * C + ci) * 9 + t] * g[co][t];
-      vu_st(din + o + ci * ss, acc);
-    }
-  }
-}
-
-// dW[co][ci][ky][kx] += sum_pix dOut[co,y,x] * in[ci,y+ky-1,x+kx-1] ; dbias[co] += sum dOut
-template <typename TDO, typename TI, int C>
-__global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const TDO* __restrict__ dout,
-                                                            const TI* __restrict__ in,
-                                                            float* dw, float* dbias,
-                                                            long long npix, int s) {
-  constexpr int NW = C * C * 9;
-  __shared__ float red[4][NW + C];
-  const int ss = s * s;
-  float acc[NW];
-  float accb[C];
-#pragma unroll
-  for (int i = 0; i < NW; ++i) acc[i] = 0.f;
-#pragma unroll
-  for (int i = 0; i < C; ++i) accb[i] = 0.f;
-  for (long long pix = blockIdx.x * (long long)blockDim.x + threadIdx.x; pix < npix;
-       pix += (long long)gridDim.x * blockDim.x) {
-    const long long patch = pix / ss;
-    const int rem = (int)(pix - patch * ss), y = rem / s, x = rem - y * s;
-    const TI* ib = in + patch * (long long)(C * ss);
-    const TDO* db = dout + patch * (long long)(C * ss) + rem;
-    float a[C][9];
-#pragma unroll
-    for (int ci = 0; ci < C; ++ci)
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const int yy = y + ky - 1, xx = x + kx - 1;
-          a[ci][ky * 3 + kx] = (yy >= 0 && yy < s && xx >= 0 && xx < s) ? vu_ld(ib + ci * ss + yy * s + xx) : 0.f;
-        }
-#pragma unroll
-    for (int co = 0; co < C; ++co) {
-      const float d = vu_ld(db + co * ss);
-      accb[co] += d;
-#pragma unroll
-      for (int ci = 0; ci < C; ++ci)
-#pragma unroll
-        for (int t = 0; t < 9; ++t) acc[(co * C + ci) * 9 + t] += d * a[ci][t];
-    }
-  }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int i = 0; i < NW; ++i) {
-    const float v = vu_wave_sum(acc[i]);
-    if (lane == 0) red[wave][i] = v;
-  }
-#pragma unroll
-  for (int i = 0; i < C; ++i) {
-    const float v = vu_wave_sum(accb[i]);
-    if (lane == 0) red[wave][NW + i] = v;
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < NW + C; i += blockDim.x) {
-    const float v = red[0][i] + red[1][i] + red[2][i] + red[3][i];
-    if (i < NW) atomicAdd(dw + i, v);
-    else if (dbias) atomicAdd(dbias + (i - NW), v);
-  }
-}
-
-#define VU_CONV_C(Cv, ...) \
-  switch (Cv) { case 1: { constexpr int CC = 1; __VA_ARGS__ } break; case 2: { constexpr int CC = 2; __VA_ARGS__ } break; \
-                case 3: { constexpr int CC = 3; __VA_ARGS__ } break; case 4: { constexpr int CC = 4; __VA_ARGS__ } break; \
-                default: vu_set_error("conv3x3: num_channels %d not supported (1..4)", Cv); return VU_EUNSUPPORTED; }
-
-int vu_k_conv3x3_fwd(int dtype, int out_f32, const void* in, const float* w, const float* bias,
-                     void* out, long long npatch, int C, int s, hipStream_t st) {
-  const long long npix = npatch * s * s;
-  if (npix == 0) return VU_OK;
-  const int grid = grid_for(npix, 256, 256 * 32);
-  const bool fo = out_f32 || dtype == 0;
-  VU_CONV_C(C,
-    if (dtype == 0) hipLaunchKernelGGL((conv3x3_fwd_kernel<float, float, CC>), dim3(grid), dim3(256), 0, st, (const float*)in, w, bias, (float*)out, npix, s);
-    else if (fo) hipLaunchKernelGGL((conv3x3_fwd_kernel<bf16_t, float, CC>), dim3(grid), dim3(256), 0, st, (const bf16_t*)in, w, bias, (float*)out, npix, s);
-    else hipLaunchKernelGGL((conv3x3_fwd_kernel<bf16_t, bf16_t, CC>), dim3(grid), dim3(256), 0, st, (const bf16_t*)in, w, bias, (bf16_t*)out, npix, s);)
-  if (vu_prof_on()) vu_prof_note("conv3x3_fwd_kernel", 0.0, (double)npix * C * 2 * (dtype == 0 ? 4.0 : 2.0));
-  return vu_check_launch("vu_conv3x3_fwd");
-}
-int vu_k_conv3x3_dgrad(int dtype, int dout_f32, const void* dout, const float* w, const void* add,
-                       void* din, long long npatch, int C, int s, hipStream_t st) {
-  const long long npix = npatch * s * s;
-  if (npix == 0) return VU_OK;
-  const int grid = grid_for(npix, 256, 256 * 32);
-  VU_CONV_C(C,
-    if (dtype == 0) hipLaunchKernelGGL((conv3x3_dgrad_kernel<float, float, CC>), dim3(grid), dim3(256), 0, st, (const float*)dout, w, (const float*)add, (float*)din, npix, s);
-    else if (dout_f32) hipLaunchKernelGGL((conv3x3_dgrad_kernel<float, bf16_t, CC>), dim3(grid), dim3(256), 0, st, (const float*)dout, w, (const bf16_t*)add, (bf16_t*)din, npix, s);
-    else hipLaunchKernelGGL((conv3x3_dgrad_kernel<bf16_t, bf16_t, CC>), dim3(grid), dim3(256), 0, st, (const bf16_t*)dout, w, (const bf16_t*)add, (bf16_t*)din, npix, s);)
-  if (vu_prof_on()) vu_prof_note("conv3x3_dgrad_kernel", 0.0, (double)npix * C * 3 * (dtype == 0 ? 4.0 : 2.0));
-  return vu_check_launch("vu_conv3x3_dgrad");
-}
-int vu_k_conv3x3_wgrad(int dtype, int dout_f32, const void* dout, const void* in, float* dw,
-                       float* dbias, long long npatch, int C, int s, hipStream_t st) {
-  const long long npix = npatch * s * s;
-  if (npix == 0) return VU_OK;
-  const int grid = grid_for(npix, 256, 1024);
-  VU_CONV_C(C,
-    if (dtype == 0) hipLaunchKernelGGL((conv3x3_wgrad_kernel<float, float, CC>), dim3(grid), dim3(256), 0, st, (const float*)dout, (const float*)in, dw, dbias, npix, s);
-    else if (dout_f32) hipLaunchKernelGGL((conv3x3_wgrad_kernel<float, bf16_t, CC>), dim3(grid), dim3(256), 0, st, (const float*)dout, (const bf16_t*)in, dw, dbias, npix, s);
-    else hipLaunchKernelGGL((conv3x3_wgrad_kernel<bf16_t, bf16_t, CC>), dim3(grid), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)in, dw, dbias, npix, s);)
-  if (vu_prof_on()) vu_prof_note("conv3x3_wgrad_kernel", 0.0, (double)npix * C * 2 * (dtype == 0 ? 4.0 : 2.0));
-  return vu_check_launch("vu_conv3x3_wgrad");
-}
-
-// =============================================================================================
 // K7+K8 softmax + dropout (model.py:156-157).  One wave per row; probabilities are stored
 // sign-tagged: +p kept, -p dropped (p > 0 always), so every later pass recovers both the
 // pre-dropout probability |p| and the mask without re-running the RNG.
@@ -640,7 +460,7 @@ int vu_k_bn_bwd_finalize(const float* partials, int nblocks, float* stats, float
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, partials, nblocks, stats, dgamma, dbeta, H, count, training);
   return vu_check_launch("vu_bn_bwd_finalize");
 }
-int vu_k_map_bwd(int dtype, const void* Ps, void* dAhat_dS, const float* W, const float* c, const float* gamma,
+int vu_k_map_bwd_2sweep(int dtype, const void* Ps, void* dAhat_dS, const float* W, const float* c, const float* gamma,
                  const float* stats, float* dW, float* dc, int B, int H, int N, int ld, float inv_keep,
                  float scale, hipStream_t st) {
   const long long rows = (long long)B * N;

@@ -169,9 +169,7 @@ int attn_forward(const AttnDims& d, const vu_attn_params& p, const void* xq, con
   const int dt = d.dtype, B = d.B, N = d.N, D = d.D, H = d.H, ld = d.ld;
   const int dh = D / H;
   const long long npatch = (long long)B * N;
-  VU_TRY(vu_k_conv3x3_fwd(dt, 0, xq, p.wq, nullptr, a.q, npatch, d.C, d.s, st));
-  VU_TRY(vu_k_conv3x3_fwd(dt, 0, xkv, p.wk, nullptr, a.k, npatch, d.C, d.s, st));
-  VU_TRY(vu_k_conv3x3_fwd(dt, 0, xkv, p.wv, nullptr, a.v, npatch, d.C, d.s, st));
+  VU_TRY(vu_k_conv3x3_qkv_fwd(dt, xq, xkv, p.wq, p.wk, p.wv, a.q, a.k, a.v, npatch, d.C, d.s, st));
   vu_rng ra = vu_make_rng(seed, 2 * stream_id, training ? attn_drop : 0.f);
   ra.salt = salt;
   int fused = vu_k_attn_scores(dt, a.q, a.k, a.Ps, B, N, D, H, ld, 1.0f / sqrtf((float)dh), ra, st);
@@ -282,18 +280,8 @@ int attn_backward(const AttnDims& d, const vu_attn_params& p, const vu_attn_grad
     g.sB1 = (long long)N * D; g.sB2 = dh; g.sC1 = (long long)N * D; g.sC2 = dh; g.alpha = 1.f;
     VU_TRY(vu_gemm_launch(dt, 0, g, st));
   }
-  VU_TRY(vu_k_conv3x3_wgrad(dt, 0, sc.dq, xq, gr.wq, nullptr, npatch, d.C, d.s, st));
-  VU_TRY(vu_k_conv3x3_wgrad(dt, 0, sc.dk, xkv, gr.wk, nullptr, npatch, d.C, d.s, st));
-  VU_TRY(vu_k_conv3x3_wgrad(dt, 0, sc.dv, xkv, gr.wv, nullptr, npatch, d.C, d.s, st));
-  if (dxkv == nullptr) {
-    VU_TRY(vu_k_conv3x3_dgrad(dt, 0, sc.dq, p.wq, add_q, dxq, npatch, d.C, d.s, st));
-    VU_TRY(vu_k_conv3x3_dgrad(dt, 0, sc.dk, p.wk, dxq, dxq, npatch, d.C, d.s, st));
-    VU_TRY(vu_k_conv3x3_dgrad(dt, 0, sc.dv, p.wv, dxq, dxq, npatch, d.C, d.s, st));
-  } else {
-    VU_TRY(vu_k_conv3x3_dgrad(dt, 0, sc.dq, p.wq, add_q, dxq, npatch, d.C, d.s, st));
-    VU_TRY(vu_k_conv3x3_dgrad(dt, 0, sc.dk, p.wk, add_kv, dxkv, npatch, d.C, d.s, st));
-    VU_TRY(vu_k_conv3x3_dgrad(dt, 0, sc.dv, p.wv, dxkv, dxkv, npatch, d.C, d.s, st));
-  }
+  VU_TRY(vu_k_conv3x3_qkv_wgrad(dt, sc.dq, sc.dk, sc.dv, xq, xkv, gr.wq, gr.wk, gr.wv, npatch, d.C, d.s, st));
+  VU_TRY(vu_k_conv3x3_qkv_dgrad(dt, sc.dq, sc.dk, sc.dv, p.wq, p.wk, p.wv, add_q, add_kv, dxq, dxkv, npatch, d.C, d.s, st));
   return VU_OK;
 }
 
