@@ -160,8 +160,7 @@ def keep_mask(numel: int, p: float, seed: int, stream: int) -> torch.Tensor:
     w = idx >> np.uint64(1)
     lo = w & _M32
     hi = w >> np.uint64(32)
-    x = _mix32(lo ^ np.uint64(k0))
-    x = _mix32((x + hi * np.uint64(0x9E3779B9) + np.uint64(k1)) & _M32)
+    x = (_mix32(lo ^ np.uint64(k0)) + hi * np.uint64(0x9E3779B9) + np.uint64(k1)) & _M32
     r = np.where((idx & np.uint64(1)) == 1, x >> np.uint64(16), x & np.uint64(0xFFFF))
     return torch.from_numpy(r >= np.uint64(thr))
 

@@ -128,11 +128,11 @@ def test_tiny_bf16_train(golden_dir, name, drop):
     ref = O.forward(wr, cfg, x.cpu(), training=True, seed=31337, storage=torch.bfloat16)
     # Both sides round to bf16 at the same points; fp32 summation order still flips individual
     # bf16 roundings (1 ulp = 0.4 %), which the softmax / BatchNorm chain amplifies: the check is
-    # statistical - relative RMS error 1e-1, max error 0.3 of the output scale (deepest tiny model: 7 re-attentions).
+    # statistical - relative RMS error 0.2, max error 0.5 of the output scale (deepest tiny model: 7 re-attentions).
     d = (out.detach().cpu().double() - ref.detach().double())
     rel_rms = (d.pow(2).mean().sqrt() / ref.detach().double().pow(2).mean().sqrt()).item()
-    assert rel_rms < 1e-1, rel_rms
-    assert serr(out, ref) < 0.3
+    assert rel_rms < 0.2, rel_rms
+    assert serr(out, ref) < 0.5
     loss = torch.nn.MSELoss()(out, y)
     loss.backward()
     O.mse_loss(ref, y.cpu()).backward()

@@ -97,6 +97,10 @@ __global__ __launch_bounds__(WAVES * 64) void attn_scores_kernel(const T* __rest
   }
   __syncthreads();
 
+  // Swapped product S^T = K Q^T: the accumulator of tile nt holds, for query i0+l15 (the lane's
+  // column), keys nt*16 + lg*4 + r (r = 0..3) - four consecutive keys per lane, so the row
+  // softmax reduces in-lane plus two shuffles, a dropout hash word serves an in-lane key pair,
+  // and the store is one 4-element vector per tile.
   const int ntiles = (N + 15) >> 4;
   f32x4 acc[NT];
 #pragma unroll
@@ -110,66 +114,63 @@ __global__ __launch_bounds__(WAVES * 64) void attn_scores_kernel(const T* __rest
         Frag kf;
         if constexpr (MM::FE == 1) kf = kv ? (float)Ks[key * LDK + ks * MM::KS + lg] : 0.f;
         else kf = kv ? *reinterpret_cast<const Frag*>(&Ks[key * LDK + ks * MM::KS + lg * MM::FE]) : MM::zero();
-        acc[nt] = MM::mma(qf[ks], kf, acc[nt]);
+        acc[nt] = MM::mma(kf, qf[ks], acc[nt]);
       }
     }
   }
-  // ---- row softmax: lane holds rows lg*4+r (r=0..3), column nt*16+l15 ---------------------------
-  // logits are rounded to the storage type first so that fused and unfused paths agree bit for bit
-  float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    if (nt < ntiles) {
-      const bool cv = nt * 16 + l15 < N;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float s = acc[nt][r] * scale;
-        if constexpr (sizeof(T) == 2) s = (float)(bf16_t)s;
-        s = cv ? s : -INFINITY;
-        acc[nt][r] = s;
-        mx[r] = fmaxf(mx[r], s);
-      }
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) mx[r] = fmaxf(mx[r], __shfl_xor(mx[r], o, 64));
-  }
-  float sum[4] = {0.f, 0.f, 0.f, 0.f};
+  // ---- row softmax (logits rounded to the storage type first, like the unfused path) ------------
+  float mx = -INFINITY;
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     if (nt < ntiles) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float e = __expf(acc[nt][r] - mx[r]);   // exp(-inf) = 0 for masked columns
+        float sv = acc[nt][r] * scale;
+        if constexpr (sizeof(T) == 2) sv = (float)(bf16_t)sv;
+        sv = (nt * 16 + lg * 4 + r < N) ? sv : -INFINITY;
+        acc[nt][r] = sv;
+        mx = fmaxf(mx, sv);
+      }
+    }
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    if (nt < ntiles) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = __expf(acc[nt][r] - mx);   // exp(-inf) = 0 for masked keys
         acc[nt][r] = e;
-        sum[r] += e;
+        sum += e;
       }
     }
   }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) sum[r] += __shfl_xor(sum[r], o, 64);
-    sum[r] = 1.0f / sum[r];
-  }
+  sum += __shfl_xor(sum, 16, 64);
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.0f / sum;
   // ---- dropout + sign-tagged store -------------------------------------------------------------
-  T* pb = Ps + (long long)bz * N * ld;
+  const int i = i0 + l15;
+  if (i < N) {
+    T* prow = Ps + ((long long)bz * N + i) * ld;
+    const uint64_t ibase = ((uint64_t)bz * N + i) * (uint64_t)N;
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    if (nt < ntiles) {
-      const int j = nt * 16 + l15;
+    for (int nt = 0; nt < NT; ++nt) {
+      if (nt < ntiles) {
+        const int j0 = nt * 16 + lg * 4;
+        if (j0 < ld) {
+          vu_f4 o;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = i0 + lg * 4 + r;
-        if (i < N && j < ld) {
-          float v = 0.f;
-          if (j < N) {
-            v = acc[nt][r] * sum[r];
-            if (rng.thr && !vu_keep(rng, ((uint64_t)bz * N + i) * (uint64_t)N + j)) v = -v;
+          for (int r = 0; r < 4; ++r) {
+            float v = 0.f;
+            if (j0 + r < N) {
+              v = acc[nt][r] * inv;
+              if (rng.thr && !vu_keep(rng, ibase + j0 + r)) v = -v;
+            }
+            o.v[r] = v;
           }
-          vu_st(pb + (long long)i * ld + j, v);
+          vu_st4(prow + j0, o);
         }
       }
     }

@@ -89,9 +89,7 @@ __host__ __device__ __forceinline__ uint32_t vu_mix32(uint32_t x) {
 }
 __host__ __device__ __forceinline__ uint32_t vu_hash_pair(const vu_rng& r, uint64_t idx) {
   uint64_t w = idx >> 1;
-  uint32_t x = vu_mix32((uint32_t)w ^ r.k0);
-  x = vu_mix32(x + (uint32_t)(w >> 32) * 0x9e3779b9u + r.k1);
-  return x;
+  return vu_mix32((uint32_t)w ^ r.k0) + (uint32_t)(w >> 32) * 0x9e3779b9u + r.k1;
 }
 __host__ __device__ __forceinline__ bool vu_keep(const vu_rng& r, uint64_t idx) {
   uint32_t x = vu_hash_pair(r, idx);

@@ -46,14 +46,8 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const TI* __restrict__ in
                                                        const float* __restrict__ w2, const float* __restrict__ bias,
                                                        TO* __restrict__ o0, TO* __restrict__ o1, TO* __restrict__ o2,
                                                        long long nquads, int s) {
-  __shared__ float ws[NOUT][C * C * 9];
-  __shared__ float bs[C];
-  for (int i = threadIdx.x; i < C * C * 9; i += blockDim.x) {
-    ws[0][i] = w0[i];
-    if (NOUT == 3) { ws[1][i] = w1[i]; ws[2][i] = w2[i]; }
-  }
-  if (threadIdx.x < C) bs[threadIdx.x] = bias ? bias[threadIdx.x] : 0.f;
-  __syncthreads();
+  // weights are wave-uniform: indexed with compile-time constants off a kernel-argument pointer
+  // they come through scalar loads into SGPRs (no LDS, no VGPRs)
   const int ss = s * s;
   const bool same = (in0 == in1);
   for (long long qid = blockIdx.x * (long long)blockDim.x + threadIdx.x; qid < nquads;
@@ -65,25 +59,27 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const TI* __restrict__ in
     float win[C][3][6];
 #pragma unroll
     for (int ci = 0; ci < C; ++ci) load_win(in0 + pbase + ci * ss, s, y, x0, win[ci]);
-#pragma unroll
+#pragma unroll 1
     for (int o = 0; o < NOUT; ++o) {
       if (NOUT == 3 && o == 1 && !same) {
 #pragma unroll
         for (int ci = 0; ci < C; ++ci) load_win(in1 + pbase + ci * ss, s, y, x0, win[ci]);
       }
       TO* op = o == 0 ? o0 : (o == 1 ? o1 : o2);
+      const float* __restrict__ wp = o == 0 ? w0 : (o == 1 ? w1 : w2);
 #pragma unroll
       for (int co = 0; co < C; ++co) {
         vu_f4 acc;
+        const float b0 = bias ? bias[co] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc.v[i] = bs[co];
+        for (int i = 0; i < 4; ++i) acc.v[i] = b0;
 #pragma unroll
         for (int ci = 0; ci < C; ++ci)
 #pragma unroll
           for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
-              const float wv = ws[o][(co * C + ci) * 9 + ky * 3 + kx];
+              const float wv = wp[(co * C + ci) * 9 + ky * 3 + kx];
 #pragma unroll
               for (int i = 0; i < 4; ++i) acc.v[i] += wv * win[ci][ky][i + kx];
             }
@@ -104,12 +100,6 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(const TDO* __restrict__
                                                          const float* __restrict__ w1, const float* __restrict__ w2,
                                                          const T* add0, const T* add1, T* din0, T* din1,
                                                          long long nquads, int s) {
-  __shared__ float ws[NIN][C * C * 9];
-  for (int i = threadIdx.x; i < C * C * 9; i += blockDim.x) {
-    ws[0][i] = w0[i];
-    if (NIN == 3) { ws[1][i] = w1[i]; ws[2][i] = w2[i]; }
-  }
-  __syncthreads();
   const int ss = s * s;
   const bool cross = (NIN == 3) && (din1 != nullptr);
   for (long long qid = blockIdx.x * (long long)blockDim.x + threadIdx.x; qid < nquads;
@@ -127,9 +117,10 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(const TDO* __restrict__
 #pragma unroll
       for (int i = 0; i < 4; ++i) { acc0[ci][i] = a0.v[i]; acc1[ci][i] = a1.v[i]; }
     }
-#pragma unroll
+#pragma unroll 1
     for (int t = 0; t < NIN; ++t) {
       const TDO* dp = t == 0 ? d0 : (t == 1 ? d1 : d2);
+      const float* __restrict__ wp = t == 0 ? w0 : (t == 1 ? w1 : w2);
       float win[C][3][6];
 #pragma unroll
       for (int co = 0; co < C; ++co) load_win(dp + pbase + co * ss, s, y, x0, win[co]);
@@ -145,7 +136,7 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(const TDO* __restrict__
           for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
-              const float wv = ws[t][(co * C + ci) * 9 + ky * 3 + kx];
+              const float wv = wp[(co * C + ci) * 9 + ky * 3 + kx];
 #pragma unroll
               for (int i = 0; i < 4; ++i) tmp[ci][i] += wv * win[co][2 - ky][i + 2 - kx];
             }

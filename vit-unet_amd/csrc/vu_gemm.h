@@ -32,6 +32,8 @@ struct vu_gemm_args {
   int dropout;         // apply dropout(rng) to result; element index = (z*M + m)*N + n
   vu_rng rng;
   int vecA, vecB;      // 16-byte vector loads legal for A / B
+  int swap;            // operands were exchanged by the launcher: the kernel computes C^T (vector stores)
+  int vecC;            // 4-element vector access to C rows is aligned
   int ksplit;          // >1: K is split over blockIdx.z and C is accumulated with float atomics
 };
 
@@ -220,36 +222,92 @@ __global__ __launch_bounds__(256) void vu_gemm_kernel(const vu_gemm_args g) {
   }
 
   // ---- epilogue -----------------------------------------------------------------------------
+  // Kernel space: rows km (the lane's 4 accumulator registers are 4 CONSECUTIVE rows), column kn.
+  // With g.swap the launcher exchanged the operands (C^T = B^T A^T): kernel rows are the original
+  // columns, so the 4 registers are 4 consecutive elements of one row of C -> one vector store.
   const vu_rng rng = g.dropout ? vu_rng_resolve(g.rng) : g.rng;
   const long long coff = z1 * g.sC1 + z2 * g.sC2;
   TC* Cb = (TC*)g.C + coff;
   T* auxb = g.aux ? (T*)g.aux + coff : nullptr;
   const T* addb = g.addend ? (const T*)g.addend + coff : nullptr;
+  const bool lead = blockIdx.z == 0;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int n = n_base + wn * (BN / 2) + j * 16 + l15;
-      if (n >= g.N) continue;
-      const float bv = (g.bias && blockIdx.z == 0) ? g.bias[n] : 0.f;
+      const int kn = n_base + wn * (BN / 2) + j * 16 + l15;
+      const int km0 = m_base + wm * (BM / 2) + i * 16 + lg * 4;
+      if (kn >= g.N || km0 >= g.M) continue;
+      if (g.swap) {
+        // original element (om = kn, on = km0 + r)
+        const long long o = (long long)kn * g.ldc + km0;
+        const int nv = g.M - km0 < 4 ? g.M - km0 : 4;
+        float v[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = m_base + wm * (BM / 2) + i * 16 + lg * 4 + r;
-        if (m >= g.M) continue;
-        float v = acc[i][j][r] * g.alpha + bv;
-        const long long o = (long long)m * g.ldc + n;
-        if (g.act == VU_ACT_GELU) { vu_st(auxb + o, v); v = vu_gelu(v); }
-        else if (g.act == VU_ACT_DGELU) { v *= vu_gelu_grad(vu_ld(auxb + o)); }
-        if (g.dropout) {
-          const uint64_t idx = ((uint64_t)z * g.M + m) * (uint64_t)g.N + n;
-          v = vu_keep(rng, idx) ? v * rng.inv_keep : 0.f;
+        for (int r = 0; r < 4; ++r) {
+          v[r] = acc[i][j][r] * g.alpha;
+          if (g.bias && lead && r < nv) v[r] += g.bias[km0 + r];
         }
-        if (addb) v += vu_ld(addb + o);
+        if (g.act == VU_ACT_GELU) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (r < nv) { vu_st(auxb + o + r, v[r]); v[r] = vu_gelu(v[r]); }
+        } else if (g.act == VU_ACT_DGELU) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (r < nv) v[r] *= vu_gelu_grad(vu_ld(auxb + o + r));
+        }
+        if (g.dropout) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const uint64_t idx = ((uint64_t)z * g.N + kn) * (uint64_t)g.M + km0 + r;
+            v[r] = vu_keep(rng, idx) ? v[r] * rng.inv_keep : 0.f;
+          }
+        }
+        if (addb) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (r < nv) v[r] += vu_ld(addb + o + r);
+        }
         if constexpr (sizeof(TC) == 4) {
           float* cp = (float*)Cb + o;
-          if (g.ksplit > 1) atomicAdd(cp, v); else if (g.accumulate) *cp += v; else *cp = v;
+          if (g.ksplit > 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (r < nv) atomicAdd(cp + r, v[r]);
+          } else if (nv == 4 && g.vecC) {
+            float4 c4 = g.accumulate ? *reinterpret_cast<float4*>(cp) : make_float4(0.f, 0.f, 0.f, 0.f);
+            c4.x += v[0]; c4.y += v[1]; c4.z += v[2]; c4.w += v[3];
+            *reinterpret_cast<float4*>(cp) = c4;
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (r < nv) { if (g.accumulate) cp[r] += v[r]; else cp[r] = v[r]; }
+          }
         } else {
-          vu_st((T*)Cb + o, v);
+          T* cp = (T*)Cb + o;
+          if (nv == 4 && g.vecC) { vu_f4 t4 = {{v[0], v[1], v[2], v[3]}}; vu_st4(cp, t4); }
+          else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (r < nv) vu_st(cp + r, v[r]);
+          }
+        }
+      } else {
+        const float bv = (g.bias && lead) ? g.bias[kn] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = km0 + r;
+          if (m >= g.M) continue;
+          float v = acc[i][j][r] * g.alpha + bv;
+          const long long o = (long long)m * g.ldc + kn;
+          if (g.act == VU_ACT_GELU) { vu_st(auxb + o, v); v = vu_gelu(v); }
+          else if (g.act == VU_ACT_DGELU) { v *= vu_gelu_grad(vu_ld(auxb + o)); }
+          if (g.dropout) {
+            const uint64_t idx = ((uint64_t)z * g.M + m) * (uint64_t)g.N + kn;
+            v = vu_keep(rng, idx) ? v * rng.inv_keep : 0.f;
+          }
+          if (addb) v += vu_ld(addb + o);
+          if constexpr (sizeof(TC) == 4) {
+            float* cp = (float*)Cb + o;
+            if (g.ksplit > 1) atomicAdd(cp, v); else if (g.accumulate) *cp += v; else *cp = v;
+          } else {
+            vu_st((T*)Cb + o, v);
+          }
         }
       }
     }

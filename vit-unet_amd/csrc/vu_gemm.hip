@@ -21,8 +21,9 @@ static int launch_one(const vu_gemm_args& g, hipStream_t st) {
     char tag[96];
     static const bool shapes = getenv("VU_PROF_SHAPES") != nullptr;
     if (shapes)
-      snprintf(tag, sizeof(tag), "gemm<%s,%s,%c%c,%dx%d> M%d N%d K%d Z%d s%d", sizeof(T) == 2 ? "bf16" : "f32",
-               sizeof(TC) == 2 ? "bf16" : "f32", TA ? 'T' : 'N', TB ? 'T' : 'N', BM, BN, g.M, g.N, g.K, g.Z1 * g.Z2, ga.ksplit);
+      snprintf(tag, sizeof(tag), "gemm<%s,%s,%c%c,%dx%d> M%d N%d K%d Z%d s%d%s", sizeof(T) == 2 ? "bf16" : "f32",
+               sizeof(TC) == 2 ? "bf16" : "f32", TA ? 'T' : 'N', TB ? 'T' : 'N', BM, BN, g.M, g.N, g.K, g.Z1 * g.Z2, ga.ksplit,
+               g.swap ? " swapped" : "");
     else
       snprintf(tag, sizeof(tag), "vu_gemm_kernel<%s,%s,%c%c,%dx%d>", sizeof(T) == 2 ? "bf16" : "f32",
                sizeof(TC) == 2 ? "bf16" : "f32", TA ? 'T' : 'N', TB ? 'T' : 'N', BM, BN);
@@ -42,7 +43,20 @@ static int launch_tiles(const vu_gemm_args& g, hipStream_t st) {
 }
 
 template <typename T>
-static int launch_layout(vu_gemm_args& g, int c_float, hipStream_t st) {
+static int launch_layout(vu_gemm_args& g0, int c_float, hipStream_t st) {
+  vu_gemm_args g = g0;
+  g.swap = 0; g.vecC = 0;
+  const size_t csz = (sizeof(T) == 2 && !c_float) ? 2 : 4;
+  // C^T = B^T A^T: same arithmetic, but each lane then owns 4 consecutive elements of a C row,
+  // so the epilogue stores (and reads aux / addend) as vectors.  Needs >= 64 original columns.
+  if (g0.N >= 64) {
+    g.A = g0.B; g.B = g0.A; g.M = g0.N; g.N = g0.M;
+    g.sAm = g0.sBn; g.sAk = g0.sBk; g.sBk = g0.sAk; g.sBn = g0.sAm;
+    g.sA1 = g0.sB1; g.sA2 = g0.sB2; g.sB1 = g0.sA1; g.sB2 = g0.sA2;
+    g.swap = 1;
+    g.vecC = ((uintptr_t)g0.C % (4 * csz) == 0) && (g0.ldc % 4 == 0) && (g0.sC1 % 4 == 0) && (g0.sC2 % 4 == 0) &&
+             (!g0.aux || (uintptr_t)g0.aux % 8 == 0) && (!g0.addend || (uintptr_t)g0.addend % 8 == 0);
+  }
   const bool TA = g.sAk != 1, TB = g.sBk != 1;
   if (TA && g.sAm != 1) { vu_set_error("vu_gemm: A must have a unit stride"); return VU_EINVAL; }
   if (TB && g.sBn != 1) { vu_set_error("vu_gemm: B must have a unit stride"); return VU_EINVAL; }
@@ -55,15 +69,14 @@ static int launch_layout(vu_gemm_args& g, int c_float, hipStream_t st) {
   if (sizeof(T) == 2 && c_float) {
     if (TA && TB) return launch_tiles<T, float, true, true>(g, st);
     if (!TA && !TB) return launch_tiles<T, float, false, false>(g, st);
-    vu_set_error("vu_gemm: float output only for NT / TT operand forms");
+    vu_set_error("vu_gemm: float output only for NN / TT operand forms");
     return VU_EUNSUPPORTED;
   }
   if (sizeof(T) == 2 && g.accumulate) { vu_set_error("vu_gemm: accumulate needs float C"); return VU_EINVAL; }
   if (!TA && !TB) return launch_tiles<T, T, false, false>(g, st);
   if (!TA && TB) return launch_tiles<T, T, false, true>(g, st);
-  if (TA && TB) return launch_tiles<T, T, true, true>(g, st);
-  vu_set_error("vu_gemm: (A row-contiguous, B k-contiguous) form is not instantiated");
-  return VU_EUNSUPPORTED;
+  if (TA && !TB) return launch_tiles<T, T, true, false>(g, st);
+  return launch_tiles<T, T, true, true>(g, st);
 }
 
 // dtype: 0 = fp32 storage, 1 = bf16 storage.
