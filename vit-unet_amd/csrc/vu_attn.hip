@@ -379,3 +379,81 @@ int vu_k_map_bwd(int dtype, const void* Ps, void* dAhat_dS, const float* W, cons
   vu_set_error("map_bwd: num_heads %d not supported", H);
   return VU_EUNSUPPORTED;
 }
+
+// =============================================================================================
+// BatchNorm-backward statistics WITHOUT a pass over the maps.  With dAhat_g = dO_g v_g^T:
+//   s1_g = sum dAhat_g                 = sum_b sum_t (sum_i dO_g[i,t]) (sum_j v_g[j,t])
+//   r_g  = sum dAhat_g * Ahat_g        = sum_{b,i,t} dO_g[i,t] O_g[i,t]        (O = Ahat v, saved)
+// and, because Ahat = gamma*xhat + beta,   s2_g = sum dAhat_g*xhat_g = (r_g - beta_g s1_g) / gamma_g.
+// Reads three (B,N,D) tensors instead of two (B,h,N,N) maps.
+// =============================================================================================
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_small_kernel(const T* __restrict__ dO, const T* __restrict__ O,
+                                                           const T* __restrict__ v, float* partials, int N, int D, int H) {
+  __shared__ float sm[16];
+  __shared__ float sdo[256], sv[256];
+  const int b = blockIdx.x, g = blockIdx.y, d = D / H;
+  const long long base = (long long)b * N * D + g * d;
+  int TCOL = 256;                       // feature columns handled side by side (power of two >= min(d,256))
+  while (TCOL / 2 >= d) TCOL /= 2;
+  const int RL = 256 / TCOL;            // row lanes per column
+  const int tc = threadIdx.x % TCOL, rl = threadIdx.x / TCOL;
+  float s1 = 0.f, r = 0.f;
+  for (int t0 = 0; t0 < d; t0 += TCOL) {
+    const int t = t0 + tc;
+    float cdo = 0.f, cv = 0.f;
+    if (t < d) {
+      for (int i = rl; i < N; i += RL) {
+        const float a = vu_ld(dO + base + (long long)i * D + t);
+        cdo += a;
+        cv += vu_ld(v + base + (long long)i * D + t);
+        r += a * vu_ld(O + base + (long long)i * D + t);
+      }
+    }
+    sdo[threadIdx.x] = cdo; sv[threadIdx.x] = cv;
+    __syncthreads();
+    if (rl == 0 && t < d) {
+      float a = 0.f, c = 0.f;
+      for (int q = 0; q < RL; ++q) { a += sdo[q * TCOL + tc]; c += sv[q * TCOL + tc]; }
+      s1 += a * c;
+    }
+    __syncthreads();
+  }
+  s1 = vu_block_sum(s1, sm);
+  r = vu_block_sum(r, sm);
+  if (threadIdx.x == 0) {
+    partials[(long long)b * 2 * H + g] = s1;
+    partials[(long long)b * 2 * H + H + g] = r;
+  }
+}
+
+// stats layout: Wf[H*H] cf[H] mean[H] rstd[H] m1[H] m2[H]
+__global__ void bn_bwd_small_finalize_kernel(const float* partials, int nb, const float* gamma, const float* beta,
+                                             float* stats, float* dgamma, float* dbeta, int H, double count, int training) {
+  const int g = threadIdx.x;
+  if (g >= H) return;
+  double s1 = 0.0, r = 0.0;
+  for (int i = 0; i < nb; ++i) { s1 += (double)partials[i * 2 * H + g]; r += (double)partials[i * 2 * H + H + g]; }
+  const double gm = gamma[g];
+  const double s2 = fabs(gm) > 1e-20 ? (r - (double)beta[g] * s1) / gm : 0.0;
+  dbeta[g] += (float)s1;
+  dgamma[g] += (float)s2;
+  stats[H * H + 3 * H + g] = training ? (float)(s1 / count) : 0.f;
+  stats[H * H + 4 * H + g] = training ? (float)(s2 / count) : 0.f;
+}
+
+}  // namespace
+
+// partials: >= B*2*H floats
+int vu_k_bn_bwd_small(int dtype, const void* dO, const void* O, const void* v, const float* gamma, const float* beta,
+                      float* stats, float* dgamma, float* dbeta, float* partials, int B, int N, int D, int H,
+                      int training, hipStream_t st) {
+  if (dtype == 0) hipLaunchKernelGGL((bn_bwd_small_kernel<float>), dim3(B, H), dim3(256), 0, st, (const float*)dO, (const float*)O, (const float*)v, partials, N, D, H);
+  else hipLaunchKernelGGL((bn_bwd_small_kernel<bf16_t>), dim3(B, H), dim3(256), 0, st, (const bf16_t*)dO, (const bf16_t*)O, (const bf16_t*)v, partials, N, D, H);
+  hipLaunchKernelGGL(bn_bwd_small_finalize_kernel, dim3(1), dim3(64), 0, st, partials, B, gamma, beta, stats, dgamma, dbeta, H,
+                     (double)B * N * N, training);
+  if (vu_prof_on()) vu_prof_note("bn_bwd_small(2 kernels)", 0.0, 3.0 * B * N * D * (dtype == 0 ? 4.0 : 2.0));
+  return vu_check_launch("vu_bn_bwd_small");
+}

@@ -39,6 +39,106 @@ struct vu_gemm_args {
 
 template <typename T> struct vu_vec { static constexpr int N = 16 / sizeof(T); };
 
+template <typename T, typename TC> struct vu_epi_ctx {
+  vu_rng rng; TC* Cb; T* auxb; const T* addb; bool lead; int z;
+};
+
+// Kernel space: rows km (the lane's 4 accumulator registers are 4 CONSECUTIVE rows), column kn.
+// Plain form: C[km][kn], scalar stores.
+template <typename T, typename TC>
+__device__ __forceinline__ void vu_epilogue_plain(const vu_gemm_args& g, const vu_epi_ctx<T, TC>& ec, f32x4 a, int km0, int kn) {
+  if (kn >= g.N || km0 >= g.M) return;
+  const float bv = (g.bias && ec.lead) ? g.bias[kn] : 0.f;
+  const float av[4] = {a[0], a[1], a[2], a[3]};
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int m = km0 + r;
+    if (m < g.M) {
+      float v = av[r] * g.alpha + bv;
+      const long long o = (long long)m * g.ldc + kn;
+      if (g.act == VU_ACT_GELU) { vu_st(ec.auxb + o, v); v = vu_gelu(v); }
+      else if (g.act == VU_ACT_DGELU) { v *= vu_gelu_grad(vu_ld(ec.auxb + o)); }
+      if (g.dropout) {
+        const uint64_t idx = ((uint64_t)ec.z * g.M + m) * (uint64_t)g.N + kn;
+        v = vu_keep(ec.rng, idx) ? v * ec.rng.inv_keep : 0.f;
+      }
+      if (ec.addb) v += vu_ld(ec.addb + o);
+      if constexpr (sizeof(TC) == 4) {
+        float* cp = (float*)ec.Cb + o;
+        if (g.ksplit > 1) atomicAdd(cp, v); else if (g.accumulate) *cp += v; else *cp = v;
+      } else {
+        vu_st((T*)ec.Cb + o, v);
+      }
+    }
+  }
+}
+
+// Swapped form (the launcher exchanged the operands, the kernel computes C^T): kernel rows are the
+// ORIGINAL columns, so the 4 registers are 4 consecutive elements of one row of C: vector access.
+template <typename T, typename TC>
+__device__ __forceinline__ void vu_epilogue_swapped(const vu_gemm_args& g, const vu_epi_ctx<T, TC>& ec, f32x4 a, int km0, int kn) {
+  if (kn >= g.N || km0 >= g.M) return;
+  const long long o = (long long)kn * g.ldc + km0;   // original element (row kn, columns km0..km0+3)
+  const int nv = g.M - km0 < 4 ? g.M - km0 : 4;
+  float v0 = a[0] * g.alpha, v1 = a[1] * g.alpha, v2 = a[2] * g.alpha, v3 = a[3] * g.alpha;
+  if (g.bias && ec.lead) {
+    v0 += g.bias[km0];
+    if (nv > 1) v1 += g.bias[km0 + 1];
+    if (nv > 2) v2 += g.bias[km0 + 2];
+    if (nv > 3) v3 += g.bias[km0 + 3];
+  }
+  const bool vec = (nv == 4) && g.vecC;
+  if (g.act == VU_ACT_GELU) {
+    if (vec) { vu_f4 t4 = {{v0, v1, v2, v3}}; vu_st4(ec.auxb + o, t4); }
+    else { vu_st(ec.auxb + o, v0); if (nv > 1) vu_st(ec.auxb + o + 1, v1); if (nv > 2) vu_st(ec.auxb + o + 2, v2); if (nv > 3) vu_st(ec.auxb + o + 3, v3); }
+    v0 = vu_gelu(v0); v1 = vu_gelu(v1); v2 = vu_gelu(v2); v3 = vu_gelu(v3);
+  } else if (g.act == VU_ACT_DGELU) {
+    if (vec) { const vu_f4 t4 = vu_ld4(ec.auxb + o); v0 *= vu_gelu_grad(t4.v[0]); v1 *= vu_gelu_grad(t4.v[1]); v2 *= vu_gelu_grad(t4.v[2]); v3 *= vu_gelu_grad(t4.v[3]); }
+    else {
+      v0 *= vu_gelu_grad(vu_ld(ec.auxb + o));
+      if (nv > 1) v1 *= vu_gelu_grad(vu_ld(ec.auxb + o + 1));
+      if (nv > 2) v2 *= vu_gelu_grad(vu_ld(ec.auxb + o + 2));
+      if (nv > 3) v3 *= vu_gelu_grad(vu_ld(ec.auxb + o + 3));
+    }
+  }
+  if (g.dropout) {
+    const uint64_t idx = ((uint64_t)ec.z * g.N + kn) * (uint64_t)g.M + km0;
+    v0 = vu_keep(ec.rng, idx) ? v0 * ec.rng.inv_keep : 0.f;
+    v1 = vu_keep(ec.rng, idx + 1) ? v1 * ec.rng.inv_keep : 0.f;
+    v2 = vu_keep(ec.rng, idx + 2) ? v2 * ec.rng.inv_keep : 0.f;
+    v3 = vu_keep(ec.rng, idx + 3) ? v3 * ec.rng.inv_keep : 0.f;
+  }
+  if (ec.addb) {
+    if (vec) { const vu_f4 t4 = vu_ld4(ec.addb + o); v0 += t4.v[0]; v1 += t4.v[1]; v2 += t4.v[2]; v3 += t4.v[3]; }
+    else {
+      v0 += vu_ld(ec.addb + o);
+      if (nv > 1) v1 += vu_ld(ec.addb + o + 1);
+      if (nv > 2) v2 += vu_ld(ec.addb + o + 2);
+      if (nv > 3) v3 += vu_ld(ec.addb + o + 3);
+    }
+  }
+  if constexpr (sizeof(TC) == 4) {
+    float* cp = (float*)ec.Cb + o;
+    if (g.ksplit > 1) {
+      atomicAdd(cp, v0);
+      if (nv > 1) atomicAdd(cp + 1, v1);
+      if (nv > 2) atomicAdd(cp + 2, v2);
+      if (nv > 3) atomicAdd(cp + 3, v3);
+    } else if (vec) {
+      float4 c4 = make_float4(v0, v1, v2, v3);
+      if (g.accumulate) { const float4 p4 = *reinterpret_cast<const float4*>(cp); c4.x += p4.x; c4.y += p4.y; c4.z += p4.z; c4.w += p4.w; }
+      *reinterpret_cast<float4*>(cp) = c4;
+    } else {
+      if (g.accumulate) { v0 += cp[0]; if (nv > 1) v1 += cp[1]; if (nv > 2) v2 += cp[2]; if (nv > 3) v3 += cp[3]; }
+      cp[0] = v0; if (nv > 1) cp[1] = v1; if (nv > 2) cp[2] = v2; if (nv > 3) cp[3] = v3;
+    }
+  } else {
+    T* cp = (T*)ec.Cb + o;
+    if (vec) { vu_f4 t4 = {{v0, v1, v2, v3}}; vu_st4(cp, t4); }
+    else { vu_st(cp, v0); if (nv > 1) vu_st(cp + 1, v1); if (nv > 2) vu_st(cp + 2, v2); if (nv > 3) vu_st(cp + 3, v3); }
+  }
+}
+
 template <typename T, typename TC, bool TA, bool TB, int BM, int BN>
 __global__ __launch_bounds__(256) void vu_gemm_kernel(const vu_gemm_args g) {
   constexpr int BK = 32;
@@ -222,93 +322,21 @@ __global__ __launch_bounds__(256) void vu_gemm_kernel(const vu_gemm_args g) {
   }
 
   // ---- epilogue -----------------------------------------------------------------------------
-  // Kernel space: rows km (the lane's 4 accumulator registers are 4 CONSECUTIVE rows), column kn.
-  // With g.swap the launcher exchanged the operands (C^T = B^T A^T): kernel rows are the original
-  // columns, so the 4 registers are 4 consecutive elements of one row of C -> one vector store.
-  const vu_rng rng = g.dropout ? vu_rng_resolve(g.rng) : g.rng;
+  vu_epi_ctx<T, TC> ec;
+  ec.rng = g.dropout ? vu_rng_resolve(g.rng) : g.rng;
   const long long coff = z1 * g.sC1 + z2 * g.sC2;
-  TC* Cb = (TC*)g.C + coff;
-  T* auxb = g.aux ? (T*)g.aux + coff : nullptr;
-  const T* addb = g.addend ? (const T*)g.addend + coff : nullptr;
-  const bool lead = blockIdx.z == 0;
+  ec.Cb = (TC*)g.C + coff;
+  ec.auxb = g.aux ? (T*)g.aux + coff : nullptr;
+  ec.addb = g.addend ? (const T*)g.addend + coff : nullptr;
+  ec.lead = blockIdx.z == 0;
+  ec.z = z;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int kn = n_base + wn * (BN / 2) + j * 16 + l15;
       const int km0 = m_base + wm * (BM / 2) + i * 16 + lg * 4;
-      if (kn >= g.N || km0 >= g.M) continue;
-      if (g.swap) {
-        // original element (om = kn, on = km0 + r)
-        const long long o = (long long)kn * g.ldc + km0;
-        const int nv = g.M - km0 < 4 ? g.M - km0 : 4;
-        float v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          v[r] = acc[i][j][r] * g.alpha;
-          if (g.bias && lead && r < nv) v[r] += g.bias[km0 + r];
-        }
-        if (g.act == VU_ACT_GELU) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) if (r < nv) { vu_st(auxb + o + r, v[r]); v[r] = vu_gelu(v[r]); }
-        } else if (g.act == VU_ACT_DGELU) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) if (r < nv) v[r] *= vu_gelu_grad(vu_ld(auxb + o + r));
-        }
-        if (g.dropout) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const uint64_t idx = ((uint64_t)z * g.N + kn) * (uint64_t)g.M + km0 + r;
-            v[r] = vu_keep(rng, idx) ? v[r] * rng.inv_keep : 0.f;
-          }
-        }
-        if (addb) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) if (r < nv) v[r] += vu_ld(addb + o + r);
-        }
-        if constexpr (sizeof(TC) == 4) {
-          float* cp = (float*)Cb + o;
-          if (g.ksplit > 1) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) if (r < nv) atomicAdd(cp + r, v[r]);
-          } else if (nv == 4 && g.vecC) {
-            float4 c4 = g.accumulate ? *reinterpret_cast<float4*>(cp) : make_float4(0.f, 0.f, 0.f, 0.f);
-            c4.x += v[0]; c4.y += v[1]; c4.z += v[2]; c4.w += v[3];
-            *reinterpret_cast<float4*>(cp) = c4;
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) if (r < nv) { if (g.accumulate) cp[r] += v[r]; else cp[r] = v[r]; }
-          }
-        } else {
-          T* cp = (T*)Cb + o;
-          if (nv == 4 && g.vecC) { vu_f4 t4 = {{v[0], v[1], v[2], v[3]}}; vu_st4(cp, t4); }
-          else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) if (r < nv) vu_st(cp + r, v[r]);
-          }
-        }
-      } else {
-        const float bv = (g.bias && lead) ? g.bias[kn] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int m = km0 + r;
-          if (m >= g.M) continue;
-          float v = acc[i][j][r] * g.alpha + bv;
-          const long long o = (long long)m * g.ldc + kn;
-          if (g.act == VU_ACT_GELU) { vu_st(auxb + o, v); v = vu_gelu(v); }
-          else if (g.act == VU_ACT_DGELU) { v *= vu_gelu_grad(vu_ld(auxb + o)); }
-          if (g.dropout) {
-            const uint64_t idx = ((uint64_t)z * g.M + m) * (uint64_t)g.N + kn;
-            v = vu_keep(rng, idx) ? v * rng.inv_keep : 0.f;
-          }
-          if (addb) v += vu_ld(addb + o);
-          if constexpr (sizeof(TC) == 4) {
-            float* cp = (float*)Cb + o;
-            if (g.ksplit > 1) atomicAdd(cp, v); else if (g.accumulate) *cp += v; else *cp = v;
-          } else {
-            vu_st((T*)Cb + o, v);
-          }
-        }
-      }
+      if (g.swap) vu_epilogue_swapped<T, TC>(g, ec, acc[i][j], km0, kn);
+      else vu_epilogue_plain<T, TC>(g, ec, acc[i][j], km0, kn);
     }
 }

@@ -49,7 +49,11 @@ static int launch_layout(vu_gemm_args& g0, int c_float, hipStream_t st) {
   const size_t csz = (sizeof(T) == 2 && !c_float) ? 2 : 4;
   // C^T = B^T A^T: same arithmetic, but each lane then owns 4 consecutive elements of a C row,
   // so the epilogue stores (and reads aux / addend) as vectors.  Needs >= 64 original columns.
-  if (g0.N >= 64) {
+  static const bool noswap = getenv("VU_GEMM_NOSWAP") != nullptr;
+  static const bool noswapf = getenv("VU_GEMM_NOSWAP_F32") != nullptr;
+  // split-K weight-gradient GEMMs add with float atomics: keep their 64-byte-contiguous plain pattern
+  const bool will_split = g0.accumulate && (long long)vu_cdiv(g0.M, 128) * vu_cdiv(g0.N, 128) * g0.Z1 * g0.Z2 < 512;
+  if (g0.N >= 64 && !noswap && !will_split && !(noswapf && csz == 4 && sizeof(T) == 2)) {
     g.A = g0.B; g.B = g0.A; g.M = g0.N; g.N = g0.M;
     g.sAm = g0.sBn; g.sAk = g0.sBk; g.sBk = g0.sAk; g.sBn = g0.sAm;
     g.sA1 = g0.sB1; g.sA2 = g0.sB2; g.sB1 = g0.sA1; g.sB2 = g0.sA2;

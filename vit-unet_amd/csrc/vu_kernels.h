@@ -56,6 +56,10 @@ int vu_k_bn_bwd_stats(int dtype, const void* Ps, const void* dAhat, const float*
                       float inv_keep, hipStream_t st);
 int vu_k_bn_bwd_finalize(const float* partials, int nblocks, float* stats, float* dgamma,
                          float* dbeta, int H, double count, int training, hipStream_t st);
+// the same statistics from dO, O and v only (no pass over the maps); partials >= B*2*H floats
+int vu_k_bn_bwd_small(int dtype, const void* dO, const void* O, const void* v, const float* gamma, const float* beta,
+                      float* stats, float* dgamma, float* dbeta, float* partials, int B, int N, int D, int H,
+                      int training, hipStream_t st);
 // dS written over dAhat.  dW (H*H) and dc (H) are accumulated with atomics.
 int vu_k_map_bwd(int dtype, const void* Ps, void* dAhat_dS, const float* W, const float* c,
                  const float* gamma, const float* stats, float* dW, float* dc, int B, int H, int N,

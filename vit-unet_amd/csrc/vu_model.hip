@@ -258,8 +258,9 @@ int attn_backward(const AttnDims& d, const vu_attn_params& p, const vu_attn_grad
     VU_TRY(vu_gemm_launch(dt, 0, g, st));
   }
   const double count = (double)B * N * N;
-  VU_TRY(vu_k_bn_bwd_stats(dt, a.Ps, sc.dA, p.mix_w, p.mix_b, a.stats, sc.partials, sc.nblocks, B, H, N, ld, inv_keep, st));
-  VU_TRY(vu_k_bn_bwd_finalize(sc.partials, sc.nblocks, a.stats, gr.bn_w, gr.bn_b, H, count, training, st));
+  // BatchNorm-backward statistics from dO, O, v (vu_attn.hip) - no pass over the maps
+  (void)count;
+  VU_TRY(vu_k_bn_bwd_small(dt, sc.dO, a.O, a.v, p.bn_w, p.bn_b, a.stats, gr.bn_w, gr.bn_b, sc.partials, B, N, D, H, training, st));
   VU_TRY(vu_k_map_bwd(dt, a.Ps, sc.dA, p.mix_w, p.mix_b, p.bn_w, a.stats, gr.mix_w, gr.mix_b, B, H, N, ld, inv_keep,
                       1.0f / sqrtf((float)dh), st));
   {  // dq = dS k
@@ -350,7 +351,7 @@ void carve_model(const Plan& pl, int B, char* base, ModelWS& w) {
   w.asc.dA = bp.take(map);
   w.asc.nblocks = nb;
   for (int j = 0; j < c.depth; ++j) w.dskip[j] = bp.take(act);
-  w.partials = bp.takef((size_t)nb * 2 * H + 1024);
+  w.partials = bp.takef((size_t)std::max(nb, B) * 2 * H + 1024);
   w.asc.partials = w.partials;
   w.lnp = bp.takef((size_t)B * vu_ln_nchunks(P) * 3);
   w.lnp2 = bp.takef((size_t)B * vu_ln_nbchunks(P) * 2);
@@ -698,7 +699,7 @@ static void carve_attn_ws(Bump& bp, const AttnDims& d, AttnBuf& a, AttnScratch& 
   sc.dO = bp.take(act); sc.dq = bp.take(act); sc.dk = bp.take(act); sc.dv = bp.take(act); sc.dA = bp.take(map);
   *dzbuf = bp.take(act);
   sc.nblocks = stats_blocks(d);
-  sc.partials = bp.takef((size_t)sc.nblocks * 2 * d.H);
+  sc.partials = bp.takef((size_t)std::max(sc.nblocks, d.B) * 2 * d.H);
 }
 size_t vu_attn_workspace_bytes(int dtype, int B, int N, int D, int H) {
   AttnDims d{dtype, B, N, D, H, 1, 4, round_up(N, 8)};
