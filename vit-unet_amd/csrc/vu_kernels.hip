@@ -189,21 +189,27 @@ __global__ __launch_bounds__(256) void mix_stats_kernel(const T* __restrict__ Ps
     partials[blockIdx.x * 2 * H + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
-// single block; H <= 16.  stats layout: Wf[H*H] cf[H] mean[H] rstd[H] m1[H] m2[H]
+// single block of 256 threads; H <= 16.  stats layout: Wf[H*H] cf[H] mean[H] rstd[H] m1[H] m2[H]
+// All 2H partial columns are reduced side by side: thread t sums column t % 2H over blocks
+// t / 2H, t / 2H + 256 / 2H, ... (coalesced), then an LDS tree per column, in fp64.
 __global__ void bn_finalize_kernel(const float* partials, int nblocks, const float* W, const float* c,
                                    const float* gamma, const float* beta, float* run_mean, float* run_var,
                                    float* stats, int H, int N, double count, int training, float momentum, float eps) {
   __shared__ double sd[256];
-  __shared__ float smean[16], srstd[16];
-  for (int q = 0; q < 2 * H; ++q) {   // q < H: first moment, else second
-    double a = 0.0;
-    if (training) for (int i = threadIdx.x; i < nblocks; i += blockDim.x) a += (double)partials[i * 2 * H + q];
-    sd[threadIdx.x] = a;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) sd[threadIdx.x] += sd[threadIdx.x + o]; __syncthreads(); }
-    if (threadIdx.x == 0) { if (q < H) smean[q] = (float)(sd[0] / count); else srstd[q - H] = (float)(sd[0] / count); }
-    __syncthreads();
+  __shared__ float smom[32];
+  const int Q = 2 * H, per = 256 / Q;          // Q <= 32 columns, `per` row lanes
+  const int q = threadIdx.x % Q, rl = threadIdx.x / Q;
+  double a = 0.0;
+  if (training && rl < per)
+    for (int i = rl; i < nblocks; i += per) a += (double)partials[i * Q + q];
+  sd[threadIdx.x] = a;
+  __syncthreads();
+  if (threadIdx.x < Q) {
+    double t = 0.0;
+    for (int r = 0; r < per; ++r) t += sd[r * Q + threadIdx.x];
+    smom[threadIdx.x] = (float)(t / count);
   }
+  __syncthreads();
   if (threadIdx.x < H) {
     const int g = threadIdx.x;
     float mean, var;
@@ -211,7 +217,7 @@ __global__ void bn_finalize_kernel(const float* partials, int nblocks, const flo
       float sw = 0.f;
       for (int h = 0; h < H; ++h) sw += W[g * H + h];
       const float shift = c[g] + sw / (float)N;
-      const float d1 = smean[g], d2 = srstd[g];
+      const float d1 = smom[g], d2 = smom[H + g];
       mean = shift + d1;
       var = fmaxf(d2 - d1 * d1, 0.f);
       const float unb = count > 1.0 ? (float)(count / (count - 1.0)) : 1.f;
@@ -582,7 +588,11 @@ int vu_k_add_ln_fwd(int dtype, const void* a, const void* x, void* z, const floa
 template <typename T>
 __global__ __launch_bounds__(256) void ln_bwd_stats_kernel(const T* __restrict__ dy, const T* __restrict__ z,
                                                            const float* __restrict__ w, const float* __restrict__ stats,
-                                                           float* dw, float* db, float* partials2, int B, long long P) {
+                                                           float* dw, float* db, float* partials2, int B, long long P,
+                                                           int bgroup) {
+  // grid (chunks of 1024 elements, sample groups): per-(sample,chunk) partial sums c1 = sum dy*w,
+  // c2 = sum dy*w*xhat, and the affine gradients of this chunk summed over the group's samples
+  // (float atomics when there is more than one group).
   __shared__ float red[2][4];
   const int c = blockIdx.x, nch = gridDim.x;
   const long long e = (long long)c * VU_LN_BCHUNK + threadIdx.x * 4;
@@ -591,7 +601,9 @@ __global__ __launch_bounds__(256) void ln_bwd_stats_kernel(const T* __restrict__
   if (ok) ww = *reinterpret_cast<const float4*>(w + e);
   float gw[4] = {0, 0, 0, 0}, gb[4] = {0, 0, 0, 0};
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int b = 0; b < B; ++b) {
+  const int b0 = blockIdx.y * bgroup;
+  const int b1 = b0 + bgroup < B ? b0 + bgroup : B;
+  for (int b = b0; b < b1; ++b) {
     const float mean = stats[2 * b], rstd = stats[2 * b + 1];
     float c1 = 0.f, c2 = 0.f;
     if (ok) {
@@ -614,11 +626,16 @@ __global__ __launch_bounds__(256) void ln_bwd_stats_kernel(const T* __restrict__
     __syncthreads();
   }
   if (ok) {
-    float4* pw = reinterpret_cast<float4*>(dw + e); float4* pb = reinterpret_cast<float4*>(db + e);
-    float4 a = *pw, bq = *pb;
-    a.x += gw[0]; a.y += gw[1]; a.z += gw[2]; a.w += gw[3];
-    bq.x += gb[0]; bq.y += gb[1]; bq.z += gb[2]; bq.w += gb[3];
-    *pw = a; *pb = bq;
+    if (gridDim.y == 1) {
+      float4* pw = reinterpret_cast<float4*>(dw + e); float4* pb = reinterpret_cast<float4*>(db + e);
+      float4 a = *pw, bq = *pb;
+      a.x += gw[0]; a.y += gw[1]; a.z += gw[2]; a.w += gw[3];
+      bq.x += gb[0]; bq.y += gb[1]; bq.z += gb[2]; bq.w += gb[3];
+      *pw = a; *pb = bq;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { atomicAdd(dw + e + q, gw[q]); atomicAdd(db + e + q, gb[q]); }
+    }
   }
 }
 
@@ -669,8 +686,12 @@ int vu_k_ln_bwd(int dtype, const void* dy, const void* z, const float* w, const 
                 hipStream_t st) {
   VU_REQUIRE(P % 4 == 0, "layernorm: P %% 4");
   const int nbch = vu_ln_nbchunks(P), nch = vu_ln_nchunks(P);
+  int ngroups = 1;                       // enough blocks to fill the chip: ~1024
+  while (nbch * ngroups < 1024 && ngroups * 2 <= B) ngroups *= 2;
+  const int bgroup = (B + ngroups - 1) / ngroups;
+  ngroups = (B + bgroup - 1) / bgroup;
   VU_DISPATCH_T(dtype,
-    hipLaunchKernelGGL((ln_bwd_stats_kernel<T>), dim3(nbch), dim3(256), 0, st, (const T*)dy, (const T*)z, w, stats, dw, db, partials2, B, P);
+    hipLaunchKernelGGL((ln_bwd_stats_kernel<T>), dim3(nbch, ngroups), dim3(256), 0, st, (const T*)dy, (const T*)z, w, stats, dw, db, partials2, B, P, bgroup);
     hipLaunchKernelGGL((ln_bwd_apply_kernel<T>), dim3(nch, B), dim3(256), 0, st, (const T*)dy, (const T*)z, w, stats, partials2, nbch, (T*)dz, (T*)dz_drop, rng, P);)
   if (vu_prof_on()) vu_prof_note("ln_bwd(2 kernels)", 0.0, (double)B * P * 5 * (dtype == 0 ? 4.0 : 2.0) + (double)P * 24);
   return vu_check_launch("vu_ln_bwd");
