@@ -232,8 +232,11 @@ def test_attention_fwd_bwd(dt, N, Cn, s, H, mode, cross):
         assert serr(dxkv, xkv_r.grad) < bt, "dxkv"
     for k, g in zip(GRAD_KEYS, grads):
         if training and k == "reatten_matrix.bias":
-            # exactly zero in exact arithmetic (train-mode BN removes the mean)
-            assert g.abs().max().item() < 1e-2 * grads[0].abs().max().item() + 1e-6
+            # exactly zero in exact arithmetic (train-mode BN removes the mean); what is left is
+            # rounding noise (bf16: the BN-backward means come from dO, O, v, not from the
+            # bf16-rounded map, so the cancellation is only as good as bf16)
+            lim = 1e-2 if dt == torch.float32 else 0.3
+            assert g.abs().max().item() < lim * grads[0].abs().max().item() + 1e-6
             continue
         assert serr(g, pr[k].grad) < bt, k
 
