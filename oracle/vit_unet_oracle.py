@@ -165,12 +165,18 @@ def keep_mask(numel: int, p: float, seed: int, stream: int) -> torch.Tensor:
     return torch.from_numpy(r >= np.uint64(thr))
 
 
-def _dropout(x: torch.Tensor, p: float, training: bool, seed: Optional[int], stream: int):
+def _dropout(x: torch.Tensor, p: float, training: bool, seed: Optional[int], stream: int, row_pad: int = 1):
+    """`row_pad` > 1: the last dimension is indexed with its length rounded up to a multiple of
+    row_pad (the HIP attention maps are stored with 8-element-aligned rows and the mask index of
+    element (row, j) is row * ld + j)."""
     if (not training) or p <= 0.0:
         return x
     if seed is None:   # timing-only path (bench.py cpu_baseline): torch's own Bernoulli, as the reference
         return F.dropout(x, p, True)
-    m = keep_mask(x.numel(), p, seed, stream).reshape(x.shape).to(x.dtype)
+    n = x.shape[-1]
+    ld = (n + row_pad - 1) // row_pad * row_pad
+    rows = x.numel() // n
+    m = keep_mask(rows * ld, p, seed, stream).reshape(rows, ld)[:, :n].reshape(x.shape).to(x.dtype)
     return x * m / (1.0 - p)
 
 
@@ -210,7 +216,7 @@ def reattention(xq, xkv, p: Dict[str, torch.Tensor], pre: str, h: int, C: int, *
     v = _r(conv3x3_per_patch(xkv, C, p[pre + "vconv2d.weight"]), st).reshape(B, N, h, d).permute(0, 2, 1, 3)
     s = _r(torch.matmul(q, k.transpose(-2, -1)) * (d ** -0.5), st)    # model.py:155
     a = _r(torch.softmax(s, dim=-1), st)                              # :156
-    a = _dropout(a, attn_drop, training, seed, 2 * stream)           # :157
+    a = _dropout(a, attn_drop, training, seed, 2 * stream, row_pad=8)   # :157
     w = p[pre + "reatten_matrix.weight"].reshape(h, h)               # 1x1 conv across heads :159
     a = torch.einsum("gh,bhij->bgij", w, a) + p[pre + "reatten_matrix.bias"].reshape(1, h, 1, 1)
     gam, bet = p[pre + "var_norm.weight"], p[pre + "var_norm.bias"]

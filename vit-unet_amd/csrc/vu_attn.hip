@@ -48,7 +48,7 @@ __device__ __forceinline__ typename Mma<T>::Frag load_frag(const T* p, int kvali
 }
 
 // DP = head dim padded to a multiple of 32 ; NT = max 16-column tiles (N <= 16*NT)
-template <typename T, int NT, int DP, int WAVES>
+template <typename T, int NT, int DP, int WAVES, bool EXACT>
 __global__ __launch_bounds__(WAVES * 64) void attn_scores_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                           T* __restrict__ Ps, int N, int D, int H, int d, int ld,
                                                           float scale, vu_rng rng_in) {
@@ -119,6 +119,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_scores_kernel(const T* __rest
     }
   }
   // ---- row softmax (logits rounded to the storage type first, like the unfused path) ------------
+  // Only the last key tile can be partial: full tiles take a mask-free path (wave-uniform branch).
   float mx = -INFINITY;
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_scores_kernel(const T* __rest
       for (int r = 0; r < 4; ++r) {
         float sv = acc[nt][r] * scale;
         if constexpr (sizeof(T) == 2) sv = (float)(bf16_t)sv;
-        sv = (nt * 16 + lg * 4 + r < N) ? sv : -INFINITY;
+        if constexpr (!EXACT) sv = (nt * 16 + lg * 4 + r < N) ? sv : -INFINITY;
         acc[nt][r] = sv;
         mx = fmaxf(mx, sv);
       }
@@ -136,12 +137,13 @@ __global__ __launch_bounds__(WAVES * 64) void attn_scores_kernel(const T* __rest
   mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
   mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
   float sum = 0.f;
+  const float mxl = mx * 1.44269504088896340736f;
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     if (nt < ntiles) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float e = __expf(acc[nt][r] - mx);   // exp(-inf) = 0 for masked keys
+        const float e = exp2f(acc[nt][r] * 1.44269504088896340736f - mxl);   // exp(-inf) = 0 for masked keys
         acc[nt][r] = e;
         sum += e;
       }
@@ -151,25 +153,36 @@ __global__ __launch_bounds__(WAVES * 64) void attn_scores_kernel(const T* __rest
   sum += __shfl_xor(sum, 32, 64);
   const float inv = 1.0f / sum;
   // ---- dropout + sign-tagged store -------------------------------------------------------------
+  // mask index of element (row, j) = row * ld + j with ld even: keys (j0, j0+1) and (j0+2, j0+3)
+  // each share one 32-bit hash word (16 bits per element).
   const int i = i0 + l15;
   if (i < N) {
-    T* prow = Ps + ((long long)bz * N + i) * ld;
-    const uint64_t ibase = ((uint64_t)bz * N + i) * (uint64_t)N;
+    const uint64_t rowi = (uint64_t)bz * N + i;
+    T* prow = Ps + rowi * ld;
+    const uint32_t ib32 = (uint32_t)(rowi * (uint64_t)ld);   // launcher guarantees < 2^32 map elements
+    const uint32_t thr = rng.thr;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       if (nt < ntiles) {
         const int j0 = nt * 16 + lg * 4;
-        if (j0 < ld) {
-          vu_f4 o;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float v = 0.f;
-            if (j0 + r < N) {
-              v = acc[nt][r] * inv;
-              if (rng.thr && !vu_keep(rng, ibase + j0 + r)) v = -v;
-            }
-            o.v[r] = v;
+        if (EXACT || j0 < ld) {
+          float o0 = acc[nt][0] * inv, o1 = acc[nt][1] * inv, o2 = acc[nt][2] * inv, o3 = acc[nt][3] * inv;
+          if (thr) {
+            // 16-bit lanes of two hash words; (x - thr) is negative exactly when x < thr: its sign
+            // bit is the "dropped" tag, XOR-ed into the sign of the probability
+            const uint32_t wa = vu_hash_word32(rng, ib32 + j0), wb = vu_hash_word32(rng, ib32 + j0 + 2);
+            o0 = __uint_as_float(__float_as_uint(o0) ^ (((wa & 0xffffu) - thr) & 0x80000000u));
+            o1 = __uint_as_float(__float_as_uint(o1) ^ (((wa >> 16) - thr) & 0x80000000u));
+            o2 = __uint_as_float(__float_as_uint(o2) ^ (((wb & 0xffffu) - thr) & 0x80000000u));
+            o3 = __uint_as_float(__float_as_uint(o3) ^ (((wb >> 16) - thr) & 0x80000000u));
           }
+          if constexpr (!EXACT) {   // zero the padding columns of the partial tile
+            if (j0 + 0 >= N) o0 = 0.f;
+            if (j0 + 1 >= N) o1 = 0.f;
+            if (j0 + 2 >= N) o2 = 0.f;
+            if (j0 + 3 >= N) o3 = 0.f;
+          }
+          vu_f4 o = {{o0, o1, o2, o3}};
           vu_st4(prow + j0, o);
         }
       }
@@ -184,7 +197,7 @@ int launch_scores(const T* q, const T* k, T* Ps, int B, int N, int D, int H, int
   constexpr int LDK = DP + (sizeof(T) == 2 ? 8 : 4);
   const size_t lds = (size_t)N * LDK * sizeof(T);
   constexpr int WAVES = NT > 13 ? 8 : 4;
-  auto kern = attn_scores_kernel<T, NT, DP, WAVES>;
+  auto kern = (N % 16 == 0) ? attn_scores_kernel<T, NT, DP, WAVES, true> : attn_scores_kernel<T, NT, DP, WAVES, false>;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { vu_set_error("attn_scores: cannot reserve %zu bytes of LDS", lds); return VU_ELAUNCH; }
@@ -225,6 +238,7 @@ int vu_k_attn_scores(int dtype, const void* q, const void* k, void* Ps, int B, i
   const size_t es = dtype == 0 ? 4 : 2;
   const size_t lds = (size_t)N * (dp + (es == 2 ? 8 : 4)) * es;
   if (lds > 150 * 1024) return 1;
+  if ((double)B * H * N * (double)ld >= 4294967295.0) return 1;   // 32-bit mask index in the fused kernel
   if (dtype == 0) return dispatch_scores<float>(q, k, Ps, B, N, D, H, ld, scale, rng, st);
   return dispatch_scores<bf16_t>(q, k, Ps, B, N, D, H, ld, scale, rng, st);
 }

@@ -96,6 +96,10 @@ __host__ __device__ __forceinline__ bool vu_keep(const vu_rng& r, uint64_t idx) 
   uint32_t v = (idx & 1) ? (x >> 16) : (x & 0xffffu);
   return v >= r.thr;
 }
+// 32-bit fast path for an even element index < 2^32: one hash word serves elements idx, idx+1
+__device__ __forceinline__ uint32_t vu_hash_word32(const vu_rng& r, uint32_t idx_even) {
+  return vu_mix32((idx_even >> 1) ^ r.k0) + r.k1;
+}
 static inline uint64_t vu_splitmix64(uint64_t z) {
   z += 0x9E3779B97F4A7C15ull;
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;

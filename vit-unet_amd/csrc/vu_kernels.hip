@@ -102,7 +102,7 @@ __global__ void softmax_dropout_kernel(T* S, long long rows, int N, int ld, vu_r
   for (int j = lane; j < N; j += 64) sum += __expf(vu_ld(p + j) - mx);
   sum = vu_wave_sum(sum);
   const float inv = 1.0f / sum;
-  const uint64_t base = (uint64_t)row * (uint64_t)N;
+  const uint64_t base = (uint64_t)row * (uint64_t)ld;   // mask index of (row, j) = row * ld + j
   for (int j = lane; j < N; j += 64) {
     float v = __expf(vu_ld(p + j) - mx) * inv;
     if (rng.thr && !vu_keep(rng, base + j)) v = -v;
