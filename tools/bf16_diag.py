@@ -1,7 +1,7 @@
 """Diagnostic (not a test): how far do bf16-storage gradients drift from fp32 ones on full-size
 Base, for the HIP path and for the CPU oracle's bf16-storage emulation."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "vit-unet_amd")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import torch
 import vit_unet_oracle as O

@@ -1,5 +1,5 @@
 import sys, os, time, torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "vit-unet_amd"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vit-unet_amd"))
 from vit_unet.torch import _lib
 from vit_unet.torch._lib import lib, ptr, check
 L = lib()
