@@ -274,7 +274,7 @@ def test_train_step_fused_matches_autograd_path(golden_dir):
     for (k, pd_), (_, pe) in zip(md.named_parameters(), me.named_parameters()):
         if k.endswith("reatten_matrix.bias"):
             continue
-        assert serr(pd_, pe) < 1e-5, k
+        assert serr(pd_, pe) < 1e-4, k   # float atomics (split-K, map reductions) are order dependent
 
 
 def test_standalone_modules_vs_golden(golden_dir):

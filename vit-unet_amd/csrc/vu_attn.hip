@@ -363,20 +363,188 @@ __global__ __launch_bounds__(256) void map_bwd_row_kernel(const T* __restrict__ 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// map_bwd_split_kernel: same arithmetic, but the H heads of a position quad are SPLIT over LS
+// adjacent lanes (HL = H/LS heads each).  Each lane keeps only its heads' data and its rows of
+// the mix matrices in registers (<= 128 VGPRs -> 4 waves per SIMD instead of 1) and the lanes
+// of a quad exchange the post-dropout probabilities and the BatchNorm-backward gradients with
+// quad-permute DPP moves.  One 1024-thread block walks rows persistently; TPR threads per row.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int H, int LS, int TPR>
+__global__ __launch_bounds__(1024) void map_bwd_split_kernel(const T* __restrict__ Ps, T* dA, const float* __restrict__ W,
+                                                             const float* __restrict__ c, const float* __restrict__ gamma,
+                                                             const float* __restrict__ stats, float* dW, float* dc,
+                                                             long long rows, int N, int ld, float inv_keep, float scale) {
+  constexpr int HL = H / LS;
+  constexpr int RPB = 1024 / TPR;          // rows per block iteration
+  constexpr int WPR = TPR / 64;            // waves per row
+  __shared__ float redd[16][H];            // per-wave partial deltas
+  __shared__ float red[16][H * H + H];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int u = threadIdx.x % LS;          // head group of this lane
+  const int rsub = threadIdx.x / TPR, t = threadIdx.x % TPR;
+  const int jc = (t / LS) * 4;             // first column of this lane's quad
+  const long long hs = (long long)N * ld;
+  // this lane's rows / columns of the mix matrices (registers)
+  float Xr[HL][H], Xc[HL], Wc[H][HL], Gs[HL], M1[HL], M2[HL];
+#pragma unroll
+  for (int j = 0; j < HL; ++j) {
+    const int g = u * HL + j;
+    const float rstd = stats[H * H + 2 * H + g];
+#pragma unroll
+    for (int q = 0; q < H; ++q) {   // slot q (relative order) is head hq
+      const int hq = (u ^ (q / HL)) * HL + q % HL;
+      Xr[j][q] = W[g * H + hq] * rstd;      // xhat_g = sum_h W[g,h] rstd_g P~_h + ...
+      Wc[q][j] = W[hq * H + g];             // dP~_h(own h = g) = sum_g' W[g',h] dA_g'
+    }
+    Xc[j] = (c[g] - stats[H * H + H + g]) * rstd;
+    Gs[j] = gamma[g] * rstd;
+    M1[j] = stats[H * H + 3 * H + g];
+    M2[j] = stats[H * H + 4 * H + g];
+  }
+  float aW[HL][H], ac[HL];
+#pragma unroll
+  for (int j = 0; j < HL; ++j) { ac[j] = 0.f;
+#pragma unroll
+    for (int h = 0; h < H; ++h) aW[j][h] = 0.f; }
+
+  const long long nit = (rows + RPB - 1) / RPB;
+  for (long long it = blockIdx.x; it < nit; it += gridDim.x) {
+    const long long row = it * RPB + rsub;
+    const bool live = row < rows && jc < ld;
+    const long long b = live ? row / N : 0;
+    const int i = live ? (int)(row - b * N) : 0;
+    const long long off = ((b * H + u * HL) * N + i) * (long long)ld + jc;   // head u*HL of this lane
+    float pv[HL][4], dAh[HL][4], dP[HL][4], delta[HL];
+#pragma unroll
+    for (int j = 0; j < HL; ++j) {
+      delta[j] = 0.f;
+      vu_f4 v = {{0.f, 0.f, 0.f, 0.f}}, d = {{0.f, 0.f, 0.f, 0.f}};
+      if (live) { v = vu_ld4(Ps + off + j * hs); d = vu_ld4(dA + off + j * hs); }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { pv[j][e] = v.v[e]; dAh[j][e] = d.v[e]; }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const bool cv = live && (jc + e < N);
+      // post-dropout probabilities of ALL heads, in "relative" order: slot k*HL+j holds head
+      // (u^k)*HL+j, i.e. slot 0.. are the lane's own heads, then the quad partners'
+      float ptr_[H];
+#pragma unroll
+      for (int j = 0; j < HL; ++j) {
+        const float own = pv[j][e] > 0.f ? pv[j][e] * inv_keep : 0.f;
+        ptr_[j] = own;
+#pragma unroll
+        for (int k = 1; k < LS; ++k) ptr_[k * HL + j] = __shfl_xor(own, k, 64);
+      }
+      float dAg[HL];
+#pragma unroll
+      for (int j = 0; j < HL; ++j) {
+        float xh = Xc[j];
+#pragma unroll
+        for (int q = 0; q < H; ++q) xh += Xr[j][q] * ptr_[q];
+        dAg[j] = cv ? Gs[j] * (dAh[j][e] - M1[j] - xh * M2[j]) : 0.f;
+        ac[j] += dAg[j];
+#pragma unroll
+        for (int q = 0; q < H; ++q) aW[j][q] += dAg[j] * ptr_[q];
+      }
+      // dP~ of the lane's own heads needs dA of all heads (same relative order)
+      float dpa[HL];
+#pragma unroll
+      for (int j = 0; j < HL; ++j) dpa[j] = 0.f;
+#pragma unroll
+      for (int jj = 0; jj < HL; ++jj) {
+#pragma unroll
+        for (int k = 0; k < LS; ++k) {
+          const float o = (k == 0) ? dAg[jj] : __shfl_xor(dAg[jj], k, 64);
+#pragma unroll
+          for (int j = 0; j < HL; ++j) dpa[j] += Wc[k * HL + jj][j] * o;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < HL; ++j) {
+        const float dp = pv[j][e] > 0.f ? dpa[j] * inv_keep : 0.f;
+        dP[j][e] = dp;
+        delta[j] += dp * fabsf(pv[j][e]);
+      }
+    }
+    // delta over the row: lanes with the same head group u (xor offsets LS, 2LS, .. 32), then waves
+#pragma unroll
+    for (int j = 0; j < HL; ++j) {
+#pragma unroll
+      for (int o = LS; o < 64; o <<= 1) delta[j] += __shfl_xor(delta[j], o, 64);
+    }
+    if constexpr (WPR > 1) {
+      if (lane < LS) {
+#pragma unroll
+        for (int j = 0; j < HL; ++j) redd[wave][lane * HL + j] = delta[j];
+      }
+      __syncthreads();
+      const int w0 = rsub * WPR;
+#pragma unroll
+      for (int j = 0; j < HL; ++j) {
+        float a = 0.f;
+        for (int q = 0; q < WPR; ++q) a += redd[w0 + q][u * HL + j];
+        delta[j] = a;
+      }
+      __syncthreads();
+    }
+    if (live) {
+#pragma unroll
+      for (int j = 0; j < HL; ++j) {
+        vu_f4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o.v[e] = (jc + e < N) ? fabsf(pv[j][e]) * (dP[j][e] - delta[j]) * scale : 0.f;
+        vu_st4(dA + off + j * hs, o);
+      }
+    }
+  }
+  // head-mix weight gradient: reduce over lanes with the same u, then over waves, then atomics.
+  // aW[j][q] is in relative order: column q = k*HL+jj is head (u^k)*HL+jj.
+#pragma unroll
+  for (int j = 0; j < HL; ++j) {
+#pragma unroll
+    for (int q = 0; q < H; ++q) {
+      float v = aW[j][q];
+#pragma unroll
+      for (int o = LS; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+      if (lane < LS) {
+        const int k = q / HL, jj = q % HL;
+        red[wave][(lane * HL + j) * H + (lane ^ k) * HL + jj] = v;
+      }
+    }
+    float v = ac[j];
+#pragma unroll
+    for (int o = LS; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+    if (lane < LS) red[wave][H * H + lane * HL + j] = v;
+  }
+  __syncthreads();
+  for (int q = threadIdx.x; q < H * H + H; q += blockDim.x) {
+    float v = 0.f;
+    for (int w = 0; w < 16; ++w) v += red[w][q];
+    if (q < H * H) atomicAdd(dW + q, v); else atomicAdd(dc + (q - H * H), v);
+  }
+}
+
 template <typename T, int H>
 int launch_map_bwd_row(const void* Ps, void* dA, const float* W, const float* c, const float* gamma, const float* stats,
                        float* dW, float* dc, int B, int N, int ld, float inv_keep, float scale, hipStream_t st) {
+  constexpr int LS = H >= 8 ? 4 : (H >= 4 ? 2 : 1);
   const long long rows = (long long)B * N;
-  if (ld <= 256) {
-    long long grid = (rows + 3) / 4; if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL((map_bwd_row_kernel<T, H, 64>), dim3((unsigned)grid), dim3(256), 0, st, (const T*)Ps, (T*)dA, W, c, gamma,
-                       stats, dW, dc, rows, N, ld, inv_keep, scale);
-  } else {
-    long long grid = rows; if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL((map_bwd_row_kernel<T, H, 256>), dim3((unsigned)grid), dim3(256), 0, st, (const T*)Ps, (T*)dA, W, c, gamma,
-                       stats, dW, dc, rows, N, ld, inv_keep, scale);
+  const int need = (ld / 4) * LS;          // threads per row
+#define VU_MBS(TPRv)                                                                                                   \
+  {                                                                                                                    \
+    long long grid = (rows + (1024 / TPRv) - 1) / (1024 / TPRv);                                                       \
+    if (grid > 512) grid = 512;                                                                                        \
+    hipLaunchKernelGGL((map_bwd_split_kernel<T, H, LS, TPRv>), dim3((unsigned)grid), dim3(1024), 0, st, (const T*)Ps, \
+                       (T*)dA, W, c, gamma, stats, dW, dc, rows, N, ld, inv_keep, scale);                              \
   }
-  if (vu_prof_on()) vu_prof_note("map_bwd_row_kernel", 0.0, (double)B * H * N * N * 3 * sizeof(T));
+  if (need <= 64) VU_MBS(64)
+  else if (need <= 256) VU_MBS(256)
+  else if (need <= 1024) VU_MBS(1024)
+  else return 1;
+#undef VU_MBS
+  if (vu_prof_on()) vu_prof_note("map_bwd_split_kernel", 0.0, (double)B * H * N * N * 3 * sizeof(T));
   return vu_check_launch("vu_map_bwd");
 }
 
@@ -385,7 +553,8 @@ int launch_map_bwd_row(const void* Ps, void* dA, const float* W, const float* c,
 int vu_k_map_bwd(int dtype, const void* Ps, void* dAhat_dS, const float* W, const float* c, const float* gamma,
                  const float* stats, float* dW, float* dc, int B, int H, int N, int ld, float inv_keep, float scale,
                  hipStream_t st) {
-  if (ld > 1024) return vu_k_map_bwd_2sweep(dtype, Ps, dAhat_dS, W, c, gamma, stats, dW, dc, B, H, N, ld, inv_keep, scale, st);
+  const int ls = H >= 8 ? 4 : (H >= 4 ? 2 : 1);
+  if ((ld / 4) * ls > 1024) return vu_k_map_bwd_2sweep(dtype, Ps, dAhat_dS, W, c, gamma, stats, dW, dc, B, H, N, ld, inv_keep, scale, st);
 #define VU_MB(Tt, Hh) return launch_map_bwd_row<Tt, Hh>(Ps, dAhat_dS, W, c, gamma, stats, dW, dc, B, N, ld, inv_keep, scale, st)
   if (dtype == 0) { switch (H) { case 1: VU_MB(float, 1); case 2: VU_MB(float, 2); case 4: VU_MB(float, 4); case 8: VU_MB(float, 8); } }
   else { switch (H) { case 1: VU_MB(bf16_t, 1); case 2: VU_MB(bf16_t, 2); case 4: VU_MB(bf16_t, 4); case 8: VU_MB(bf16_t, 8); } }
@@ -403,43 +572,55 @@ int vu_k_map_bwd(int dtype, const void* Ps, void* dAhat_dS, const float* W, cons
 // =============================================================================================
 namespace {
 
+// one block per sample: threads = (row lanes) x (4-feature vectors of the D-wide row), coalesced
+// 8/16-byte loads; per-feature column sums are combined across row lanes in LDS, then reduced
+// per head.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_small_kernel(const T* __restrict__ dO, const T* __restrict__ O,
                                                            const T* __restrict__ v, float* partials, int N, int D, int H) {
-  __shared__ float sm[16];
-  __shared__ float sdo[256], sv[256];
-  const int b = blockIdx.x, g = blockIdx.y, d = D / H;
-  const long long base = (long long)b * N * D + g * d;
-  int TCOL = 256;                       // feature columns handled side by side (power of two >= min(d,256))
-  while (TCOL / 2 >= d) TCOL /= 2;
-  const int RL = 256 / TCOL;            // row lanes per column
-  const int tc = threadIdx.x % TCOL, rl = threadIdx.x / TCOL;
-  float s1 = 0.f, r = 0.f;
-  for (int t0 = 0; t0 < d; t0 += TCOL) {
-    const int t = t0 + tc;
-    float cdo = 0.f, cv = 0.f;
-    if (t < d) {
+  __shared__ float sdo[256][4], sv[256][4];
+  __shared__ float hs1[16], hr[16];
+  const int b = blockIdx.x, d = D / H;
+  const long long base = (long long)b * N * D;
+  const int nvec = D >> 2;
+  const int TV = nvec < 256 ? nvec : 256;     // feature vectors handled side by side
+  const int RL = 256 / TV;                    // row lanes
+  const int tv = threadIdx.x % TV, rl = threadIdx.x / TV;
+  if (threadIdx.x < 16) { hs1[threadIdx.x] = 0.f; hr[threadIdx.x] = 0.f; }
+  __syncthreads();
+  for (int v0 = 0; v0 < nvec; v0 += TV) {
+    const int vi = v0 + tv;
+    const bool ok = rl < RL && vi < nvec;
+    float cdo[4] = {0, 0, 0, 0}, cv[4] = {0, 0, 0, 0}, rr[4] = {0, 0, 0, 0};
+    if (ok) {
       for (int i = rl; i < N; i += RL) {
-        const float a = vu_ld(dO + base + (long long)i * D + t);
-        cdo += a;
-        cv += vu_ld(v + base + (long long)i * D + t);
-        r += a * vu_ld(O + base + (long long)i * D + t);
+        const long long o = base + (long long)i * D + vi * 4;
+        const vu_f4 a = vu_ld4(dO + o), c = vu_ld4(v + o), q = vu_ld4(O + o);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { cdo[e] += a.v[e]; cv[e] += c.v[e]; rr[e] += a.v[e] * q.v[e]; }
       }
     }
-    sdo[threadIdx.x] = cdo; sv[threadIdx.x] = cv;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { sdo[threadIdx.x][e] = cdo[e]; sv[threadIdx.x][e] = cv[e]; }
+    // r needs no cross-lane pairing: add straight into the head bins
+    if (ok) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) atomicAdd(&hr[(vi * 4 + e) / d], rr[e]);
+    }
     __syncthreads();
-    if (rl == 0 && t < d) {
-      float a = 0.f, c = 0.f;
-      for (int q = 0; q < RL; ++q) { a += sdo[q * TCOL + tc]; c += sv[q * TCOL + tc]; }
-      s1 += a * c;
+    if (rl == 0 && vi < nvec) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float a = 0.f, c = 0.f;
+        for (int q = 0; q < RL; ++q) { a += sdo[q * TV + tv][e]; c += sv[q * TV + tv][e]; }
+        atomicAdd(&hs1[(vi * 4 + e) / d], a * c);
+      }
     }
     __syncthreads();
   }
-  s1 = vu_block_sum(s1, sm);
-  r = vu_block_sum(r, sm);
-  if (threadIdx.x == 0) {
-    partials[(long long)b * 2 * H + g] = s1;
-    partials[(long long)b * 2 * H + H + g] = r;
+  if (threadIdx.x < H) {
+    partials[(long long)b * 2 * H + threadIdx.x] = hs1[threadIdx.x];
+    partials[(long long)b * 2 * H + H + threadIdx.x] = hr[threadIdx.x];
   }
 }
 
@@ -464,8 +645,8 @@ __global__ void bn_bwd_small_finalize_kernel(const float* partials, int nb, cons
 int vu_k_bn_bwd_small(int dtype, const void* dO, const void* O, const void* v, const float* gamma, const float* beta,
                       float* stats, float* dgamma, float* dbeta, float* partials, int B, int N, int D, int H,
                       int training, hipStream_t st) {
-  if (dtype == 0) hipLaunchKernelGGL((bn_bwd_small_kernel<float>), dim3(B, H), dim3(256), 0, st, (const float*)dO, (const float*)O, (const float*)v, partials, N, D, H);
-  else hipLaunchKernelGGL((bn_bwd_small_kernel<bf16_t>), dim3(B, H), dim3(256), 0, st, (const bf16_t*)dO, (const bf16_t*)O, (const bf16_t*)v, partials, N, D, H);
+  if (dtype == 0) hipLaunchKernelGGL((bn_bwd_small_kernel<float>), dim3(B), dim3(256), 0, st, (const float*)dO, (const float*)O, (const float*)v, partials, N, D, H);
+  else hipLaunchKernelGGL((bn_bwd_small_kernel<bf16_t>), dim3(B), dim3(256), 0, st, (const bf16_t*)dO, (const bf16_t*)O, (const bf16_t*)v, partials, N, D, H);
   hipLaunchKernelGGL(bn_bwd_small_finalize_kernel, dim3(1), dim3(64), 0, st, partials, B, gamma, beta, stats, dgamma, dbeta, H,
                      (double)B * N * N, training);
   if (vu_prof_on()) vu_prof_note("bn_bwd_small(2 kernels)", 0.0, 3.0 * B * N * D * (dtype == 0 ? 4.0 : 2.0));
