@@ -6,6 +6,7 @@
 // 49 accumulator tiles), does the row softmax with 16-lane shuffles, draws the dropout mask from
 // the counter hash and writes the sign-tagged probabilities - the (B,h,N,N) logits never touch
 // HBM.  Algorithmic traffic: one write of the map (E*|T|) + q, k reads.
+#include <type_traits>
 #include "vu_kernels.h"
 
 namespace {
@@ -48,7 +49,7 @@ __device__ __forceinline__ typename Mma<T>::Frag load_frag(const T* p, int kvali
 }
 
 // DP = head dim padded to a multiple of 32 ; NT = max 16-column tiles (N <= 16*NT)
-template <typename T, int NT, int DP, int WAVES, bool EXACT>
+template <typename T, int NT, int DP, int WAVES, bool EXACT, bool SOFTMAX>
 __global__ __launch_bounds__(WAVES * 64) void attn_scores_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                           T* __restrict__ Ps, int N, int D, int H, int d, int ld,
                                                           float scale, vu_rng rng_in) {
@@ -117,6 +118,25 @@ __global__ __launch_bounds__(WAVES * 64) void attn_scores_kernel(const T* __rest
         acc[nt] = MM::mma(kf, qf[ks], acc[nt]);
       }
     }
+  }
+  if constexpr (!SOFTMAX) {   // plain product (dAhat = dO v^T in the backward): scaled vector stores
+    const int i = i0 + l15;
+    if (i < N) {
+      T* prow = Ps + ((long long)bz * N + i) * ld;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        if (nt < ntiles) {
+          const int j0 = nt * 16 + lg * 4;
+          if (EXACT || j0 < ld) {
+            vu_f4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o.v[r] = (EXACT || j0 + r < N) ? acc[nt][r] * scale : 0.f;
+            vu_st4(prow + j0, o);
+          }
+        }
+      }
+    }
+    return;
   }
   // ---- row softmax (logits rounded to the storage type first, like the unfused path) ------------
   // Only the last key tile can be partial: full tiles take a mask-free path (wave-uniform branch).
@@ -192,30 +212,31 @@ __global__ __launch_bounds__(WAVES * 64) void attn_scores_kernel(const T* __rest
 
 template <typename T, int NT, int DP>
 int launch_scores(const T* q, const T* k, T* Ps, int B, int N, int D, int H, int ld, float scale, vu_rng rng,
-                  hipStream_t st) {
+                  bool softmax, hipStream_t st) {
   const int d = D / H;
   constexpr int LDK = DP + (sizeof(T) == 2 ? 8 : 4);
   const size_t lds = (size_t)N * LDK * sizeof(T);
   constexpr int WAVES = NT > 13 ? 8 : 4;
-  auto kern = (N % 16 == 0) ? attn_scores_kernel<T, NT, DP, WAVES, true> : attn_scores_kernel<T, NT, DP, WAVES, false>;
+  auto kern = softmax ? ((N % 16 == 0) ? attn_scores_kernel<T, NT, DP, WAVES, true, true> : attn_scores_kernel<T, NT, DP, WAVES, false, true>)
+                      : ((N % 16 == 0) ? attn_scores_kernel<T, NT, DP, WAVES, true, false> : attn_scores_kernel<T, NT, DP, WAVES, false, false>);
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { vu_set_error("attn_scores: cannot reserve %zu bytes of LDS", lds); return VU_ELAUNCH; }
   }
   dim3 grid((unsigned)((N + WAVES * 16 - 1) / (WAVES * 16)), (unsigned)(B * H));
   hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, st, q, k, Ps, N, D, H, d, ld, scale, rng);
-  if (vu_prof_on()) vu_prof_note("attn_scores_kernel", 2.0 * B * H * (double)N * N * d,
+  if (vu_prof_on()) vu_prof_note(softmax ? "attn_scores_kernel" : "attn_dscores_kernel", 2.0 * B * H * (double)N * N * d,
                                  ((double)B * H * N * N + 2.0 * B * N * D) * sizeof(T));
   return vu_check_launch("vu_attn_scores");
 }
 
 template <typename T>
 int dispatch_scores(const void* q, const void* k, void* Ps, int B, int N, int D, int H, int ld, float scale, vu_rng rng,
-                    hipStream_t st) {
+                    bool softmax, hipStream_t st) {
   const int d = D / H;
   const int dp = (d + 31) / 32 * 32;
   const int nt = (N + 15) / 16;
-#define VU_SC(NTv, DPv) return launch_scores<T, NTv, DPv>((const T*)q, (const T*)k, (T*)Ps, B, N, D, H, ld, scale, rng, st)
+#define VU_SC(NTv, DPv) return launch_scores<T, NTv, DPv>((const T*)q, (const T*)k, (T*)Ps, B, N, D, H, ld, scale, rng, softmax, st)
   if (nt <= 4) {
     if (dp == 32) VU_SC(4, 32); if (dp == 64) VU_SC(4, 64); if (dp == 96) VU_SC(4, 96); if (dp == 128) VU_SC(4, 128);
     if (dp == 192) VU_SC(4, 192); if (dp == 384) VU_SC(4, 384);
@@ -239,8 +260,21 @@ int vu_k_attn_scores(int dtype, const void* q, const void* k, void* Ps, int B, i
   const size_t lds = (size_t)N * (dp + (es == 2 ? 8 : 4)) * es;
   if (lds > 150 * 1024) return 1;
   if ((double)B * H * N * (double)ld >= 4294967295.0) return 1;   // 32-bit mask index in the fused kernel
-  if (dtype == 0) return dispatch_scores<float>(q, k, Ps, B, N, D, H, ld, scale, rng, st);
-  return dispatch_scores<bf16_t>(q, k, Ps, B, N, D, H, ld, scale, rng, st);
+  if (dtype == 0) return dispatch_scores<float>(q, k, Ps, B, N, D, H, ld, scale, rng, true, st);
+  return dispatch_scores<bf16_t>(q, k, Ps, B, N, D, H, ld, scale, rng, true, st);
+}
+
+// out[b,g,i,j] = scale * sum_t a[b,i,g*d+t] * bmat[b,j,g*d+t]   (dAhat = dO v^T); 1 = shape not covered
+int vu_k_attn_outer(int dtype, const void* a, const void* bmat, void* out, int B, int N, int D, int H, int ld, float scale,
+                    hipStream_t st) {
+  const int d = D / H;
+  const int dp = (d + 31) / 32 * 32;
+  const size_t es = dtype == 0 ? 4 : 2;
+  const size_t lds = (size_t)N * (dp + (es == 2 ? 8 : 4)) * es;
+  if (lds > 150 * 1024) return 1;
+  vu_rng none = vu_make_rng(0, 0, 0.f);
+  if (dtype == 0) return dispatch_scores<float>(a, bmat, out, B, N, D, H, ld, scale, none, false, st);
+  return dispatch_scores<bf16_t>(a, bmat, out, B, N, D, H, ld, scale, none, false, st);
 }
 
 // =============================================================================================
@@ -370,6 +404,20 @@ __global__ __launch_bounds__(256) void map_bwd_row_kernel(const T* __restrict__ 
 // of a quad exchange the post-dropout probabilities and the BatchNorm-backward gradients with
 // quad-permute DPP moves.  One 1024-thread block walks rows persistently; TPR threads per row.
 // ---------------------------------------------------------------------------------------------
+// value of lane (lane ^ K) inside the lane's quad, K = 1..3, as one DPP quad_perm move
+template <int K>
+__device__ __forceinline__ float quad_xor(float v) {
+  constexpr int ctrl = K == 1 ? 0xB1 : (K == 2 ? 0x4E : 0x1B);   // quad_perm [1,0,3,2] / [2,3,0,1] / [3,2,1,0]
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, 0xf, true));
+}
+template <int LS>
+__device__ __forceinline__ float quad_get(float v, int k) {   // k is a compile-time constant after unrolling
+  if (k == 1) return quad_xor<1>(v);
+  if (k == 2) return quad_xor<2>(v);
+  if (k == 3) return quad_xor<3>(v);
+  return v;
+}
+
 template <typename T, int H, int LS, int TPR>
 __global__ __launch_bounds__(1024) void map_bwd_split_kernel(const T* __restrict__ Ps, T* dA, const float* __restrict__ W,
                                                              const float* __restrict__ c, const float* __restrict__ gamma,
@@ -385,23 +433,26 @@ __global__ __launch_bounds__(1024) void map_bwd_split_kernel(const T* __restrict
   const int rsub = threadIdx.x / TPR, t = threadIdx.x % TPR;
   const int jc = (t / LS) * 4;             // first column of this lane's quad
   const long long hs = (long long)N * ld;
-  // this lane's rows / columns of the mix matrices (registers)
-  float Xr[HL][H], Xc[HL], Wc[H][HL], Gs[HL], M1[HL], M2[HL];
-#pragma unroll
-  for (int j = 0; j < HL; ++j) {
-    const int g = u * HL + j;
-    const float rstd = stats[H * H + 2 * H + g];
-#pragma unroll
-    for (int q = 0; q < H; ++q) {   // slot q (relative order) is head hq
-      const int hq = (u ^ (q / HL)) * HL + q % HL;
-      Xr[j][q] = W[g * H + hq] * rstd;      // xhat_g = sum_h W[g,h] rstd_g P~_h + ...
-      Wc[q][j] = W[hq * H + g];             // dP~_h(own h = g) = sum_g' W[g',h] dA_g'
-    }
-    Xc[j] = (c[g] - stats[H * H + H + g]) * rstd;
-    Gs[j] = gamma[g] * rstd;
-    M1[j] = stats[H * H + 3 * H + g];
-    M2[j] = stats[H * H + 4 * H + g];
+  // mix-matrix rows / columns of every head group, in that group's relative slot order, in LDS
+  // (re-read per use: keeping them in registers pushes the 128-VGPR budget into scratch)
+  __shared__ __attribute__((aligned(16))) float sXr[LS][HL][H];   // W[g][hq] * rstd_g
+  __shared__ __attribute__((aligned(16))) float sWc[LS][H][HL];   // W[hq][g]
+  __shared__ float sK[LS][HL][4];                                  // Xc, Gs, M1, M2
+  for (int q0 = threadIdx.x; q0 < LS * HL * H; q0 += blockDim.x) {
+    const int uu = q0 / (HL * H), j = (q0 / H) % HL, q = q0 % H;
+    const int g = uu * HL + j, hq = (uu ^ (q / HL)) * HL + q % HL;
+    sXr[uu][j][q] = W[g * H + hq] * stats[H * H + 2 * H + g];
+    sWc[uu][q][j] = W[hq * H + g];
   }
+  for (int q0 = threadIdx.x; q0 < LS * HL; q0 += blockDim.x) {
+    const int g = q0;
+    const float rstd = stats[H * H + 2 * H + g];
+    sK[g / HL][g % HL][0] = (c[g] - stats[H * H + H + g]) * rstd;
+    sK[g / HL][g % HL][1] = gamma[g] * rstd;
+    sK[g / HL][g % HL][2] = stats[H * H + 3 * H + g];
+    sK[g / HL][g % HL][3] = stats[H * H + 4 * H + g];
+  }
+  __syncthreads();
   float aW[HL][H], ac[HL];
 #pragma unroll
   for (int j = 0; j < HL; ++j) { ac[j] = 0.f;
@@ -424,8 +475,8 @@ __global__ __launch_bounds__(1024) void map_bwd_split_kernel(const T* __restrict
 #pragma unroll
       for (int e = 0; e < 4; ++e) { pv[j][e] = v.v[e]; dAh[j][e] = d.v[e]; }
     }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    auto step = [&](auto ec) __attribute__((always_inline)) {
+      constexpr int e = decltype(ec)::value;
       const bool cv = live && (jc + e < N);
       // post-dropout probabilities of ALL heads, in "relative" order: slot k*HL+j holds head
       // (u^k)*HL+j, i.e. slot 0.. are the lane's own heads, then the quad partners'
@@ -435,15 +486,18 @@ __global__ __launch_bounds__(1024) void map_bwd_split_kernel(const T* __restrict
         const float own = pv[j][e] > 0.f ? pv[j][e] * inv_keep : 0.f;
         ptr_[j] = own;
 #pragma unroll
-        for (int k = 1; k < LS; ++k) ptr_[k * HL + j] = __shfl_xor(own, k, 64);
+        for (int k = 1; k < LS; ++k) ptr_[k * HL + j] = quad_get<LS>(own, k);
       }
       float dAg[HL];
+      int zz = 0;
+      asm volatile("" : "+v"(zz));          // opaque zero: keeps the LDS table reads inside the loop
+      const int uz = u + zz;
 #pragma unroll
       for (int j = 0; j < HL; ++j) {
-        float xh = Xc[j];
+        float xh = sK[uz][j][0];
 #pragma unroll
-        for (int q = 0; q < H; ++q) xh += Xr[j][q] * ptr_[q];
-        dAg[j] = cv ? Gs[j] * (dAh[j][e] - M1[j] - xh * M2[j]) : 0.f;
+        for (int q = 0; q < H; ++q) xh += sXr[uz][j][q] * ptr_[q];
+        dAg[j] = cv ? sK[uz][j][1] * (dAh[j][e] - sK[uz][j][2] - xh * sK[uz][j][3]) : 0.f;
         ac[j] += dAg[j];
 #pragma unroll
         for (int q = 0; q < H; ++q) aW[j][q] += dAg[j] * ptr_[q];
@@ -456,9 +510,9 @@ __global__ __launch_bounds__(1024) void map_bwd_split_kernel(const T* __restrict
       for (int jj = 0; jj < HL; ++jj) {
 #pragma unroll
         for (int k = 0; k < LS; ++k) {
-          const float o = (k == 0) ? dAg[jj] : __shfl_xor(dAg[jj], k, 64);
+          const float o = (k == 0) ? dAg[jj] : quad_get<LS>(dAg[jj], k);
 #pragma unroll
-          for (int j = 0; j < HL; ++j) dpa[j] += Wc[k * HL + jj][j] * o;
+          for (int j = 0; j < HL; ++j) dpa[j] += sWc[uz][k * HL + jj][j] * o;
         }
       }
 #pragma unroll
@@ -467,7 +521,9 @@ __global__ __launch_bounds__(1024) void map_bwd_split_kernel(const T* __restrict
         dP[j][e] = dp;
         delta[j] += dp * fabsf(pv[j][e]);
       }
-    }
+    };
+    step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{});
+    step(std::integral_constant<int, 2>{}); step(std::integral_constant<int, 3>{});
     // delta over the row: lanes with the same head group u (xor offsets LS, 2LS, .. 32), then waves
 #pragma unroll
     for (int j = 0; j < HL; ++j) {

@@ -40,6 +40,9 @@ int vu_k_softmax_dropout(int dtype, void* S, long long rows, int N, int ld, vu_r
 int vu_k_attn_scores(int dtype, const void* q, const void* k, void* Ps, int B, int N, int D, int H, int ld,
                      float scale, vu_rng rng, hipStream_t st);
 
+int vu_k_attn_outer(int dtype, const void* a, const void* bmat, void* out, int B, int N, int D, int H, int ld,
+                    float scale, hipStream_t st);
+
 // K9+K10: head mixing + BatchNorm on sign-tagged maps (B,H,N,ld).
 // stats buffer layout (floats): Wf[H*H] cf[H] mean[H] rstd[H] m1[H] m2[H]
 #define VU_BN_STATS_FLOATS(H) ((H) * (H) + 5 * (H))

@@ -239,7 +239,9 @@ int attn_backward(const AttnDims& d, const vu_attn_params& p, const vu_attn_grad
     g.sAm = D; g.sAk = 1; g.sBk = D; g.sBn = 1; g.ldc = D; g.Z1 = 1; g.Z2 = 1; g.alpha = 1.f;
     VU_TRY(vu_gemm_launch(dt, 0, g, st));
   }
-  {  // dAhat = dO v^T
+  int fo = vu_k_attn_outer(dt, sc.dO, a.v, sc.dA, B, N, D, H, ld, 1.0f, st);   // dAhat = dO v^T (fused, vector stores)
+  if (fo < 0) return fo;
+  if (fo == 1) {
     vu_gemm_args g;
     memset(&g, 0, sizeof(g));
     g.A = sc.dO; g.B = a.v; g.C = sc.dA; g.M = N; g.N = N; g.K = dh;
