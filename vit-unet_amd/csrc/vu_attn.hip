@@ -398,209 +398,154 @@ __global__ __launch_bounds__(256) void map_bwd_row_kernel(const T* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
-// map_bwd_split_kernel: same arithmetic, but the H heads of a position quad are SPLIT over LS
-// adjacent lanes (HL = H/LS heads each).  Each lane keeps only its heads' data and its rows of
-// the mix matrices in registers (<= 128 VGPRs -> 4 waves per SIMD instead of 1) and the lanes
-// of a quad exchange the post-dropout probabilities and the BatchNorm-backward gradients with
-// quad-permute DPP moves.  One 1024-thread block walks rows persistently; TPR threads per row.
+// map_bwd_mfma_kernel (bf16 storage, one 256-thread block per row, ld <= 1024): as
+// map_bwd_row_kernel, but the head-mix weight gradient dW[g,h] = sum_pos dA_g P~_h is taken off the
+// VALU: every lane drops its dA and P~ values (bf16) into two [16][row] LDS images and the four
+// waves contract them over the row's positions with v_mfma_f32_16x16x32_bf16 (a ones row in the
+// P~ image yields dc = sum dA_g for free).  Without the 64 per-lane accumulators the kernel fits
+// two waves per SIMD.
 // ---------------------------------------------------------------------------------------------
-// value of lane (lane ^ K) inside the lane's quad, K = 1..3, as one DPP quad_perm move
-template <int K>
-__device__ __forceinline__ float quad_xor(float v) {
-  constexpr int ctrl = K == 1 ? 0xB1 : (K == 2 ? 0x4E : 0x1B);   // quad_perm [1,0,3,2] / [2,3,0,1] / [3,2,1,0]
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, 0xf, true));
-}
-template <int LS>
-__device__ __forceinline__ float quad_get(float v, int k) {   // k is a compile-time constant after unrolling
-  if (k == 1) return quad_xor<1>(v);
-  if (k == 2) return quad_xor<2>(v);
-  if (k == 3) return quad_xor<3>(v);
-  return v;
-}
-
-template <typename T, int H, int LS, int TPR>
-__global__ __launch_bounds__(1024) void map_bwd_split_kernel(const T* __restrict__ Ps, T* dA, const float* __restrict__ W,
-                                                             const float* __restrict__ c, const float* __restrict__ gamma,
-                                                             const float* __restrict__ stats, float* dW, float* dc,
-                                                             long long rows, int N, int ld, float inv_keep, float scale) {
-  constexpr int HL = H / LS;
-  constexpr int RPB = 1024 / TPR;          // rows per block iteration
-  constexpr int WPR = TPR / 64;            // waves per row
-  __shared__ float redd[16][H];            // per-wave partial deltas
-  __shared__ float red[16][H * H + H];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int u = threadIdx.x % LS;          // head group of this lane
-  const int rsub = threadIdx.x / TPR, t = threadIdx.x % TPR;
-  const int jc = (t / LS) * 4;             // first column of this lane's quad
-  const long long hs = (long long)N * ld;
-  // mix-matrix rows / columns of every head group, in that group's relative slot order, in LDS
-  // (re-read per use: keeping them in registers pushes the 128-VGPR budget into scratch)
-  __shared__ __attribute__((aligned(16))) float sXr[LS][HL][H];   // W[g][hq] * rstd_g
-  __shared__ __attribute__((aligned(16))) float sWc[LS][H][HL];   // W[hq][g]
-  __shared__ float sK[LS][HL][4];                                  // Xc, Gs, M1, M2
-  for (int q0 = threadIdx.x; q0 < LS * HL * H; q0 += blockDim.x) {
-    const int uu = q0 / (HL * H), j = (q0 / H) % HL, q = q0 % H;
-    const int g = uu * HL + j, hq = (uu ^ (q / HL)) * HL + q % HL;
-    sXr[uu][j][q] = W[g * H + hq] * stats[H * H + 2 * H + g];
-    sWc[uu][q][j] = W[hq * H + g];
-  }
-  for (int q0 = threadIdx.x; q0 < LS * HL; q0 += blockDim.x) {
-    const int g = q0;
-    const float rstd = stats[H * H + 2 * H + g];
-    sK[g / HL][g % HL][0] = (c[g] - stats[H * H + H + g]) * rstd;
-    sK[g / HL][g % HL][1] = gamma[g] * rstd;
-    sK[g / HL][g % HL][2] = stats[H * H + 3 * H + g];
-    sK[g / HL][g % HL][3] = stats[H * H + 4 * H + g];
+template <int H>
+__global__ __launch_bounds__(256, 2) void map_bwd_mfma_kernel(const bf16_t* __restrict__ Ps, bf16_t* dA,
+                                                              const float* __restrict__ W, const float* __restrict__ c,
+                                                              const float* __restrict__ gamma, const float* __restrict__ stats,
+                                                              float* dW, float* dc, long long rows, int N, int ld,
+                                                              float inv_keep, float scale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  // W and the backward tables are wave-uniform and indexed with compile-time constants: they
+  // arrive through scalar loads (SGPRs), not through LDS / VGPRs
+  const float* __restrict__ tX = stats + H * H + 5 * H;     // X[H*H], Xc[H], Gs[H]
+  const float* __restrict__ tM = stats + H * H + 3 * H;     // m1[H], m2[H]
+  __shared__ float redd[4][H];
+  __shared__ float red[4][256];
+  const int ldk = (ld + 31) / 32 * 32;        // positions rounded up to whole k-steps
+  const int LDP = ldk + 8;                    // image row stride (elements)
+  bf16_t* sA = reinterpret_cast<bf16_t*>(smem_raw);   // [16][LDP]  rows g: dA_g        (rows >= H stay 0)
+  bf16_t* sB = sA + 16 * LDP;                         // [16][LDP]  rows h: P~_h, row H: ones
+  for (int i = threadIdx.x; i < 32 * LDP; i += blockDim.x) {
+    const int r = i / LDP, col = i % LDP;
+    sA[i] = (r == 16 + H && col < N) ? (bf16_t)1.0f : (bf16_t)0.0f;   // sB row H = ones over the valid positions
   }
   __syncthreads();
-  float aW[HL][H], ac[HL];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int jc = threadIdx.x * 4;
+  const long long hs = (long long)N * ld;
+  const int nks = ldk / 32;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
+    const bool live = jc < ld;
+    const long long b = row / N;
+    const int i = (int)(row - b * N);
+    const long long off = (b * H * N + i) * (long long)ld + jc;
+    float pv[H][4], dP[H][4], dAg[H][4], delta[H];
 #pragma unroll
-  for (int j = 0; j < HL; ++j) { ac[j] = 0.f;
+    for (int h = 0; h < H; ++h) delta[h] = 0.f;
+    if (live) {
 #pragma unroll
-    for (int h = 0; h < H; ++h) aW[j][h] = 0.f; }
-
-  const long long nit = (rows + RPB - 1) / RPB;
-  for (long long it = blockIdx.x; it < nit; it += gridDim.x) {
-    const long long row = it * RPB + rsub;
-    const bool live = row < rows && jc < ld;
-    const long long b = live ? row / N : 0;
-    const int i = live ? (int)(row - b * N) : 0;
-    const long long off = ((b * H + u * HL) * N + i) * (long long)ld + jc;   // head u*HL of this lane
-    float pv[HL][4], dAh[HL][4], dP[HL][4], delta[HL];
+      for (int h = 0; h < H; ++h) {
+        const vu_f4 v = vu_ld4(Ps + off + h * hs);
+        const vu_f4 d = vu_ld4(dA + off + h * hs);
 #pragma unroll
-    for (int j = 0; j < HL; ++j) {
-      delta[j] = 0.f;
-      vu_f4 v = {{0.f, 0.f, 0.f, 0.f}}, d = {{0.f, 0.f, 0.f, 0.f}};
-      if (live) { v = vu_ld4(Ps + off + j * hs); d = vu_ld4(dA + off + j * hs); }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { pv[j][e] = v.v[e]; dAh[j][e] = d.v[e]; }
-    }
-    auto step = [&](auto ec) __attribute__((always_inline)) {
-      constexpr int e = decltype(ec)::value;
-      const bool cv = live && (jc + e < N);
-      // post-dropout probabilities of ALL heads, in "relative" order: slot k*HL+j holds head
-      // (u^k)*HL+j, i.e. slot 0.. are the lane's own heads, then the quad partners'
-      float ptr_[H];
-#pragma unroll
-      for (int j = 0; j < HL; ++j) {
-        const float own = pv[j][e] > 0.f ? pv[j][e] * inv_keep : 0.f;
-        ptr_[j] = own;
-#pragma unroll
-        for (int k = 1; k < LS; ++k) ptr_[k * HL + j] = quad_get<LS>(own, k);
+        for (int e = 0; e < 4; ++e) { pv[h][e] = v.v[e]; dAg[h][e] = d.v[e]; }
       }
-      float dAg[HL];
-      int zz = 0;
-      asm volatile("" : "+v"(zz));          // opaque zero: keeps the LDS table reads inside the loop
-      const int uz = u + zz;
 #pragma unroll
-      for (int j = 0; j < HL; ++j) {
-        float xh = sK[uz][j][0];
+      for (int e = 0; e < 4; ++e) {
+        const bool cv = jc + e < N;
+        float pt[H];
 #pragma unroll
-        for (int q = 0; q < H; ++q) xh += sXr[uz][j][q] * ptr_[q];
-        dAg[j] = cv ? sK[uz][j][1] * (dAh[j][e] - sK[uz][j][2] - xh * sK[uz][j][3]) : 0.f;
-        ac[j] += dAg[j];
+        for (int h = 0; h < H; ++h) pt[h] = pv[h][e] > 0.f ? pv[h][e] * inv_keep : 0.f;
 #pragma unroll
-        for (int q = 0; q < H; ++q) aW[j][q] += dAg[j] * ptr_[q];
-      }
-      // dP~ of the lane's own heads needs dA of all heads (same relative order)
-      float dpa[HL];
+        for (int g = 0; g < H; ++g) {
+          float xh = tX[H * H + g];
 #pragma unroll
-      for (int j = 0; j < HL; ++j) dpa[j] = 0.f;
+          for (int h = 0; h < H; ++h) xh += tX[g * H + h] * pt[h];
+          dAg[g][e] = cv ? tX[H * H + H + g] * (dAg[g][e] - tM[g] - xh * tM[H + g]) : 0.f;
+        }
 #pragma unroll
-      for (int jj = 0; jj < HL; ++jj) {
+        for (int h = 0; h < H; ++h) {
+          float dp = 0.f;
 #pragma unroll
-        for (int k = 0; k < LS; ++k) {
-          const float o = (k == 0) ? dAg[jj] : quad_get<LS>(dAg[jj], k);
-#pragma unroll
-          for (int j = 0; j < HL; ++j) dpa[j] += sWc[uz][k * HL + jj][j] * o;
+          for (int g = 0; g < H; ++g) dp += W[g * H + h] * dAg[g][e];
+          dp = pv[h][e] > 0.f ? dp * inv_keep : 0.f;
+          dP[h][e] = dp;
+          delta[h] += dp * fabsf(pv[h][e]);
         }
       }
+      // LDS images for the MFMA contraction (4 consecutive positions per store)
 #pragma unroll
-      for (int j = 0; j < HL; ++j) {
-        const float dp = pv[j][e] > 0.f ? dpa[j] * inv_keep : 0.f;
-        dP[j][e] = dp;
-        delta[j] += dp * fabsf(pv[j][e]);
+      for (int h = 0; h < H; ++h) {
+        vu_f4 a4, p4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a4.v[e] = dAg[h][e]; p4.v[e] = pv[h][e] > 0.f ? pv[h][e] * inv_keep : 0.f; }
+        vu_st4(sA + h * LDP + jc, a4);
+        vu_st4(sB + h * LDP + jc, p4);
       }
-    };
-    step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{});
-    step(std::integral_constant<int, 2>{}); step(std::integral_constant<int, 3>{});
-    // delta over the row: lanes with the same head group u (xor offsets LS, 2LS, .. 32), then waves
-#pragma unroll
-    for (int j = 0; j < HL; ++j) {
-#pragma unroll
-      for (int o = LS; o < 64; o <<= 1) delta[j] += __shfl_xor(delta[j], o, 64);
     }
-    if constexpr (WPR > 1) {
-      if (lane < LS) {
 #pragma unroll
-        for (int j = 0; j < HL; ++j) redd[wave][lane * HL + j] = delta[j];
-      }
-      __syncthreads();
-      const int w0 = rsub * WPR;
+    for (int h = 0; h < H; ++h) {
+      const float v = vu_wave_sum(delta[h]);
+      if (lane == 0) redd[wave][h] = v;
+    }
+    __syncthreads();
 #pragma unroll
-      for (int j = 0; j < HL; ++j) {
-        float a = 0.f;
-        for (int q = 0; q < WPR; ++q) a += redd[w0 + q][u * HL + j];
-        delta[j] = a;
-      }
-      __syncthreads();
+    for (int h = 0; h < H; ++h) delta[h] = redd[0][h] + redd[1][h] + redd[2][h] + redd[3][h];
+    // contraction over the row's positions, k-steps dealt round-robin to the 4 waves
+    for (int ks = wave; ks < nks; ks += 4) {
+      const bf16x8 af = *reinterpret_cast<const bf16x8*>(sA + l15 * LDP + ks * 32 + lg * 8);
+      const bf16x8 bf = *reinterpret_cast<const bf16x8*>(sB + l15 * LDP + ks * 32 + lg * 8);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, acc, 0, 0, 0);
     }
     if (live) {
 #pragma unroll
-      for (int j = 0; j < HL; ++j) {
+      for (int h = 0; h < H; ++h) {
         vu_f4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o.v[e] = (jc + e < N) ? fabsf(pv[j][e]) * (dP[j][e] - delta[j]) * scale : 0.f;
-        vu_st4(dA + off + j * hs, o);
+        for (int e = 0; e < 4; ++e) o.v[e] = (jc + e < N) ? fabsf(pv[h][e]) * (dP[h][e] - delta[h]) * scale : 0.f;
+        vu_st4(dA + off + h * hs, o);
       }
     }
+    __syncthreads();     // images and redd are rewritten by the next row
   }
-  // head-mix weight gradient: reduce over lanes with the same u, then over waves, then atomics.
-  // aW[j][q] is in relative order: column q = k*HL+jj is head (u^k)*HL+jj.
+  // acc: C[row g = lg*4 + r][col = l15]; columns < H are dW[g][h], column H is dc[g]
 #pragma unroll
-  for (int j = 0; j < HL; ++j) {
-#pragma unroll
-    for (int q = 0; q < H; ++q) {
-      float v = aW[j][q];
-#pragma unroll
-      for (int o = LS; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
-      if (lane < LS) {
-        const int k = q / HL, jj = q % HL;
-        red[wave][(lane * HL + j) * H + (lane ^ k) * HL + jj] = v;
-      }
-    }
-    float v = ac[j];
-#pragma unroll
-    for (int o = LS; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
-    if (lane < LS) red[wave][H * H + lane * HL + j] = v;
-  }
+  for (int r = 0; r < 4; ++r) red[wave][(lg * 4 + r) * 16 + l15] = acc[r];
   __syncthreads();
-  for (int q = threadIdx.x; q < H * H + H; q += blockDim.x) {
-    float v = 0.f;
-    for (int w = 0; w < 16; ++w) v += red[w][q];
-    if (q < H * H) atomicAdd(dW + q, v); else atomicAdd(dc + (q - H * H), v);
+  {
+    const int g = threadIdx.x / 16, hcol = threadIdx.x % 16;
+    const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (g < H && hcol < H) atomicAdd(dW + g * H + hcol, v);
+    else if (g < H && hcol == H) atomicAdd(dc + g, v);
   }
 }
 
 template <typename T, int H>
 int launch_map_bwd_row(const void* Ps, void* dA, const float* W, const float* c, const float* gamma, const float* stats,
                        float* dW, float* dc, int B, int N, int ld, float inv_keep, float scale, hipStream_t st) {
-  constexpr int LS = H >= 8 ? 4 : (H >= 4 ? 2 : 1);
   const long long rows = (long long)B * N;
-  const int need = (ld / 4) * LS;          // threads per row
-#define VU_MBS(TPRv)                                                                                                   \
-  {                                                                                                                    \
-    long long grid = (rows + (1024 / TPRv) - 1) / (1024 / TPRv);                                                       \
-    if (grid > 512) grid = 512;                                                                                        \
-    hipLaunchKernelGGL((map_bwd_split_kernel<T, H, LS, TPRv>), dim3((unsigned)grid), dim3(1024), 0, st, (const T*)Ps, \
-                       (T*)dA, W, c, gamma, stats, dW, dc, rows, N, ld, inv_keep, scale);                              \
+  if (ld <= 256) {
+    long long grid = (rows + 3) / 4; if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL((map_bwd_row_kernel<T, H, 64>), dim3((unsigned)grid), dim3(256), 0, st, (const T*)Ps, (T*)dA, W, c, gamma,
+                       stats, dW, dc, rows, N, ld, inv_keep, scale);
+    if (vu_prof_on()) vu_prof_note("map_bwd_row_kernel", 0.0, (double)B * H * N * N * 3 * sizeof(T));
+  } else if (sizeof(T) == 2 && H < 16) {
+    const int ldk = (ld + 31) / 32 * 32;
+    const size_t lds = (size_t)32 * (ldk + 8) * 2;
+    auto kern = map_bwd_mfma_kernel<H>;
+    if (lds > 40 * 1024) {
+      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) { vu_set_error("map_bwd: cannot reserve %zu bytes of LDS", lds); return VU_ELAUNCH; }
+    }
+    long long grid = rows; if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, (const bf16_t*)Ps, (bf16_t*)dA, W, c, gamma, stats, dW, dc,
+                       rows, N, ld, inv_keep, scale);
+    if (vu_prof_on()) vu_prof_note("map_bwd_mfma_kernel", 0.0, (double)B * H * N * N * 3 * sizeof(T));
+  } else {
+    long long grid = rows; if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL((map_bwd_row_kernel<T, H, 256>), dim3((unsigned)grid), dim3(256), 0, st, (const T*)Ps, (T*)dA, W, c, gamma,
+                       stats, dW, dc, rows, N, ld, inv_keep, scale);
+    if (vu_prof_on()) vu_prof_note("map_bwd_row_kernel", 0.0, (double)B * H * N * N * 3 * sizeof(T));
   }
-  if (need <= 64) VU_MBS(64)
-  else if (need <= 256) VU_MBS(256)
-  else if (need <= 1024) VU_MBS(1024)
-  else return 1;
-#undef VU_MBS
-  if (vu_prof_on()) vu_prof_note("map_bwd_split_kernel", 0.0, (double)B * H * N * N * 3 * sizeof(T));
   return vu_check_launch("vu_map_bwd");
 }
 
@@ -609,8 +554,7 @@ int launch_map_bwd_row(const void* Ps, void* dA, const float* W, const float* c,
 int vu_k_map_bwd(int dtype, const void* Ps, void* dAhat_dS, const float* W, const float* c, const float* gamma,
                  const float* stats, float* dW, float* dc, int B, int H, int N, int ld, float inv_keep, float scale,
                  hipStream_t st) {
-  const int ls = H >= 8 ? 4 : (H >= 4 ? 2 : 1);
-  if ((ld / 4) * ls > 1024) return vu_k_map_bwd_2sweep(dtype, Ps, dAhat_dS, W, c, gamma, stats, dW, dc, B, H, N, ld, inv_keep, scale, st);
+  if (ld > 1024) return vu_k_map_bwd_2sweep(dtype, Ps, dAhat_dS, W, c, gamma, stats, dW, dc, B, H, N, ld, inv_keep, scale, st);
 #define VU_MB(Tt, Hh) return launch_map_bwd_row<Tt, Hh>(Ps, dAhat_dS, W, c, gamma, stats, dW, dc, B, N, ld, inv_keep, scale, st)
   if (dtype == 0) { switch (H) { case 1: VU_MB(float, 1); case 2: VU_MB(float, 2); case 4: VU_MB(float, 4); case 8: VU_MB(float, 8); } }
   else { switch (H) { case 1: VU_MB(bf16_t, 1); case 2: VU_MB(bf16_t, 2); case 4: VU_MB(bf16_t, 4); case 8: VU_MB(bf16_t, 8); } }
@@ -628,63 +572,60 @@ int vu_k_map_bwd(int dtype, const void* Ps, void* dAhat_dS, const float* W, cons
 // =============================================================================================
 namespace {
 
-// one block per sample: threads = (row lanes) x (4-feature vectors of the D-wide row), coalesced
-// 8/16-byte loads; per-feature column sums are combined across row lanes in LDS, then reduced
-// per head.
+// one block per (sample, head): feature columns side by side, row lanes stacked, LDS combine
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_small_kernel(const T* __restrict__ dO, const T* __restrict__ O,
                                                            const T* __restrict__ v, float* partials, int N, int D, int H) {
-  __shared__ float sdo[256][4], sv[256][4];
-  __shared__ float hs1[16], hr[16];
-  const int b = blockIdx.x, d = D / H;
-  const long long base = (long long)b * N * D;
-  const int nvec = D >> 2;
-  const int TV = nvec < 256 ? nvec : 256;     // feature vectors handled side by side
-  const int RL = 256 / TV;                    // row lanes
-  const int tv = threadIdx.x % TV, rl = threadIdx.x / TV;
-  if (threadIdx.x < 16) { hs1[threadIdx.x] = 0.f; hr[threadIdx.x] = 0.f; }
-  __syncthreads();
-  for (int v0 = 0; v0 < nvec; v0 += TV) {
-    const int vi = v0 + tv;
-    const bool ok = rl < RL && vi < nvec;
-    float cdo[4] = {0, 0, 0, 0}, cv[4] = {0, 0, 0, 0}, rr[4] = {0, 0, 0, 0};
-    if (ok) {
+  __shared__ float sm[16];
+  __shared__ float sdo[256], sv[256];
+  const int b = blockIdx.x, g = blockIdx.y, d = D / H;
+  const long long base = (long long)b * N * D + g * d;
+  int TCOL = 256;                       // feature columns handled side by side (power of two >= min(d,256))
+  while (TCOL / 2 >= d) TCOL /= 2;
+  const int RL = 256 / TCOL;            // row lanes per column
+  const int tc = threadIdx.x % TCOL, rl = threadIdx.x / TCOL;
+  float s1 = 0.f, r = 0.f;
+  for (int t0 = 0; t0 < d; t0 += TCOL) {
+    const int t = t0 + tc;
+    float cdo = 0.f, cv = 0.f;
+    if (t < d) {
       for (int i = rl; i < N; i += RL) {
-        const long long o = base + (long long)i * D + vi * 4;
-        const vu_f4 a = vu_ld4(dO + o), c = vu_ld4(v + o), q = vu_ld4(O + o);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { cdo[e] += a.v[e]; cv[e] += c.v[e]; rr[e] += a.v[e] * q.v[e]; }
+        const float a = vu_ld(dO + base + (long long)i * D + t);
+        cdo += a;
+        cv += vu_ld(v + base + (long long)i * D + t);
+        r += a * vu_ld(O + base + (long long)i * D + t);
       }
     }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { sdo[threadIdx.x][e] = cdo[e]; sv[threadIdx.x][e] = cv[e]; }
-    // r needs no cross-lane pairing: add straight into the head bins
-    if (ok) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) atomicAdd(&hr[(vi * 4 + e) / d], rr[e]);
-    }
+    sdo[threadIdx.x] = cdo; sv[threadIdx.x] = cv;
     __syncthreads();
-    if (rl == 0 && vi < nvec) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float a = 0.f, c = 0.f;
-        for (int q = 0; q < RL; ++q) { a += sdo[q * TV + tv][e]; c += sv[q * TV + tv][e]; }
-        atomicAdd(&hs1[(vi * 4 + e) / d], a * c);
-      }
+    if (rl == 0 && t < d) {
+      float a = 0.f, c = 0.f;
+      for (int q = 0; q < RL; ++q) { a += sdo[q * TCOL + tc]; c += sv[q * TCOL + tc]; }
+      s1 += a * c;
     }
     __syncthreads();
   }
-  if (threadIdx.x < H) {
-    partials[(long long)b * 2 * H + threadIdx.x] = hs1[threadIdx.x];
-    partials[(long long)b * 2 * H + H + threadIdx.x] = hr[threadIdx.x];
+  s1 = vu_block_sum(s1, sm);
+  r = vu_block_sum(r, sm);
+  if (threadIdx.x == 0) {
+    partials[(long long)b * 2 * H + g] = s1;
+    partials[(long long)b * 2 * H + H + g] = r;
   }
 }
 
 // stats layout: Wf[H*H] cf[H] mean[H] rstd[H] m1[H] m2[H]
 __global__ void bn_bwd_small_finalize_kernel(const float* partials, int nb, const float* gamma, const float* beta,
-                                             float* stats, float* dgamma, float* dbeta, int H, double count, int training) {
+                                             const float* W, const float* c, float* stats, float* dgamma, float* dbeta,
+                                             int H, double count, int training) {
   const int g = threadIdx.x;
   if (g >= H) return;
+  {  // tables read by the map-backward kernels through scalar loads
+    const float rstd = stats[H * H + 2 * H + g];
+    float* X = stats + H * H + 5 * H;
+    for (int h = 0; h < H; ++h) X[g * H + h] = W[g * H + h] * rstd;
+    X[H * H + g] = (c[g] - stats[H * H + H + g]) * rstd;
+    X[H * H + H + g] = gamma[g] * rstd;
+  }
   double s1 = 0.0, r = 0.0;
   for (int i = 0; i < nb; ++i) { s1 += (double)partials[i * 2 * H + g]; r += (double)partials[i * 2 * H + H + g]; }
   const double gm = gamma[g];
@@ -699,11 +640,11 @@ __global__ void bn_bwd_small_finalize_kernel(const float* partials, int nb, cons
 
 // partials: >= B*2*H floats
 int vu_k_bn_bwd_small(int dtype, const void* dO, const void* O, const void* v, const float* gamma, const float* beta,
-                      float* stats, float* dgamma, float* dbeta, float* partials, int B, int N, int D, int H,
+                      const float* W, const float* c, float* stats, float* dgamma, float* dbeta, float* partials, int B, int N, int D, int H,
                       int training, hipStream_t st) {
-  if (dtype == 0) hipLaunchKernelGGL((bn_bwd_small_kernel<float>), dim3(B), dim3(256), 0, st, (const float*)dO, (const float*)O, (const float*)v, partials, N, D, H);
-  else hipLaunchKernelGGL((bn_bwd_small_kernel<bf16_t>), dim3(B), dim3(256), 0, st, (const bf16_t*)dO, (const bf16_t*)O, (const bf16_t*)v, partials, N, D, H);
-  hipLaunchKernelGGL(bn_bwd_small_finalize_kernel, dim3(1), dim3(64), 0, st, partials, B, gamma, beta, stats, dgamma, dbeta, H,
+  if (dtype == 0) hipLaunchKernelGGL((bn_bwd_small_kernel<float>), dim3(B, H), dim3(256), 0, st, (const float*)dO, (const float*)O, (const float*)v, partials, N, D, H);
+  else hipLaunchKernelGGL((bn_bwd_small_kernel<bf16_t>), dim3(B, H), dim3(256), 0, st, (const bf16_t*)dO, (const bf16_t*)O, (const bf16_t*)v, partials, N, D, H);
+  hipLaunchKernelGGL(bn_bwd_small_finalize_kernel, dim3(1), dim3(64), 0, st, partials, B, gamma, beta, W, c, stats, dgamma, dbeta, H,
                      (double)B * N * N, training);
   if (vu_prof_on()) vu_prof_note("bn_bwd_small(2 kernels)", 0.0, 3.0 * B * N * D * (dtype == 0 ? 4.0 : 2.0));
   return vu_check_launch("vu_bn_bwd_small");

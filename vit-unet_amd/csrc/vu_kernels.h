@@ -45,7 +45,8 @@ int vu_k_attn_outer(int dtype, const void* a, const void* bmat, void* out, int B
 
 // K9+K10: head mixing + BatchNorm on sign-tagged maps (B,H,N,ld).
 // stats buffer layout (floats): Wf[H*H] cf[H] mean[H] rstd[H] m1[H] m2[H]
-#define VU_BN_STATS_FLOATS(H) ((H) * (H) + 5 * (H))
+// backward tables appended: X[H*H] = W*rstd_g, Xc[H] = (c-mean)*rstd, Gs[H] = gamma*rstd
+#define VU_BN_STATS_FLOATS(H) (2 * (H) * (H) + 8 * (H))
 int vu_k_mix_stats(int dtype, const void* Ps, const float* W, const float* c, float* partials,
                    int nblocks, int B, int H, int N, int ld, float inv_keep, hipStream_t st);
 int vu_k_bn_finalize(const float* partials, int nblocks, const float* W, const float* c,
@@ -61,7 +62,7 @@ int vu_k_bn_bwd_finalize(const float* partials, int nblocks, float* stats, float
                          float* dbeta, int H, double count, int training, hipStream_t st);
 // the same statistics from dO, O and v only (no pass over the maps); partials >= B*2*H floats
 int vu_k_bn_bwd_small(int dtype, const void* dO, const void* O, const void* v, const float* gamma, const float* beta,
-                      float* stats, float* dgamma, float* dbeta, float* partials, int B, int N, int D, int H,
+                      const float* W, const float* c, float* stats, float* dgamma, float* dbeta, float* partials, int B, int N, int D, int H,
                       int training, hipStream_t st);
 // dS written over dAhat.  dW (H*H) and dc (H) are accumulated with atomics.
 int vu_k_map_bwd(int dtype, const void* Ps, void* dAhat_dS, const float* W, const float* c,

@@ -262,7 +262,7 @@ int attn_backward(const AttnDims& d, const vu_attn_params& p, const vu_attn_grad
   const double count = (double)B * N * N;
   // BatchNorm-backward statistics from dO, O, v (vu_attn.hip) - no pass over the maps
   (void)count;
-  VU_TRY(vu_k_bn_bwd_small(dt, sc.dO, a.O, a.v, p.bn_w, p.bn_b, a.stats, gr.bn_w, gr.bn_b, sc.partials, B, N, D, H, training, st));
+  VU_TRY(vu_k_bn_bwd_small(dt, sc.dO, a.O, a.v, p.bn_w, p.bn_b, p.mix_w, p.mix_b, a.stats, gr.bn_w, gr.bn_b, sc.partials, B, N, D, H, training, st));
   VU_TRY(vu_k_map_bwd(dt, a.Ps, sc.dA, p.mix_w, p.mix_b, p.bn_w, a.stats, gr.mix_w, gr.mix_b, B, H, N, ld, inv_keep,
                       1.0f / sqrtf((float)dh), st));
   {  // dq = dS k
