@@ -6,6 +6,7 @@
 // 49 accumulator tiles), does the row softmax with 16-lane shuffles, draws the dropout mask from
 // the counter hash and writes the sign-tagged probabilities - the (B,h,N,N) logits never touch
 // HBM.  Algorithmic traffic: one write of the map (E*|T|) + q, k reads.
+#include <stdlib.h>
 #include <type_traits>
 #include "vu_kernels.h"
 
@@ -210,13 +211,12 @@ __global__ __launch_bounds__(WAVES * 64) void attn_scores_kernel(const T* __rest
   }
 }
 
-template <typename T, int NT, int DP>
-int launch_scores(const T* q, const T* k, T* Ps, int B, int N, int D, int H, int ld, float scale, vu_rng rng,
-                  bool softmax, hipStream_t st) {
+template <typename T, int NT, int DP, int WAVES>
+int launch_scores_w(const T* q, const T* k, T* Ps, int B, int N, int D, int H, int ld, float scale, vu_rng rng,
+                    bool softmax, hipStream_t st) {
   const int d = D / H;
   constexpr int LDK = DP + (sizeof(T) == 2 ? 8 : 4);
   const size_t lds = (size_t)N * LDK * sizeof(T);
-  constexpr int WAVES = NT > 13 ? 8 : 4;
   auto kern = softmax ? ((N % 16 == 0) ? attn_scores_kernel<T, NT, DP, WAVES, true, true> : attn_scores_kernel<T, NT, DP, WAVES, false, true>)
                       : ((N % 16 == 0) ? attn_scores_kernel<T, NT, DP, WAVES, true, false> : attn_scores_kernel<T, NT, DP, WAVES, false, false>);
   if (lds > 48 * 1024) {
@@ -228,6 +228,16 @@ int launch_scores(const T* q, const T* k, T* Ps, int B, int N, int D, int H, int
   if (vu_prof_on()) vu_prof_note(softmax ? "attn_scores_kernel" : "attn_dscores_kernel", 2.0 * B * H * (double)N * N * d,
                                  ((double)B * H * N * N + 2.0 * B * N * D) * sizeof(T));
   return vu_check_launch("vu_attn_scores");
+}
+
+template <typename T, int NT, int DP>
+int launch_scores(const T* q, const T* k, T* Ps, int B, int N, int D, int H, int ld, float scale, vu_rng rng,
+                  bool softmax, hipStream_t st) {
+  // 64-row workgroups (4 waves, 256 VGPRs each): two of them share a CU, so one can stage its K
+  // while the other computes; VU_SCORES_WAVES=8 selects the 128-row form for experiments.
+  static const bool w8 = getenv("VU_SCORES_WAVES") && atoi(getenv("VU_SCORES_WAVES")) == 8;
+  if (NT > 13 && w8) return launch_scores_w<T, NT, DP, 8>(q, k, Ps, B, N, D, H, ld, scale, rng, softmax, st);
+  return launch_scores_w<T, NT, DP, 4>(q, k, Ps, B, N, D, H, ld, scale, rng, softmax, st);
 }
 
 template <typename T>
@@ -292,19 +302,11 @@ __global__ __launch_bounds__(256) void map_bwd_row_kernel(const T* __restrict__ 
                                                           const float* __restrict__ stats, float* dW, float* dc,
                                                           long long rows, int N, int ld, float inv_keep, float scale) {
   constexpr int RPB = 256 / TPR;
-  __shared__ float sW[H * H];
-  __shared__ float sX[H * H + H];
-  __shared__ float sG[3 * H];
+  // W and the backward tables (written by bn_bwd_small_finalize_kernel) come through scalar loads
+  const float* __restrict__ tX = stats + H * H + 5 * H;     // X[H*H], Xc[H], Gs[H]
+  const float* __restrict__ tM = stats + H * H + 3 * H;     // m1[H], m2[H]
   __shared__ float redd[4][H];
   __shared__ float red[4][H * H + H];
-  for (int i = threadIdx.x; i < H * H; i += blockDim.x) { sW[i] = W[i]; sX[i] = W[i] * stats[H * H + 2 * H + i / H]; }
-  for (int i = threadIdx.x; i < H; i += blockDim.x) {
-    sX[H * H + i] = (c[i] - stats[H * H + H + i]) * stats[H * H + 2 * H + i];
-    sG[i] = gamma[i] * stats[H * H + 2 * H + i];
-    sG[H + i] = stats[H * H + 3 * H + i];
-    sG[2 * H + i] = stats[H * H + 4 * H + i];
-  }
-  __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int rsub = threadIdx.x / TPR, t = threadIdx.x % TPR;
   const int jc = t * 4;
@@ -342,10 +344,10 @@ __global__ __launch_bounds__(256) void map_bwd_row_kernel(const T* __restrict__ 
         for (int h = 0; h < H; ++h) pt[h] = pv[h][e] > 0.f ? pv[h][e] * inv_keep : 0.f;
 #pragma unroll
         for (int g = 0; g < H; ++g) {
-          float xh = sX[H * H + g];
+          float xh = tX[H * H + g];
 #pragma unroll
-          for (int h = 0; h < H; ++h) xh += sX[g * H + h] * pt[h];
-          dAg[g] = cv ? sG[g] * (dAh[g][e] - sG[H + g] - xh * sG[2 * H + g]) : 0.f;
+          for (int h = 0; h < H; ++h) xh += tX[g * H + h] * pt[h];
+          dAg[g] = cv ? tX[H * H + H + g] * (dAh[g][e] - tM[g] - xh * tM[H + g]) : 0.f;
           ac[g] += dAg[g];
 #pragma unroll
           for (int h = 0; h < H; ++h) aW[g * H + h] += dAg[g] * pt[h];
@@ -354,7 +356,7 @@ __global__ __launch_bounds__(256) void map_bwd_row_kernel(const T* __restrict__ 
         for (int h = 0; h < H; ++h) {
           float dp = 0.f;
 #pragma unroll
-          for (int g = 0; g < H; ++g) dp += sW[g * H + h] * dAg[g];
+          for (int g = 0; g < H; ++g) dp += W[g * H + h] * dAg[g];
           dp = pv[h][e] > 0.f ? dp * inv_keep : 0.f;
           dP[h][e] = dp;
           delta[h] += dp * fabsf(pv[h][e]);

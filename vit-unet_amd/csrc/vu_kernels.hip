@@ -143,16 +143,16 @@ template <typename T, int H>
 __global__ __launch_bounds__(256) void mix_stats_kernel(const T* __restrict__ Ps, const float* __restrict__ W,
                                                         const float* __restrict__ c, float* partials,
                                                         int B, int N, int ld, float inv_keep) {
-  __shared__ float sW[H * H + H];
+  // W is wave-uniform and indexed with compile-time constants: scalar loads, no LDS / VGPR copy
   __shared__ float red[4][2 * H];
-  for (int i = threadIdx.x; i < H * H; i += blockDim.x) sW[i] = W[i];
-  __syncthreads();
-  if (threadIdx.x < H) {  // shift_g = c_g + sum_h W[g,h] / N  (the exact mean without dropout)
-    float s = 0.f;
-    for (int h = 0; h < H; ++h) s += sW[threadIdx.x * H + h];
-    sW[H * H + threadIdx.x] = s / (float)N;   // bias cancels in (A - shift)
+  float shift[H];   // shift_g = sum_h W[g,h] / N  (the exact mean without dropout; the bias cancels)
+#pragma unroll
+  for (int g = 0; g < H; ++g) {
+    float sacc = 0.f;
+#pragma unroll
+    for (int h = 0; h < H; ++h) sacc += W[g * H + h];
+    shift[g] = sacc / (float)N;
   }
-  __syncthreads();
   const int ld4 = ld >> 2;
   const long long total = (long long)B * N * ld4;
   const long long hs = (long long)N * ld;
@@ -171,9 +171,9 @@ __global__ __launch_bounds__(256) void mix_stats_kernel(const T* __restrict__ Ps
     for (int g = 0; g < H; ++g) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float a = -sW[H * H + g];
+        float a = -shift[g];
 #pragma unroll
-        for (int h = 0; h < H; ++h) a += sW[g * H + h] * pt[h][e];
+        for (int h = 0; h < H; ++h) a += W[g * H + h] * pt[h][e];
         if (jc + e < N) { s1[g] += a; s2[g] += a * a; }
       }
     }
@@ -242,9 +242,6 @@ template <typename T, int H>
 __global__ __launch_bounds__(256) void mix_apply_kernel(const T* __restrict__ Ps, T* __restrict__ Ah,
                                                         const float* __restrict__ stats, int B, int N, int ld,
                                                         float inv_keep) {
-  __shared__ float sW[H * H + H];
-  for (int i = threadIdx.x; i < H * H + H; i += blockDim.x) sW[i] = stats[i];
-  __syncthreads();
   const int ld4 = ld >> 2;
   const long long total = (long long)B * N * ld4;
   const long long hs = (long long)N * ld;
@@ -262,9 +259,9 @@ __global__ __launch_bounds__(256) void mix_apply_kernel(const T* __restrict__ Ps
       vu_f4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float a = sW[H * H + g];
+        float a = stats[H * H + g];          // folded tables: scalar loads
 #pragma unroll
-        for (int h = 0; h < H; ++h) a += sW[g * H + h] * pt[h][e];
+        for (int h = 0; h < H; ++h) a += stats[g * H + h] * pt[h][e];
         o.v[e] = (jc + e < N) ? a : 0.f;
       }
       vu_st4(Ah + off + g * hs, o);
