@@ -233,11 +233,10 @@ int launch_scores_w(const T* q, const T* k, T* Ps, int B, int N, int D, int H, i
 template <typename T, int NT, int DP>
 int launch_scores(const T* q, const T* k, T* Ps, int B, int N, int D, int H, int ld, float scale, vu_rng rng,
                   bool softmax, hipStream_t st) {
-  // 64-row workgroups (4 waves, 256 VGPRs each): two of them share a CU, so one can stage its K
-  // while the other computes; VU_SCORES_WAVES=8 selects the 128-row form for experiments.
-  static const bool w8 = getenv("VU_SCORES_WAVES") && atoi(getenv("VU_SCORES_WAVES")) == 8;
-  if (NT > 13 && w8) return launch_scores_w<T, NT, DP, 8>(q, k, Ps, B, N, D, H, ld, scale, rng, softmax, st);
-  return launch_scores_w<T, NT, DP, 4>(q, k, Ps, B, N, D, H, ld, scale, rng, softmax, st);
+  // long rows (N > 208): 128-row workgroups (8 waves) halve the K re-staging; measured 2.0 ms vs
+  // 3.25 ms per step against 64-row workgroups on Base (profiles/).
+  if constexpr (NT > 13) return launch_scores_w<T, NT, DP, 8>(q, k, Ps, B, N, D, H, ld, scale, rng, softmax, st);
+  else return launch_scores_w<T, NT, DP, 4>(q, k, Ps, B, N, D, H, ld, scale, rng, softmax, st);
 }
 
 template <typename T>

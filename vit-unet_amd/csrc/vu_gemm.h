@@ -11,7 +11,7 @@
 // T = float uses the exact-fp32 v_mfma_f32_16x16x4_f32 (parity mode).
 //
 // 256 threads = 4 waves in a 2x2 arrangement; wave tile (BM/2)x(BN/2) of 16x16 MFMA tiles;
-// BK = 32; register-prefetched global loads (tile t+1 in flight while tile t is multiplied).
+// BK = 32..128 (template); register-prefetched global loads (tile t+1 in flight while tile t is multiplied).
 #pragma once
 #include "vu_common.h"
 
@@ -139,9 +139,8 @@ __device__ __forceinline__ void vu_epilogue_swapped(const vu_gemm_args& g, const
   }
 }
 
-template <typename T, typename TC, bool TA, bool TB, int BM, int BN>
+template <typename T, typename TC, bool TA, bool TB, int BM, int BN, int BK>
 __global__ __launch_bounds__(256) void vu_gemm_kernel(const vu_gemm_args g) {
-  constexpr int BK = 32;
   constexpr int VEC = vu_vec<T>::N;            // elements per 16 B
   constexpr bool IS_BF16 = sizeof(T) == 2;
   constexpr int PADK = IS_BF16 ? 8 : 4;        // [row][k] images: row stride 80 B / 144 B
@@ -260,20 +259,22 @@ __global__ __launch_bounds__(256) void vu_gemm_kernel(const vu_gemm_args g) {
     if (kt + 1 < nk) load_tile((kt + 1) * BK);
     if constexpr (IS_BF16) {
       typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+#pragma unroll
+      for (int k32 = 0; k32 < BK; k32 += 32) {
       bf16x8 af[TM], bfr[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int r0 = wm * (BM / 2) + i * 16;
         if constexpr (TA) {
           const int q = l15 >> 2, p = l15 & 3;
-          const bf16_t* a0 = (const bf16_t*)&As[(8 * lg + q) * LDA + r0 + 4 * p];
+          const bf16_t* a0 = (const bf16_t*)&As[(k32 + 8 * lg + q) * LDA + r0 + 4 * p];
           s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)a0);
           s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(a0 + 4 * LDA));
           typedef __attribute__((ext_vector_type(8))) short s16x8;
           s16x8 t = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
           af[i] = __builtin_bit_cast(bf16x8, t);
         } else {
-          af[i] = *reinterpret_cast<const bf16x8*>(&As[(r0 + l15) * LDA + 8 * lg]);
+          af[i] = *reinterpret_cast<const bf16x8*>(&As[(r0 + l15) * LDA + k32 + 8 * lg]);
         }
       }
 #pragma unroll
@@ -281,14 +282,14 @@ __global__ __launch_bounds__(256) void vu_gemm_kernel(const vu_gemm_args g) {
         const int c0 = wn * (BN / 2) + j * 16;
         if constexpr (TB) {
           const int q = l15 >> 2, p = l15 & 3;
-          const bf16_t* b0 = (const bf16_t*)&Bs[(8 * lg + q) * LDB + c0 + 4 * p];
+          const bf16_t* b0 = (const bf16_t*)&Bs[(k32 + 8 * lg + q) * LDB + c0 + 4 * p];
           s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)b0);
           s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(b0 + 4 * LDB));
           typedef __attribute__((ext_vector_type(8))) short s16x8;
           s16x8 t = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
           bfr[j] = __builtin_bit_cast(bf16x8, t);
         } else {
-          bfr[j] = *reinterpret_cast<const bf16x8*>(&Bs[(c0 + l15) * LDB + 8 * lg]);
+          bfr[j] = *reinterpret_cast<const bf16x8*>(&Bs[(c0 + l15) * LDB + k32 + 8 * lg]);
         }
       }
 #pragma unroll
@@ -296,6 +297,7 @@ __global__ __launch_bounds__(256) void vu_gemm_kernel(const vu_gemm_args g) {
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      }
     } else {
 #pragma unroll
       for (int ks = 0; ks < BK / 4; ++ks) {

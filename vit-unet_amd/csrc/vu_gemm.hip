@@ -3,20 +3,20 @@
 #include <stdlib.h>
 #include "vu_gemm.h"
 
-template <typename T, typename TC, bool TA, bool TB, int BM, int BN>
-static int launch_one(const vu_gemm_args& g, hipStream_t st) {
+template <typename T, typename TC, bool TA, bool TB, int BM, int BN, int BK>
+static int launch_bk(const vu_gemm_args& g, hipStream_t st) {
   vu_gemm_args ga = g;
   const long long blocks = (long long)vu_cdiv(g.M, BM) * vu_cdiv(g.N, BN) * g.Z1 * g.Z2;
   ga.ksplit = 1;
   if (sizeof(TC) == 4 && g.accumulate && !g.act && !g.dropout && !g.addend && blocks < 512) {
     // small output, long K (weight gradients over B*N rows): split K so the chip is filled
     int want = (int)((1024 + blocks - 1) / blocks);
-    const int maxs = vu_cdiv(g.K, 256);
+    const int maxs = vu_cdiv(g.K, 4 * BK);
     ga.ksplit = want < maxs ? want : maxs;
     if (ga.ksplit < 1) ga.ksplit = 1;
   }
   dim3 grid((unsigned)(vu_cdiv(g.M, BM) * vu_cdiv(g.N, BN)), (unsigned)(g.Z1 * g.Z2), (unsigned)ga.ksplit);
-  hipLaunchKernelGGL((vu_gemm_kernel<T, TC, TA, TB, BM, BN>), grid, dim3(256), 0, st, ga);
+  hipLaunchKernelGGL((vu_gemm_kernel<T, TC, TA, TB, BM, BN, BK>), grid, dim3(256), 0, st, ga);
   if (vu_prof_on()) {
     char tag[96];
     static const bool shapes = getenv("VU_PROF_SHAPES") != nullptr;
@@ -34,6 +34,15 @@ static int launch_one(const vu_gemm_args& g, hipStream_t st) {
   return vu_check_launch("vu_gemm");
 }
 
+template <typename T, typename TC, bool TA, bool TB, int BM, int BN>
+static int launch_one(const vu_gemm_args& g, hipStream_t st) {
+  // k-tile depth: bf16 tiles run fewer, longer k-steps (one barrier pair per BK); the narrow
+  // 128x32 tile (map x small-matrix products) takes BK = 128.  fp32 keeps 32 (LDS size).
+  // measured (tools/gemm_bench.py, 3072-class GEMMs): BK 64 is +10..12 % over BK 32
+  if constexpr (sizeof(T) == 4) return launch_bk<T, TC, TA, TB, BM, BN, 32>(g, st);
+  else return launch_bk<T, TC, TA, TB, BM, BN, 64>(g, st);
+}
+
 template <typename T, typename TC, bool TA, bool TB>
 static int launch_tiles(const vu_gemm_args& g, hipStream_t st) {
   if (g.N <= 32) return launch_one<T, TC, TA, TB, 128, 32>(g, st);
@@ -49,11 +58,9 @@ static int launch_layout(vu_gemm_args& g0, int c_float, hipStream_t st) {
   const size_t csz = (sizeof(T) == 2 && !c_float) ? 2 : 4;
   // C^T = B^T A^T: same arithmetic, but each lane then owns 4 consecutive elements of a C row,
   // so the epilogue stores (and reads aux / addend) as vectors.  Needs >= 64 original columns.
-  static const bool noswap = getenv("VU_GEMM_NOSWAP") != nullptr;
-  static const bool noswapf = getenv("VU_GEMM_NOSWAP_F32") != nullptr;
   // split-K weight-gradient GEMMs add with float atomics: keep their 64-byte-contiguous plain pattern
   const bool will_split = g0.accumulate && (long long)vu_cdiv(g0.M, 128) * vu_cdiv(g0.N, 128) * g0.Z1 * g0.Z2 < 512;
-  if (g0.N >= 64 && !noswap && !will_split && !(noswapf && csz == 4 && sizeof(T) == 2)) {
+  if (g0.N >= 64 && !will_split) {
     g.A = g0.B; g.B = g0.A; g.M = g0.N; g.N = g0.M;
     g.sAm = g0.sBn; g.sAk = g0.sBk; g.sBk = g0.sAk; g.sBn = g0.sAm;
     g.sA1 = g0.sB1; g.sA2 = g0.sB2; g.sB1 = g0.sA1; g.sB2 = g0.sA2;
