@@ -1,0 +1,30 @@
+# HBM traffic counters for the dominant kernels (separate --pmc passes, no other tracing domains)
+set -x
+cd $GRAFT_REPO_ROOT
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+cd /tmp && export TMPDIR=/tmp
+for C in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$C -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph --no-roofline > $GRAFT_REPO_ROOT/gpurun_out/pmc_$C.log 2>&1
+  tail -c 200 $GRAFT_REPO_ROOT/gpurun_out/pmc_$C.log
+done
+cd $GRAFT_REPO_ROOT
+python - <<'PY'
+import csv, glob, collections
+for C in ("FETCH_SIZE", "WRITE_SIZE"):
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for f in glob.glob(f"gpurun_out/pmc_{C}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r.get("Counter_Name") == C:
+                k = r["Kernel_Name"][:90]
+                agg[k][0] += 1; agg[k][1] += float(r["Counter_Value"])
+    rows = sorted(agg.items(), key=lambda kv: -kv[1][1])[:12]
+    with open(f"gpurun_out/pmc_{C}_summary.csv", "w") as o:
+        o.write("kernel,launches,sum_%s,avg_per_launch\n" % C)
+        for k, (n, v) in rows:
+            o.write('"%s",%d,%.1f,%.1f\n' % (k, n, v, v / n))
+            print(C, n, "%.1f" % (v / n), k)
+    # drop the bulky raw files
+import shutil
+for C in ("FETCH_SIZE", "WRITE_SIZE"):
+    shutil.rmtree(f"gpurun_out/pmc_{C}", ignore_errors=True)
+PY
