@@ -173,7 +173,19 @@ def main():
             else:
                 ach = d["bytes"] / d["count"] / avg_s / 1e9
                 roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
-            roof.update({"traffic": None, "kernel": name, "avg_launch_us": avg_s * 1e6,
+            traffic, tsrc = None, None
+            try:      # HBM bytes per launch from the committed rocprofv3 --pmc passes (not collectable in-process)
+                import glob
+                for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))[::-1]:
+                    for sym, rec in json.load(open(f))["kernels"].items():
+                        if name.split("<")[0] in sym and rec.get("traffic_bytes"):
+                            traffic, tsrc = rec["traffic_bytes"], os.path.basename(f)
+                            break
+                    if traffic:
+                        break
+            except Exception:
+                pass
+            roof.update({"traffic": traffic, "traffic_source": tsrc, "kernel": name, "avg_launch_us": avg_s * 1e6,
                          "launches_per_step": d["count"] / a.profile_steps,
                          "share_of_step": d["ms"] / tot_ms,
                          "step_mfma_frac": value * TRAIN_GFLOP_PER_IMG[a.model] / 1e3 / MFMA_PEAK_TFLOPS,
