@@ -207,7 +207,8 @@ def conv3x3_per_patch(tok: torch.Tensor, C: int, w: torch.Tensor, b: Optional[to
 # --------------------------------------------------------------------------------------------
 def reattention(xq, xkv, p: Dict[str, torch.Tensor], pre: str, h: int, C: int, *, training: bool,
                 attn_drop: float, proj_drop: float, seed: Optional[int] = None, stream: int = 0,
-                bn_momentum: float = 0.1, eps: float = 1e-5, return_map: bool = False, storage=None):
+                bn_momentum: float = 0.1, eps: float = 1e-5, return_map: bool = False, storage=None,
+                round_out: bool = True):
     B, N, D = xq.shape
     d = D // h
     st = storage
@@ -234,7 +235,9 @@ def reattention(xq, xkv, p: Dict[str, torch.Tensor], pre: str, h: int, C: int, *
     a = _r(a * gam.reshape(1, h, 1, 1) + bet.reshape(1, h, 1, 1), st)  # reatten_scale == 1.0 (:140)
     o = _r(torch.matmul(a, v).transpose(1, 2).reshape(B, N, D), st)   # :161
     y = F.linear(o, _r(p[pre + "proj.weight"], st), p[pre + "proj.bias"])     # :162
-    y = _r(_dropout(y, proj_drop, training, seed, 2 * stream + 1), st)        # :163
+    y = _dropout(y, proj_drop, training, seed, 2 * stream + 1)                # :163
+    if round_out:   # inside a block the HIP projection epilogue adds the residual before storing
+        y = _r(y, st)
     return (y, a) if return_map else y
 
 
@@ -247,12 +250,13 @@ def te_block(x, p, pre: str, cfg: Config, *, training: bool, seed=None, stream: 
     """ReAttentionTransformerEncoder.forward (model.py:201-207), post-norm."""
     st = storage
     a = reattention(x, x, p, pre + "ReAttn.", cfg.num_heads, cfg.num_channels, training=training,
-                    attn_drop=cfg.attn_drop, proj_drop=cfg.proj_drop, seed=seed, stream=stream, storage=st)
+                    attn_drop=cfg.attn_drop, proj_drop=cfg.proj_drop, seed=seed, stream=stream, storage=st,
+                    round_out=False)
     x = _r(_layernorm_nd(_r(a + x, st), p[pre + "LN1.weight"], p[pre + "LN1.bias"]), st)
     hdn = _r(F.gelu(F.linear(x, _r(p[pre + "FeedForward.net.0.weight"], st), p[pre + "FeedForward.net.0.bias"])), st)
     # linear_drop is 0 in every preset (model.py:451,467,483); Dropout(0) is the identity.
     assert cfg.linear_drop == 0.0 or not training, "oracle: linear_drop>0 in train mode not restated"
-    f = _r(F.linear(hdn, _r(p[pre + "FeedForward.net.3.weight"], st), p[pre + "FeedForward.net.3.bias"]), st)
+    f = F.linear(hdn, _r(p[pre + "FeedForward.net.3.weight"], st), p[pre + "FeedForward.net.3.bias"])
     return _r(_layernorm_nd(_r(f + x, st), p[pre + "LN2.weight"], p[pre + "LN2.bias"]), st)
 
 

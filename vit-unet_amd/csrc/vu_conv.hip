@@ -169,18 +169,19 @@ struct WgradSet { const void* dout[3]; const void* in[3]; float* dw[3]; float* d
 
 template <typename TDO, typename TI, int C>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradSet set, long long nquads, int s) {
-  constexpr int NW = C * C * 9;
-  __shared__ float red[4][NW + C];
-  const TDO* dout = (const TDO*)set.dout[blockIdx.y];
-  const TI* in = (const TI*)set.in[blockIdx.y];
-  float* dw = set.dw[blockIdx.y];
-  float* dbias = set.dbias[blockIdx.y];
+  // blockIdx.y = conv * C + co: one output channel of one convolution per block (27 accumulators
+  // for C = 3 instead of 81: twice the waves per SIMD; the input windows come from L1/L2)
+  constexpr int NW = C * 9;
+  __shared__ float red[4][NW + 1];
+  const int cv = blockIdx.y / C, co = blockIdx.y % C;
+  const TDO* dout = (const TDO*)set.dout[cv];
+  const TI* in = (const TI*)set.in[cv];
+  float* dw = set.dw[cv] + co * NW;
+  float* dbias = set.dbias[cv];
   const int ss = s * s;
-  float acc[NW], accb[C];
+  float acc[NW], accb = 0.f;
 #pragma unroll
   for (int i = 0; i < NW; ++i) acc[i] = 0.f;
-#pragma unroll
-  for (int i = 0; i < C; ++i) accb[i] = 0.f;
   for (long long qid = blockIdx.x * (long long)blockDim.x + threadIdx.x; qid < nquads;
        qid += (long long)gridDim.x * blockDim.x) {
     long long patch; int y, x0;
@@ -190,22 +191,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradSet set, long long
     float win[C][3][6];
 #pragma unroll
     for (int ci = 0; ci < C; ++ci) load_win(in + pbase + ci * ss, s, y, x0, win[ci]);
+    const vu_f4 d = vu_ld4(dout + obase + co * ss);
+    accb += d.v[0] + d.v[1] + d.v[2] + d.v[3];
 #pragma unroll
-    for (int co = 0; co < C; ++co) {
-      const vu_f4 d = vu_ld4(dout + obase + co * ss);
-      accb[co] += d.v[0] + d.v[1] + d.v[2] + d.v[3];
+    for (int ci = 0; ci < C; ++ci)
 #pragma unroll
-      for (int ci = 0; ci < C; ++ci)
+      for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
+        for (int kx = 0; kx < 3; ++kx) {
+          float a = 0.f;
 #pragma unroll
-          for (int kx = 0; kx < 3; ++kx) {
-            float a = 0.f;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) a += d.v[i] * win[ci][ky][i + kx];
-            acc[(co * C + ci) * 9 + ky * 3 + kx] += a;
-          }
-    }
+          for (int i = 0; i < 4; ++i) a += d.v[i] * win[ci][ky][i + kx];
+          acc[ci * 9 + ky * 3 + kx] += a;
+        }
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -213,16 +211,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradSet set, long long
     const float v = vu_wave_sum(acc[i]);
     if (lane == 0) red[wave][i] = v;
   }
-#pragma unroll
-  for (int i = 0; i < C; ++i) {
-    const float v = vu_wave_sum(accb[i]);
-    if (lane == 0) red[wave][NW + i] = v;
+  {
+    const float v = vu_wave_sum(accb);
+    if (lane == 0) red[wave][NW] = v;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < NW + C; i += blockDim.x) {
+  for (int i = threadIdx.x; i < NW + 1; i += blockDim.x) {
     const float v = red[0][i] + red[1][i] + red[2][i] + red[3][i];
     if (i < NW) atomicAdd(dw + i, v);
-    else if (dbias) atomicAdd(dbias + (i - NW), v);
+    else if (dbias) atomicAdd(dbias + co, v);
   }
 }
 
@@ -302,11 +299,11 @@ static int wgrad_launch(int dtype, int dout_f32, const WgradSet& set, int nconv,
   VU_REQUIRE(s % 4 == 0, "conv3x3: patch size must be a multiple of 4");
   const long long nq = npatch * s * s / 4;
   if (nq == 0) return VU_OK;
-  const int gx = grid_for(nq, nconv == 1 ? 1024 : 512);
+  const int gx = grid_for(nq, nconv == 1 ? 512 : 256);
   VU_CONV_C(C,
-    if (dtype == 0) hipLaunchKernelGGL((conv_wgrad_kernel<float, float, CC>), dim3(gx, nconv), dim3(256), 0, st, set, nq, s);
-    else if (dout_f32) hipLaunchKernelGGL((conv_wgrad_kernel<float, bf16_t, CC>), dim3(gx, nconv), dim3(256), 0, st, set, nq, s);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, bf16_t, CC>), dim3(gx, nconv), dim3(256), 0, st, set, nq, s);)
+    if (dtype == 0) hipLaunchKernelGGL((conv_wgrad_kernel<float, float, CC>), dim3(gx, nconv * CC), dim3(256), 0, st, set, nq, s);
+    else if (dout_f32) hipLaunchKernelGGL((conv_wgrad_kernel<float, bf16_t, CC>), dim3(gx, nconv * CC), dim3(256), 0, st, set, nq, s);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, bf16_t, CC>), dim3(gx, nconv * CC), dim3(256), 0, st, set, nq, s);)
   if (vu_prof_on()) vu_prof_note(nconv == 1 ? "conv_wgrad_kernel<1>" : "conv_wgrad_kernel<3>", 0.0,
                                  (double)nq * 4 * C * nconv * ((dout_f32 || dtype == 0 ? 4.0 : 2.0) + (dtype == 0 ? 4.0 : 2.0)));
   return vu_check_launch("vu_conv3x3_wgrad");

@@ -480,8 +480,8 @@ int vu_k_map_bwd_2sweep(int dtype, const void* Ps, void* dAhat_dS, const float* 
 // with Chan merge, apply), two backward.
 // =============================================================================================
 template <typename T>
-__global__ __launch_bounds__(256) void add_ln_stats_kernel(const T* __restrict__ a, const T* __restrict__ x,
-                                                           T* __restrict__ z, float* partials, long long P) {
+__global__ __launch_bounds__(256) void add_ln_stats_kernel(const T* a, const T* __restrict__ x,
+                                                           T* z, float* partials, long long P) {
   __shared__ float sm[16];
   const int c = blockIdx.x, b = blockIdx.y, nch = gridDim.x;
   const long long base = (long long)c * VU_LN_CHUNK;
@@ -494,10 +494,12 @@ __global__ __launch_bounds__(256) void add_ln_stats_kernel(const T* __restrict__
     const long long e = base + (it * 256 + threadIdx.x) * 4;
     if (e < P) {
       vu_f4 t = vu_ld4(a + sb + e);
-      if (x) { const vu_f4 u = vu_ld4(x + sb + e); t.v[0] += u.v[0]; t.v[1] += u.v[1]; t.v[2] += u.v[2]; t.v[3] += u.v[3]; }
-      vu_st4(z + sb + e, t);
-      // statistics are taken on the values as stored (so forward and backward agree bit for bit)
-      t = vu_ld4(z + sb + e);
+      if (x || z != a) {   // (z == a, no x: the sum was already formed by the producing GEMM's epilogue)
+        if (x) { const vu_f4 u = vu_ld4(x + sb + e); t.v[0] += u.v[0]; t.v[1] += u.v[1]; t.v[2] += u.v[2]; t.v[3] += u.v[3]; }
+        vu_st4(z + sb + e, t);
+        // statistics are taken on the values as stored (so forward and backward agree bit for bit)
+        t = vu_ld4(z + sb + e);
+      }
 #pragma unroll
       for (int q = 0; q < 4; ++q) { v[it * 4 + q] = t.v[q]; sum += t.v[q]; }
       cnt += 4;

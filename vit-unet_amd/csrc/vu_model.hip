@@ -165,7 +165,7 @@ void carve_attn(Bump& bp, const AttnDims& d, AttnBuf& a) {
 
 int attn_forward(const AttnDims& d, const vu_attn_params& p, const void* xq, const void* xkv, void* y,
                  AttnBuf& a, float* partials, float attn_drop, float proj_drop, int training, uint64_t seed,
-                 uint64_t stream_id, const uint32_t* salt, hipStream_t st) {
+                 uint64_t stream_id, const uint32_t* salt, hipStream_t st, const void* resid = nullptr) {
   const int dt = d.dtype, B = d.B, N = d.N, D = d.D, H = d.H, ld = d.ld;
   const int dh = D / H;
   const long long npatch = (long long)B * N;
@@ -206,6 +206,7 @@ int attn_forward(const AttnDims& d, const vu_attn_params& p, const void* xq, con
     g.A = a.O; g.B = p.proj_w; g.C = y; g.M = B * N; g.N = D; g.K = D;
     g.sAm = D; g.sAk = 1; g.sBk = 1; g.sBn = D; g.ldc = D; g.Z1 = 1; g.Z2 = 1;
     g.alpha = 1.f; g.bias = p.proj_b;
+    g.addend = resid;   // block residual: y = dropout(O Wp^T + bp) + x leaves the GEMM in one pass
     g.rng = vu_make_rng(seed, 2 * stream_id + 1, training ? proj_drop : 0.f);
     g.rng.salt = salt;
     g.dropout = g.rng.thr != 0;
@@ -392,9 +393,9 @@ int block_forward(Ctx& cx, const BlockP& bp, BlockBuf& bb, const void* x, uint64
   const long long P = (long long)L.N * L.D;
   AttnDims d{dt, B, L.N, L.D, c.num_heads, c.num_channels, L.s, L.ld};
   vu_attn_params ap = attn_params(bp.at, c, cx.prm, cx.shadow, cx.bn);
-  VU_TRY(attn_forward(d, ap, x, x, cx.w->y_attn, bb.at, cx.w->partials, c.attn_drop, c.proj_drop, cx.training,
-                      cx.seed, stream_id, cx.salt, cx.st));
-  VU_TRY(vu_k_add_ln_fwd(dt, cx.w->y_attn, x, bb.z1, cx.prm + bp.ln1w, cx.prm + bp.ln1b, bb.x1, cx.w->lnp, bb.ln1s,
+  VU_TRY(attn_forward(d, ap, x, x, bb.z1, bb.at, cx.w->partials, c.attn_drop, c.proj_drop, cx.training,
+                      cx.seed, stream_id, cx.salt, cx.st, x));          // z1 = attn(x) + x
+  VU_TRY(vu_k_add_ln_fwd(dt, bb.z1, nullptr, bb.z1, cx.prm + bp.ln1w, cx.prm + bp.ln1b, bb.x1, cx.w->lnp, bb.ln1s,
                          B, P, 1e-5f, cx.st));
   {  // hact = gelu(x1 W1^T + b1)  (model.py:102-104)
     vu_gemm_args g;
@@ -407,12 +408,12 @@ int block_forward(Ctx& cx, const BlockP& bp, BlockBuf& bb, const void* x, uint64
   {  // f = hact W2^T + b2  (model.py:106)
     vu_gemm_args g;
     memset(&g, 0, sizeof(g));
-    g.A = bb.hact; g.B = wptr(c, cx.prm, cx.shadow, bp.w2); g.C = cx.w->f_ff;
+    g.A = bb.hact; g.B = wptr(c, cx.prm, cx.shadow, bp.w2); g.C = bb.z2;
     g.M = B * L.N; g.N = L.D; g.K = L.hid; g.sAm = L.hid; g.sAk = 1; g.sBk = 1; g.sBn = L.hid; g.ldc = L.D;
-    g.Z1 = 1; g.Z2 = 1; g.alpha = 1.f; g.bias = cx.prm + bp.b2;
+    g.Z1 = 1; g.Z2 = 1; g.alpha = 1.f; g.bias = cx.prm + bp.b2; g.addend = bb.x1;   // z2 = FF(x1) + x1
     VU_TRY(vu_gemm_launch(dt, 0, g, cx.st));
   }
-  VU_TRY(vu_k_add_ln_fwd(dt, cx.w->f_ff, bb.x1, bb.z2, cx.prm + bp.ln2w, cx.prm + bp.ln2b, bb.out, cx.w->lnp, bb.ln2s,
+  VU_TRY(vu_k_add_ln_fwd(dt, bb.z2, nullptr, bb.z2, cx.prm + bp.ln2w, cx.prm + bp.ln2b, bb.out, cx.w->lnp, bb.ln2s,
                          B, P, 1e-5f, cx.st));
   return VU_OK;
 }
