@@ -34,6 +34,8 @@ struct vu_gemm_args {
   int vecA, vecB;      // 16-byte vector loads legal for A / B
   int swap;            // operands were exchanged by the launcher: the kernel computes C^T (vector stores)
   int vecC;            // 4-element vector access to C rows is aligned
+  float* colsum;       // optional: += column sums over k of an operand (bias gradients), see colsum_side
+  int colsum_side;     // kernel space: 1 = sum_k A(m,k) -> colsum[m] ; 2 = sum_k B(k,n) -> colsum[n]
   int ksplit;          // >1: K is split over blockIdx.z and C is accumulated with float atomics
 };
 
@@ -252,11 +254,22 @@ __global__ __launch_bounds__(256) void vu_gemm_kernel(const vu_gemm_args g) {
     kt0 = blockIdx.z * per;
     nk = kt0 + per < nk_all ? kt0 + per : nk_all;
   }
+  float csum = 0.f;   // bias-gradient column sum carried by the first tile column / row of blocks
+  const bool do_cs = g.colsum && ((g.colsum_side == 1 && tile_n == 0 && tid < BM) || (g.colsum_side == 2 && tile_m == 0 && tid < BN));
   if (kt0 < nk) load_tile(kt0 * BK);
   for (int kt = kt0; kt < nk; ++kt) {
     store_tile();
     __syncthreads();
     if (kt + 1 < nk) load_tile((kt + 1) * BK);
+    if (do_cs) {
+      if (g.colsum_side == 1) {
+#pragma unroll 8
+        for (int kk = 0; kk < BK; ++kk) csum += (float)(TA ? As[kk * LDA + tid] : As[tid * LDA + kk]);
+      } else {
+#pragma unroll 8
+        for (int kk = 0; kk < BK; ++kk) csum += (float)(TB ? Bs[kk * LDB + tid] : Bs[tid * LDB + kk]);
+      }
+    }
     if constexpr (IS_BF16) {
       typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 #pragma unroll
@@ -323,6 +336,12 @@ __global__ __launch_bounds__(256) void vu_gemm_kernel(const vu_gemm_args g) {
     __syncthreads();
   }
 
+  if (do_cs) {
+    const int idx = (g.colsum_side == 1 ? m_base : n_base) + tid;
+    if (idx < (g.colsum_side == 1 ? g.M : g.N)) {
+      if (g.ksplit > 1) atomicAdd(g.colsum + idx, csum); else g.colsum[idx] += csum;
+    }
+  }
   // ---- epilogue -----------------------------------------------------------------------------
   vu_epi_ctx<T, TC> ec;
   ec.rng = g.dropout ? vu_rng_resolve(g.rng) : g.rng;

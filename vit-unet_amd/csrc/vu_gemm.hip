@@ -65,6 +65,7 @@ static int launch_layout(vu_gemm_args& g0, int c_float, hipStream_t st) {
     g.sAm = g0.sBn; g.sAk = g0.sBk; g.sBk = g0.sAk; g.sBn = g0.sAm;
     g.sA1 = g0.sB1; g.sA2 = g0.sB2; g.sB1 = g0.sA1; g.sB2 = g0.sA2;
     g.swap = 1;
+    if (g0.colsum_side) g.colsum_side = 3 - g0.colsum_side;   // the operands changed places
     g.vecC = ((uintptr_t)g0.C % (4 * csz) == 0) && (g0.ldc % 4 == 0) && (g0.sC1 % 4 == 0) && (g0.sC2 % 4 == 0) &&
              (!g0.aux || (uintptr_t)g0.aux % 8 == 0) && (!g0.addend || (uintptr_t)g0.addend % 8 == 0);
   }

@@ -225,12 +225,12 @@ int attn_backward(const AttnDims& d, const vu_attn_params& p, const vu_attn_grad
   const int dh = D / H;
   const long long npatch = (long long)B * N, rows = (long long)B * N;
   const float inv_keep = (training && attn_drop > 0.f) ? 1.f / (1.f - attn_drop) : 1.f;
-  VU_TRY(vu_k_colsum(dt, dz, gr.proj_b, rows, D, D, st));
-  {  // dWp += dz^T O
+  {  // dWp += dz^T O ; dbp += column sums of dz (carried by the same GEMM)
     vu_gemm_args g;
     memset(&g, 0, sizeof(g));
     g.A = dz; g.B = a.O; g.C = gr.proj_w; g.M = D; g.N = D; g.K = (int)rows;
     g.sAm = 1; g.sAk = D; g.sBk = D; g.sBn = 1; g.ldc = D; g.Z1 = 1; g.Z2 = 1; g.alpha = 1.f; g.accumulate = 1;
+    g.colsum = gr.proj_b; g.colsum_side = 1;
     VU_TRY(vu_gemm_launch(dt, 1, g, st));
   }
   {  // dO = dz Wp
@@ -430,12 +430,12 @@ int block_backward(Ctx& cx, const BlockP& bp, BlockBuf& bb, const void* x, void*
   // LN2 backward: dz2 -> ga
   VU_TRY(vu_k_ln_bwd(dt, dout, bb.z2, cx.prm + bp.ln2w, bb.ln2s, G + bp.ln2w, G + bp.ln2b, w.lnp2, w.ga, nullptr, none, B, P, cx.st));
   // FeedForward backward
-  VU_TRY(vu_k_colsum(dt, w.ga, G + bp.b2, rows, L.D, L.D, cx.st));
-  {  // dW2 += dz2^T hact
+  {  // dW2 += dz2^T hact ; db2 += column sums of dz2
     vu_gemm_args g;
     memset(&g, 0, sizeof(g));
     g.A = w.ga; g.B = bb.hact; g.C = G + bp.w2; g.M = L.D; g.N = L.hid; g.K = (int)rows;
     g.sAm = 1; g.sAk = L.D; g.sBk = L.hid; g.sBn = 1; g.ldc = L.hid; g.Z1 = 1; g.Z2 = 1; g.alpha = 1.f; g.accumulate = 1;
+    g.colsum = G + bp.b2; g.colsum_side = 1;
     VU_TRY(vu_gemm_launch(dt, 1, g, cx.st));
   }
   {  // dh = (dz2 W2) * gelu'(hpre)
@@ -446,12 +446,12 @@ int block_backward(Ctx& cx, const BlockP& bp, BlockBuf& bb, const void* x, void*
     g.Z1 = 1; g.Z2 = 1; g.alpha = 1.f; g.act = VU_ACT_DGELU;
     VU_TRY(vu_gemm_launch(dt, 0, g, cx.st));
   }
-  VU_TRY(vu_k_colsum(dt, w.gh, G + bp.b1, rows, L.hid, L.hid, cx.st));
-  {  // dW1 += dh^T x1
+  {  // dW1 += dh^T x1 ; db1 += column sums of dh
     vu_gemm_args g;
     memset(&g, 0, sizeof(g));
     g.A = w.gh; g.B = bb.x1; g.C = G + bp.w1; g.M = L.hid; g.N = L.D; g.K = (int)rows;
     g.sAm = 1; g.sAk = L.hid; g.sBk = L.D; g.sBn = 1; g.ldc = L.D; g.Z1 = 1; g.Z2 = 1; g.alpha = 1.f; g.accumulate = 1;
+    g.colsum = G + bp.b1; g.colsum_side = 1;
     VU_TRY(vu_gemm_launch(dt, 1, g, cx.st));
   }
   {  // dx1 = dh W1 + dz2  -> gb
