@@ -31,11 +31,16 @@ __device__ __forceinline__ void load_win(const T* __restrict__ plane, int s, int
 }
 
 __device__ __forceinline__ void quad_coords(long long qid, int s, long long& patch, int& y, int& x0) {
-  const int qpp = (s * s) >> 2;   // quads per channel plane
-  patch = qid / qpp;
-  const int rem = (int)(qid - patch * qpp) << 2;
-  y = rem / s;
-  x0 = rem - y * s;
+  // 32-bit unsigned arithmetic (the launchers guarantee nquads < 2^32): a 64-bit division by a
+  // run-time value costs >100 instructions per quad
+  const unsigned qpp = (unsigned)(s * s) >> 2;   // quads per channel plane
+  const unsigned q = (unsigned)qid;
+  const unsigned pch = q / qpp;
+  const unsigned rem = (q - pch * qpp) << 2;
+  const unsigned yy = rem / (unsigned)s;
+  patch = pch;
+  y = (int)yy;
+  x0 = (int)(rem - yy * (unsigned)s);
 }
 
 // ---- forward ---------------------------------------------------------------------------------
@@ -240,6 +245,7 @@ inline int grid_for(long long items, int cap) {
 int vu_k_conv3x3_fwd(int dtype, int out_f32, const void* in, const float* w, const float* bias, void* out,
                      long long npatch, int C, int s, hipStream_t st) {
   VU_REQUIRE(s % 4 == 0, "conv3x3: patch size must be a multiple of 4");
+  VU_REQUIRE(npatch * s * s / 4 < 4294967295LL, "conv3x3: more than 2^32 pixel quads");
   const long long nq = npatch * s * s / 4;
   if (nq == 0) return VU_OK;
   const int grid = grid_for(nq, 256 * 16);
@@ -255,6 +261,7 @@ int vu_k_conv3x3_fwd(int dtype, int out_f32, const void* in, const float* w, con
 int vu_k_conv3x3_qkv_fwd(int dtype, const void* xq, const void* xkv, const float* wq, const float* wk, const float* wv,
                          void* q, void* k, void* v, long long npatch, int C, int s, hipStream_t st) {
   VU_REQUIRE(s % 4 == 0, "conv3x3: patch size must be a multiple of 4");
+  VU_REQUIRE(npatch * s * s / 4 < 4294967295LL, "conv3x3: more than 2^32 pixel quads");
   const long long nq = npatch * s * s / 4;
   if (nq == 0) return VU_OK;
   const int grid = grid_for(nq, 256 * 16);
@@ -268,6 +275,7 @@ int vu_k_conv3x3_qkv_fwd(int dtype, const void* xq, const void* xkv, const float
 int vu_k_conv3x3_dgrad(int dtype, int dout_f32, const void* dout, const float* w, const void* add, void* din,
                        long long npatch, int C, int s, hipStream_t st) {
   VU_REQUIRE(s % 4 == 0, "conv3x3: patch size must be a multiple of 4");
+  VU_REQUIRE(npatch * s * s / 4 < 4294967295LL, "conv3x3: more than 2^32 pixel quads");
   const long long nq = npatch * s * s / 4;
   if (nq == 0) return VU_OK;
   const int grid = grid_for(nq, 256 * 16);
@@ -284,6 +292,7 @@ int vu_k_conv3x3_qkv_dgrad(int dtype, const void* dq, const void* dk, const void
                            const float* wv, const void* add_q, const void* add_kv, void* dxq, void* dxkv,
                            long long npatch, int C, int s, hipStream_t st) {
   VU_REQUIRE(s % 4 == 0, "conv3x3: patch size must be a multiple of 4");
+  VU_REQUIRE(npatch * s * s / 4 < 4294967295LL, "conv3x3: more than 2^32 pixel quads");
   const long long nq = npatch * s * s / 4;
   if (nq == 0) return VU_OK;
   const int grid = grid_for(nq, 256 * 16);
@@ -297,6 +306,7 @@ int vu_k_conv3x3_qkv_dgrad(int dtype, const void* dq, const void* dk, const void
 static int wgrad_launch(int dtype, int dout_f32, const WgradSet& set, int nconv, long long npatch, int C, int s,
                         hipStream_t st) {
   VU_REQUIRE(s % 4 == 0, "conv3x3: patch size must be a multiple of 4");
+  VU_REQUIRE(npatch * s * s / 4 < 4294967295LL, "conv3x3: more than 2^32 pixel quads");
   const long long nq = npatch * s * s / 4;
   if (nq == 0) return VU_OK;
   const int gx = grid_for(nq, nconv == 1 ? 512 : 256);

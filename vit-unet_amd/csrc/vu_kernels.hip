@@ -28,8 +28,9 @@ __global__ void retile_kernel(const TI* __restrict__ in, TO* __restrict__ out,
   const int P4 = P >> 2;
   for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total4;
        t += (long long)gridDim.x * blockDim.x) {
-    const long long b = t / P4;
-    const int r = (int)(t - b * P4) << 2;
+    const unsigned t32 = (unsigned)t;                 // launcher guarantees total4 < 2^32
+    const long long b = t32 / (unsigned)P4;
+    const int r = (int)(t32 - (unsigned)b * (unsigned)P4) << 2;
     const int n_out = r / D_out, f = r - n_out * D_out;
     const int ch = f / ss_out, rem = f - ch * ss_out;
     const int i = rem / s_out, j = rem - i * s_out;
@@ -52,6 +53,7 @@ int vu_k_retile(int dtype, int in_f32, int out_f32, const void* in, void* out, c
   const int P = C * im * im;
   const long long total4 = (long long)B * (P / 4);
   if (total4 == 0) return VU_OK;
+  VU_REQUIRE(total4 < 4294967295LL, "vu_retile: more than 2^32 element quads");
   const int grid = grid_for(total4);
   const bool fi = in_f32 || dtype == 0, fo = out_f32 || dtype == 0;
   if (fi && fo) hipLaunchKernelGGL((retile_kernel<float, float>), dim3(grid), dim3(256), 0, st, (const float*)in, (float*)out, pos, total4, P, C, im, s_in, s_out);
@@ -161,10 +163,13 @@ __global__ __launch_bounds__(256) void mix_stats_kernel(const T* __restrict__ Ps
   for (int g = 0; g < H; ++g) { s1[g] = 0.f; s2[g] = 0.f; }
   for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
        t += (long long)gridDim.x * blockDim.x) {
-    const long long row = t / ld4;
-    const int jc = (int)(t - row * ld4) << 2;
-    const long long b = row / N;
-    const int i = (int)(row - b * N);
+    // 32-bit index arithmetic (launcher guarantees < 2^32 vector positions): 64-bit divisions by
+    // run-time values cost more than the mix itself
+    const unsigned t32 = (unsigned)t;
+    const unsigned row = t32 / (unsigned)ld4;
+    const int jc = (int)(t32 - row * (unsigned)ld4) << 2;
+    const long long b = row / (unsigned)N;
+    const int i = (int)(row - (unsigned)b * (unsigned)N);
     float pt[H][4], pa[H][4];
     load_heads4<T, H>(Ps + (b * H * N + i) * (long long)ld + jc, hs, inv_keep, pt, pa);
 #pragma unroll
@@ -247,10 +252,13 @@ __global__ __launch_bounds__(256) void mix_apply_kernel(const T* __restrict__ Ps
   const long long hs = (long long)N * ld;
   for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
        t += (long long)gridDim.x * blockDim.x) {
-    const long long row = t / ld4;
-    const int jc = (int)(t - row * ld4) << 2;
-    const long long b = row / N;
-    const int i = (int)(row - b * N);
+    // 32-bit index arithmetic (launcher guarantees < 2^32 vector positions): 64-bit divisions by
+    // run-time values cost more than the mix itself
+    const unsigned t32 = (unsigned)t;
+    const unsigned row = t32 / (unsigned)ld4;
+    const int jc = (int)(t32 - row * (unsigned)ld4) << 2;
+    const long long b = row / (unsigned)N;
+    const int i = (int)(row - (unsigned)b * (unsigned)N);
     const long long off = (b * H * N + i) * (long long)ld + jc;
     float pt[H][4], pa[H][4];
     load_heads4<T, H>(Ps + off, hs, inv_keep, pt, pa);
@@ -288,10 +296,13 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const T* __restrict__
   for (int g = 0; g < H; ++g) { s1[g] = 0.f; s2[g] = 0.f; }
   for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
        t += (long long)gridDim.x * blockDim.x) {
-    const long long row = t / ld4;
-    const int jc = (int)(t - row * ld4) << 2;
-    const long long b = row / N;
-    const int i = (int)(row - b * N);
+    // 32-bit index arithmetic (launcher guarantees < 2^32 vector positions): 64-bit divisions by
+    // run-time values cost more than the mix itself
+    const unsigned t32 = (unsigned)t;
+    const unsigned row = t32 / (unsigned)ld4;
+    const int jc = (int)(t32 - row * (unsigned)ld4) << 2;
+    const long long b = row / (unsigned)N;
+    const int i = (int)(row - (unsigned)b * (unsigned)N);
     const long long off = (b * H * N + i) * (long long)ld + jc;
     float pt[H][4], pa[H][4];
     load_heads4<T, H>(Ps + off, hs, inv_keep, pt, pa);
@@ -432,6 +443,7 @@ __global__ __launch_bounds__(256) void map_bwd_kernel(const T* __restrict__ Ps, 
 int vu_k_mix_stats(int dtype, const void* Ps, const float* W, const float* c, float* partials, int nblocks,
                    int B, int H, int N, int ld, float inv_keep, hipStream_t st) {
   VU_REQUIRE(ld % 4 == 0, "mix_stats: ld %% 4");
+  VU_REQUIRE((long long)B * N * (ld / 4) < 4294967295LL, "mix kernels: more than 2^32 vector positions");
   VU_HEADS(H, VU_DISPATCH_T(dtype, hipLaunchKernelGGL((mix_stats_kernel<T, HH>), dim3(nblocks), dim3(256), 0, st, (const T*)Ps, W, c, partials, B, N, ld, inv_keep);))
   if (vu_prof_on()) vu_prof_note("mix_stats_kernel", 0.0, (double)B * H * N * N * (dtype == 0 ? 4.0 : 2.0));
   return vu_check_launch("vu_mix_stats");
@@ -592,7 +604,7 @@ __global__ __launch_bounds__(256) void ln_bwd_stats_kernel(const T* __restrict__
   // grid (chunks of 1024 elements, sample groups): per-(sample,chunk) partial sums c1 = sum dy*w,
   // c2 = sum dy*w*xhat, and the affine gradients of this chunk summed over the group's samples
   // (float atomics when there is more than one group).
-  __shared__ float red[2][4];
+  __shared__ float red[64][2][4];     // [sample in group][c1|c2][wave]
   const int c = blockIdx.x, nch = gridDim.x;
   const long long e = (long long)c * VU_LN_BCHUNK + threadIdx.x * 4;
   const bool ok = e < P;
@@ -616,13 +628,12 @@ __global__ __launch_bounds__(256) void ln_bwd_stats_kernel(const T* __restrict__
       }
     }
     c1 = vu_wave_sum(c1); c2 = vu_wave_sum(c2);
-    if (lane == 0) { red[0][wave] = c1; red[1][wave] = c2; }
-    __syncthreads();
-    if (threadIdx.x < 2) {
-      float* o = partials2 + ((long long)b * nch + c) * 2;
-      o[threadIdx.x] = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
-    }
-    __syncthreads();
+    if (lane == 0) { red[b - b0][0][wave] = c1; red[b - b0][1][wave] = c2; }   // one slot per sample: no barrier in the loop
+  }
+  __syncthreads();
+  for (int q = threadIdx.x; q < (b1 - b0) * 2; q += blockDim.x) {
+    const int bl = q >> 1, which = q & 1;
+    partials2[((long long)(b0 + bl) * nch + c) * 2 + which] = red[bl][which][0] + red[bl][which][1] + red[bl][which][2] + red[bl][which][3];
   }
   if (ok) {
     if (gridDim.y == 1) {
@@ -687,7 +698,8 @@ int vu_k_ln_bwd(int dtype, const void* dy, const void* z, const float* w, const 
   const int nbch = vu_ln_nbchunks(P), nch = vu_ln_nchunks(P);
   int ngroups = 1;                       // enough blocks to fill the chip: ~1024
   while (nbch * ngroups < 1024 && ngroups * 2 <= B) ngroups *= 2;
-  const int bgroup = (B + ngroups - 1) / ngroups;
+  int bgroup = (B + ngroups - 1) / ngroups;
+  if (bgroup > 64) bgroup = 64;             // LDS slots per block
   ngroups = (B + bgroup - 1) / bgroup;
   VU_DISPATCH_T(dtype,
     hipLaunchKernelGGL((ln_bwd_stats_kernel<T>), dim3(nbch, ngroups), dim3(256), 0, st, (const T*)dy, (const T*)z, w, stats, dw, db, partials2, B, P, bgroup);
