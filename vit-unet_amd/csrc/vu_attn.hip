@@ -406,8 +406,8 @@ __global__ __launch_bounds__(256) void map_bwd_row_kernel(const T* __restrict__ 
 // P~ image yields dc = sum dA_g for free).  Without the 64 per-lane accumulators the kernel fits
 // two waves per SIMD.
 // ---------------------------------------------------------------------------------------------
-template <int H>
-__global__ __launch_bounds__(256, 2) void map_bwd_mfma_kernel(const bf16_t* __restrict__ Ps, bf16_t* dA,
+template <int H, int NWV>
+__global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void map_bwd_mfma_kernel(const bf16_t* __restrict__ Ps, bf16_t* dA,
                                                               const float* __restrict__ W, const float* __restrict__ c,
                                                               const float* __restrict__ gamma, const float* __restrict__ stats,
                                                               float* dW, float* dc, long long rows, int N, int ld,
@@ -417,15 +417,15 @@ __global__ __launch_bounds__(256, 2) void map_bwd_mfma_kernel(const bf16_t* __re
   // arrive through scalar loads (SGPRs), not through LDS / VGPRs
   const float* __restrict__ tX = stats + H * H + 5 * H;     // X[H*H], Xc[H], Gs[H]
   const float* __restrict__ tM = stats + H * H + 3 * H;     // m1[H], m2[H]
-  __shared__ float redd[4][H];
-  __shared__ float red[4][256];
+  __shared__ float redd[NWV][H];
+  __shared__ float red[NWV][256];
   const int ldk = (ld + 31) / 32 * 32;        // positions rounded up to whole k-steps
   const int LDP = ldk + 8;                    // image row stride (elements)
-  bf16_t* sA = reinterpret_cast<bf16_t*>(smem_raw);   // [16][LDP]  rows g: dA_g        (rows >= H stay 0)
-  bf16_t* sB = sA + 16 * LDP;                         // [16][LDP]  rows h: P~_h, row H: ones
-  for (int i = threadIdx.x; i < 32 * LDP; i += blockDim.x) {
+  bf16_t* sA = reinterpret_cast<bf16_t*>(smem_raw);   // [H][LDP]    rows g: dA_g   (MFMA rows >= H read as zero)
+  bf16_t* sB = sA + H * LDP;                          // [H+1][LDP]  rows h: P~_h, row H: ones
+  for (int i = threadIdx.x; i < (2 * H + 1) * LDP; i += blockDim.x) {
     const int r = i / LDP, col = i % LDP;
-    sA[i] = (r == 16 + H && col < N) ? (bf16_t)1.0f : (bf16_t)0.0f;   // sB row H = ones over the valid positions
+    sA[i] = (r == 2 * H && col < N) ? (bf16_t)1.0f : (bf16_t)0.0f;   // sB row H = ones over the valid positions
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -490,11 +490,15 @@ __global__ __launch_bounds__(256, 2) void map_bwd_mfma_kernel(const bf16_t* __re
     }
     __syncthreads();
 #pragma unroll
-    for (int h = 0; h < H; ++h) delta[h] = redd[0][h] + redd[1][h] + redd[2][h] + redd[3][h];
+    for (int h = 0; h < H; ++h) { float dsum = 0.f;
+#pragma unroll
+      for (int q = 0; q < NWV; ++q) dsum += redd[q][h];
+      delta[h] = dsum; }
     // contraction over the row's positions, k-steps dealt round-robin to the 4 waves
-    for (int ks = wave; ks < nks; ks += 4) {
-      const bf16x8 af = *reinterpret_cast<const bf16x8*>(sA + l15 * LDP + ks * 32 + lg * 8);
-      const bf16x8 bf = *reinterpret_cast<const bf16x8*>(sB + l15 * LDP + ks * 32 + lg * 8);
+    for (int ks = wave; ks < nks; ks += NWV) {
+      const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+      const bf16x8 af = l15 < H ? *reinterpret_cast<const bf16x8*>(sA + l15 * LDP + ks * 32 + lg * 8) : zero8;
+      const bf16x8 bf = l15 <= H ? *reinterpret_cast<const bf16x8*>(sB + l15 * LDP + ks * 32 + lg * 8) : zero8;
       acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, acc, 0, 0, 0);
     }
     if (live) {
@@ -512,9 +516,11 @@ __global__ __launch_bounds__(256, 2) void map_bwd_mfma_kernel(const bf16_t* __re
 #pragma unroll
   for (int r = 0; r < 4; ++r) red[wave][(lg * 4 + r) * 16 + l15] = acc[r];
   __syncthreads();
-  {
+  if (threadIdx.x < 256) {
     const int g = threadIdx.x / 16, hcol = threadIdx.x % 16;
-    const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    float v = 0.f;
+#pragma unroll
+    for (int q = 0; q < NWV; ++q) v += red[q][threadIdx.x];
     if (g < H && hcol < H) atomicAdd(dW + g * H + hcol, v);
     else if (g < H && hcol == H) atomicAdd(dc + g, v);
   }
@@ -529,18 +535,22 @@ int launch_map_bwd_row(const void* Ps, void* dA, const float* W, const float* c,
     hipLaunchKernelGGL((map_bwd_row_kernel<T, H, 64>), dim3((unsigned)grid), dim3(256), 0, st, (const T*)Ps, (T*)dA, W, c, gamma,
                        stats, dW, dc, rows, N, ld, inv_keep, scale);
     if (vu_prof_on()) vu_prof_note("map_bwd_row_kernel", 0.0, (double)B * H * N * N * 3 * sizeof(T));
-  } else if (sizeof(T) == 2 && H < 16) {
+  } else if (sizeof(T) == 2 && (ld <= 1024 || (ld <= 4096 && H <= 4))) {
+    // one block per row: 256 threads (ld <= 1024) or 1024 threads (ld <= 4096; 128-VGPR budget -> H <= 4)
     const int ldk = (ld + 31) / 32 * 32;
-    const size_t lds = (size_t)32 * (ldk + 8) * 2;
-    auto kern = map_bwd_mfma_kernel<H>;
+    const size_t lds = (size_t)(2 * H + 1) * (ldk + 8) * 2;
+    const bool big = ld > 1024;
+    auto kern = big ? map_bwd_mfma_kernel<(H <= 4 ? H : 4), 16> : map_bwd_mfma_kernel<H, 4>;
     if (lds > 40 * 1024) {
       hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) { vu_set_error("map_bwd: cannot reserve %zu bytes of LDS", lds); return VU_ELAUNCH; }
     }
     long long grid = rows; if (grid > 1024) grid = 1024;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, (const bf16_t*)Ps, (bf16_t*)dA, W, c, gamma, stats, dW, dc,
-                       rows, N, ld, inv_keep, scale);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(big ? 1024 : 256), lds, st, (const bf16_t*)Ps, (bf16_t*)dA, W, c, gamma,
+                       stats, dW, dc, rows, N, ld, inv_keep, scale);
     if (vu_prof_on()) vu_prof_note("map_bwd_mfma_kernel", 0.0, (double)B * H * N * N * 3 * sizeof(T));
+  } else if (ld > 1024) {
+    return 1;   // caller falls back to the two-sweep kernel
   } else {
     long long grid = rows; if (grid > 2048) grid = 2048;
     hipLaunchKernelGGL((map_bwd_row_kernel<T, H, 256>), dim3((unsigned)grid), dim3(256), 0, st, (const T*)Ps, (T*)dA, W, c, gamma,
@@ -555,7 +565,8 @@ int launch_map_bwd_row(const void* Ps, void* dA, const float* W, const float* c,
 int vu_k_map_bwd(int dtype, const void* Ps, void* dAhat_dS, const float* W, const float* c, const float* gamma,
                  const float* stats, float* dW, float* dc, int B, int H, int N, int ld, float inv_keep, float scale,
                  hipStream_t st) {
-  if (ld > 1024) return vu_k_map_bwd_2sweep(dtype, Ps, dAhat_dS, W, c, gamma, stats, dW, dc, B, H, N, ld, inv_keep, scale, st);
+  if (ld > 4096 || (ld > 1024 && (dtype == 0 || H > 4)))
+    return vu_k_map_bwd_2sweep(dtype, Ps, dAhat_dS, W, c, gamma, stats, dW, dc, B, H, N, ld, inv_keep, scale, st);
 #define VU_MB(Tt, Hh) return launch_map_bwd_row<Tt, Hh>(Ps, dAhat_dS, W, c, gamma, stats, dW, dc, B, N, ld, inv_keep, scale, st)
   if (dtype == 0) { switch (H) { case 1: VU_MB(float, 1); case 2: VU_MB(float, 2); case 4: VU_MB(float, 4); case 8: VU_MB(float, 8); } }
   else { switch (H) { case 1: VU_MB(bf16_t, 1); case 2: VU_MB(bf16_t, 2); case 4: VU_MB(bf16_t, 4); case 8: VU_MB(bf16_t, 8); } }
