@@ -239,6 +239,152 @@ int launch_scores(const T* q, const T* k, T* Ps, int B, int N, int D, int H, int
   else return launch_scores_w<T, NT, DP, 4>(q, k, Ps, B, N, D, H, ld, scale, rng, softmax, st);
 }
 
+// ---------------------------------------------------------------------------------------------
+// attn_scores_long_kernel: rows too long for the register-resident form (N > 784, d <= 32:
+// Lite level 2 has N = 3136, the 512x512 config N = 4096).  K streams through LDS in chunks of
+// 512 keys; with softmax the kernel sweeps the keys twice - sweep 1 keeps an online (max, sum)
+// per lane, sweep 2 recomputes the logits with MFMA (K = d is tiny) and writes the tagged
+// probabilities - so the logits still never reach HBM.
+// ---------------------------------------------------------------------------------------------
+template <typename T, bool EXACT, bool SOFTMAX>
+__global__ __launch_bounds__(512) void attn_scores_long_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                               T* __restrict__ Ps, int N, int D, int H, int d, int ld,
+                                                               float scale, vu_rng rng_in) {
+  typedef Mma<T> MM;
+  typedef typename MM::Frag Frag;
+  constexpr int DP = 32, CH = 512, WAVES = 8;
+  constexpr int KSTEPS = DP / MM::KS;
+  constexpr int LDK = DP + (sizeof(T) == 2 ? 8 : 4);
+  __shared__ __attribute__((aligned(16))) T Ks[CH * LDK];
+  const vu_rng rng = vu_rng_resolve(rng_in);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int bz = blockIdx.y, b = bz / H, g = bz % H;
+  const T* qb = q + (long long)b * N * D + g * d;
+  const T* kb = k + (long long)b * N * D + g * d;
+  const bool vec = (d % (16 / (int)sizeof(T)) == 0);
+  const int i0 = blockIdx.x * (WAVES * 16) + wave * 16;
+  Frag qf[KSTEPS];
+  {
+    const int row = i0 + l15;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      const int k0 = ks * MM::KS + lg * MM::FE;
+      qf[ks] = (row < N) ? load_frag<T>(qb + (long long)row * D + k0, d - k0, vec) : MM::zero();
+    }
+  }
+  const int i = i0 + l15;
+  const uint64_t rowi = (uint64_t)bz * N + (i < N ? i : 0);
+  T* prow = Ps + rowi * ld;
+  const uint32_t ib32 = (uint32_t)(rowi * (uint64_t)ld);
+  const uint32_t thr = rng.thr;
+  float mrun = -INFINITY, srun = 0.f, Mx = 0.f, inv = 0.f;
+  constexpr float L2E = 1.44269504088896340736f;
+  for (int sweep = 0; sweep < (SOFTMAX ? 2 : 1); ++sweep) {
+    for (int c0 = 0; c0 < N; c0 += CH) {
+      __syncthreads();
+      {  // stage keys [c0, c0+CH) (zero-padded to DP columns)
+        constexpr int VE = 16 / sizeof(T);
+        constexpr int cpr = DP / VE;
+        for (int c = tid; c < CH * cpr; c += WAVES * 64) {
+          const int row = c / cpr, kc = (c % cpr) * VE;
+          alignas(16) T tmp[VE];
+          const int key = c0 + row;
+          if (key < N && vec && kc + VE <= d) {
+            *reinterpret_cast<uint4*>(tmp) = *reinterpret_cast<const uint4*>(kb + (long long)key * D + kc);
+          } else {
+#pragma unroll
+            for (int e = 0; e < VE; ++e) tmp[e] = (key < N && kc + e < d) ? kb[(long long)key * D + kc + e] : (T)0.f;
+          }
+          *reinterpret_cast<uint4*>(&Ks[row * LDK + kc]) = *reinterpret_cast<uint4*>(tmp);
+        }
+      }
+      __syncthreads();
+      const int ntl = (N - c0 < CH ? N - c0 : CH);
+      for (int nt = 0; nt * 16 < ntl; ++nt) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const int key = nt * 16 + l15;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+          Frag kf;
+          if constexpr (MM::FE == 1) kf = (float)Ks[key * LDK + ks * MM::KS + lg];
+          else kf = *reinterpret_cast<const Frag*>(&Ks[key * LDK + ks * MM::KS + lg * MM::FE]);
+          acc = MM::mma(kf, qf[ks], acc);
+        }
+        const int j0 = c0 + nt * 16 + lg * 4;       // this lane's 4 consecutive keys
+        float x[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float sv = acc[r] * scale;
+          if constexpr (SOFTMAX) {
+            if constexpr (sizeof(T) == 2) sv = (float)(bf16_t)sv;
+            if constexpr (!EXACT) sv = (j0 + r < N) ? sv : -INFINITY;
+          }
+          x[r] = sv;
+        }
+        if constexpr (!SOFTMAX) {
+          if (i < N && (EXACT || j0 < ld)) {
+            vu_f4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o.v[r] = (EXACT || j0 + r < N) ? x[r] : 0.f;
+            vu_st4(prow + j0, o);
+          }
+        } else if (sweep == 0) {
+          const float tm = fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3]));
+          const float mn = fmaxf(mrun, tm);
+          if (mn > -INFINITY) {
+            const float ml = mn * L2E;
+            srun = srun * exp2f(mrun * L2E - ml) + exp2f(x[0] * L2E - ml) + exp2f(x[1] * L2E - ml) +
+                   exp2f(x[2] * L2E - ml) + exp2f(x[3] * L2E - ml);
+            mrun = mn;
+          }
+        } else if (i < N && (EXACT || j0 < ld)) {
+          const float ml = Mx * L2E;
+          float o0 = exp2f(x[0] * L2E - ml) * inv, o1 = exp2f(x[1] * L2E - ml) * inv;
+          float o2 = exp2f(x[2] * L2E - ml) * inv, o3 = exp2f(x[3] * L2E - ml) * inv;
+          if (thr) {
+            const uint32_t wa = vu_hash_word32(rng, ib32 + j0), wb = vu_hash_word32(rng, ib32 + j0 + 2);
+            o0 = __uint_as_float(__float_as_uint(o0) ^ (((wa & 0xffffu) - thr) & 0x80000000u));
+            o1 = __uint_as_float(__float_as_uint(o1) ^ (((wa >> 16) - thr) & 0x80000000u));
+            o2 = __uint_as_float(__float_as_uint(o2) ^ (((wb & 0xffffu) - thr) & 0x80000000u));
+            o3 = __uint_as_float(__float_as_uint(o3) ^ (((wb >> 16) - thr) & 0x80000000u));
+          }
+          if constexpr (!EXACT) {
+            if (j0 + 0 >= N) o0 = 0.f;
+            if (j0 + 1 >= N) o1 = 0.f;
+            if (j0 + 2 >= N) o2 = 0.f;
+            if (j0 + 3 >= N) o3 = 0.f;
+          }
+          vu_f4 o = {{o0, o1, o2, o3}};
+          vu_st4(prow + j0, o);
+        }
+      }
+    }
+    if (SOFTMAX && sweep == 0) {   // combine the 4 lanes (lg = 0..3) that share a query
+      float M = fmaxf(mrun, __shfl_xor(mrun, 16, 64));
+      M = fmaxf(M, __shfl_xor(M, 32, 64));
+      float sc = (mrun > -INFINITY) ? srun * exp2f((mrun - M) * L2E) : 0.f;
+      sc += __shfl_xor(sc, 16, 64);
+      sc += __shfl_xor(sc, 32, 64);
+      Mx = M;
+      inv = 1.0f / sc;
+    }
+  }
+}
+
+template <typename T>
+int launch_scores_long(const void* q, const void* k, void* Ps, int B, int N, int D, int H, int ld, float scale, vu_rng rng,
+                       bool softmax, hipStream_t st) {
+  const int d = D / H;
+  auto kern = softmax ? ((N % 16 == 0) ? attn_scores_long_kernel<T, true, true> : attn_scores_long_kernel<T, false, true>)
+                      : ((N % 16 == 0) ? attn_scores_long_kernel<T, true, false> : attn_scores_long_kernel<T, false, false>);
+  dim3 grid((unsigned)((N + 127) / 128), (unsigned)(B * H));
+  hipLaunchKernelGGL(kern, grid, dim3(512), 0, st, (const T*)q, (const T*)k, (T*)Ps, N, D, H, d, ld, scale, rng);
+  if (vu_prof_on()) vu_prof_note(softmax ? "attn_scores_long_kernel" : "attn_dscores_long_kernel",
+                                 (softmax ? 4.0 : 2.0) * B * H * (double)N * N * d, ((double)B * H * N * N + 2.0 * B * N * D) * sizeof(T));
+  return vu_check_launch("vu_attn_scores_long");
+}
+
 template <typename T>
 int dispatch_scores(const void* q, const void* k, void* Ps, int B, int N, int D, int H, int ld, float scale, vu_rng rng,
                     bool softmax, hipStream_t st) {
@@ -253,6 +399,8 @@ int dispatch_scores(const void* q, const void* k, void* Ps, int B, int N, int D,
     if (dp == 32) VU_SC(13, 32); if (dp == 64) VU_SC(13, 64); if (dp == 96) VU_SC(13, 96); if (dp == 128) VU_SC(13, 128);
   } else if (nt <= 49) {
     if (dp == 32) VU_SC(49, 32); if (dp == 64) VU_SC(49, 64);
+  } else if (dp == 32) {
+    return launch_scores_long<T>(q, k, Ps, B, N, D, H, ld, scale, rng, softmax, st);
   }
 #undef VU_SC
   return 1;   // shape not covered: the caller falls back to GEMM + softmax kernels
@@ -267,7 +415,7 @@ int vu_k_attn_scores(int dtype, const void* q, const void* k, void* Ps, int B, i
   const int dp = (d + 31) / 32 * 32;
   const size_t es = dtype == 0 ? 4 : 2;
   const size_t lds = (size_t)N * (dp + (es == 2 ? 8 : 4)) * es;
-  if (lds > 150 * 1024) return 1;
+  if (lds > 150 * 1024 && !(N > 784 && dp == 32)) return 1;      // (long rows stream K in chunks)
   if ((double)B * H * N * (double)ld >= 4294967295.0) return 1;   // 32-bit mask index in the fused kernel
   if (dtype == 0) return dispatch_scores<float>(q, k, Ps, B, N, D, H, ld, scale, rng, true, st);
   return dispatch_scores<bf16_t>(q, k, Ps, B, N, D, H, ld, scale, rng, true, st);
@@ -280,7 +428,7 @@ int vu_k_attn_outer(int dtype, const void* a, const void* bmat, void* out, int B
   const int dp = (d + 31) / 32 * 32;
   const size_t es = dtype == 0 ? 4 : 2;
   const size_t lds = (size_t)N * (dp + (es == 2 ? 8 : 4)) * es;
-  if (lds > 150 * 1024) return 1;
+  if (lds > 150 * 1024 && !(N > 784 && dp == 32)) return 1;
   vu_rng none = vu_make_rng(0, 0, 0.f);
   if (dtype == 0) return dispatch_scores<float>(a, bmat, out, B, N, D, H, ld, scale, none, false, st);
   return dispatch_scores<bf16_t>(a, bmat, out, B, N, D, H, ld, scale, none, false, st);
