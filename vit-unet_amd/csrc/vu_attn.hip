@@ -399,7 +399,7 @@ int dispatch_scores(const void* q, const void* k, void* Ps, int B, int N, int D,
     if (dp == 32) VU_SC(13, 32); if (dp == 64) VU_SC(13, 64); if (dp == 96) VU_SC(13, 96); if (dp == 128) VU_SC(13, 128);
   } else if (nt <= 49) {
     if (dp == 32) VU_SC(49, 32); if (dp == 64) VU_SC(49, 64);
-  } else if (dp == 32) {
+  } else if (dp == 32 && !getenv("VU_NO_LONG")) {
     return launch_scores_long<T>(q, k, Ps, B, N, D, H, ld, scale, rng, softmax, st);
   }
 #undef VU_SC
