@@ -158,13 +158,12 @@ __global__ __launch_bounds__(WAVES * 64) void attn_scores_kernel(const T* __rest
   mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
   mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
   float sum = 0.f;
-  const float mxl = mx * 1.44269504088896340736f;
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     if (nt < ntiles) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float e = exp2f(acc[nt][r] * 1.44269504088896340736f - mxl);   // exp(-inf) = 0 for masked keys
+        const float e = __expf(acc[nt][r] - mx);   // subtract first: exact for nearby floats; exp(-inf) = 0 for masked keys
         acc[nt][r] = e;
         sum += e;
       }
@@ -279,7 +278,6 @@ __global__ __launch_bounds__(512) void attn_scores_long_kernel(const T* __restri
   const uint32_t ib32 = (uint32_t)(rowi * (uint64_t)ld);
   const uint32_t thr = rng.thr;
   float mrun = -INFINITY, srun = 0.f, Mx = 0.f, inv = 0.f;
-  constexpr float L2E = 1.44269504088896340736f;
   for (int sweep = 0; sweep < (SOFTMAX ? 2 : 1); ++sweep) {
     for (int c0 = 0; c0 < N; c0 += CH) {
       __syncthreads();
@@ -332,16 +330,13 @@ __global__ __launch_bounds__(512) void attn_scores_long_kernel(const T* __restri
         } else if (sweep == 0) {
           const float tm = fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3]));
           const float mn = fmaxf(mrun, tm);
-          if (mn > -INFINITY) {
-            const float ml = mn * L2E;
-            srun = srun * exp2f(mrun * L2E - ml) + exp2f(x[0] * L2E - ml) + exp2f(x[1] * L2E - ml) +
-                   exp2f(x[2] * L2E - ml) + exp2f(x[3] * L2E - ml);
+          if (mn > -INFINITY) {   // differences first (exact for nearby floats), then the exponential
+            srun = srun * __expf(mrun - mn) + __expf(x[0] - mn) + __expf(x[1] - mn) + __expf(x[2] - mn) + __expf(x[3] - mn);
             mrun = mn;
           }
         } else if (i < N && (EXACT || j0 < ld)) {
-          const float ml = Mx * L2E;
-          float o0 = exp2f(x[0] * L2E - ml) * inv, o1 = exp2f(x[1] * L2E - ml) * inv;
-          float o2 = exp2f(x[2] * L2E - ml) * inv, o3 = exp2f(x[3] * L2E - ml) * inv;
+          float o0 = __expf(x[0] - Mx) * inv, o1 = __expf(x[1] - Mx) * inv;
+          float o2 = __expf(x[2] - Mx) * inv, o3 = __expf(x[3] - Mx) * inv;
           if (thr) {
             const uint32_t wa = vu_hash_word32(rng, ib32 + j0), wb = vu_hash_word32(rng, ib32 + j0 + 2);
             o0 = __uint_as_float(__float_as_uint(o0) ^ (((wa & 0xffffu) - thr) & 0x80000000u));
@@ -363,7 +358,7 @@ __global__ __launch_bounds__(512) void attn_scores_long_kernel(const T* __restri
     if (SOFTMAX && sweep == 0) {   // combine the 4 lanes (lg = 0..3) that share a query
       float M = fmaxf(mrun, __shfl_xor(mrun, 16, 64));
       M = fmaxf(M, __shfl_xor(M, 32, 64));
-      float sc = (mrun > -INFINITY) ? srun * exp2f((mrun - M) * L2E) : 0.f;
+      float sc = (mrun > -INFINITY) ? srun * __expf(mrun - M) : 0.f;
       sc += __shfl_xor(sc, 16, 64);
       sc += __shfl_xor(sc, 32, 64);
       Mx = M;
@@ -399,7 +394,7 @@ int dispatch_scores(const void* q, const void* k, void* Ps, int B, int N, int D,
     if (dp == 32) VU_SC(13, 32); if (dp == 64) VU_SC(13, 64); if (dp == 96) VU_SC(13, 96); if (dp == 128) VU_SC(13, 128);
   } else if (nt <= 49) {
     if (dp == 32) VU_SC(49, 32); if (dp == 64) VU_SC(49, 64);
-  } else if (dp == 32 && !getenv("VU_NO_LONG")) {
+  } else if (dp == 32) {
     return launch_scores_long<T>(q, k, Ps, B, N, D, H, ld, scale, rng, softmax, st);
   }
 #undef VU_SC
