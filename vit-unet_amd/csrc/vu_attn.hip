@@ -564,11 +564,12 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void map_bwd_mfma_kerne
   __shared__ float red[NWV][256];
   const int ldk = (ld + 31) / 32 * 32;        // positions rounded up to whole k-steps
   const int LDP = ldk + 8;                    // image row stride (elements)
-  bf16_t* sA = reinterpret_cast<bf16_t*>(smem_raw);   // [H][LDP]    rows g: dA_g   (MFMA rows >= H read as zero)
-  bf16_t* sB = sA + H * LDP;                          // [H+1][LDP]  rows h: P~_h, row H: ones
-  for (int i = threadIdx.x; i < (2 * H + 1) * LDP; i += blockDim.x) {
+  bf16_t* sA = reinterpret_cast<bf16_t*>(smem_raw);   // [H][LDP]    rows g: dA_g, high bf16 part (MFMA rows >= H read as zero)
+  bf16_t* sL = sA + H * LDP;                          // [H][LDP]    low part: dA = hi + lo keeps 16 significant bits
+  bf16_t* sB = sL + H * LDP;                          // [H+1][LDP]  rows h: P~_h, row H: ones
+  for (int i = threadIdx.x; i < (3 * H + 1) * LDP; i += blockDim.x) {
     const int r = i / LDP, col = i % LDP;
-    sA[i] = (r == 2 * H && col < N) ? (bf16_t)1.0f : (bf16_t)0.0f;   // sB row H = ones over the valid positions
+    sA[i] = (r == 3 * H && col < N) ? (bf16_t)1.0f : (bf16_t)0.0f;   // sB row H = ones over the valid positions
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -619,10 +620,15 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void map_bwd_mfma_kerne
       // LDS images for the MFMA contraction (4 consecutive positions per store)
 #pragma unroll
       for (int h = 0; h < H; ++h) {
-        vu_f4 a4, p4;
+        vu_f4 a4, l4, p4;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { a4.v[e] = dAg[h][e]; p4.v[e] = pv[h][e] > 0.f ? pv[h][e] * inv_keep : 0.f; }
+        for (int e = 0; e < 4; ++e) {
+          a4.v[e] = dAg[h][e];
+          l4.v[e] = dAg[h][e] - (float)(bf16_t)dAg[h][e];
+          p4.v[e] = pv[h][e] > 0.f ? pv[h][e] * inv_keep : 0.f;
+        }
         vu_st4(sA + h * LDP + jc, a4);
+        vu_st4(sL + h * LDP + jc, l4);
         vu_st4(sB + h * LDP + jc, p4);
       }
     }
@@ -641,8 +647,10 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void map_bwd_mfma_kerne
     for (int ks = wave; ks < nks; ks += NWV) {
       const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
       const bf16x8 af = l15 < H ? *reinterpret_cast<const bf16x8*>(sA + l15 * LDP + ks * 32 + lg * 8) : zero8;
+      const bf16x8 lf = l15 < H ? *reinterpret_cast<const bf16x8*>(sL + l15 * LDP + ks * 32 + lg * 8) : zero8;
       const bf16x8 bf = l15 <= H ? *reinterpret_cast<const bf16x8*>(sB + l15 * LDP + ks * 32 + lg * 8) : zero8;
       acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lf, bf, acc, 0, 0, 0);
     }
     if (live) {
 #pragma unroll
@@ -681,7 +689,7 @@ int launch_map_bwd_row(const void* Ps, void* dA, const float* W, const float* c,
   } else if (sizeof(T) == 2 && (ld <= 1024 || (ld <= 4096 && H <= 4))) {
     // one block per row: 256 threads (ld <= 1024) or 1024 threads (ld <= 4096; 128-VGPR budget -> H <= 4)
     const int ldk = (ld + 31) / 32 * 32;
-    const size_t lds = (size_t)(2 * H + 1) * (ldk + 8) * 2;
+    const size_t lds = (size_t)(3 * H + 1) * (ldk + 8) * 2;
     const bool big = ld > 1024;
     auto kern = big ? map_bwd_mfma_kernel<(H <= 4 ? H : 4), 16> : map_bwd_mfma_kernel<H, 4>;
     if (lds > 40 * 1024) {
