@@ -558,8 +558,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void map_bwd_mfma_kerne
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   // W and the backward tables are wave-uniform and indexed with compile-time constants: they
   // arrive through scalar loads (SGPRs), not through LDS / VGPRs
-  const float* __restrict__ tX = stats + H * H + 5 * H;     // X[H*H], Xc[H], Gs[H]
-  const float* __restrict__ tM = stats + H * H + 3 * H;     // m1[H], m2[H]
+  const float* __restrict__ tX0 = stats + H * H + 5 * H;    // X[H*H], Xc[H], Gs[H]
+  const float* __restrict__ tM0 = stats + H * H + 3 * H;    // m1[H], m2[H]
   __shared__ float redd[NWV][H];
   __shared__ float red[NWV][256];
   const int ldk = (ld + 31) / 32 * 32;        // positions rounded up to whole k-steps
@@ -583,6 +583,10 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void map_bwd_mfma_kerne
     const long long b = row / N;
     const int i = (int)(row - b * N);
     const long long off = (b * H * N + i) * (long long)ld + jc;
+    // re-derive the table pointers every row through an opaque move: the scalar loads then stay
+    // inside the loop (scalar-cache hits) instead of being hoisted and spilled to VGPR lanes
+    const float* tX = tX0; const float* tM = tM0; const float* Wt = W;
+    asm volatile("" : "+s"(tX), "+s"(tM), "+s"(Wt));
     float pv[H][4], dP[H][4], dAg[H][4], delta[H];
 #pragma unroll
     for (int h = 0; h < H; ++h) delta[h] = 0.f;
@@ -594,6 +598,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void map_bwd_mfma_kerne
 #pragma unroll
         for (int e = 0; e < 4; ++e) { pv[h][e] = v.v[e]; dAg[h][e] = d.v[e]; }
       }
+      // two phases so that only one 8x8 table (X, then W) is live in scalar registers at a time
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const bool cv = jc + e < N;
@@ -604,17 +609,21 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void map_bwd_mfma_kerne
         for (int g = 0; g < H; ++g) {
           float xh = tX[H * H + g];
 #pragma unroll
-          for (int h = 0; h < H; ++h) xh += tX[g * H + h] * pt[h];
+          for (int h = 0; h < H; ++h) xh = fmaf(tX[g * H + h], pt[h], xh);
           dAg[g][e] = cv ? tX[H * H + H + g] * (dAg[g][e] - tM[g] - xh * tM[H + g]) : 0.f;
         }
+      }
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
 #pragma unroll
         for (int h = 0; h < H; ++h) {
           float dp = 0.f;
 #pragma unroll
-          for (int g = 0; g < H; ++g) dp += W[g * H + h] * dAg[g][e];
+          for (int g = 0; g < H; ++g) dp = fmaf(Wt[g * H + h], dAg[g][e], dp);
           dp = pv[h][e] > 0.f ? dp * inv_keep : 0.f;
           dP[h][e] = dp;
-          delta[h] += dp * fabsf(pv[h][e]);
+          delta[h] = fmaf(dp, fabsf(pv[h][e]), delta[h]);
         }
       }
       // LDS images for the MFMA contraction (4 consecutive positions per store)
