@@ -685,6 +685,227 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void map_bwd_mfma_kerne
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// map_bwd_mm_kernel (bf16 storage, H = 8, one 256-thread block per row, ld <= 1024): all three
+// 8x8 head contractions of the map backward run on the matrix cores.
+//   "own" layout    : thread t owns the position quad 4t..4t+3, all 8 heads  (B operand of MFMA #1)
+//   "result" layout : what v_mfma_f32_16x16x32 returns when four position sets (one per 16-lane
+//                     group) are stacked along K with a block-diagonal A operand: lane (l15, lg)
+//                     gets heads 4*(lg&1)..+3 of the quads owned by lanes (l15, lg>>1) ["A"] and
+//                     (l15, 2 + (lg>>1)) ["B"].
+// MFMA #1: xhat pre-activation  = X  (8x8) . P~   -> result layout
+// elementwise (result layout, dAhat / P loaded from HBM directly in that layout):  dA, later dP, dS
+// MFMA #2: dP~ = W^T (8x8) . dA : the accumulators of #1's layout ARE its B operand (k-slot
+//          (lg, 4m+r)), and its output lands in the same result layout - no lane movement.
+// MFMA #3: dW[g,h] = sum_pos dA_g P~_h through two [head][position] LDS images (as
+//          map_bwd_mfma_kernel), dA split hi/lo.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bf16x8 pack8(const float (&v)[8]) {
+  bf16x8 r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = (bf16_t)v[j];
+  return r;
+}
+
+__device__ __forceinline__ float unpk(const uint2& q, int e) {
+  const unsigned wv = (e < 2) ? q.x : q.y;
+  return __uint_as_float((e & 1) ? (wv & 0xffff0000u) : (wv << 16));
+}
+
+__global__ __launch_bounds__(256, 2) void map_bwd_mm_kernel(const bf16_t* __restrict__ Ps, bf16_t* dA,
+                                                            const float* __restrict__ W, const float* __restrict__ c,
+                                                            const float* __restrict__ gamma, const float* __restrict__ stats,
+                                                            float* dW, float* dc, long long rows, int N, int ld,
+                                                            float inv_keep, float scale) {
+  constexpr int H = 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __shared__ float redd[4][H];
+  __shared__ float red[4][256];
+  const int ldk = (ld + 31) / 32 * 32;
+  const int LDP = ldk + 8;
+  bf16_t* sA = reinterpret_cast<bf16_t*>(smem_raw);   // [H][LDP]   dA hi
+  bf16_t* sL = sA + H * LDP;                          // [H][LDP]   dA lo
+  bf16_t* sB = sL + H * LDP;                          // [H+1][LDP] P~, row H = ones
+  for (int i = threadIdx.x; i < (3 * H + 1) * LDP; i += blockDim.x) {
+    const int r = i / LDP, col = i % LDP;
+    sA[i] = (r == 3 * H && col < N) ? (bf16_t)1.0f : (bf16_t)0.0f;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const float* tX = stats + H * H + 5 * H;     // X[H*H] = W*rstd_g, Xc[H], Gs[H]
+  const float* tM = stats + H * H + 3 * H;     // m1[H], m2[H]
+  // ---- constant A operands (block diagonal over the four lane-group position sets) ------------
+  // #1, MFMA m: row16 = l15 -> (q' = 2m + l15/8, g = l15%8); k-slot (lg, j): X[g][j] if lg == q'
+  // #2, MFMA m2: row16 = l15 -> (q'' = 2m2 + l15/8, h = l15%8); k-slot (lg, j = 4m + r) is
+  //     (q' = 2m + lg/2, g = 4(lg&1) + r): W[g][h] if q' == q''
+  bf16x8 A1[2], A2[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    float v1[8], v2[8];
+    const int qrow = 2 * m + (l15 >> 3), hr = l15 & 7;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      v1[j] = (lg == qrow) ? tX[hr * H + j] : 0.f;
+      const int mk = j >> 2, r = j & 3;
+      const int qk = 2 * mk + (lg >> 1), gk = 4 * (lg & 1) + r;
+      v2[j] = (qk == qrow) ? W[gk * H + hr] : 0.f;
+    }
+    A1[m] = pack8(v1);
+    A2[m] = pack8(v2);
+  }
+  const int hbase = 4 * (lg & 1);
+  float Xc4[4], Gs4[4], M14[4], M24[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    Xc4[r] = tX[H * H + hbase + r]; Gs4[r] = tX[H * H + H + hbase + r];
+    M14[r] = tM[hbase + r]; M24[r] = tM[H + hbase + r];
+  }
+  __syncthreads();
+  const unsigned hs = (unsigned)N * (unsigned)ld;     // launcher guarantees 8 * N * ld < 2^31
+  const int nks = ldk / 32;
+  const int nquads = ld >> 2;
+  const int qown = threadIdx.x;                          // own quad
+  const int qA = 64 * wave + 16 * (lg >> 1) + l15;       // result-layout quads
+  const int qB = qA + 32;
+  f32x4 accw = {0.f, 0.f, 0.f, 0.f};
+  for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
+    const long long b = row / N;
+    const int i = (int)(row - b * N);
+    const bf16_t* __restrict__ Prow = Ps + (b * H * N + i) * (long long)ld;   // wave-uniform bases,
+    bf16_t* Drow = dA + (b * H * N + i) * (long long)ld;                      // 32-bit lane offsets
+    // ---- loads ---------------------------------------------------------------------------------
+    uint2 pown[H];
+    uint2 PA[4], PB[4];      // packed bf16 quads, unpacked where used
+    vu_f4 DA[4], DB[4];
+#pragma unroll
+    for (int h = 0; h < H; ++h) pown[h] = make_uint2(0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      PA[r] = make_uint2(0, 0); PB[r] = make_uint2(0, 0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { DA[r].v[e] = 0.f; DB[r].v[e] = 0.f; }
+    }
+    if (qown < nquads) {
+#pragma unroll
+      for (int h = 0; h < H; ++h) pown[h] = *reinterpret_cast<const uint2*>(Prow + (h * hs + 4u * qown));
+    }
+    if (qA < nquads) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const unsigned o = (hbase + r) * hs + 4u * qA;
+        PA[r] = *reinterpret_cast<const uint2*>(Prow + o);
+        DA[r] = vu_ld4(Drow + o);
+      }
+    }
+    if (qB < nquads) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const unsigned o = (hbase + r) * hs + 4u * qB;
+        PB[r] = *reinterpret_cast<const uint2*>(Prow + o);
+        DB[r] = vu_ld4(Drow + o);
+      }
+    }
+    float dPa[4][4], dPb[4][4], delta[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      // B operand of #1: the 8 heads of the own quad's element e (post-dropout probabilities)
+      float pt[8];
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        const float v = unpk(pown[h], e);
+        pt[h] = v > 0.f ? v * inv_keep : 0.f;
+      }
+      const bf16x8 b1 = pack8(pt);
+      f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+      c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1[0], b1, c0, 0, 0, 0);   // quads of lane groups 0,1
+      c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1[1], b1, c1, 0, 0, 0);   // quads of lane groups 2,3
+      // dA in the result layout
+      float v2[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool va = 4 * qA + e < N, vb = 4 * qB + e < N;
+        const float da = va ? Gs4[r] * (DA[r].v[e] - M14[r] - (c0[r] + Xc4[r]) * M24[r]) : 0.f;
+        const float db = vb ? Gs4[r] * (DB[r].v[e] - M14[r] - (c1[r] + Xc4[r]) * M24[r]) : 0.f;
+        DA[r].v[e] = da; DB[r].v[e] = db;      // dAhat is dead: keep dA in place
+        v2[r] = da; v2[4 + r] = db;
+      }
+      const bf16x8 b2 = pack8(v2);
+      f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+      d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2[0], b2, d0, 0, 0, 0);
+      d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2[1], b2, d1, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pa = unpk(PA[r], e), pb = unpk(PB[r], e);
+        const float xa = pa > 0.f ? d0[r] * inv_keep : 0.f;
+        const float xb = pb > 0.f ? d1[r] * inv_keep : 0.f;
+        dPa[r][e] = xa; dPb[r][e] = xb;
+        delta[r] = fmaf(xa, fabsf(pa), fmaf(xb, fabsf(pb), delta[r]));
+      }
+    }
+    // ---- LDS images for dW (result layout -> [head][position]) --------------------------------
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      vu_f4 lo, pt4;
+      if (qA < nquads) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { lo.v[e] = DA[r].v[e] - (float)(bf16_t)DA[r].v[e]; { const float pa = unpk(PA[r], e); pt4.v[e] = pa > 0.f ? pa * inv_keep : 0.f; } }
+        vu_st4(sA + (hbase + r) * LDP + 4 * qA, DA[r]);
+        vu_st4(sL + (hbase + r) * LDP + 4 * qA, lo);
+        vu_st4(sB + (hbase + r) * LDP + 4 * qA, pt4);
+      }
+      if (qB < nquads) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { lo.v[e] = DB[r].v[e] - (float)(bf16_t)DB[r].v[e]; { const float pb = unpk(PB[r], e); pt4.v[e] = pb > 0.f ? pb * inv_keep : 0.f; } }
+        vu_st4(sA + (hbase + r) * LDP + 4 * qB, DB[r]);
+        vu_st4(sL + (hbase + r) * LDP + 4 * qB, lo);
+        vu_st4(sB + (hbase + r) * LDP + 4 * qB, pt4);
+      }
+    }
+    // ---- delta_h over the row: lanes with the same (lg & 1) hold the same heads ----------------
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v = delta[r];
+      v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (l15 == 0 && lg < 2) redd[wave][4 * lg + r] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) delta[r] = redd[0][hbase + r] + redd[1][hbase + r] + redd[2][hbase + r] + redd[3][hbase + r];
+    for (int ks = wave; ks < nks; ks += 4) {
+      const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+      const bf16x8 af = l15 < H ? *reinterpret_cast<const bf16x8*>(sA + l15 * LDP + ks * 32 + lg * 8) : zero8;
+      const bf16x8 lf = l15 < H ? *reinterpret_cast<const bf16x8*>(sL + l15 * LDP + ks * 32 + lg * 8) : zero8;
+      const bf16x8 bf = l15 <= H ? *reinterpret_cast<const bf16x8*>(sB + l15 * LDP + ks * 32 + lg * 8) : zero8;
+      accw = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, accw, 0, 0, 0);
+      accw = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lf, bf, accw, 0, 0, 0);
+    }
+    // ---- dS = |p| (dP - delta) scale, result layout, 4 consecutive positions per store ----------
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const unsigned o = (hbase + r) * hs;
+      vu_f4 oa, ob;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        oa.v[e] = (4 * qA + e < N) ? fabsf(unpk(PA[r], e)) * (dPa[r][e] - delta[r]) * scale : 0.f;
+        ob.v[e] = (4 * qB + e < N) ? fabsf(unpk(PB[r], e)) * (dPb[r][e] - delta[r]) * scale : 0.f;
+      }
+      if (qA < nquads) vu_st4(Drow + (o + 4u * qA), oa);
+      if (qB < nquads) vu_st4(Drow + (o + 4u * qB), ob);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[wave][(lg * 4 + r) * 16 + l15] = accw[r];
+  __syncthreads();
+  {
+    const int g = threadIdx.x / 16, hcol = threadIdx.x % 16;
+    const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (g < H && hcol < H) atomicAdd(dW + g * H + hcol, v);
+    else if (g < H && hcol == H) atomicAdd(dc + g, v);
+  }
+}
+
 template <typename T, int H>
 int launch_map_bwd_row(const void* Ps, void* dA, const float* W, const float* c, const float* gamma, const float* stats,
                        float* dW, float* dc, int B, int N, int ld, float inv_keep, float scale, hipStream_t st) {
@@ -699,6 +920,21 @@ int launch_map_bwd_row(const void* Ps, void* dA, const float* W, const float* c,
     const int ldk = (ld + 31) / 32 * 32;
     const size_t lds = (size_t)(3 * H + 1) * (ldk + 8) * 2;
     const bool big = ld > 1024;
+    if constexpr (H == 8) {
+      if (!big && !getenv("VU_MAP_BWD_VALU")) {
+        const size_t lds8 = (size_t)(3 * 8 + 1) * (ldk + 8) * 2;
+        auto k8 = map_bwd_mm_kernel;
+        if (lds8 > 40 * 1024) {
+          hipError_t e = hipFuncSetAttribute((const void*)k8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8);
+          if (e != hipSuccess) { vu_set_error("map_bwd: cannot reserve %zu bytes of LDS", lds8); return VU_ELAUNCH; }
+        }
+        long long grid8 = rows; if (grid8 > 1024) grid8 = 1024;
+        hipLaunchKernelGGL(k8, dim3((unsigned)grid8), dim3(256), lds8, st, (const bf16_t*)Ps, (bf16_t*)dA, W, c, gamma, stats, dW,
+                           dc, rows, N, ld, inv_keep, scale);
+        if (vu_prof_on()) vu_prof_note("map_bwd_mm_kernel", 0.0, (double)B * H * N * N * 3 * sizeof(T));
+        return vu_check_launch("vu_map_bwd");
+      }
+    }
     auto kern = big ? map_bwd_mfma_kernel<(H <= 4 ? H : 4), 16> : map_bwd_mfma_kernel<H, 4>;
     if (lds > 40 * 1024) {
       hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
