@@ -700,6 +700,25 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void map_bwd_mfma_kerne
 // MFMA #3: dW[g,h] = sum_pos dA_g P~_h through two [head][position] LDS images (as
 //          map_bwd_mfma_kernel), dA split hi/lo.
 // ---------------------------------------------------------------------------------------------
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// zero the bf16 halves whose sign bit is set (the dropped probabilities): packed signed-16 max with 0
+__device__ __forceinline__ unsigned keep_pos(unsigned w) {
+  const s16x2 z = {0, 0};
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, w), z));
+}
+__device__ __forceinline__ float half_f(unsigned w, int odd) { return __uint_as_float(odd ? (w & 0xffff0000u) : (w << 16)); }
+__device__ __forceinline__ float unpk(const uint2& q, int e) { return half_f(e < 2 ? q.x : q.y, e & 1); }
+__device__ __forceinline__ unsigned pk2(float a, float b) {
+  const bf16x2v v = {(bf16_t)a, (bf16_t)b};
+  return __builtin_bit_cast(unsigned, v);
+}
+// word made of the low (odd = 0) or high (odd = 1) bf16 halves of x (-> low half) and y (-> high half)
+__device__ __forceinline__ unsigned halves(unsigned x, unsigned y, int odd) {
+  return __builtin_amdgcn_perm(y, x, odd ? 0x07060302u : 0x05040100u);
+}
 __device__ __forceinline__ bf16x8 pack8(const float (&v)[8]) {
   bf16x8 r;
 #pragma unroll
@@ -707,11 +726,8 @@ __device__ __forceinline__ bf16x8 pack8(const float (&v)[8]) {
   return r;
 }
 
-__device__ __forceinline__ float unpk(const uint2& q, int e) {
-  const unsigned wv = (e < 2) ? q.x : q.y;
-  return __uint_as_float((e & 1) ? (wv & 0xffff0000u) : (wv << 16));
-}
-
+// EXACT: N % 4 == 0, position quads are wholly valid or wholly padding
+template <bool EXACT>
 __global__ __launch_bounds__(256, 2) void map_bwd_mm_kernel(const bf16_t* __restrict__ Ps, bf16_t* dA,
                                                             const float* __restrict__ W, const float* __restrict__ c,
                                                             const float* __restrict__ gamma, const float* __restrict__ stats,
@@ -725,7 +741,7 @@ __global__ __launch_bounds__(256, 2) void map_bwd_mm_kernel(const bf16_t* __rest
   const int LDP = ldk + 8;
   bf16_t* sA = reinterpret_cast<bf16_t*>(smem_raw);   // [H][LDP]   dA hi
   bf16_t* sL = sA + H * LDP;                          // [H][LDP]   dA lo
-  bf16_t* sB = sL + H * LDP;                          // [H+1][LDP] P~, row H = ones
+  bf16_t* sB = sL + H * LDP;                          // [H+1][LDP] kept P (without 1/keep), row H = ones
   for (int i = threadIdx.x; i < (3 * H + 1) * LDP; i += blockDim.x) {
     const int r = i / LDP, col = i % LDP;
     sA[i] = (r == 3 * H && col < N) ? (bf16_t)1.0f : (bf16_t)0.0f;
@@ -735,9 +751,9 @@ __global__ __launch_bounds__(256, 2) void map_bwd_mm_kernel(const bf16_t* __rest
   const float* tX = stats + H * H + 5 * H;     // X[H*H] = W*rstd_g, Xc[H], Gs[H]
   const float* tM = stats + H * H + 3 * H;     // m1[H], m2[H]
   // ---- constant A operands (block diagonal over the four lane-group position sets) ------------
-  // #1, MFMA m: row16 = l15 -> (q' = 2m + l15/8, g = l15%8); k-slot (lg, j): X[g][j] if lg == q'
+  // #1, MFMA m: row16 = l15 -> (q' = 2m + l15/8, g = l15%8); k-slot (lg, j): X[g][j]/keep if lg == q'
   // #2, MFMA m2: row16 = l15 -> (q'' = 2m2 + l15/8, h = l15%8); k-slot (lg, j = 4m + r) is
-  //     (q' = 2m + lg/2, g = 4(lg&1) + r): W[g][h] if q' == q''
+  //     (q' = 2m + lg/2, g = 4(lg&1) + r): W[g][h] scale/keep if q' == q''
   bf16x8 A1[2], A2[2];
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
@@ -745,122 +761,138 @@ __global__ __launch_bounds__(256, 2) void map_bwd_mm_kernel(const bf16_t* __rest
     const int qrow = 2 * m + (l15 >> 3), hr = l15 & 7;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      v1[j] = (lg == qrow) ? tX[hr * H + j] : 0.f;
+      v1[j] = (lg == qrow) ? tX[hr * H + j] * inv_keep : 0.f;
       const int mk = j >> 2, r = j & 3;
       const int qk = 2 * mk + (lg >> 1), gk = 4 * (lg & 1) + r;
-      v2[j] = (qk == qrow) ? W[gk * H + hr] : 0.f;
+      v2[j] = (qk == qrow) ? W[gk * H + hr] * (inv_keep * scale) : 0.f;
     }
     A1[m] = pack8(v1);
     A2[m] = pack8(v2);
   }
   const int hbase = 4 * (lg & 1);
-  float Xc4[4], Gs4[4], M14[4], M24[4];
+  // dA = Gs (dAhat - m1 - (acc + Xc) m2) = Gs dAhat + K1 + K2 acc
+  float Gs4[4], K1[4], K2[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    Xc4[r] = tX[H * H + hbase + r]; Gs4[r] = tX[H * H + H + hbase + r];
-    M14[r] = tM[hbase + r]; M24[r] = tM[H + hbase + r];
+    const float gs = tX[H * H + H + hbase + r], xc = tX[H * H + hbase + r];
+    const float m1 = tM[hbase + r], m2 = tM[H + hbase + r];
+    Gs4[r] = gs; K1[r] = -gs * (m1 + xc * m2); K2[r] = -gs * m2;
   }
   __syncthreads();
   const unsigned hs = (unsigned)N * (unsigned)ld;     // launcher guarantees 8 * N * ld < 2^31
   const int nks = ldk / 32;
-  const int nquads = ld >> 2;
+  const int nquads = EXACT ? (N >> 2) : (ld >> 2);
   const int qown = threadIdx.x;                          // own quad
   const int qA = 64 * wave + 16 * (lg >> 1) + l15;       // result-layout quads
   const int qB = qA + 32;
   f32x4 accw = {0.f, 0.f, 0.f, 0.f};
-  for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
+
+  uint2 pown[H], PA[4], PB[4], QA[4], QB[4];             // packed bf16 quads: P (own / result layout), dAhat
+  auto load_row = [&](long long row, uint2 (&po)[H], uint2 (&pa)[4], uint2 (&pb)[4], uint2 (&qa)[4], uint2 (&qb)[4]) {
     const long long b = row / N;
     const int i = (int)(row - b * N);
-    const bf16_t* __restrict__ Prow = Ps + (b * H * N + i) * (long long)ld;   // wave-uniform bases,
-    bf16_t* Drow = dA + (b * H * N + i) * (long long)ld;                      // 32-bit lane offsets
-    // ---- loads ---------------------------------------------------------------------------------
-    uint2 pown[H];
-    uint2 PA[4], PB[4];      // packed bf16 quads, unpacked where used
-    vu_f4 DA[4], DB[4];
+    const long long base = (b * H * N + i) * (long long)ld;
+    const bf16_t* __restrict__ Prow = Ps + base;
+    const bf16_t* Drow = dA + base;
 #pragma unroll
-    for (int h = 0; h < H; ++h) pown[h] = make_uint2(0, 0);
+    for (int h = 0; h < H; ++h) po[h] = make_uint2(0, 0);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      PA[r] = make_uint2(0, 0); PB[r] = make_uint2(0, 0);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { DA[r].v[e] = 0.f; DB[r].v[e] = 0.f; }
-    }
+    for (int r = 0; r < 4; ++r) { pa[r] = make_uint2(0, 0); pb[r] = make_uint2(0, 0); qa[r] = make_uint2(0, 0); qb[r] = make_uint2(0, 0); }
     if (qown < nquads) {
 #pragma unroll
-      for (int h = 0; h < H; ++h) pown[h] = *reinterpret_cast<const uint2*>(Prow + (h * hs + 4u * qown));
+      for (int h = 0; h < H; ++h) po[h] = *reinterpret_cast<const uint2*>(Prow + (h * hs + 4u * qown));
     }
     if (qA < nquads) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const unsigned o = (hbase + r) * hs + 4u * qA;
-        PA[r] = *reinterpret_cast<const uint2*>(Prow + o);
-        DA[r] = vu_ld4(Drow + o);
+        pa[r] = *reinterpret_cast<const uint2*>(Prow + o);
+        qa[r] = *reinterpret_cast<const uint2*>(Drow + o);
       }
     }
     if (qB < nquads) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const unsigned o = (hbase + r) * hs + 4u * qB;
-        PB[r] = *reinterpret_cast<const uint2*>(Prow + o);
-        DB[r] = vu_ld4(Drow + o);
+        pb[r] = *reinterpret_cast<const uint2*>(Prow + o);
+        qb[r] = *reinterpret_cast<const uint2*>(Drow + o);
       }
     }
+  };
+  if ((long long)blockIdx.x < rows) load_row(blockIdx.x, pown, PA, PB, QA, QB);
+  for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
+    // ---- own layout: kept probabilities, P image, B operands of #1 -------------------------------
+    unsigned b1w[4][4];
+#pragma unroll
+    for (int h = 0; h < H; ++h) { pown[h].x = keep_pos(pown[h].x); pown[h].y = keep_pos(pown[h].y); }
+    if (qown < nquads) {
+#pragma unroll
+      for (int h = 0; h < H; ++h) *reinterpret_cast<uint2*>(sB + h * LDP + 4 * qown) = pown[h];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      b1w[0][j] = halves(pown[2 * j].x, pown[2 * j + 1].x, 0);
+      b1w[1][j] = halves(pown[2 * j].x, pown[2 * j + 1].x, 1);
+      b1w[2][j] = halves(pown[2 * j].y, pown[2 * j + 1].y, 0);
+      b1w[3][j] = halves(pown[2 * j].y, pown[2 * j + 1].y, 1);
+    }
+    unsigned hiw[4][4], low[4][4];        // [e][word]: bf16 pairs (r0,r1),(r2,r3) of quad A, then of quad B
     float dPa[4][4], dPb[4][4], delta[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      // B operand of #1: the 8 heads of the own quad's element e (post-dropout probabilities)
-      float pt[8];
-#pragma unroll
-      for (int h = 0; h < H; ++h) {
-        const float v = unpk(pown[h], e);
-        pt[h] = v > 0.f ? v * inv_keep : 0.f;
-      }
-      const bf16x8 b1 = pack8(pt);
+      const u32x4 b1u = {b1w[e][0], b1w[e][1], b1w[e][2], b1w[e][3]};
+      const bf16x8 b1 = __builtin_bit_cast(bf16x8, b1u);
       f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
       c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1[0], b1, c0, 0, 0, 0);   // quads of lane groups 0,1
       c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1[1], b1, c1, 0, 0, 0);   // quads of lane groups 2,3
-      // dA in the result layout
-      float v2[8];
+      float va[4], vb[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const bool va = 4 * qA + e < N, vb = 4 * qB + e < N;
-        const float da = va ? Gs4[r] * (DA[r].v[e] - M14[r] - (c0[r] + Xc4[r]) * M24[r]) : 0.f;
-        const float db = vb ? Gs4[r] * (DB[r].v[e] - M14[r] - (c1[r] + Xc4[r]) * M24[r]) : 0.f;
-        DA[r].v[e] = da; DB[r].v[e] = db;      // dAhat is dead: keep dA in place
-        v2[r] = da; v2[4 + r] = db;
+        va[r] = fmaf(K2[r], c0[r], fmaf(Gs4[r], unpk(QA[r], e), K1[r]));
+        vb[r] = fmaf(K2[r], c1[r], fmaf(Gs4[r], unpk(QB[r], e), K1[r]));
+        if (!EXACT) { va[r] = (4 * qA + e < N) ? va[r] : 0.f; vb[r] = (4 * qB + e < N) ? vb[r] : 0.f; }
       }
-      const bf16x8 b2 = pack8(v2);
+      hiw[e][0] = pk2(va[0], va[1]); hiw[e][1] = pk2(va[2], va[3]);
+      hiw[e][2] = pk2(vb[0], vb[1]); hiw[e][3] = pk2(vb[2], vb[3]);
+      low[e][0] = pk2(va[0] - half_f(hiw[e][0], 0), va[1] - half_f(hiw[e][0], 1));
+      low[e][1] = pk2(va[2] - half_f(hiw[e][1], 0), va[3] - half_f(hiw[e][1], 1));
+      low[e][2] = pk2(vb[0] - half_f(hiw[e][2], 0), vb[1] - half_f(hiw[e][2], 1));
+      low[e][3] = pk2(vb[2] - half_f(hiw[e][3], 0), vb[3] - half_f(hiw[e][3], 1));
+      const u32x4 b2u = {hiw[e][0], hiw[e][1], hiw[e][2], hiw[e][3]};
+      const bf16x8 b2 = __builtin_bit_cast(bf16x8, b2u);
       f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
       d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2[0], b2, d0, 0, 0, 0);
       d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2[1], b2, d1, 0, 0, 0);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float pa = unpk(PA[r], e), pb = unpk(PB[r], e);
-        const float xa = pa > 0.f ? d0[r] * inv_keep : 0.f;
-        const float xb = pb > 0.f ? d1[r] * inv_keep : 0.f;
+        const float xa = pa > 0.f ? d0[r] : 0.f;        // = dP scale (1/keep and scale sit in A2)
+        const float xb = pb > 0.f ? d1[r] : 0.f;
         dPa[r][e] = xa; dPb[r][e] = xb;
         delta[r] = fmaf(xa, fabsf(pa), fmaf(xb, fabsf(pb), delta[r]));
       }
     }
-    // ---- LDS images for dW (result layout -> [head][position]) --------------------------------
+    // ---- LDS images of dA for dW (result layout -> [head][position]) ----------------------------
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      vu_f4 lo, pt4;
+      const int wv = r >> 1, od = r & 1;
       if (qA < nquads) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { lo.v[e] = DA[r].v[e] - (float)(bf16_t)DA[r].v[e]; { const float pa = unpk(PA[r], e); pt4.v[e] = pa > 0.f ? pa * inv_keep : 0.f; } }
-        vu_st4(sA + (hbase + r) * LDP + 4 * qA, DA[r]);
-        vu_st4(sL + (hbase + r) * LDP + 4 * qA, lo);
-        vu_st4(sB + (hbase + r) * LDP + 4 * qA, pt4);
+        *reinterpret_cast<uint2*>(sA + (hbase + r) * LDP + 4 * qA) =
+            make_uint2(halves(hiw[0][wv], hiw[1][wv], od), halves(hiw[2][wv], hiw[3][wv], od));
+        *reinterpret_cast<uint2*>(sL + (hbase + r) * LDP + 4 * qA) =
+            make_uint2(halves(low[0][wv], low[1][wv], od), halves(low[2][wv], low[3][wv], od));
       }
       if (qB < nquads) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { lo.v[e] = DB[r].v[e] - (float)(bf16_t)DB[r].v[e]; { const float pb = unpk(PB[r], e); pt4.v[e] = pb > 0.f ? pb * inv_keep : 0.f; } }
-        vu_st4(sA + (hbase + r) * LDP + 4 * qB, DB[r]);
-        vu_st4(sL + (hbase + r) * LDP + 4 * qB, lo);
-        vu_st4(sB + (hbase + r) * LDP + 4 * qB, pt4);
+        *reinterpret_cast<uint2*>(sA + (hbase + r) * LDP + 4 * qB) =
+            make_uint2(halves(hiw[0][2 + wv], hiw[1][2 + wv], od), halves(hiw[2][2 + wv], hiw[3][2 + wv], od));
+        *reinterpret_cast<uint2*>(sL + (hbase + r) * LDP + 4 * qB) =
+            make_uint2(halves(low[0][2 + wv], low[1][2 + wv], od), halves(low[2][2 + wv], low[3][2 + wv], od));
       }
     }
+    // ---- next row's loads fly during the reduction / contraction / store phase --------------------
+    uint2 nP[4], nPB[4];
+    const long long nrow = row + gridDim.x;
+    if (nrow < rows) load_row(nrow, pown, nP, nPB, QA, QB);
     // ---- delta_h over the row: lanes with the same (lg & 1) hold the same heads ----------------
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -881,18 +913,30 @@ __global__ __launch_bounds__(256, 2) void map_bwd_mm_kernel(const bf16_t* __rest
       accw = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lf, bf, accw, 0, 0, 0);
     }
     // ---- dS = |p| (dP - delta) scale, result layout, 4 consecutive positions per store ----------
+    {
+      const long long b = row / N;
+      const int i = (int)(row - b * N);
+      bf16_t* Drow = dA + (b * H * N + i) * (long long)ld;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const unsigned o = (hbase + r) * hs;
-      vu_f4 oa, ob;
+      for (int r = 0; r < 4; ++r) {
+        const unsigned o = (hbase + r) * hs;
+        float oa[4], ob[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        oa.v[e] = (4 * qA + e < N) ? fabsf(unpk(PA[r], e)) * (dPa[r][e] - delta[r]) * scale : 0.f;
-        ob.v[e] = (4 * qB + e < N) ? fabsf(unpk(PB[r], e)) * (dPb[r][e] - delta[r]) * scale : 0.f;
+        for (int e = 0; e < 4; ++e) {
+          oa[e] = fabsf(unpk(PA[r], e)) * (dPa[r][e] - delta[r]);
+          ob[e] = fabsf(unpk(PB[r], e)) * (dPb[r][e] - delta[r]);
+          if (!EXACT) { oa[e] = (4 * qA + e < N) ? oa[e] : 0.f; ob[e] = (4 * qB + e < N) ? ob[e] : 0.f; }
+        }
+        if (qA < nquads) *reinterpret_cast<uint2*>(Drow + (o + 4u * qA)) = make_uint2(pk2(oa[0], oa[1]), pk2(oa[2], oa[3]));
+        if (qB < nquads) *reinterpret_cast<uint2*>(Drow + (o + 4u * qB)) = make_uint2(pk2(ob[0], ob[1]), pk2(ob[2], ob[3]));
       }
-      if (qA < nquads) vu_st4(Drow + (o + 4u * qA), oa);
-      if (qB < nquads) vu_st4(Drow + (o + 4u * qB), ob);
+      if (EXACT && qown >= nquads && 4 * qown < ld) {      // the padding quad of the row
+#pragma unroll
+        for (int h = 0; h < H; ++h) *reinterpret_cast<uint2*>(Drow + (h * hs + 4u * qown)) = make_uint2(0, 0);
+      }
     }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { PA[r] = nP[r]; PB[r] = nPB[r]; }
     __syncthreads();
   }
 #pragma unroll
@@ -901,7 +945,7 @@ __global__ __launch_bounds__(256, 2) void map_bwd_mm_kernel(const bf16_t* __rest
   {
     const int g = threadIdx.x / 16, hcol = threadIdx.x % 16;
     const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-    if (g < H && hcol < H) atomicAdd(dW + g * H + hcol, v);
+    if (g < H && hcol < H) atomicAdd(dW + g * H + hcol, v * inv_keep);    // the P image holds kept p, not p/keep
     else if (g < H && hcol == H) atomicAdd(dc + g, v);
   }
 }
@@ -923,7 +967,7 @@ int launch_map_bwd_row(const void* Ps, void* dA, const float* W, const float* c,
     if constexpr (H == 8) {
       if (!big && !getenv("VU_MAP_BWD_VALU")) {
         const size_t lds8 = (size_t)(3 * 8 + 1) * (ldk + 8) * 2;
-        auto k8 = map_bwd_mm_kernel;
+        auto k8 = (N % 4 == 0) ? map_bwd_mm_kernel<true> : map_bwd_mm_kernel<false>;
         if (lds8 > 40 * 1024) {
           hipError_t e = hipFuncSetAttribute((const void*)k8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8);
           if (e != hipSuccess) { vu_set_error("map_bwd: cannot reserve %zu bytes of LDS", lds8); return VU_ELAUNCH; }
