@@ -74,7 +74,7 @@ int vu_k_map_bwd_2sweep(int dtype, const void* Ps, void* dAhat_dS, const float* 
 
 // K13: residual add + LayerNorm over all P elements of a sample.
 #define VU_LN_CHUNK 4096
-#define VU_LN_BCHUNK 1024
+#define VU_LN_BCHUNK 256
 static inline int vu_ln_nchunks(long long P) { return (int)((P + VU_LN_CHUNK - 1) / VU_LN_CHUNK); }
 static inline int vu_ln_nbchunks(long long P) { return (int)((P + VU_LN_BCHUNK - 1) / VU_LN_BCHUNK); }
 // partials: B*nchunks*3 floats ; stats: B*2 floats (mean, rstd)

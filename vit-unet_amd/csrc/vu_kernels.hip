@@ -539,20 +539,28 @@ __global__ __launch_bounds__(256) void add_ln_stats_kernel(const T* a, const T* 
   }
 }
 
+// Pooled mean / variance of a sample from its per-chunk (count, mean, M2) triples, by the first wave
+// of the block in parallel: mu = sum n_c mu_c / sum n_c ;  M2 = sum (M2_c + n_c (mu_c - mu)^2).
 __device__ __forceinline__ void ln_merge_stats(const float* partials, int b, int nch, float eps, float* sm2,
                                                float& mean, float& rstd) {
-  if (threadIdx.x == 0) {
-    double n = 0.0, mu = 0.0, M2 = 0.0;
-    for (int c = 0; c < nch; ++c) {
+  if (threadIdx.x < 64) {
+    double n = 0.0, s = 0.0;
+    for (int c = threadIdx.x; c < nch; c += 64) {
       const float* o = partials + ((long long)b * nch + c) * 3;
-      const double nb = o[0], mb = o[1], Mb = o[2];
-      const double d = mb - mu, nn = n + nb;
-      mu += d * nb / nn;
-      M2 += Mb + d * d * n * nb / nn;
-      n = nn;
+      n += (double)o[0]; s += (double)o[0] * (double)o[1];
     }
-    sm2[0] = (float)mu;
-    sm2[1] = (float)(1.0 / sqrt(M2 / n + (double)eps));
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { n += __shfl_xor(n, m, 64); s += __shfl_xor(s, m, 64); }
+    const double mu = s / n;
+    double M2 = 0.0;
+    for (int c = threadIdx.x; c < nch; c += 64) {
+      const float* o = partials + ((long long)b * nch + c) * 3;
+      const double d = (double)o[1] - mu;
+      M2 += (double)o[2] + (double)o[0] * d * d;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) M2 += __shfl_xor(M2, m, 64);
+    if (threadIdx.x == 0) { sm2[0] = (float)mu; sm2[1] = (float)(1.0 / sqrt(M2 / n + (double)eps)); }
   }
   __syncthreads();
   mean = sm2[0]; rstd = sm2[1];
@@ -564,15 +572,21 @@ __global__ __launch_bounds__(256) void ln_apply_kernel(const T* __restrict__ z, 
                                                        const float* partials, float* stats, long long P, float eps) {
   __shared__ float sm2[2];
   const int c = blockIdx.x, b = blockIdx.y, nch = gridDim.x;
+  const long long base = (long long)c * VU_LN_CHUNK, sb = (long long)b * P;
+  vu_f4 tz[4];       // the chunk's values are in flight while the statistics are merged
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const long long e = base + (it * 256 + threadIdx.x) * 4;
+    if (e < P) tz[it] = vu_ld4(z + sb + e);
+  }
   float mean, rstd;
   ln_merge_stats(partials, b, nch, eps, sm2, mean, rstd);
   if (c == 0 && threadIdx.x == 0) { stats[2 * b] = mean; stats[2 * b + 1] = rstd; }
-  const long long base = (long long)c * VU_LN_CHUNK, sb = (long long)b * P;
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const long long e = base + (it * 256 + threadIdx.x) * 4;
     if (e < P) {
-      vu_f4 t = vu_ld4(z + sb + e);
+      vu_f4 t = tz[it];
       const float4 ww = *reinterpret_cast<const float4*>(w + e), bb = *reinterpret_cast<const float4*>(bias + e);
       t.v[0] = (t.v[0] - mean) * rstd * ww.x + bb.x;
       t.v[1] = (t.v[1] - mean) * rstd * ww.y + bb.y;
@@ -594,58 +608,64 @@ int vu_k_add_ln_fwd(int dtype, const void* a, const void* x, void* z, const floa
   return vu_check_launch("vu_add_ln_fwd");
 }
 
-// backward A: per chunk of P (1024 elements), loop over samples: parameter gradients for the
-// chunk's elements and per-(sample,chunk) partial sums c1 = sum dy*w, c2 = sum dy*w*xhat.
+// backward A: one block per chunk of 256 elements of P.  Thread = (tx: 8 consecutive elements,
+// ts: sample slice b = ts, ts+8, ...): the affine gradients of the chunk are summed over the batch
+// inside the block (registers, then one LDS exchange across the 8 slices - no atomics), and the
+// per-(sample,chunk) partial sums c1 = sum dy*w, c2 = sum dy*w*xhat go to partials2.
 template <typename T>
 __global__ __launch_bounds__(256) void ln_bwd_stats_kernel(const T* __restrict__ dy, const T* __restrict__ z,
                                                            const float* __restrict__ w, const float* __restrict__ stats,
-                                                           float* dw, float* db, float* partials2, int B, long long P,
-                                                           int bgroup) {
-  // grid (chunks of 1024 elements, sample groups): per-(sample,chunk) partial sums c1 = sum dy*w,
-  // c2 = sum dy*w*xhat, and the affine gradients of this chunk summed over the group's samples
-  // (float atomics when there is more than one group).
-  __shared__ float red[64][2][4];     // [sample in group][c1|c2][wave]
+                                                           float* dw, float* db, float* partials2, int B, long long P) {
+  __shared__ float red[2][8][8][33];     // [gw|gb][slice][q][tx]
+  const int tx = threadIdx.x & 31, ts = threadIdx.x >> 5;
   const int c = blockIdx.x, nch = gridDim.x;
-  const long long e = (long long)c * VU_LN_BCHUNK + threadIdx.x * 4;
-  const bool ok = e < P;
-  float4 ww = make_float4(0, 0, 0, 0);
-  if (ok) ww = *reinterpret_cast<const float4*>(w + e);
-  float gw[4] = {0, 0, 0, 0}, gb[4] = {0, 0, 0, 0};
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int b0 = blockIdx.y * bgroup;
-  const int b1 = b0 + bgroup < B ? b0 + bgroup : B;
-  for (int b = b0; b < b1; ++b) {
-    const float mean = stats[2 * b], rstd = stats[2 * b + 1];
-    float c1 = 0.f, c2 = 0.f;
-    if (ok) {
-      const vu_f4 d = vu_ld4(dy + (long long)b * P + e), zz = vu_ld4(z + (long long)b * P + e);
-      const float wv[4] = {ww.x, ww.y, ww.z, ww.w};
+  const long long e = (long long)c * VU_LN_BCHUNK + tx * 8;
+  const bool ok0 = e < P, ok1 = e + 4 < P;
+  float wv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (ok0) { const float4 t = *reinterpret_cast<const float4*>(w + e); wv[0] = t.x; wv[1] = t.y; wv[2] = t.z; wv[3] = t.w; }
+  if (ok1) { const float4 t = *reinterpret_cast<const float4*>(w + e + 4); wv[4] = t.x; wv[5] = t.y; wv[6] = t.z; wv[7] = t.w; }
+  float gw[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const vu_f4 zero = {{0.f, 0.f, 0.f, 0.f}};
+  for (int bb = ts; bb < B; bb += 32) {        // 4 samples (16 loads) in flight per thread
+    vu_f4 d0[4], d1[4], z0[4], z1[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float xh = (zz.v[q] - mean) * rstd, g = d.v[q] * wv[q];
-        gw[q] += d.v[q] * xh; gb[q] += d.v[q];
-        c1 += g; c2 += g * xh;
+    for (int k = 0; k < 4; ++k) {
+      const int b = bb + 8 * k;
+      const long long o = (long long)b * P + e;
+      const bool v0 = ok0 && b < B, v1 = ok1 && b < B;
+      d0[k] = v0 ? vu_ld4(dy + o) : zero; z0[k] = v0 ? vu_ld4(z + o) : zero;
+      d1[k] = v1 ? vu_ld4(dy + o + 4) : zero; z1[k] = v1 ? vu_ld4(z + o + 4) : zero;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int b = bb + 8 * k;
+      if (b < B) {
+        const float mean = stats[2 * b], rstd = stats[2 * b + 1];
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const float dv = q < 4 ? d0[k].v[q & 3] : d1[k].v[q & 3], zv = q < 4 ? z0[k].v[q & 3] : z1[k].v[q & 3];
+          const bool okq = q < 4 ? ok0 : ok1;
+          const float xh = okq ? (zv - mean) * rstd : 0.f, g = dv * wv[q];
+          gw[q] = fmaf(dv, xh, gw[q]); gb[q] += dv;
+          c1 += g; c2 = fmaf(g, xh, c2);
+        }
+#pragma unroll
+        for (int m = 16; m >= 1; m >>= 1) { c1 += __shfl_xor(c1, m, 64); c2 += __shfl_xor(c2, m, 64); }
+        if (tx == 0) { float* o2 = partials2 + ((long long)b * nch + c) * 2; o2[0] = c1; o2[1] = c2; }
       }
     }
-    c1 = vu_wave_sum(c1); c2 = vu_wave_sum(c2);
-    if (lane == 0) { red[b - b0][0][wave] = c1; red[b - b0][1][wave] = c2; }   // one slot per sample: no barrier in the loop
   }
-  __syncthreads();
-  for (int q = threadIdx.x; q < (b1 - b0) * 2; q += blockDim.x) {
-    const int bl = q >> 1, which = q & 1;
-    partials2[((long long)(b0 + bl) * nch + c) * 2 + which] = red[bl][which][0] + red[bl][which][1] + red[bl][which][2] + red[bl][which][3];
-  }
-  if (ok) {
-    if (gridDim.y == 1) {
-      float4* pw = reinterpret_cast<float4*>(dw + e); float4* pb = reinterpret_cast<float4*>(db + e);
-      float4 a = *pw, bq = *pb;
-      a.x += gw[0]; a.y += gw[1]; a.z += gw[2]; a.w += gw[3];
-      bq.x += gb[0]; bq.y += gb[1]; bq.z += gb[2]; bq.w += gb[3];
-      *pw = a; *pb = bq;
-    } else {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { atomicAdd(dw + e + q, gw[q]); atomicAdd(db + e + q, gb[q]); }
-    }
+  for (int q = 0; q < 8; ++q) { red[0][ts][q][tx] = gw[q]; red[1][ts][q][tx] = gb[q]; }
+  __syncthreads();
+  {
+    const int t = threadIdx.x, q = t & 7, x = t >> 3;       // chunk element t = x*8 + q
+    float sw = 0.f, sb2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { sw += red[0][k][q][x]; sb2 += red[1][k][q][x]; }
+    const long long et = (long long)c * VU_LN_BCHUNK + t;
+    if (et < P) { dw[et] += sw; db[et] += sb2; }
   }
 }
 
@@ -657,20 +677,26 @@ __global__ __launch_bounds__(256) void ln_bwd_apply_kernel(const T* __restrict__
   const vu_rng rng = vu_rng_resolve(rng_in);
   __shared__ float sm[16];
   const int c = blockIdx.x, b = blockIdx.y;
+  const long long base = (long long)c * VU_LN_CHUNK, sb = (long long)b * P;
+  vu_f4 td[4], tz[4];      // in flight while the sample's partial sums are reduced
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const long long e = base + (it * 256 + threadIdx.x) * 4;
+    if (e < P) { td[it] = vu_ld4(dy + sb + e); tz[it] = vu_ld4(z + sb + e); }
+  }
   float a1 = 0.f, a2 = 0.f;
   for (int i = threadIdx.x; i < nbch; i += blockDim.x) {
-    const float* o = partials2 + ((long long)b * nbch + i) * 2;
-    a1 += o[0]; a2 += o[1];
+    const float2 o = *reinterpret_cast<const float2*>(partials2 + ((long long)b * nbch + i) * 2);
+    a1 += o.x; a2 += o.y;
   }
   const float c1 = vu_block_sum(a1, sm) / (float)P;
   const float c2 = vu_block_sum(a2, sm) / (float)P;
   const float mean = stats[2 * b], rstd = stats[2 * b + 1];
-  const long long base = (long long)c * VU_LN_CHUNK, sb = (long long)b * P;
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const long long e = base + (it * 256 + threadIdx.x) * 4;
     if (e < P) {
-      const vu_f4 d = vu_ld4(dy + sb + e), zz = vu_ld4(z + sb + e);
+      const vu_f4 d = td[it], zz = tz[it];
       const float4 ww = *reinterpret_cast<const float4*>(w + e);
       const float wv[4] = {ww.x, ww.y, ww.z, ww.w};
       vu_f4 o, od;
@@ -696,13 +722,8 @@ int vu_k_ln_bwd(int dtype, const void* dy, const void* z, const float* w, const 
                 hipStream_t st) {
   VU_REQUIRE(P % 4 == 0, "layernorm: P %% 4");
   const int nbch = vu_ln_nbchunks(P), nch = vu_ln_nchunks(P);
-  int ngroups = 1;                       // enough blocks to fill the chip: ~1024
-  while (nbch * ngroups < 1024 && ngroups * 2 <= B) ngroups *= 2;
-  int bgroup = (B + ngroups - 1) / ngroups;
-  if (bgroup > 64) bgroup = 64;             // LDS slots per block
-  ngroups = (B + bgroup - 1) / bgroup;
   VU_DISPATCH_T(dtype,
-    hipLaunchKernelGGL((ln_bwd_stats_kernel<T>), dim3(nbch, ngroups), dim3(256), 0, st, (const T*)dy, (const T*)z, w, stats, dw, db, partials2, B, P, bgroup);
+    hipLaunchKernelGGL((ln_bwd_stats_kernel<T>), dim3(nbch), dim3(256), 0, st, (const T*)dy, (const T*)z, w, stats, dw, db, partials2, B, P);
     hipLaunchKernelGGL((ln_bwd_apply_kernel<T>), dim3(nch, B), dim3(256), 0, st, (const T*)dy, (const T*)z, w, stats, partials2, nbch, (T*)dz, (T*)dz_drop, rng, P);)
   if (vu_prof_on()) vu_prof_note("ln_bwd(2 kernels)", 0.0, (double)B * P * 5 * (dtype == 0 ? 4.0 : 2.0) + (double)P * 24);
   return vu_check_launch("vu_ln_bwd");
