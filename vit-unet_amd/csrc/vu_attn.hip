@@ -83,11 +83,18 @@ __global__ __launch_bounds__(WAVES * 64) void attn_scores_kernel(const T* __rest
 #pragma unroll
         for (int e = 0; e < VE; ++e) tmp[e] = (kc + e < d) ? kb[(long long)row * D + kc + e] : (T)0.f;
       }
-      *reinterpret_cast<uint4*>(&Ks[row * LDK + kc]) = *reinterpret_cast<uint4*>(tmp);
+      // keys of whole 64-key groups are stored with their two 2-bit index fields exchanged
+      // (key 64u + 16a + 4b + c -> LDS row 64u + 16b + 4a + c): see the tile -> key map below
+      const int lrow = row < ((N >> 6) << 6) ? ((row & ~60) | (((row >> 2) & 3) << 4) | (((row >> 4) & 3) << 2)) : row;
+      *reinterpret_cast<uint4*>(&Ks[lrow * LDK + kc]) = *reinterpret_cast<uint4*>(tmp);
     }
   }
-  // ---- this wave's q fragments (16 rows x DP) ------------------------------------------------
-  const int i0 = blockIdx.x * (WAVES * 16) + wave * 16;
+  __syncthreads();
+  // The workgroup staged K_g once; its waves now walk the 16-row query tiles of this (sample, head)
+  // with no further barrier: a wave's stores drain while it multiplies its next tile.
+  const int nrt = (N + 15) >> 4;
+  for (int rt = blockIdx.x * WAVES + wave; rt < nrt; rt += gridDim.x * WAVES) {
+  const int i0 = rt * 16;
   Frag qf[KSTEPS];
   {
     const int row = i0 + l15;
@@ -97,19 +104,24 @@ __global__ __launch_bounds__(WAVES * 64) void attn_scores_kernel(const T* __rest
       qf[ks] = (row < N) ? load_frag<T>(qb + (long long)row * D + k0, d - k0, vec) : MM::zero();
     }
   }
-  __syncthreads();
 
   // Swapped product S^T = K Q^T: the accumulator of tile nt holds, for query i0+l15 (the lane's
-  // column), keys nt*16 + lg*4 + r (r = 0..3) - four consecutive keys per lane, so the row
-  // softmax reduces in-lane plus two shuffles, a dropout hash word serves an in-lane key pair,
-  // and the store is one 4-element vector per tile.
+  // column), four consecutive keys j0(nt) + r (r = 0..3), so the row softmax reduces in-lane plus
+  // two shuffles, a dropout hash word serves an in-lane key pair, and the stores are vectors.
+  // Which key an accumulator row stands for is free (it only picks the K row an A-operand lane
+  // reads): whole groups of 4 tiles (64 keys) are dealt so that a lane's 4 tiles hold 16
+  // CONSECUTIVE keys, 64u + 16 lg + 4 s + r - a query row is then written in full 128-byte
+  // segments (4 lanes x 32 B) with 16-byte stores instead of 32-byte segments of 8-byte stores.
+  // The permutation lives in the K staging pass (LDS row order), so fragment reads stay conflict-free.
   const int ntiles = (N + 15) >> 4;
+  const int ngt = (N >> 6) << 2;                    // tiles that belong to whole (fully valid) groups of 64 keys
+  auto j0_of = [&](int nt) { return nt < ngt ? ((nt >> 2) << 6) + (lg << 4) + ((nt & 3) << 2) : nt * 16 + lg * 4; };
   f32x4 acc[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (nt < ntiles) {
-      const int key = nt * 16 + l15;
+      const int key = nt * 16 + l15;       // LDS row (the staging pass applied the group permutation)
       const bool kv = key < N;
 #pragma unroll
       for (int ks = 0; ks < KSTEPS; ++ks) {
@@ -120,24 +132,44 @@ __global__ __launch_bounds__(WAVES * 64) void attn_scores_kernel(const T* __rest
       }
     }
   }
+  // store tiles nt (and nt+1 when both sit in a whole group: 8 consecutive keys, one 16-byte store for bf16)
+  auto store_tiles = [&](T* prow, int nt, bool pair, const vu_f4& oa, const vu_f4& ob) {
+    const int j0 = j0_of(nt);
+    if constexpr (sizeof(T) == 2) {
+      if (pair) {
+        union { uint4 u; bf16_t h[8]; } pk;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { pk.h[r] = (bf16_t)oa.v[r]; pk.h[4 + r] = (bf16_t)ob.v[r]; }
+        *reinterpret_cast<uint4*>(prow + j0) = pk.u;
+        return;
+      }
+    }
+    if (EXACT || j0 < ld) vu_st4(prow + j0, oa);
+    if (pair) { const int j1 = j0_of(nt + 1); if (EXACT || j1 < ld) vu_st4(prow + j1, ob); }
+  };
   if constexpr (!SOFTMAX) {   // plain product (dAhat = dO v^T in the backward): scaled vector stores
     const int i = i0 + l15;
     if (i < N) {
       T* prow = Ps + ((long long)bz * N + i) * ld;
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
+      for (int nt = 0; nt < NT; nt += 2) {
         if (nt < ntiles) {
-          const int j0 = nt * 16 + lg * 4;
-          if (EXACT || j0 < ld) {
-            vu_f4 o;
+          const bool pair = (nt + 1 < NT) && (nt + 1 < ntiles);
+          vu_f4 oa, ob = {{0.f, 0.f, 0.f, 0.f}};
+          const int ja = j0_of(nt);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o.v[r] = (EXACT || j0 + r < N) ? acc[nt][r] * scale : 0.f;
-            vu_st4(prow + j0, o);
+          for (int r = 0; r < 4; ++r) oa.v[r] = (EXACT || ja + r < N) ? acc[nt][r] * scale : 0.f;
+          if (nt + 1 < NT) {
+            const int jb = j0_of(nt + 1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ob.v[r] = (EXACT || jb + r < N) ? acc[nt + 1][r] * scale : 0.f;
           }
+          if (pair && nt + 1 < ngt) store_tiles(prow, nt, true, oa, ob);
+          else { store_tiles(prow, nt, false, oa, oa); if (pair) store_tiles(prow, nt + 1, false, ob, ob); }
         }
       }
     }
-    return;
+    continue;
   }
   // ---- row softmax (logits rounded to the storage type first, like the unfused path) ------------
   // Only the last key tile can be partial: full tiles take a mask-free path (wave-uniform branch).
@@ -145,11 +177,12 @@ __global__ __launch_bounds__(WAVES * 64) void attn_scores_kernel(const T* __rest
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     if (nt < ntiles) {
+      const int j0 = j0_of(nt);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float sv = acc[nt][r] * scale;
         if constexpr (sizeof(T) == 2) sv = (float)(bf16_t)sv;
-        if constexpr (!EXACT) sv = (nt * 16 + lg * 4 + r < N) ? sv : -INFINITY;
+        if constexpr (!EXACT) sv = (j0 + r < N) ? sv : -INFINITY;
         acc[nt][r] = sv;
         mx = fmaxf(mx, sv);
       }
@@ -181,33 +214,40 @@ __global__ __launch_bounds__(WAVES * 64) void attn_scores_kernel(const T* __rest
     T* prow = Ps + rowi * ld;
     const uint32_t ib32 = (uint32_t)(rowi * (uint64_t)ld);   // launcher guarantees < 2^32 map elements
     const uint32_t thr = rng.thr;
+    auto tile_out = [&](int nt, const f32x4& a) {
+      const int j0 = j0_of(nt);
+      float o0 = a[0] * inv, o1 = a[1] * inv, o2 = a[2] * inv, o3 = a[3] * inv;
+      if (thr) {
+        // 16-bit lanes of two hash words; (x - thr) is negative exactly when x < thr: its sign
+        // bit is the "dropped" tag, XOR-ed into the sign of the probability
+        const uint32_t wa = vu_hash_word32(rng, ib32 + j0), wb = vu_hash_word32(rng, ib32 + j0 + 2);
+        o0 = __uint_as_float(__float_as_uint(o0) ^ (((wa & 0xffffu) - thr) & 0x80000000u));
+        o1 = __uint_as_float(__float_as_uint(o1) ^ (((wa >> 16) - thr) & 0x80000000u));
+        o2 = __uint_as_float(__float_as_uint(o2) ^ (((wb & 0xffffu) - thr) & 0x80000000u));
+        o3 = __uint_as_float(__float_as_uint(o3) ^ (((wb >> 16) - thr) & 0x80000000u));
+      }
+      if constexpr (!EXACT) {   // zero the padding columns of the partial tile
+        if (j0 + 0 >= N) o0 = 0.f;
+        if (j0 + 1 >= N) o1 = 0.f;
+        if (j0 + 2 >= N) o2 = 0.f;
+        if (j0 + 3 >= N) o3 = 0.f;
+      }
+      const vu_f4 o = {{o0, o1, o2, o3}};
+      return o;
+    };
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
+    for (int nt = 0; nt < NT; nt += 2) {
       if (nt < ntiles) {
-        const int j0 = nt * 16 + lg * 4;
-        if (EXACT || j0 < ld) {
-          float o0 = acc[nt][0] * inv, o1 = acc[nt][1] * inv, o2 = acc[nt][2] * inv, o3 = acc[nt][3] * inv;
-          if (thr) {
-            // 16-bit lanes of two hash words; (x - thr) is negative exactly when x < thr: its sign
-            // bit is the "dropped" tag, XOR-ed into the sign of the probability
-            const uint32_t wa = vu_hash_word32(rng, ib32 + j0), wb = vu_hash_word32(rng, ib32 + j0 + 2);
-            o0 = __uint_as_float(__float_as_uint(o0) ^ (((wa & 0xffffu) - thr) & 0x80000000u));
-            o1 = __uint_as_float(__float_as_uint(o1) ^ (((wa >> 16) - thr) & 0x80000000u));
-            o2 = __uint_as_float(__float_as_uint(o2) ^ (((wb & 0xffffu) - thr) & 0x80000000u));
-            o3 = __uint_as_float(__float_as_uint(o3) ^ (((wb >> 16) - thr) & 0x80000000u));
-          }
-          if constexpr (!EXACT) {   // zero the padding columns of the partial tile
-            if (j0 + 0 >= N) o0 = 0.f;
-            if (j0 + 1 >= N) o1 = 0.f;
-            if (j0 + 2 >= N) o2 = 0.f;
-            if (j0 + 3 >= N) o3 = 0.f;
-          }
-          vu_f4 o = {{o0, o1, o2, o3}};
-          vu_st4(prow + j0, o);
-        }
+        const bool pair = (nt + 1 < NT) && (nt + 1 < ntiles);
+        const vu_f4 oa = tile_out(nt, acc[nt]);
+        vu_f4 ob = oa;
+        if (nt + 1 < NT) { if (pair) ob = tile_out(nt + 1, acc[nt + 1]); }
+        if (pair && nt + 1 < ngt) store_tiles(prow, nt, true, oa, ob);
+        else { store_tiles(prow, nt, false, oa, oa); if (pair) store_tiles(prow, nt + 1, false, ob, ob); }
       }
     }
   }
+  }   // row tiles
 }
 
 template <typename T, int NT, int DP, int WAVES>
@@ -222,7 +262,14 @@ int launch_scores_w(const T* q, const T* k, T* Ps, int B, int N, int D, int H, i
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { vu_set_error("attn_scores: cannot reserve %zu bytes of LDS", lds); return VU_ELAUNCH; }
   }
-  dim3 grid((unsigned)((N + WAVES * 16 - 1) / (WAVES * 16)), (unsigned)(B * H));
+  // one workgroup per (sample, head) stages K once and walks all row tiles; small batches split the
+  // row tiles over several workgroups so that at least ~512 are in flight
+  const int nrt = (N + 15) / 16, maxsplit = (nrt + WAVES - 1) / WAVES;
+  int nsplit = (512 + B * H - 1) / (B * H);
+  if (softmax && N > 208) nsplit = maxsplit;   // VALU-bound form: one tile per wave, finer-grained balance (measured)
+  if (nsplit > maxsplit) nsplit = maxsplit;
+  if (nsplit < 1) nsplit = 1;
+  dim3 grid((unsigned)nsplit, (unsigned)(B * H));
   hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, st, q, k, Ps, N, D, H, d, ld, scale, rng);
   if (vu_prof_on()) vu_prof_note(softmax ? "attn_scores_kernel" : "attn_dscores_kernel", 2.0 * B * H * (double)N * N * d,
                                  ((double)B * H * N * N + 2.0 * B * N * D) * sizeof(T));
@@ -234,7 +281,12 @@ int launch_scores(const T* q, const T* k, T* Ps, int B, int N, int D, int H, int
                   bool softmax, hipStream_t st) {
   // long rows (N > 208): 128-row workgroups (8 waves) halve the K re-staging; measured 2.0 ms vs
   // 3.25 ms per step against 64-row workgroups on Base (profiles/).
-  if constexpr (NT > 13) return launch_scores_w<T, NT, DP, 8>(q, k, Ps, B, N, D, H, ld, scale, rng, softmax, st);
+  // long rows: the plain product is store-bound and takes 7 waves (49 row tiles = 7 x 7 at N = 784); the
+  // softmax form is VALU-bound (exp + dropout hash) and wants all 8 wave slots of the CU
+  if constexpr (NT > 13) {
+    if (softmax) return launch_scores_w<T, NT, DP, 8>(q, k, Ps, B, N, D, H, ld, scale, rng, softmax, st);
+    return launch_scores_w<T, NT, DP, 7>(q, k, Ps, B, N, D, H, ld, scale, rng, softmax, st);
+  }
   else return launch_scores_w<T, NT, DP, 4>(q, k, Ps, B, N, D, H, ld, scale, rng, softmax, st);
 }
 
