@@ -85,7 +85,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_scores_kernel(const T* __rest
       }
       // keys of whole 64-key groups are stored with their two 2-bit index fields exchanged
       // (key 64u + 16a + 4b + c -> LDS row 64u + 16b + 4a + c): see the tile -> key map below
-      const int lrow = row < ((N >> 6) << 6) ? ((row & ~60) | (((row >> 2) & 3) << 4) | (((row >> 4) & 3) << 2)) : row;
+      const int lrow = row < (EXACT ? ((NT * 16) >> 6) << 6 : (N >> 6) << 6) ? ((row & ~60) | (((row >> 2) & 3) << 4) | (((row >> 4) & 3) << 2)) : row;
       *reinterpret_cast<uint4*>(&Ks[lrow * LDK + kc]) = *reinterpret_cast<uint4*>(tmp);
     }
   }
@@ -113,16 +113,21 @@ __global__ __launch_bounds__(WAVES * 64) void attn_scores_kernel(const T* __rest
   // CONSECUTIVE keys, 64u + 16 lg + 4 s + r - a query row is then written in full 128-byte
   // segments (4 lanes x 32 B) with 16-byte stores instead of 32-byte segments of 8-byte stores.
   // The permutation lives in the K staging pass (LDS row order), so fragment reads stay conflict-free.
-  const int ntiles = (N + 15) >> 4;
-  const int ngt = (N >> 6) << 2;                    // tiles that belong to whole (fully valid) groups of 64 keys
-  auto j0_of = [&](int nt) { return nt < ngt ? ((nt >> 2) << 6) + (lg << 4) + ((nt & 3) << 2) : nt * 16 + lg * 4; };
+  // EXACT: N == 16 * NT - every tile exists and is full, so all tile conditions fold at compile time
+  const int ntiles = EXACT ? NT : (N + 15) >> 4;
+  const int ngt = EXACT ? ((NT * 16) >> 6) << 2 : (N >> 6) << 2;   // tiles in whole (fully valid) groups of 64 keys
+  // (opaque copy of lg: otherwise every per-tile column / hash index is hoisted out of the row-tile loop as a
+  // loop invariant, ~60 live registers that spill - and a scratch reload's vmcnt wait drains the store stream)
+  int lgv = lg;
+  asm volatile("" : "+v"(lgv));
+  auto j0_of = [&](int nt) { return nt < ngt ? ((nt >> 2) << 6) + (lgv << 4) + ((nt & 3) << 2) : nt * 16 + lgv * 4; };
   f32x4 acc[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (nt < ntiles) {
       const int key = nt * 16 + l15;       // LDS row (the staging pass applied the group permutation)
-      const bool kv = key < N;
+      const bool kv = EXACT || key < N;
 #pragma unroll
       for (int ks = 0; ks < KSTEPS; ++ks) {
         Frag kf;
@@ -131,6 +136,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_scores_kernel(const T* __rest
         acc[nt] = MM::mma(kf, qf[ks], acc[nt]);
       }
     }
+    if constexpr (NT > 16) { if (nt % 7 == 6) __builtin_amdgcn_sched_barrier(0); }   // bound the K fragments in flight
   }
   // store tiles nt (and nt+1 when both sit in a whole group: 8 consecutive keys, one 16-byte store for bf16)
   auto store_tiles = [&](T* prow, int nt, bool pair, const vu_f4& oa, const vu_f4& ob) {
@@ -191,12 +197,17 @@ __global__ __launch_bounds__(WAVES * 64) void attn_scores_kernel(const T* __rest
   mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
   mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
   float sum = 0.f;
+  const float mxl = mx * 1.44269504088896341f;
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     if (nt < ntiles) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float e = __expf(acc[nt][r] - mx);   // subtract first: exact for nearby floats; exp(-inf) = 0 for masked keys
+        float e;
+        // fp32 storage: subtract first (exact for nearby floats; large logits would lose bits in x*log2e - m*log2e).
+        // bf16 storage: the logits were just rounded to 8 significant bits, one fma + exp2 is ample.
+        if constexpr (sizeof(T) == 2) e = __builtin_amdgcn_exp2f(fmaf(acc[nt][r], 1.44269504088896341f, -mxl));
+        else e = __expf(acc[nt][r] - mx);          // exp(-inf) = 0 for masked keys
         acc[nt][r] = e;
         sum += e;
       }
@@ -245,6 +256,8 @@ __global__ __launch_bounds__(WAVES * 64) void attn_scores_kernel(const T* __rest
         if (pair && nt + 1 < ngt) store_tiles(prow, nt, true, oa, ob);
         else { store_tiles(prow, nt, false, oa, oa); if (pair) store_tiles(prow, nt + 1, false, ob, ob); }
       }
+      // keep the tiles' hash / tag / store chains apart: scheduled together they need > 256 registers
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   }   // row tiles
@@ -256,8 +269,9 @@ int launch_scores_w(const T* q, const T* k, T* Ps, int B, int N, int D, int H, i
   const int d = D / H;
   constexpr int LDK = DP + (sizeof(T) == 2 ? 8 : 4);
   const size_t lds = (size_t)N * LDK * sizeof(T);
-  auto kern = softmax ? ((N % 16 == 0) ? attn_scores_kernel<T, NT, DP, WAVES, true, true> : attn_scores_kernel<T, NT, DP, WAVES, false, true>)
-                      : ((N % 16 == 0) ? attn_scores_kernel<T, NT, DP, WAVES, true, false> : attn_scores_kernel<T, NT, DP, WAVES, false, false>);
+  const bool full = N == 16 * NT;
+  auto kern = softmax ? (full ? attn_scores_kernel<T, NT, DP, WAVES, true, true> : attn_scores_kernel<T, NT, DP, WAVES, false, true>)
+                      : (full ? attn_scores_kernel<T, NT, DP, WAVES, true, false> : attn_scores_kernel<T, NT, DP, WAVES, false, false>);
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { vu_set_error("attn_scores: cannot reserve %zu bytes of LDS", lds); return VU_ELAUNCH; }
