@@ -40,6 +40,9 @@ int vu_k_softmax_dropout(int dtype, void* S, long long rows, int N, int ld, vu_r
 int vu_k_attn_scores(int dtype, const void* q, const void* k, void* Ps, int B, int N, int D, int H, int ld,
                      float scale, vu_rng rng, hipStream_t st);
 
+// map x head-slice products for long rows / small head dims (streaming MFMA kernels); 1 = shape not covered
+int vu_k_attn_map_prod(int dtype, int cols, const void* M, const void* X, void* out, int B, int N, int D, int H, int ld,
+                       hipStream_t st);
 int vu_k_attn_outer(int dtype, const void* a, const void* bmat, void* out, int B, int N, int D, int H, int ld,
                     float scale, hipStream_t st);
 

@@ -190,7 +190,9 @@ int attn_forward(const AttnDims& d, const vu_attn_params& p, const void* xq, con
   VU_TRY(vu_k_bn_finalize(partials, stats_blocks(d), p.mix_w, p.mix_b, p.bn_w, p.bn_b, p.run_mean, p.run_var,
                           a.stats, H, N, count, training, 0.1f, 1e-5f, st));
   VU_TRY(vu_k_mix_apply(dt, a.Ps, a.Ah, a.stats, B, H, N, ld, ra.inv_keep, st));
-  {  // O = Ahat v  (model.py:161)
+  int mp = vu_k_attn_map_prod(dt, 0, a.Ah, a.v, a.O, B, N, D, H, ld, st);   // streaming kernel for long rows
+  if (mp < 0) return mp;
+  if (mp == 1) {  // O = Ahat v  (model.py:161)
     vu_gemm_args g;
     memset(&g, 0, sizeof(g));
     g.A = a.Ah; g.B = a.v; g.C = a.O; g.M = N; g.N = dh; g.K = N;
@@ -251,7 +253,9 @@ int attn_backward(const AttnDims& d, const vu_attn_params& p, const vu_attn_grad
     g.sC1 = (long long)H * N * ld; g.sC2 = (long long)N * ld; g.alpha = 1.f;
     VU_TRY(vu_gemm_launch(dt, 0, g, st));
   }
-  {  // dv = Ahat^T dO
+  int mp = vu_k_attn_map_prod(dt, 1, a.Ah, sc.dO, sc.dv, B, N, D, H, ld, st);
+  if (mp < 0) return mp;
+  if (mp == 1) {  // dv = Ahat^T dO
     vu_gemm_args g;
     memset(&g, 0, sizeof(g));
     g.A = a.Ah; g.B = sc.dO; g.C = sc.dv; g.M = N; g.N = dh; g.K = N;
@@ -266,7 +270,9 @@ int attn_backward(const AttnDims& d, const vu_attn_params& p, const vu_attn_grad
   VU_TRY(vu_k_bn_bwd_small(dt, sc.dO, a.O, a.v, p.bn_w, p.bn_b, p.mix_w, p.mix_b, a.stats, gr.bn_w, gr.bn_b, sc.partials, B, N, D, H, training, st));
   VU_TRY(vu_k_map_bwd(dt, a.Ps, sc.dA, p.mix_w, p.mix_b, p.bn_w, a.stats, gr.mix_w, gr.mix_b, B, H, N, ld, inv_keep,
                       1.0f / sqrtf((float)dh), st));
-  {  // dq = dS k
+  mp = vu_k_attn_map_prod(dt, 0, sc.dA, a.k, sc.dq, B, N, D, H, ld, st);
+  if (mp < 0) return mp;
+  if (mp == 1) {  // dq = dS k
     vu_gemm_args g;
     memset(&g, 0, sizeof(g));
     g.A = sc.dA; g.B = a.k; g.C = sc.dq; g.M = N; g.N = dh; g.K = N;
@@ -275,7 +281,9 @@ int attn_backward(const AttnDims& d, const vu_attn_params& p, const vu_attn_grad
     g.sB1 = (long long)N * D; g.sB2 = dh; g.sC1 = (long long)N * D; g.sC2 = dh; g.alpha = 1.f;
     VU_TRY(vu_gemm_launch(dt, 0, g, st));
   }
-  {  // dk = dS^T q
+  mp = vu_k_attn_map_prod(dt, 1, sc.dA, a.q, sc.dk, B, N, D, H, ld, st);
+  if (mp < 0) return mp;
+  if (mp == 1) {  // dk = dS^T q
     vu_gemm_args g;
     memset(&g, 0, sizeof(g));
     g.A = sc.dA; g.B = a.q; g.C = sc.dk; g.M = N; g.N = dh; g.K = N;
