@@ -17,7 +17,7 @@ for C in ("FETCH_SIZE", "WRITE_SIZE"):
             if r.get("Counter_Name") == C:
                 k = r["Kernel_Name"][:90]
                 agg[k][0] += 1; agg[k][1] += float(r["Counter_Value"])
-    rows = sorted(agg.items(), key=lambda kv: -kv[1][1])[:12]
+    rows = sorted(agg.items(), key=lambda kv: -kv[1][1])[:24]
     with open(f"gpurun_out/pmc_{C}_summary.csv", "w") as o:
         o.write("kernel,launches,sum_%s,avg_per_launch\n" % C)
         for k, (n, v) in rows:

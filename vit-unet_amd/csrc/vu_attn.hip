@@ -1245,32 +1245,45 @@ __global__ __launch_bounds__(WAVES * 64) void attn_map_rows_kernel(const bf16_t*
     const bf16_t* r1 = Mb + (long long)min(rt * 16 + 8 + lrow, N - 1) * ld;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     // (named registers, not an array: hipcc left an indexed ring in scratch memory)
-    uint4 ma0, mb0, ma1, mb1, ma2, mb2, ma3, mb3;
+    uint4 ma0, mb0, ma1, mb1, ma2, mb2, ma3, mb3, ma4, mb4, ma5, mb5;
     auto fetch = [&](int step, uint4& ma, uint4& mb) {
       const int j = min(step * 64 + lch, ld - 8);
       ma = *reinterpret_cast<const uint4*>(r0 + j);
       mb = *reinterpret_cast<const uint4*>(r1 + j);
     };
-    auto step = [&](int sidx, uint4& ma, uint4& mb) {
+    auto put = [&](const uint4& ma, const uint4& mb) {
       *reinterpret_cast<uint4*>(T + lrow * MP_LDT + lch) = ma;
       *reinterpret_cast<uint4*>(T + (8 + lrow) * MP_LDT + lch) = mb;
-      fetch(sidx + 4, ma, mb);
-      if (sidx < nsteps) {
-        // B operand: lane (l15 = map row, lg): columns 16 lg + [0,8) and + [8,16) of the step: k-slots of two MFMAs
-        const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(T + l15 * MP_LDT + 16 * lg);
-        const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(T + l15 * MP_LDT + 16 * lg + 8);
-        const bf16_t* xa = x0 + sidx * 64;
-        const bf16_t* xb = x1 + sidx * 64;
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(xa), b0, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(xb), b0, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(xa + 8), b1, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(xb + 8), b1, acc1, 0, 0, 0);
-      }
     };
-    fetch(0, ma0, mb0); fetch(1, ma1, mb1); fetch(2, ma2, mb2); fetch(3, ma3, mb3);
-    for (int s0 = 0; s0 < nsteps; s0 += 4) {
-      step(s0, ma0, mb0); step(s0 + 1, ma1, mb1); step(s0 + 2, ma2, mb2); step(s0 + 3, ma3, mb3);
+    auto mult = [&](int sidx) {
+      // B operand: lane (l15 = map row, lg): columns 16 lg + [0,8) and + [8,16) of the step: k-slots of two MFMAs
+      const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(T + l15 * MP_LDT + 16 * lg);
+      const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(T + l15 * MP_LDT + 16 * lg + 8);
+      const bf16_t* xa = x0 + sidx * 64;
+      const bf16_t* xb = x1 + sidx * 64;
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(xa), b0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(xb), b0, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(xa + 8), b1, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(xb + 8), b1, acc1, 0, 0, 0);
+    };
+    auto step = [&](int sidx, uint4& ma, uint4& mb) {
+      put(ma, mb);                      // the tile leaves the ring registers ...
+      fetch(sidx + 6, ma, mb);          // ... which are re-issued at once, 6 steps ahead
+      mult(sidx);
+    };
+    fetch(0, ma0, mb0); fetch(1, ma1, mb1); fetch(2, ma2, mb2); fetch(3, ma3, mb3); fetch(4, ma4, mb4); fetch(5, ma5, mb5);
+    // the main loop is branch-free so that hipcc can count its vmcnt waits (a conditional step makes it drain
+    // the whole ring, vmcnt(0), once per trip); the last nsteps % 6 steps follow
+    const int nfull = nsteps / 6 * 6;
+    for (int s0 = 0; s0 < nfull; s0 += 6) {
+      step(s0, ma0, mb0); step(s0 + 1, ma1, mb1); step(s0 + 2, ma2, mb2);
+      step(s0 + 3, ma3, mb3); step(s0 + 4, ma4, mb4); step(s0 + 5, ma5, mb5);
     }
+    if (nfull + 0 < nsteps) { put(ma0, mb0); mult(nfull + 0); }
+    if (nfull + 1 < nsteps) { put(ma1, mb1); mult(nfull + 1); }
+    if (nfull + 2 < nsteps) { put(ma2, mb2); mult(nfull + 2); }
+    if (nfull + 3 < nsteps) { put(ma3, mb3); mult(nfull + 3); }
+    if (nfull + 4 < nsteps) { put(ma4, mb4); mult(nfull + 4); }
     // C[row = t = 4 lg + r (+16)][col = token i]
     const int i = rt * 16 + l15;
     if (i < N) {
@@ -1318,34 +1331,41 @@ __global__ __launch_bounds__(WAVES * 64) void attn_map_cols_kernel(const bf16_t*
       m2 = *reinterpret_cast<const uint4*>(Mb + (long long)min(i0 + 16 + lrow, N - 1) * ld + jc);
       m3 = *reinterpret_cast<const uint4*>(Mb + (long long)min(i0 + 24 + lrow, N - 1) * ld + jc);
     };
-    auto step = [&](int i0, uint4& m0, uint4& m1, uint4& m2, uint4& m3) {
+    auto put = [&](const uint4& m0, const uint4& m1, const uint4& m2, const uint4& m3) {
       *reinterpret_cast<uint4*>(T + lrow * MP_LDT + lch) = m0;
       *reinterpret_cast<uint4*>(T + (8 + lrow) * MP_LDT + lch) = m1;
       *reinterpret_cast<uint4*>(T + (16 + lrow) * MP_LDT + lch) = m2;
       *reinterpret_cast<uint4*>(T + (24 + lrow) * MP_LDT + lch) = m3;
-      fetch(i0 + 64, m0, m1, m2, m3);
-      if (i0 < nrows) {
-        // A operand: Xt rows t, k-slots = map rows i0 + 8 lg + e
-        const bf16x8 xa0 = *reinterpret_cast<const bf16x8*>(Xt + l15 * LDV + i0 + 8 * lg);
-        const bf16x8 xa1 = *reinterpret_cast<const bf16x8*>(Xt + (16 + l15) * LDV + i0 + 8 * lg);
+    };
+    auto mult = [&](int i0) {
+      // A operand: Xt rows t, k-slots = map rows i0 + 8 lg + e
+      const bf16x8 xa0 = *reinterpret_cast<const bf16x8*>(Xt + l15 * LDV + i0 + 8 * lg);
+      const bf16x8 xa1 = *reinterpret_cast<const bf16x8*>(Xt + (16 + l15) * LDV + i0 + 8 * lg);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const bf16_t* tb = T + (8 * lg + q) * MP_LDT + 16 * u + 4 * pq;
-          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)tb);
-          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(tb + 4 * MP_LDT));
-          const s16x8 t8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-          const bf16x8 bm = __builtin_bit_cast(bf16x8, t8);
-          acc[u][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa0, bm, acc[u][0], 0, 0, 0);
-          acc[u][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa1, bm, acc[u][1], 0, 0, 0);
-        }
+      for (int u = 0; u < 4; ++u) {
+        const bf16_t* tb = T + (8 * lg + q) * MP_LDT + 16 * u + 4 * pq;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)tb);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(tb + 4 * MP_LDT));
+        const s16x8 t8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        const bf16x8 bm = __builtin_bit_cast(bf16x8, t8);
+        acc[u][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa0, bm, acc[u][0], 0, 0, 0);
+        acc[u][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa1, bm, acc[u][1], 0, 0, 0);
       }
+    };
+    auto step = [&](int i0, uint4& m0, uint4& m1, uint4& m2, uint4& m3) {
+      put(m0, m1, m2, m3);
+      fetch(i0 + 64, m0, m1, m2, m3);
+      mult(i0);
     };
     fetch(0, p0, p1, p2, p3);
     fetch(32, q0, q1, q2, q3);
-    for (int i00 = 0; i00 < nrows; i00 += 64) {
+    // branch-free main loop (counted vmcnt waits), then the odd last step
+    const int nfull = nrows / 64 * 64;
+    for (int i00 = 0; i00 < nfull; i00 += 64) {
       step(i00, p0, p1, p2, p3);
       step(i00 + 32, q0, q1, q2, q3);
     }
+    if (nfull < nrows) { put(p0, p1, p2, p3); mult(nfull); }
     // C[row = t = 4 lg + r (+16)][col = token j0 + 16 u + l15]
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
