@@ -1016,6 +1016,118 @@ __global__ __launch_bounds__(256, 2) void map_bwd_mm_kernel(const bf16_t* __rest
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// mix_stats_mm_kernel (bf16 storage, H = 8, 256 < ld <= 1024): the BatchNorm batch statistics of
+// the mixed maps, s1_g = sum (a_g - shift_g), s2_g = sum (a_g - shift_g)^2 with
+// a_g = sum_h W[g,h] P~_h, one 256-thread block per map row.  The 8x8 mix runs on the matrix cores
+// exactly as MFMA #1 of map_bwd_mm_kernel (own-layout B operand, block-diagonal A, result layout
+// out); W/keep enters as a bf16 hi + lo pair (16 significant bits) and -shift_g as the accumulator
+// input, so that the VALU only squares and sums.
+// ---------------------------------------------------------------------------------------------
+template <bool EXACT>
+__global__ __launch_bounds__(256) void mix_stats_mm_kernel(const bf16_t* __restrict__ Ps, const float* __restrict__ W,
+                                                           float* __restrict__ partials, long long rows, int N, int ld,
+                                                           float inv_keep) {
+  constexpr int H = 8;
+  __shared__ float red[4][2 * H];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, lg = lane >> 4;
+  bf16x8 Ah[2], Al[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    float vh[8], vl[8];
+    const int qrow = 2 * m + (l15 >> 3), hr = l15 & 7;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float v = (lg == qrow) ? W[hr * H + j] * inv_keep : 0.f;
+      vh[j] = (float)(bf16_t)v;
+      vl[j] = v - vh[j];
+    }
+    Ah[m] = pack8(vh);
+    Al[m] = pack8(vl);
+  }
+  const int hbase = 4 * (lg & 1);
+  f32x4 cin;       // -shift_g, shift_g = sum_h W[g,h] / N  (the exact mean without dropout; the bias cancels)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float sacc = 0.f;
+#pragma unroll
+    for (int h = 0; h < H; ++h) sacc += W[(hbase + r) * H + h];
+    cin[r] = -sacc / (float)N;
+  }
+  const unsigned hs = (unsigned)N * (unsigned)ld;
+  const int nquads = EXACT ? (N >> 2) : (ld >> 2);
+  const int qown = threadIdx.x;
+  const int qA = 64 * wave + 16 * (lg >> 1) + l15, qB = qA + 32;
+  float mA[4], mB[4];       // validity of the result-layout positions (1 / 0)
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    mA[e] = (EXACT ? qA < nquads : 4 * qA + e < N) ? 1.f : 0.f;
+    mB[e] = (EXACT ? qB < nquads : 4 * qB + e < N) ? 1.f : 0.f;
+  }
+  float s1a[4] = {0.f, 0.f, 0.f, 0.f}, s2a[4] = {0.f, 0.f, 0.f, 0.f}, s1b[4] = {0.f, 0.f, 0.f, 0.f}, s2b[4] = {0.f, 0.f, 0.f, 0.f};
+  uint2 pown[H];
+  auto load_row = [&](long long row) {
+    const long long b = row / N;
+    const int i = (int)(row - b * N);
+    const bf16_t* __restrict__ Prow = Ps + (b * H * N + i) * (long long)ld;
+#pragma unroll
+    for (int h = 0; h < H; ++h) pown[h] = make_uint2(0, 0);
+    if (qown < nquads) {
+#pragma unroll
+      for (int h = 0; h < H; ++h) pown[h] = *reinterpret_cast<const uint2*>(Prow + (h * hs + 4u * qown));
+    }
+  };
+  if ((long long)blockIdx.x < rows) load_row(blockIdx.x);
+  for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
+    unsigned b1w[4][4];
+#pragma unroll
+    for (int h = 0; h < H; ++h) { pown[h].x = keep_pos(pown[h].x); pown[h].y = keep_pos(pown[h].y); }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      b1w[0][j] = halves(pown[2 * j].x, pown[2 * j + 1].x, 0);
+      b1w[1][j] = halves(pown[2 * j].x, pown[2 * j + 1].x, 1);
+      b1w[2][j] = halves(pown[2 * j].y, pown[2 * j + 1].y, 0);
+      b1w[3][j] = halves(pown[2 * j].y, pown[2 * j + 1].y, 1);
+    }
+    const long long nrow = row + gridDim.x;
+    if (nrow < rows) load_row(nrow);          // the next row is in flight during the MFMAs
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const u32x4 b1u = {b1w[e][0], b1w[e][1], b1w[e][2], b1w[e][3]};
+      const bf16x8 b1 = __builtin_bit_cast(bf16x8, b1u);
+      f32x4 c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[0], b1, cin, 0, 0, 0);
+      f32x4 c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[1], b1, cin, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al[0], b1, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al[1], b1, c1, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if constexpr (EXACT) {
+          s1a[r] += c0[r]; s2a[r] = fmaf(c0[r], c0[r], s2a[r]);
+          s1b[r] += c1[r]; s2b[r] = fmaf(c1[r], c1[r], s2b[r]);
+        } else {
+          const float a = c0[r] * mA[e], bq = c1[r] * mB[e];
+          s1a[r] += a; s2a[r] = fmaf(a, a, s2a[r]);
+          s1b[r] += bq; s2b[r] = fmaf(bq, bq, s2b[r]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    // (EXACT: a lane's two quads are valid or padding for every row - drop the padding sums here)
+    float v1 = EXACT ? s1a[r] * mA[0] + s1b[r] * mB[0] : s1a[r] + s1b[r];
+    float v2 = EXACT ? s2a[r] * mA[0] + s2b[r] * mB[0] : s2a[r] + s2b[r];
+#pragma unroll
+    for (int m = 1; m <= 8; m <<= 1) { v1 += __shfl_xor(v1, m, 64); v2 += __shfl_xor(v2, m, 64); }
+    v1 += __shfl_xor(v1, 32, 64); v2 += __shfl_xor(v2, 32, 64);
+    if (l15 == 0 && lg < 2) { red[wave][4 * lg + r] = v1; red[wave][H + 4 * lg + r] = v2; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * H)
+    partials[blockIdx.x * 2 * H + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
 template <typename T, int H>
 int launch_map_bwd_row(const void* Ps, void* dA, const float* W, const float* c, const float* gamma, const float* stats,
                        float* dW, float* dc, int B, int N, int ld, float inv_keep, float scale, hipStream_t st) {
@@ -1078,6 +1190,19 @@ int vu_k_map_bwd(int dtype, const void* Ps, void* dAhat_dS, const float* W, cons
 #undef VU_MB
   vu_set_error("map_bwd: num_heads %d not supported", H);
   return VU_EUNSUPPORTED;
+}
+
+// returns VU_OK, a negative error, or 1 when the shape is not covered (the caller uses mix_stats_kernel)
+int vu_k_mix_stats_mm(int dtype, const void* Ps, const float* W, float* partials, int nblocks, int B, int H, int N, int ld,
+                      float inv_keep, hipStream_t st) {
+  if (dtype != 1 || H != 8 || ld <= 256 || ld > 1024 || ld % 8 != 0 || (long long)H * N * ld >= 2147483647LL) return 1;
+  const long long rows = (long long)B * N;
+  if (N % 4 == 0)
+    hipLaunchKernelGGL(mix_stats_mm_kernel<true>, dim3(nblocks), dim3(256), 0, st, (const bf16_t*)Ps, W, partials, rows, N, ld, inv_keep);
+  else
+    hipLaunchKernelGGL(mix_stats_mm_kernel<false>, dim3(nblocks), dim3(256), 0, st, (const bf16_t*)Ps, W, partials, rows, N, ld, inv_keep);
+  if (vu_prof_on()) vu_prof_note("mix_stats_mm_kernel", 0.0, (double)B * H * N * N * 2.0);
+  return vu_check_launch("vu_mix_stats_mm");
 }
 
 // =============================================================================================

@@ -52,6 +52,8 @@ int vu_k_attn_outer(int dtype, const void* a, const void* bmat, void* out, int B
 #define VU_BN_STATS_FLOATS(H) (2 * (H) * (H) + 8 * (H))
 int vu_k_mix_stats(int dtype, const void* Ps, const float* W, const float* c, float* partials,
                    int nblocks, int B, int H, int N, int ld, float inv_keep, hipStream_t st);
+int vu_k_mix_stats_mm(int dtype, const void* Ps, const float* W, float* partials, int nblocks, int B, int H, int N, int ld,
+                      float inv_keep, hipStream_t st);   // MFMA form (bf16, H = 8, 256 < ld <= 1024); 1 = not covered
 int vu_k_bn_finalize(const float* partials, int nblocks, const float* W, const float* c,
                      const float* gamma, const float* beta, float* run_mean, float* run_var,
                      float* stats, int H, int N, double count, int training, float momentum,

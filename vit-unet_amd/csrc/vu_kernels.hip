@@ -444,6 +444,10 @@ int vu_k_mix_stats(int dtype, const void* Ps, const float* W, const float* c, fl
                    int B, int H, int N, int ld, float inv_keep, hipStream_t st) {
   VU_REQUIRE(ld % 4 == 0, "mix_stats: ld %% 4");
   VU_REQUIRE((long long)B * N * (ld / 4) < 4294967295LL, "mix kernels: more than 2^32 vector positions");
+  {
+    const int mm = vu_k_mix_stats_mm(dtype, Ps, W, partials, nblocks, B, H, N, ld, inv_keep, st);
+    if (mm <= 0) return mm;
+  }
   VU_HEADS(H, VU_DISPATCH_T(dtype, hipLaunchKernelGGL((mix_stats_kernel<T, HH>), dim3(nblocks), dim3(256), 0, st, (const T*)Ps, W, c, partials, B, N, ld, inv_keep);))
   if (vu_prof_on()) vu_prof_note("mix_stats_kernel", 0.0, (double)B * H * N * N * (dtype == 0 ? 4.0 : 2.0));
   return vu_check_launch("vu_mix_stats");
