@@ -1305,13 +1305,15 @@ int vu_k_bn_bwd_small(int dtype, const void* dO, const void* O, const void* v, c
 // =============================================================================================
 namespace {
 
-// Xt[t][n] = X[n][t] for n < N, t < d; zero elsewhere (t < 32, n < ldk).  LDV = ldk + 8: consecutive
+// Xt[t][n] = X[n][t] for n < N, t < d; zero elsewhere (t < 16 TT, n < ldk).  LDV = ldk + 8: consecutive
 // rows start 4 banks apart, 16 lanes reading 16 B of 16 different rows cover all 64 banks once.
+template <int TT>
 __device__ __forceinline__ void stage_slice_T(bf16_t* Xt, const bf16_t* __restrict__ Xg, int N, int D, int d, int ldk, int LDV,
                                               int tid, int nthr) {
   const bool vec = (d % 8 == 0) && (D % 8 == 0);
-  for (int c = tid; c < ldk * 4; c += nthr) {
-    const int n = c >> 2, t0 = (c & 3) * 8;
+  constexpr int CPT = 2 * TT;          // 8-element chunks per token
+  for (int c = tid; c < ldk * CPT; c += nthr) {
+    const int n = c / CPT, t0 = (c % CPT) * 8;
     union { uint4 u; bf16_t h[8]; } x;
     x.u = make_uint4(0, 0, 0, 0);
     if (n < N && t0 < d) {
@@ -1345,30 +1347,31 @@ __device__ __forceinline__ void store_t4(bf16_t* orow, int t0, int d, bool vec, 
 // operations of one wave complete in order, so no barrier is involved.
 constexpr int MP_LDT = 72;     // tile row stride in elements (144 B: 16 rows x 16 B cover all banks once)
 
-template <int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void attn_map_rows_kernel(const bf16_t* __restrict__ M, const bf16_t* __restrict__ X,
+template <int WAVES, int TT>
+__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4, 8))) void attn_map_rows_kernel(const bf16_t* __restrict__ M, const bf16_t* __restrict__ X,
                                                                  bf16_t* __restrict__ out, int N, int D, int H, int d, int ld) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int ldk = (N + 63) & ~63, LDV = ldk + 8;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
-  bf16_t* Xt = reinterpret_cast<bf16_t*>(smem_raw);                       // [32][LDV] (rows >= d stay zero)
-  bf16_t* T = Xt + 32 * LDV + wave * (16 * MP_LDT);                       // this wave's [16][MP_LDT] tile
+  bf16_t* Xt = reinterpret_cast<bf16_t*>(smem_raw);                       // [16 TT][LDV] (rows >= d stay zero)
+  bf16_t* T = Xt + 16 * TT * LDV + wave * (16 * MP_LDT);                  // this wave's [16][MP_LDT] tile
   const int bz = blockIdx.y, b = bz / H, g = bz % H;
-  stage_slice_T(Xt, X + (long long)b * N * D + g * d, N, D, d, ldk, LDV, tid, WAVES * 64);
+  stage_slice_T<TT>(Xt, X + (long long)b * N * D + g * d, N, D, d, ldk, LDV, tid, WAVES * 64);
   __syncthreads();
   const bf16_t* Mb = M + (long long)bz * N * ld;
   const int nrt = (N + 15) >> 4, nsteps = ldk >> 6;
   const bool vec = (d % 4 == 0) && (D % 4 == 0);
   const int lrow = lane >> 3, lch = (lane & 7) * 8;                        // load shape: 8 rows x 8 chunks of 16 B
   const bf16_t* x0 = Xt + l15 * LDV + 16 * lg;
-  const bf16_t* x1 = x0 + 16 * LDV;
   for (int rt = blockIdx.x * WAVES + wave; rt < nrt; rt += gridDim.x * WAVES) {
     // unconditional loads at clamped addresses (rows >= N re-read row N-1, columns >= ld the row's last chunk):
     // what they return is finite map data that meets zeros of Xt or lands in rows that are never stored.
     // (Selecting between a load and a zero makes hipcc select between POINTERS and emit serialized flat loads.)
     const bf16_t* r0 = Mb + (long long)min(rt * 16 + lrow, N - 1) * ld;
     const bf16_t* r1 = Mb + (long long)min(rt * 16 + 8 + lrow, N - 1) * ld;
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[TT];
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
     // (named registers, not an array: hipcc left an indexed ring in scratch memory)
     uint4 ma0, mb0, ma1, mb1, ma2, mb2, ma3, mb3, ma4, mb4, ma5, mb5;
     auto fetch = [&](int step, uint4& ma, uint4& mb) {
@@ -1385,11 +1388,11 @@ __global__ __launch_bounds__(WAVES * 64) void attn_map_rows_kernel(const bf16_t*
       const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(T + l15 * MP_LDT + 16 * lg);
       const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(T + l15 * MP_LDT + 16 * lg + 8);
       const bf16_t* xa = x0 + sidx * 64;
-      const bf16_t* xb = x1 + sidx * 64;
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(xa), b0, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(xb), b0, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(xa + 8), b1, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(xb + 8), b1, acc1, 0, 0, 0);
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) {
+        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(xa + 16 * tt * LDV), b0, acc[tt], 0, 0, 0);
+        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(xa + 16 * tt * LDV + 8), b1, acc[tt], 0, 0, 0);
+      }
     };
     auto step = [&](int sidx, uint4& ma, uint4& mb) {
       put(ma, mb);                      // the tile leaves the ring registers ...
@@ -1413,8 +1416,8 @@ __global__ __launch_bounds__(WAVES * 64) void attn_map_rows_kernel(const bf16_t*
     const int i = rt * 16 + l15;
     if (i < N) {
       bf16_t* orow = out + ((long long)b * N + i) * D + g * d;
-      store_t4(orow, 4 * lg, d, vec, acc0);
-      store_t4(orow, 16 + 4 * lg, d, vec, acc1);
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) store_t4(orow, 16 * tt + 4 * lg, d, vec, acc[tt]);
     }
   }
 }
@@ -1422,7 +1425,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_map_rows_kernel(const bf16_t*
 // cols form: a wave owns a strip of 64 map columns and walks all rows 32 at a time; the contraction runs
 // over map rows, so the B operand (k = row, n = column) comes out of the row-major tile through the
 // transposing LDS read (ds_read_b64_tr_b16).
-template <int WAVES>
+template <int WAVES, int TT>
 __global__ __launch_bounds__(WAVES * 64) void attn_map_cols_kernel(const bf16_t* __restrict__ M, const bf16_t* __restrict__ X,
                                                                  bf16_t* __restrict__ out, int N, int D, int H, int d, int ld) {
   typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
@@ -1430,10 +1433,10 @@ __global__ __launch_bounds__(WAVES * 64) void attn_map_cols_kernel(const bf16_t*
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int ldk = (N + 63) & ~63, LDV = ldk + 8;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
-  bf16_t* Xt = reinterpret_cast<bf16_t*>(smem_raw);                       // [32][LDV]
-  bf16_t* T = Xt + 32 * LDV + wave * (32 * MP_LDT);                       // this wave's [32][MP_LDT] tile
+  bf16_t* Xt = reinterpret_cast<bf16_t*>(smem_raw);                       // [16 TT][LDV]
+  bf16_t* T = Xt + 16 * TT * LDV + wave * (32 * MP_LDT);                  // this wave's [32][MP_LDT] tile
   const int bz = blockIdx.y, b = bz / H, g = bz % H;
-  stage_slice_T(Xt, X + (long long)b * N * D + g * d, N, D, d, ldk, LDV, tid, WAVES * 64);
+  stage_slice_T<TT>(Xt, X + (long long)b * N * D + g * d, N, D, d, ldk, LDV, tid, WAVES * 64);
   __syncthreads();
   const bf16_t* Mb = M + (long long)bz * N * ld;
   const bool vec = (d % 4 == 0) && (D % 4 == 0);
@@ -1444,9 +1447,11 @@ __global__ __launch_bounds__(WAVES * 64) void attn_map_cols_kernel(const bf16_t*
   for (int strip = blockIdx.x * WAVES + wave; strip < nstrips; strip += gridDim.x * WAVES) {
     const int j0 = strip * 64;
     const int jc = min(j0 + lch, ld - 8);                // columns >= ld: any finite data, never stored
-    f32x4 acc[4][2];
+    f32x4 acc[4][TT];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { acc[u][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[u][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) acc[u][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
     // register ring two 32-row steps (8 x 16 B per lane) ahead; clamped unconditional loads: rows >= N meet zeros of Xt
     // (named registers, not an array: hipcc left an indexed ring in scratch memory)
     uint4 p0, p1, p2, p3, q0, q1, q2, q3;
@@ -1464,8 +1469,9 @@ __global__ __launch_bounds__(WAVES * 64) void attn_map_cols_kernel(const bf16_t*
     };
     auto mult = [&](int i0) {
       // A operand: Xt rows t, k-slots = map rows i0 + 8 lg + e
-      const bf16x8 xa0 = *reinterpret_cast<const bf16x8*>(Xt + l15 * LDV + i0 + 8 * lg);
-      const bf16x8 xa1 = *reinterpret_cast<const bf16x8*>(Xt + (16 + l15) * LDV + i0 + 8 * lg);
+      bf16x8 xa[TT];
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) xa[tt] = *reinterpret_cast<const bf16x8*>(Xt + (16 * tt + l15) * LDV + i0 + 8 * lg);
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const bf16_t* tb = T + (8 * lg + q) * MP_LDT + 16 * u + 4 * pq;
@@ -1473,8 +1479,8 @@ __global__ __launch_bounds__(WAVES * 64) void attn_map_cols_kernel(const bf16_t*
         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(tb + 4 * MP_LDT));
         const s16x8 t8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         const bf16x8 bm = __builtin_bit_cast(bf16x8, t8);
-        acc[u][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa0, bm, acc[u][0], 0, 0, 0);
-        acc[u][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa1, bm, acc[u][1], 0, 0, 0);
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) acc[u][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[tt], bm, acc[u][tt], 0, 0, 0);
       }
     };
     auto step = [&](int i0, uint4& m0, uint4& m1, uint4& m2, uint4& m3) {
@@ -1497,34 +1503,42 @@ __global__ __launch_bounds__(WAVES * 64) void attn_map_cols_kernel(const bf16_t*
       const int j = j0 + 16 * u + l15;
       if (j < N) {
         bf16_t* orow = out + ((long long)b * N + j) * D + g * d;
-        store_t4(orow, 4 * lg, d, vec, acc[u][0]);
-        store_t4(orow, 16 + 4 * lg, d, vec, acc[u][1]);
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) store_t4(orow, 16 * tt + 4 * lg, d, vec, acc[u][tt]);
       }
     }
   }
 }
 
-template <bool COLS>
-int launch_map_prod(const void* M, const void* X, void* out, int B, int N, int D, int H, int ld, hipStream_t st) {
+template <bool COLS, int WAVES, int TT>
+int launch_map_prod_w(const void* M, const void* X, void* out, int B, int N, int D, int H, int ld, int nsplit, hipStream_t st) {
   const int d = D / H;
   const int ldk = (N + 63) & ~63;
-  const int units = COLS ? (N + 63) / 64 : (N + 15) / 16;       // strips / row tiles per (sample, head)
-  const bool seven = units % 7 == 0 || (COLS && units > 8 && units <= 14);
-  int nsplit = (512 + B * H - 1) / (B * H);
-  const int maxsplit = (units + 7) / 8;
-  if (nsplit > maxsplit) nsplit = maxsplit;
-  if (nsplit < 1) nsplit = 1;
-  const size_t lds = (size_t)32 * (ldk + 8) * 2 + (size_t)(seven ? 7 : 8) * (COLS ? 32 : 16) * MP_LDT * 2;
-  auto kern = COLS ? (seven ? attn_map_cols_kernel<7> : attn_map_cols_kernel<8>) : (seven ? attn_map_rows_kernel<7> : attn_map_rows_kernel<8>);
+  const size_t lds = (size_t)16 * TT * (ldk + 8) * 2 + (size_t)WAVES * (COLS ? 32 : 16) * MP_LDT * 2;
+  auto kern = COLS ? attn_map_cols_kernel<WAVES, TT> : attn_map_rows_kernel<WAVES, TT>;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { vu_set_error("attn_map_prod: cannot reserve %zu bytes of LDS", lds); return VU_ELAUNCH; }
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)nsplit, (unsigned)(B * H)), dim3(seven ? 448 : 512), lds, st, (const bf16_t*)M,
+  hipLaunchKernelGGL(kern, dim3((unsigned)nsplit, (unsigned)(B * H)), dim3(WAVES * 64), lds, st, (const bf16_t*)M,
                      (const bf16_t*)X, (bf16_t*)out, N, D, H, d, ld);
   if (vu_prof_on()) vu_prof_note(COLS ? "attn_map_cols_kernel" : "attn_map_rows_kernel", 2.0 * B * H * (double)N * N * d,
                                  ((double)B * H * N * ld + 2.0 * B * N * D) * 2.0);
   return vu_check_launch("vu_attn_map_prod");
+}
+
+template <bool COLS, int TT>
+int launch_map_prod(const void* M, const void* X, void* out, int B, int N, int D, int H, int ld, hipStream_t st) {
+  const int units = COLS ? (N + 63) / 64 : (N + 15) / 16;       // strips / row tiles per (sample, head)
+  // waves per workgroup: as many as there are units, in whole rounds where possible
+  const int waves = units <= 4 ? 4 : ((units % 7 == 0 || (units > 8 && units <= 14)) ? 7 : 8);
+  int nsplit = (512 + B * H - 1) / (B * H);
+  const int maxsplit = (units + waves - 1) / waves;
+  if (nsplit > maxsplit) nsplit = maxsplit;
+  if (nsplit < 1) nsplit = 1;
+  if (waves == 4) return launch_map_prod_w<COLS, 4, TT>(M, X, out, B, N, D, H, ld, nsplit, st);
+  if (waves == 7) return launch_map_prod_w<COLS, 7, TT>(M, X, out, B, N, D, H, ld, nsplit, st);
+  return launch_map_prod_w<COLS, 8, TT>(M, X, out, B, N, D, H, ld, nsplit, st);
 }
 
 }  // namespace
@@ -1533,7 +1547,9 @@ int launch_map_prod(const void* M, const void* X, void* out, int B, int N, int D
 int vu_k_attn_map_prod(int dtype, int cols, const void* M, const void* X, void* out, int B, int N, int D, int H, int ld,
                        hipStream_t st) {
   const int d = D / H;
-  if (dtype != 1 || d > 32 || N <= 256 || ld % 8 != 0) return 1;
-  if ((size_t)32 * (((N + 63) & ~63) + 8) * 2 + 8 * 32 * MP_LDT * 2 > 150 * 1024) return 1;
-  return cols ? launch_map_prod<true>(M, X, out, B, N, D, H, ld, st) : launch_map_prod<false>(M, X, out, B, N, D, H, ld, st);
+  if (dtype != 1 || d > 96 || N < 64 || ld % 8 != 0) return 1;
+  const int tt = d <= 32 ? 2 : 6;
+  if ((size_t)16 * tt * (((N + 63) & ~63) + 8) * 2 + 8 * 32 * MP_LDT * 2 > 150 * 1024) return 1;
+  if (tt == 2) return cols ? launch_map_prod<true, 2>(M, X, out, B, N, D, H, ld, st) : launch_map_prod<false, 2>(M, X, out, B, N, D, H, ld, st);
+  return cols ? launch_map_prod<true, 6>(M, X, out, B, N, D, H, ld, st) : launch_map_prod<false, 6>(M, X, out, B, N, D, H, ld, st);
 }
