@@ -1312,19 +1312,36 @@ __device__ __forceinline__ void stage_slice_T(bf16_t* Xt, const bf16_t* __restri
                                               int tid, int nthr) {
   const bool vec = (d % 8 == 0) && (D % 8 == 0);
   constexpr int CPT = 2 * TT;          // 8-element chunks per token
-  for (int c = tid; c < ldk * CPT; c += nthr) {
-    const int n = c / CPT, t0 = (c % CPT) * 8;
-    union { uint4 u; bf16_t h[8]; } x;
-    x.u = make_uint4(0, 0, 0, 0);
-    if (n < N && t0 < d) {
-      if (vec) x.u = *reinterpret_cast<const uint4*>(Xg + (long long)n * D + t0);
-      else {
+  const int cells = ldk * CPT;
+  for (int c0 = tid; c0 < cells; c0 += 4 * nthr) {      // 4 independent 16-byte loads in flight per thread
+    uint4 x[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) x.h[e] = (t0 + e < d) ? Xg[(long long)n * D + t0 + e] : (bf16_t)0.f;
+    for (int k = 0; k < 4; ++k) {
+      const int c = c0 + k * nthr;
+      const int n = c / CPT, t0 = (c % CPT) * 8;
+      x[k] = make_uint4(0, 0, 0, 0);
+      if (c < cells && n < N && t0 < d) {
+        if (vec) x[k] = *reinterpret_cast<const uint4*>(Xg + (long long)n * D + t0);
+        else {
+          unsigned w[4] = {0, 0, 0, 0};
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (t0 + e < d) w[e >> 1] |= (unsigned)__builtin_bit_cast(unsigned short, Xg[(long long)n * D + t0 + e]) << (16 * (e & 1));
+          x[k] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
       }
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) Xt[(t0 + e) * LDV + n] = x.h[e];
+    for (int k = 0; k < 4; ++k) {
+      const int c = c0 + k * nthr;
+      if (c < cells) {
+        const int n = c / CPT, t0 = (c % CPT) * 8;
+        const unsigned w[4] = {x[k].x, x[k].y, x[k].z, x[k].w};
+        unsigned short* dst = reinterpret_cast<unsigned short*>(Xt) + t0 * LDV + n;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dst[e * LDV] = (unsigned short)(w[e >> 1] >> (16 * (e & 1)));
+      }
+    }
   }
 }
 
