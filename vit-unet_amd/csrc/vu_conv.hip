@@ -4,6 +4,7 @@
 // loads each channel's 3x6 window with three unconditional loads per row (one 4-vector + two
 // clamped halo scalars) so all loads of a thread are in flight together; q, k and v are produced
 // from one read of x; their data gradients are summed in one kernel.
+#include <stdlib.h>
 #include "vu_kernels.h"
 
 namespace {
@@ -228,6 +229,105 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradSet set, long long
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// conv_wgrad_mm_kernel (bf16 storage, C = 3, q/k/v set): the weight gradients as a GEMM on the
+// matrix cores,  dW_cv[co][tap] = sum_pixels dout_cv[co][pixel] * shifted_in[tap][pixel],
+// tap = (ci, ky, kx), contraction over pixels.  One MFMA k-step is 32 pixels = 4 row segments of 8
+// pixels (lane group lg = segment).  A operand: rows n = output channels, a lane's 8 k-slots are one
+// 16-byte load of a dout row segment.  B operand: columns = taps; a lane loads the 8-pixel segment of
+// input row y + ky - 1 of channel ci (plus the two edge pixels when the patch is wider than 8) and
+// funnel-shifts it by kx - 1: the im2col matrix is never materialised.  q uses xq, k and v use xkv:
+// two products (3 x 27 and 6 x 27), 2 tap tiles each.  Accumulators stay in registers over the
+// block's pixel stream; one LDS reduction over the 4 waves and 9 x 27 float atomics per block.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint4 shift_segment(const uint4 v, unsigned left, unsigned right, int kx) {
+  // kx = 0: [left, p0..p6] ; kx = 1: [p0..p7] ; kx = 2: [p1..p7, right]   (16-bit elements, p0 = low half of v.x)
+  const uint4 a = make_uint4(__builtin_amdgcn_alignbit(v.x, left << 16, 16), __builtin_amdgcn_alignbit(v.y, v.x, 16),
+                             __builtin_amdgcn_alignbit(v.z, v.y, 16), __builtin_amdgcn_alignbit(v.w, v.z, 16));
+  const uint4 c = make_uint4(__builtin_amdgcn_alignbit(v.y, v.x, 16), __builtin_amdgcn_alignbit(v.z, v.y, 16),
+                             __builtin_amdgcn_alignbit(v.w, v.z, 16), __builtin_amdgcn_alignbit(right, v.w, 16));
+  return kx == 0 ? a : (kx == 1 ? v : c);
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void conv_wgrad_mm_kernel(const bf16_t* __restrict__ dq, const bf16_t* __restrict__ dk,
+                                                            const bf16_t* __restrict__ dv, const bf16_t* __restrict__ xq,
+                                                            const bf16_t* __restrict__ xkv, float* dwq, float* dwk, float* dwv,
+                                                            long long nunits, int s) {
+  constexpr int C = 3, NW = 27;
+  __shared__ float red[WAVES][2][2][256];   // [wave][q | kv][tap tile][C-layout element]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, lg = lane >> 4;
+  const int ss = s * s, upp = ss >> 5;      // 32-pixel units per patch
+  const bool same = xq == xkv;
+  const bool edges = s > 8;
+  // this lane's taps (B operand column l15 of tap tile 0 / 1)
+  int tci[2], tky[2], tkx[2]; bool tv[2];
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt) {
+    const int t = tt * 16 + l15;
+    tv[tt] = t < NW;
+    const int tc = tv[tt] ? t : 0;
+    tci[tt] = tc / 9; tky[tt] = (tc % 9) / 3; tkx[tt] = tc % 3;
+  }
+  // this lane's A rows: q product row n = l15 < 3 (dq); kv product rows n < 3 (dk), 3 <= n < 6 (dv)
+  const bf16_t* aq = dq + (l15 < 3 ? l15 : 0) * ss;
+  const bf16_t* akv = (l15 < 3 ? dk : dv) + (l15 < 3 ? l15 : (l15 < 6 ? l15 - 3 : 0)) * ss;
+  f32x4 accq[2], acckv[2];
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt) { accq[tt] = f32x4{0.f, 0.f, 0.f, 0.f}; acckv[tt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  const uint4 z4 = make_uint4(0, 0, 0, 0);
+  for (long long uid = (long long)blockIdx.x * WAVES + wave; uid < nunits; uid += (long long)gridDim.x * WAVES) {
+    const long long patch = uid / upp;
+    const int u = (int)(uid - patch * upp);
+    const int px = (4 * u + lg) * 8;                 // first pixel of this lane group's segment
+    const int y = px / s, x0 = px - y * s;
+    const long long pbase = patch * (long long)(C * ss);
+    const int seg = y * s + x0;
+    uint4 a_q = z4, a_kv = z4;
+    if (l15 < 3) a_q = *reinterpret_cast<const uint4*>(aq + pbase + seg);
+    if (l15 < 6) a_kv = *reinterpret_cast<const uint4*>(akv + pbase + seg);
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      const int r = y + tky[tt] - 1;
+      const bool rv = tv[tt] && r >= 0 && r < s;
+      const long long off = pbase + tci[tt] * ss + r * s + x0;
+      uint4 bq = z4, bkv = z4;
+      unsigned lq = 0, rq = 0, lkv = 0, rkv = 0;
+      if (rv) {
+        bkv = *reinterpret_cast<const uint4*>(xkv + off);
+        if (!same) bq = *reinterpret_cast<const uint4*>(xq + off);
+        if (edges) {
+          if (x0 > 0) { lkv = __builtin_bit_cast(unsigned short, xkv[off - 1]); if (!same) lq = __builtin_bit_cast(unsigned short, xq[off - 1]); }
+          if (x0 + 8 < s) { rkv = __builtin_bit_cast(unsigned short, xkv[off + 8]); if (!same) rq = __builtin_bit_cast(unsigned short, xq[off + 8]); }
+        }
+      }
+      const uint4 skv = shift_segment(bkv, lkv, rkv, tkx[tt]);
+      const uint4 sq = same ? skv : shift_segment(bq, lq, rq, tkx[tt]);
+      accq[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a_q), __builtin_bit_cast(bf16x8, sq), accq[tt], 0, 0, 0);
+      acckv[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a_kv), __builtin_bit_cast(bf16x8, skv), acckv[tt], 0, 0, 0);
+    }
+  }
+  // C[row n = 4 lg + r][col = tap l15 (+16)]
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      red[wave][0][tt][(4 * lg + r) * 16 + l15] = accq[tt][r];
+      red[wave][1][tt][(4 * lg + r) * 16 + l15] = acckv[tt][r];
+    }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * 2 * 256; i += WAVES * 64) {
+    const int which = i >> 9, tt = (i >> 8) & 1, e = i & 255;
+    const int n = e >> 4, t = tt * 16 + (e & 15);
+    if (t >= NW || n >= (which == 0 ? 3 : 6)) continue;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) v += red[w][which][tt][e];
+    float* dst = which == 0 ? dwq + n * NW + t : (n < 3 ? dwk + n * NW + t : dwv + (n - 3) * NW + t);
+    atomicAdd(dst, v);
+  }
+}
+
 inline int grid_for(long long items, int cap) {
   long long g = (items + 255) / 256;
   if (g > cap) g = cap;
@@ -309,6 +409,17 @@ static int wgrad_launch(int dtype, int dout_f32, const WgradSet& set, int nconv,
   VU_REQUIRE(npatch * s * s / 4 < 4294967295LL, "conv3x3: more than 2^32 pixel quads");
   const long long nq = npatch * s * s / 4;
   if (nq == 0) return VU_OK;
+  if (dtype == 1 && !dout_f32 && nconv == 3 && C == 3 && s % 8 == 0 && !getenv("VU_CONV_WGRAD_VALU")) {
+    const long long nunits = npatch * s * s / 32;
+    // many waves, few blocks: every block ends in 243 float atomics on the same addresses (measured: 2048 blocks of
+    // 4 waves 131 us, 512 x 4: 93 us, 256 x 4: 141 us per launch)
+    constexpr int WV = 16;
+    long long g = (nunits + WV - 1) / WV; if (g > 256) g = 256;
+    hipLaunchKernelGGL(conv_wgrad_mm_kernel<WV>, dim3((unsigned)g), dim3(WV * 64), 0, st, (const bf16_t*)set.dout[0], (const bf16_t*)set.dout[1],
+                       (const bf16_t*)set.dout[2], (const bf16_t*)set.in[0], (const bf16_t*)set.in[1], set.dw[0], set.dw[1], set.dw[2], nunits, s);
+    if (vu_prof_on()) vu_prof_note("conv_wgrad_mm_kernel", 0.0, (double)nq * 4 * C * 5 * 2.0);
+    return vu_check_launch("vu_conv3x3_wgrad");
+  }
   const int gx = grid_for(nq, nconv == 1 ? 512 : 256);
   VU_CONV_C(C,
     if (dtype == 0) hipLaunchKernelGGL((conv_wgrad_kernel<float, float, CC>), dim3(gx, nconv * CC), dim3(256), 0, st, set, nq, s);
