@@ -792,8 +792,10 @@ __device__ __forceinline__ bf16x8 pack8(const float (&v)[8]) {
   return r;
 }
 
-// EXACT: N % 4 == 0, position quads are wholly valid or wholly padding
-template <bool EXACT>
+// EXACT: N % 4 == 0, position quads are wholly valid or wholly padding.
+// WPR = waves per map row: 4 (256 < ld <= 1024: the block's four waves share a row) or 1 (ld <= 256: every
+// wave owns a row of its own - its LDS images, its delta reduction and its dW contraction - no barriers).
+template <bool EXACT, int WPR>
 __global__ __launch_bounds__(256, 2) void map_bwd_mm_kernel(const bf16_t* __restrict__ Ps, bf16_t* dA,
                                                             const float* __restrict__ W, const float* __restrict__ c,
                                                             const float* __restrict__ gamma, const float* __restrict__ stats,
@@ -805,14 +807,16 @@ __global__ __launch_bounds__(256, 2) void map_bwd_mm_kernel(const bf16_t* __rest
   __shared__ float red[4][256];
   const int ldk = (ld + 31) / 32 * 32;
   const int LDP = ldk + 8;
-  bf16_t* sA = reinterpret_cast<bf16_t*>(smem_raw);   // [H][LDP]   dA hi
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wsub = WPR == 4 ? wave : 0;               // wave's index within its row
+  bf16_t* sbase = reinterpret_cast<bf16_t*>(smem_raw);
+  bf16_t* sA = sbase + (WPR == 4 ? 0 : wave) * (3 * H + 1) * LDP;   // [H][LDP]   dA hi
   bf16_t* sL = sA + H * LDP;                          // [H][LDP]   dA lo
   bf16_t* sB = sL + H * LDP;                          // [H+1][LDP] kept P (without 1/keep), row H = ones
-  for (int i = threadIdx.x; i < (3 * H + 1) * LDP; i += blockDim.x) {
-    const int r = i / LDP, col = i % LDP;
-    sA[i] = (r == 3 * H && col < N) ? (bf16_t)1.0f : (bf16_t)0.0f;
+  for (int i = threadIdx.x; i < (WPR == 4 ? 1 : 4) * (3 * H + 1) * LDP; i += blockDim.x) {
+    const int r = (i / LDP) % (3 * H + 1), col = i % LDP;
+    sbase[i] = (r == 3 * H && col < N) ? (bf16_t)1.0f : (bf16_t)0.0f;
   }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l15 = lane & 15, lg = lane >> 4;
   const float* tX = stats + H * H + 5 * H;     // X[H*H] = W*rstd_g, Xc[H], Gs[H]
   const float* tM = stats + H * H + 3 * H;     // m1[H], m2[H]
@@ -848,8 +852,8 @@ __global__ __launch_bounds__(256, 2) void map_bwd_mm_kernel(const bf16_t* __rest
   const unsigned hs = (unsigned)N * (unsigned)ld;     // launcher guarantees 8 * N * ld < 2^31
   const int nks = ldk / 32;
   const int nquads = EXACT ? (N >> 2) : (ld >> 2);
-  const int qown = threadIdx.x;                          // own quad
-  const int qA = 64 * wave + 16 * (lg >> 1) + l15;       // result-layout quads
+  const int qown = WPR == 4 ? threadIdx.x : lane;         // own quad
+  const int qA = 64 * wsub + 16 * (lg >> 1) + l15;        // result-layout quads
   const int qB = qA + 32;
   f32x4 accw = {0.f, 0.f, 0.f, 0.f};
 
@@ -885,8 +889,10 @@ __global__ __launch_bounds__(256, 2) void map_bwd_mm_kernel(const bf16_t* __rest
       }
     }
   };
-  if ((long long)blockIdx.x < rows) load_row(blockIdx.x, pown, PA, PB, QA, QB);
-  for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
+  const long long row0 = WPR == 4 ? (long long)blockIdx.x : (long long)blockIdx.x * 4 + wave;
+  const long long rstep = WPR == 4 ? (long long)gridDim.x : (long long)gridDim.x * 4;
+  if (row0 < rows) load_row(row0, pown, PA, PB, QA, QB);
+  for (long long row = row0; row < rows; row += rstep) {
     // ---- own layout: kept probabilities, P image, B operands of #1 -------------------------------
     unsigned b1w[4][4];
 #pragma unroll
@@ -957,7 +963,7 @@ __global__ __launch_bounds__(256, 2) void map_bwd_mm_kernel(const bf16_t* __rest
     }
     // ---- next row's loads fly during the reduction / contraction / store phase --------------------
     uint2 nP[4], nPB[4];
-    const long long nrow = row + gridDim.x;
+    const long long nrow = row + rstep;
     if (nrow < rows) load_row(nrow, pown, nP, nPB, QA, QB);
     // ---- delta_h over the row: lanes with the same (lg & 1) hold the same heads ----------------
 #pragma unroll
@@ -965,12 +971,15 @@ __global__ __launch_bounds__(256, 2) void map_bwd_mm_kernel(const bf16_t* __rest
       float v = delta[r];
       v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
       v += __shfl_xor(v, 32, 64);
-      if (l15 == 0 && lg < 2) redd[wave][4 * lg + r] = v;
+      if (WPR == 4) { if (l15 == 0 && lg < 2) redd[wave][4 * lg + r] = v; }
+      else delta[r] = v;                 // one wave = one row: the shuffles already hold the row sum
     }
-    __syncthreads();
+    if (WPR == 4) {
+      __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 4; ++r) delta[r] = redd[0][hbase + r] + redd[1][hbase + r] + redd[2][hbase + r] + redd[3][hbase + r];
-    for (int ks = wave; ks < nks; ks += 4) {
+      for (int r = 0; r < 4; ++r) delta[r] = redd[0][hbase + r] + redd[1][hbase + r] + redd[2][hbase + r] + redd[3][hbase + r];
+    }
+    for (int ks = wsub; ks < nks; ks += WPR) {
       const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
       const bf16x8 af = l15 < H ? *reinterpret_cast<const bf16x8*>(sA + l15 * LDP + ks * 32 + lg * 8) : zero8;
       const bf16x8 lf = l15 < H ? *reinterpret_cast<const bf16x8*>(sL + l15 * LDP + ks * 32 + lg * 8) : zero8;
@@ -1003,7 +1012,7 @@ __global__ __launch_bounds__(256, 2) void map_bwd_mm_kernel(const bf16_t* __rest
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) { PA[r] = nP[r]; PB[r] = nPB[r]; }
-    __syncthreads();
+    if (WPR == 4) __syncthreads();       // (WPR = 1: a wave's LDS traffic is ordered by itself)
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) red[wave][(lg * 4 + r) * 16 + l15] = accw[r];
@@ -1128,10 +1137,33 @@ __global__ __launch_bounds__(256) void mix_stats_mm_kernel(const bf16_t* __restr
     partials[blockIdx.x * 2 * H + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
+template <int WPR>
+int launch_map_bwd_mm(const void* Ps, void* dA, const float* W, const float* c, const float* gamma, const float* stats,
+                      float* dW, float* dc, int B, int N, int ld, float inv_keep, float scale, hipStream_t st) {
+  const long long rows = (long long)B * N;
+  const int ldk = (ld + 31) / 32 * 32;
+  const size_t lds = (size_t)(WPR == 4 ? 1 : 4) * (3 * 8 + 1) * (ldk + 8) * 2;
+  auto kern = (N % 4 == 0) ? map_bwd_mm_kernel<true, WPR> : map_bwd_mm_kernel<false, WPR>;
+  if (lds > 40 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { vu_set_error("map_bwd: cannot reserve %zu bytes of LDS", lds); return VU_ELAUNCH; }
+  }
+  long long grid = WPR == 4 ? rows : (rows + 3) / 4;
+  if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, (const bf16_t*)Ps, (bf16_t*)dA, W, c, gamma, stats, dW, dc,
+                     rows, N, ld, inv_keep, scale);
+  if (vu_prof_on()) vu_prof_note(WPR == 4 ? "map_bwd_mm_kernel" : "map_bwd_mm_kernel<1 wave/row>", 0.0, (double)B * 8 * N * N * 3 * 2.0);
+  return vu_check_launch("vu_map_bwd");
+}
+
 template <typename T, int H>
 int launch_map_bwd_row(const void* Ps, void* dA, const float* W, const float* c, const float* gamma, const float* stats,
                        float* dW, float* dc, int B, int N, int ld, float inv_keep, float scale, hipStream_t st) {
   const long long rows = (long long)B * N;
+  if constexpr (H == 8 && sizeof(T) == 2) {
+    if (ld <= 256 && ld >= 64 && !getenv("VU_MAP_BWD_VALU"))
+      return launch_map_bwd_mm<1>(Ps, dA, W, c, gamma, stats, dW, dc, B, N, ld, inv_keep, scale, st);
+  }
   if (ld <= 256) {
     long long grid = (rows + 3) / 4; if (grid > 2048) grid = 2048;
     hipLaunchKernelGGL((map_bwd_row_kernel<T, H, 64>), dim3((unsigned)grid), dim3(256), 0, st, (const T*)Ps, (T*)dA, W, c, gamma,
@@ -1143,19 +1175,7 @@ int launch_map_bwd_row(const void* Ps, void* dA, const float* W, const float* c,
     const size_t lds = (size_t)(3 * H + 1) * (ldk + 8) * 2;
     const bool big = ld > 1024;
     if constexpr (H == 8) {
-      if (!big && !getenv("VU_MAP_BWD_VALU")) {
-        const size_t lds8 = (size_t)(3 * 8 + 1) * (ldk + 8) * 2;
-        auto k8 = (N % 4 == 0) ? map_bwd_mm_kernel<true> : map_bwd_mm_kernel<false>;
-        if (lds8 > 40 * 1024) {
-          hipError_t e = hipFuncSetAttribute((const void*)k8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8);
-          if (e != hipSuccess) { vu_set_error("map_bwd: cannot reserve %zu bytes of LDS", lds8); return VU_ELAUNCH; }
-        }
-        long long grid8 = rows; if (grid8 > 1024) grid8 = 1024;
-        hipLaunchKernelGGL(k8, dim3((unsigned)grid8), dim3(256), lds8, st, (const bf16_t*)Ps, (bf16_t*)dA, W, c, gamma, stats, dW,
-                           dc, rows, N, ld, inv_keep, scale);
-        if (vu_prof_on()) vu_prof_note("map_bwd_mm_kernel", 0.0, (double)B * H * N * N * 3 * sizeof(T));
-        return vu_check_launch("vu_map_bwd");
-      }
+      if (!big && !getenv("VU_MAP_BWD_VALU")) return launch_map_bwd_mm<4>(Ps, dA, W, c, gamma, stats, dW, dc, B, N, ld, inv_keep, scale, st);
     }
     auto kern = big ? map_bwd_mfma_kernel<(H <= 4 ? H : 4), 16> : map_bwd_mfma_kernel<H, 4>;
     if (lds > 40 * 1024) {
