@@ -27,6 +27,9 @@ def run(M, N, K, form, c_float, acc, iters=20):
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     print(f"{form} M{M} N{N} K{K} cf{c_float} acc{acc}: {ms*1e3:8.1f} us  {2*M*N*K/ms/1e9:7.1f} TF  bk32={os.environ.get('VU_GEMM_BK32','0')}")
-for args in [(3072, 3072, 3136, "TT", 1, 1), (768, 768, 12544, "TT", 1, 1), (3072, 3072, 3136, "TT", 0, 0),
+for args in [(12544, 768, 64, "NN", 0, 0), (12544, 64, 768, "NN", 0, 0), (50176, 192, 32, "NN", 0, 0), (50176, 32, 192, "NN", 0, 0),
+             (3136, 3072, 128, "NN", 0, 0), (3136, 128, 3072, "NN", 0, 0), (12544, 768, 64, "NT", 0, 0), (50176, 192, 192, "NN", 0, 0),
+             (12544, 768, 768, "NT", 0, 0), (192, 192, 50176, "TT", 1, 1), (768, 64, 12544, "TT", 1, 1),
+             (3072, 3072, 3136, "TT", 1, 1), (768, 768, 12544, "TT", 1, 1), (3072, 3072, 3136, "TT", 0, 0),
              (3136, 3072, 3072, "NN", 0, 0), (3136, 3072, 3072, "NT", 0, 0), (12544, 768, 768, "NN", 0, 0), (50176, 192, 192, "NT", 0, 0)]:
     run(*args)
