@@ -163,14 +163,8 @@ __global__ __launch_bounds__(256) void vu_gemm_kernel(const vu_gemm_args g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int tiles_n = (g.N + BN - 1) / BN;
-  // XCD-aware tile order: consecutive workgroup ids land on different XCDs (8, round robin), each with its own
-  // L2; remap so that every XCD works through a contiguous run of tiles (neighbours share operand panels)
-  int bid = blockIdx.x;
-  {
-    const int nb = gridDim.x, xcd = bid & 7, q = nb >> 3, r = nb & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
+  // (an XCD-aware remap of the tile order was measured: no gain on the 3072-class GEMMs, tools/gemm_bench.py)
+  const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
   const int z = blockIdx.y, z1 = z / g.Z2, z2 = z % g.Z2;
   const int m_base = tile_m * BM, n_base = tile_n * BN;
 
