@@ -10,8 +10,10 @@ static int launch_bk(const vu_gemm_args& g, hipStream_t st) {
   ga.ksplit = 1;
   if (sizeof(TC) == 4 && g.accumulate && !g.act && !g.dropout && !g.addend && blocks < 512) {
     // small output, long K (weight gradients over B*N rows): split K so the chip is filled
-    int want = (int)((1024 + blocks - 1) / blocks);
-    const int maxs = vu_cdiv(g.K, 4 * BK);
+    // every split adds its whole tile with float atomics (chip-wide ~1.3 TB/s of added bytes): aim for ~2 blocks
+    // per CU and at least 8 k-steps per block rather than for the most blocks
+    int want = (int)((512 + blocks - 1) / blocks);
+    const int maxs = vu_cdiv(g.K, 8 * BK);
     ga.ksplit = want < maxs ? want : maxs;
     if (ga.ksplit < 1) ga.ksplit = 1;
   }
