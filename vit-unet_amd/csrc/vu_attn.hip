@@ -1239,33 +1239,67 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_small_kernel(const T* __restrict__ dO, const T* __restrict__ O,
                                                            const T* __restrict__ v, float* partials, int N, int D, int H) {
   __shared__ float sm[16];
-  __shared__ float sdo[256], sv[256];
+  __shared__ float sdo[4 * 256], sv[4 * 256];
   const int b = blockIdx.x, g = blockIdx.y, d = D / H;
   const long long base = (long long)b * N * D + g * d;
-  int TCOL = 256;                       // feature columns handled side by side (power of two >= min(d,256))
-  while (TCOL / 2 >= d) TCOL /= 2;
-  const int RL = 256 / TCOL;            // row lanes per column
-  const int tc = threadIdx.x % TCOL, rl = threadIdx.x / TCOL;
   float s1 = 0.f, r = 0.f;
-  for (int t0 = 0; t0 < d; t0 += TCOL) {
-    const int t = t0 + tc;
-    float cdo = 0.f, cv = 0.f;
-    if (t < d) {
-      for (int i = rl; i < N; i += RL) {
-        const float a = vu_ld(dO + base + (long long)i * D + t);
-        cdo += a;
-        cv += vu_ld(v + base + (long long)i * D + t);
-        r += a * vu_ld(O + base + (long long)i * D + t);
+  if (d % 4 == 0) {
+    // a thread owns 4 consecutive features (one vector load per tensor and row) of the rows i = rl, rl + RL, ...
+    const int nq = d >> 2;
+    int TQ = 256;                       // feature quads handled side by side (power of two >= min(nq, 256))
+    while (TQ / 2 >= nq) TQ /= 2;
+    const int RL = 256 / TQ;
+    const int tc = threadIdx.x % TQ, rl = threadIdx.x / TQ;
+    for (int q0 = 0; q0 < nq; q0 += TQ) {
+      const int qd = q0 + tc;
+      float cdo[4] = {0.f, 0.f, 0.f, 0.f}, cv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (qd < nq) {
+        const long long cb = base + 4 * qd;
+#pragma unroll 4
+        for (int i = rl; i < N; i += RL) {
+          const vu_f4 a = vu_ld4(dO + cb + (long long)i * D), vv = vu_ld4(v + cb + (long long)i * D), o = vu_ld4(O + cb + (long long)i * D);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { cdo[e] += a.v[e]; cv[e] += vv.v[e]; r = fmaf(a.v[e], o.v[e], r); }
+        }
       }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { sdo[e * 256 + threadIdx.x] = cdo[e]; sv[e * 256 + threadIdx.x] = cv[e]; }
+      __syncthreads();
+      if (rl == 0 && qd < nq) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float a = 0.f, c = 0.f;
+          for (int q = 0; q < RL; ++q) { a += sdo[e * 256 + q * TQ + tc]; c += sv[e * 256 + q * TQ + tc]; }
+          s1 = fmaf(a, c, s1);
+        }
+      }
+      __syncthreads();
     }
-    sdo[threadIdx.x] = cdo; sv[threadIdx.x] = cv;
-    __syncthreads();
-    if (rl == 0 && t < d) {
-      float a = 0.f, c = 0.f;
-      for (int q = 0; q < RL; ++q) { a += sdo[q * TCOL + tc]; c += sv[q * TCOL + tc]; }
-      s1 += a * c;
+  } else {
+    int TCOL = 256;                       // feature columns handled side by side (power of two >= min(d,256))
+    while (TCOL / 2 >= d) TCOL /= 2;
+    const int RL = 256 / TCOL;            // row lanes per column
+    const int tc = threadIdx.x % TCOL, rl = threadIdx.x / TCOL;
+    for (int t0 = 0; t0 < d; t0 += TCOL) {
+      const int t = t0 + tc;
+      float cdo = 0.f, cv = 0.f;
+      if (t < d) {
+        for (int i = rl; i < N; i += RL) {
+          const float a = vu_ld(dO + base + (long long)i * D + t);
+          cdo += a;
+          cv += vu_ld(v + base + (long long)i * D + t);
+          r += a * vu_ld(O + base + (long long)i * D + t);
+        }
+      }
+      sdo[threadIdx.x] = cdo; sv[threadIdx.x] = cv;
+      __syncthreads();
+      if (rl == 0 && t < d) {
+        float a = 0.f, c = 0.f;
+        for (int q = 0; q < RL; ++q) { a += sdo[q * TCOL + tc]; c += sv[q * TCOL + tc]; }
+        s1 += a * c;
+      }
+      __syncthreads();
     }
-    __syncthreads();
   }
   s1 = vu_block_sum(s1, sm);
   r = vu_block_sum(r, sm);
