@@ -1313,8 +1313,14 @@ __global__ __launch_bounds__(256) void bn_bwd_small_kernel(const T* __restrict__
 __global__ void bn_bwd_small_finalize_kernel(const float* partials, int nb, const float* gamma, const float* beta,
                                              const float* W, const float* c, float* stats, float* dgamma, float* dbeta,
                                              int H, double count, int training) {
-  const int g = threadIdx.x;
+  // 32 lanes per head (launched with 32 * H threads, H <= 16): strided partial sums, shuffle reduction
+  const int g = threadIdx.x >> 5, sub = threadIdx.x & 31;
   if (g >= H) return;
+  double s1 = 0.0, r = 0.0;
+  for (int i = sub; i < nb; i += 32) { s1 += (double)partials[i * 2 * H + g]; r += (double)partials[i * 2 * H + H + g]; }
+#pragma unroll
+  for (int m = 16; m >= 1; m >>= 1) { s1 += __shfl_xor(s1, m, 64); r += __shfl_xor(r, m, 64); }
+  if (sub != 0) return;
   {  // tables read by the map-backward kernels through scalar loads
     const float rstd = stats[H * H + 2 * H + g];
     float* X = stats + H * H + 5 * H;
@@ -1322,8 +1328,6 @@ __global__ void bn_bwd_small_finalize_kernel(const float* partials, int nb, cons
     X[H * H + g] = (c[g] - stats[H * H + H + g]) * rstd;
     X[H * H + H + g] = gamma[g] * rstd;
   }
-  double s1 = 0.0, r = 0.0;
-  for (int i = 0; i < nb; ++i) { s1 += (double)partials[i * 2 * H + g]; r += (double)partials[i * 2 * H + H + g]; }
   const double gm = gamma[g];
   const double s2 = fabs(gm) > 1e-20 ? (r - (double)beta[g] * s1) / gm : 0.0;
   dbeta[g] += (float)s1;
@@ -1340,7 +1344,7 @@ int vu_k_bn_bwd_small(int dtype, const void* dO, const void* O, const void* v, c
                       int training, hipStream_t st) {
   if (dtype == 0) hipLaunchKernelGGL((bn_bwd_small_kernel<float>), dim3(B, H), dim3(256), 0, st, (const float*)dO, (const float*)O, (const float*)v, partials, N, D, H);
   else hipLaunchKernelGGL((bn_bwd_small_kernel<bf16_t>), dim3(B, H), dim3(256), 0, st, (const bf16_t*)dO, (const bf16_t*)O, (const bf16_t*)v, partials, N, D, H);
-  hipLaunchKernelGGL(bn_bwd_small_finalize_kernel, dim3(1), dim3(64), 0, st, partials, B, gamma, beta, W, c, stats, dgamma, dbeta, H,
+  hipLaunchKernelGGL(bn_bwd_small_finalize_kernel, dim3(1), dim3(32 * H), 0, st, partials, B, gamma, beta, W, c, stats, dgamma, dbeta, H,
                      (double)B * N * N, training);
   if (vu_prof_on()) vu_prof_note("bn_bwd_small(2 kernels)", 0.0, 3.0 * B * N * D * (dtype == 0 ? 4.0 : 2.0));
   return vu_check_launch("vu_bn_bwd_small");

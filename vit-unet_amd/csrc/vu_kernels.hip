@@ -205,8 +205,18 @@ __global__ void bn_finalize_kernel(const float* partials, int nblocks, const flo
   const int Q = 2 * H, per = 256 / Q;          // Q <= 32 columns, `per` row lanes
   const int q = threadIdx.x % Q, rl = threadIdx.x / Q;
   double a = 0.0;
-  if (training && rl < per)
-    for (int i = rl; i < nblocks; i += per) a += (double)partials[i * Q + q];
+  if (training && rl < per) {
+    // independent loads first (8 in flight), then the fp64 sums: this single block is pure latency
+    int i = rl;
+    for (; i + 7 * per < nblocks; i += 8 * per) {
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = partials[(i + u * per) * Q + q];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a += (double)t[u];
+    }
+    for (; i < nblocks; i += per) a += (double)partials[i * Q + q];
+  }
   sd[threadIdx.x] = a;
   __syncthreads();
   if (threadIdx.x < Q) {
