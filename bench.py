@@ -177,10 +177,10 @@ def main():
             try:      # HBM bytes per launch from the committed rocprofv3 --pmc passes (not collectable in-process)
                 import glob
                 for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))[::-1]:
+                    # several template instances can share the name: the dominant launch is the one with most traffic
                     for sym, rec in json.load(open(f))["kernels"].items():
-                        if name.split("<")[0] in sym and rec.get("traffic_bytes"):
+                        if name.split("<")[0] in sym and rec.get("traffic_bytes") and rec["traffic_bytes"] > (traffic or 0):
                             traffic, tsrc = rec["traffic_bytes"], os.path.basename(f)
-                            break
                     if traffic:
                         break
             except Exception:

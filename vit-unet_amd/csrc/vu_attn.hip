@@ -93,17 +93,23 @@ __global__ __launch_bounds__(WAVES * 64) void attn_scores_kernel(const T* __rest
   // The workgroup staged K_g once; its waves now walk the 16-row query tiles of this (sample, head)
   // with no further barrier: a wave's stores drain while it multiplies its next tile.
   const int nrt = (N + 15) >> 4;
-  for (int rt = blockIdx.x * WAVES + wave; rt < nrt; rt += gridDim.x * WAVES) {
-  const int i0 = rt * 16;
-  Frag qf[KSTEPS];
-  {
-    const int row = i0 + l15;
+  // the q fragments of the next row tile are fetched while the current tile is multiplied and stored
+  Frag qn[KSTEPS];
+  auto load_q = [&](int rt) {
+    const int row = rt * 16 + l15;
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
       const int k0 = ks * MM::KS + lg * MM::FE;
-      qf[ks] = (row < N) ? load_frag<T>(qb + (long long)row * D + k0, d - k0, vec) : MM::zero();
+      qn[ks] = (rt < nrt && row < N) ? load_frag<T>(qb + (long long)row * D + k0, d - k0, vec) : MM::zero();
     }
-  }
+  };
+  load_q(blockIdx.x * WAVES + wave);
+  for (int rt = blockIdx.x * WAVES + wave; rt < nrt; rt += gridDim.x * WAVES) {
+  const int i0 = rt * 16;
+  Frag qf[KSTEPS];
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks) qf[ks] = qn[ks];
+  load_q(rt + gridDim.x * WAVES);
 
   // Swapped product S^T = K Q^T: the accumulator of tile nt holds, for query i0+l15 (the lane's
   // column), four consecutive keys j0(nt) + r (r = 0..3), so the row softmax reduces in-lane plus
