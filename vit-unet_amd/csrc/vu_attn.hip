@@ -1143,6 +1143,9 @@ __global__ __launch_bounds__(256) void mix_stats_mm_kernel(const bf16_t* __restr
     partials[blockIdx.x * 2 * H + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
+// A/B switch for measurements: VU_MAP_BWD_VALU=1 keeps the VALU map-backward kernels (read once)
+inline bool map_bwd_valu_forced() { static const bool v = getenv("VU_MAP_BWD_VALU") != nullptr; return v; }
+
 template <int WPR>
 int launch_map_bwd_mm(const void* Ps, void* dA, const float* W, const float* c, const float* gamma, const float* stats,
                       float* dW, float* dc, int B, int N, int ld, float inv_keep, float scale, hipStream_t st) {
@@ -1167,7 +1170,7 @@ int launch_map_bwd_row(const void* Ps, void* dA, const float* W, const float* c,
                        float* dW, float* dc, int B, int N, int ld, float inv_keep, float scale, hipStream_t st) {
   const long long rows = (long long)B * N;
   if constexpr (H == 8 && sizeof(T) == 2) {
-    if (ld <= 256 && ld >= 64 && !getenv("VU_MAP_BWD_VALU"))
+    if (ld <= 256 && ld >= 64 && !map_bwd_valu_forced())
       return launch_map_bwd_mm<1>(Ps, dA, W, c, gamma, stats, dW, dc, B, N, ld, inv_keep, scale, st);
   }
   if (ld <= 256) {
@@ -1181,7 +1184,7 @@ int launch_map_bwd_row(const void* Ps, void* dA, const float* W, const float* c,
     const size_t lds = (size_t)(3 * H + 1) * (ldk + 8) * 2;
     const bool big = ld > 1024;
     if constexpr (H == 8) {
-      if (!big && !getenv("VU_MAP_BWD_VALU")) return launch_map_bwd_mm<4>(Ps, dA, W, c, gamma, stats, dW, dc, B, N, ld, inv_keep, scale, st);
+      if (!big && !map_bwd_valu_forced()) return launch_map_bwd_mm<4>(Ps, dA, W, c, gamma, stats, dW, dc, B, N, ld, inv_keep, scale, st);
     }
     auto kern = big ? map_bwd_mfma_kernel<(H <= 4 ? H : 4), 16> : map_bwd_mfma_kernel<H, 4>;
     if (lds > 40 * 1024) {

@@ -403,13 +403,16 @@ int vu_k_conv3x3_qkv_dgrad(int dtype, const void* dq, const void* dk, const void
   return vu_check_launch("vu_conv3x3_qkv_dgrad");
 }
 
+// A/B switch for measurements: VU_CONV_WGRAD_VALU=1 keeps the VALU weight-gradient kernel (read once)
+static bool wgrad_valu_forced() { static const bool v = getenv("VU_CONV_WGRAD_VALU") != nullptr; return v; }
+
 static int wgrad_launch(int dtype, int dout_f32, const WgradSet& set, int nconv, long long npatch, int C, int s,
                         hipStream_t st) {
   VU_REQUIRE(s % 4 == 0, "conv3x3: patch size must be a multiple of 4");
   VU_REQUIRE(npatch * s * s / 4 < 4294967295LL, "conv3x3: more than 2^32 pixel quads");
   const long long nq = npatch * s * s / 4;
   if (nq == 0) return VU_OK;
-  if (dtype == 1 && !dout_f32 && nconv == 3 && C == 3 && s % 8 == 0 && !getenv("VU_CONV_WGRAD_VALU")) {
+  if (dtype == 1 && !dout_f32 && nconv == 3 && C == 3 && s % 8 == 0 && !wgrad_valu_forced()) {
     const long long nunits = npatch * s * s / 32;
     // many waves, few blocks: every block ends in 243 float atomics on the same addresses (measured: 2048 blocks of
     // 4 waves 131 us, 512 x 4: 93 us, 256 x 4: 141 us per launch)
