@@ -34,6 +34,7 @@ struct vu_gemm_args {
   int vecA, vecB;      // 16-byte vector loads legal for A / B
   int swap;            // operands were exchanged by the launcher: the kernel computes C^T (vector stores)
   int vecC;            // 4-element vector access to C rows is aligned
+  int vec8;            // 8-element (16-byte) access to C / aux / addend rows is aligned and the row length is a multiple of 8
   float* colsum;       // optional: += column sums over k of an operand (bias gradients), see colsum_side
   int colsum_side;     // kernel space: 1 = sum_k A(m,k) -> colsum[m] ; 2 = sum_k B(k,n) -> colsum[n]
   int ksplit;          // >1: K is split over blockIdx.z and C is accumulated with float atomics
@@ -344,6 +345,91 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     }
   }
   // ---- epilogue -----------------------------------------------------------------------------
+  if constexpr (IS_BF16 && sizeof(TC) == 2 && BM == 128 && BN == 128) {
+    if (g.vec8) {
+      // bf16 output of the big tile: the accumulators go through LDS (fp32, two passes of 64 ORIGINAL rows) so that
+      // every global access of the epilogue - C, the GELU pre-activation, the residual addend - is a 16-byte
+      // access inside a full 256-byte row segment.  (The direct form writes 16 rows x 32 B per instruction; on a
+      // K = 64 GEMM that epilogue was 20 of 23 us.)
+      constexpr int LDC = 132;
+      float* Ct = reinterpret_cast<float*>(smem);
+      static_assert(64 * LDC * 4 <= (A_ELEMS + B_ELEMS) * (int)sizeof(T), "C staging tile must fit the operand buffers");
+      const vu_rng rng = g.dropout ? vu_rng_resolve(g.rng) : g.rng;
+      const long long coff = z1 * g.sC1 + z2 * g.sC2;
+      T* Cb = (T*)g.C + coff;
+      T* auxb = g.aux ? (T*)g.aux + coff : nullptr;
+      const T* addb = g.addend ? (const T*)g.addend + coff : nullptr;
+      const int Rtot = g.swap ? g.N : g.M, Ctot = g.swap ? g.M : g.N;          // original rows / columns
+      const int row0 = g.swap ? n_base : m_base, col0 = g.swap ? m_base : n_base;
+      const bool lead = blockIdx.z == 0;
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        if (p) __syncthreads();
+        if (g.swap) {
+          if (wn == p) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int j = 0; j < TN; ++j) {
+                const float4 v4 = make_float4(acc[i][j][0] * g.alpha, acc[i][j][1] * g.alpha, acc[i][j][2] * g.alpha, acc[i][j][3] * g.alpha);
+                *reinterpret_cast<float4*>(&Ct[(j * 16 + l15) * LDC + wm * 64 + i * 16 + lg * 4]) = v4;
+              }
+          }
+        } else {
+          if (wm == p) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Ct[(i * 16 + lg * 4 + r) * LDC + wn * 64 + j * 16 + l15] = acc[i][j][r] * g.alpha;
+          }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int rl = it * 16 + (tid >> 4), c8 = (tid & 15) * 8;
+          const int orow = row0 + 64 * p + rl, ocol = col0 + c8;
+          if (orow < Rtot && ocol < Ctot) {
+            float v[8];
+            const float4 a0 = *reinterpret_cast<const float4*>(&Ct[rl * LDC + c8]), a1 = *reinterpret_cast<const float4*>(&Ct[rl * LDC + c8 + 4]);
+            v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
+            if (g.bias && lead) {
+              const float4 b0 = *reinterpret_cast<const float4*>(g.bias + ocol), b1 = *reinterpret_cast<const float4*>(g.bias + ocol + 4);
+              v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+            }
+            const long long o = (long long)orow * g.ldc + ocol;
+            union U8 { uint4 u; bf16_t h[8]; };
+            if (g.act == VU_ACT_GELU) {
+              U8 t;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) { t.h[e] = (bf16_t)v[e]; v[e] = vu_gelu(v[e]); }
+              *reinterpret_cast<uint4*>(auxb + o) = t.u;
+            } else if (g.act == VU_ACT_DGELU) {
+              U8 t; t.u = *reinterpret_cast<const uint4*>(auxb + o);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] *= vu_gelu_grad((float)t.h[e]);
+            }
+            if (g.dropout) {
+              const uint64_t idx = ((uint64_t)z * Rtot + orow) * (uint64_t)Ctot + ocol;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = vu_keep(rng, idx + e) ? v[e] * rng.inv_keep : 0.f;
+            }
+            if (addb) {
+              U8 t; t.u = *reinterpret_cast<const uint4*>(addb + o);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] += (float)t.h[e];
+            }
+            U8 w;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) w.h[e] = (bf16_t)v[e];
+            *reinterpret_cast<uint4*>(Cb + o) = w.u;
+          }
+        }
+      }
+      return;
+    }
+  }
   vu_epi_ctx<T, TC> ec;
   ec.rng = g.dropout ? vu_rng_resolve(g.rng) : g.rng;
   const long long coff = z1 * g.sC1 + z2 * g.sC2;

@@ -56,7 +56,7 @@ static int launch_tiles(const vu_gemm_args& g, hipStream_t st) {
 template <typename T>
 static int launch_layout(vu_gemm_args& g0, int c_float, hipStream_t st) {
   vu_gemm_args g = g0;
-  g.swap = 0; g.vecC = 0;
+  g.swap = 0; g.vecC = 0; g.vec8 = 0;
   const size_t csz = (sizeof(T) == 2 && !c_float) ? 2 : 4;
   // C^T = B^T A^T: same arithmetic, but each lane then owns 4 consecutive elements of a C row,
   // so the epilogue stores (and reads aux / addend) as vectors.  Needs >= 64 original columns.
@@ -71,6 +71,10 @@ static int launch_layout(vu_gemm_args& g0, int c_float, hipStream_t st) {
     g.vecC = ((uintptr_t)g0.C % (4 * csz) == 0) && (g0.ldc % 4 == 0) && (g0.sC1 % 4 == 0) && (g0.sC2 % 4 == 0) &&
              (!g0.aux || (uintptr_t)g0.aux % 8 == 0) && (!g0.addend || (uintptr_t)g0.addend % 8 == 0);
   }
+  // (original C geometry is the same with or without the operand exchange)
+  g.vec8 = (sizeof(T) == 2 && !c_float && g0.N % 8 == 0 && g0.ldc % 8 == 0 && g0.sC1 % 8 == 0 && g0.sC2 % 8 == 0 &&
+            (uintptr_t)g0.C % 16 == 0 && (!g0.aux || (uintptr_t)g0.aux % 16 == 0) && (!g0.addend || (uintptr_t)g0.addend % 16 == 0) &&
+            (!g0.bias || (uintptr_t)g0.bias % 16 == 0)) ? 1 : 0;
   const bool TA = g.sAk != 1, TB = g.sBk != 1;
   if (TA && g.sAm != 1) { vu_set_error("vu_gemm: A must have a unit stride"); return VU_EINVAL; }
   if (TB && g.sBn != 1) { vu_set_error("vu_gemm: B must have a unit stride"); return VU_EINVAL; }
