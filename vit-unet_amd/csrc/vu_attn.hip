@@ -307,6 +307,11 @@ int launch_scores(const T* q, const T* k, T* Ps, int B, int N, int D, int H, int
     if (softmax) return launch_scores_w<T, NT, DP, 8>(q, k, Ps, B, N, D, H, ld, scale, rng, softmax, st);
     return launch_scores_w<T, NT, DP, 7>(q, k, Ps, B, N, D, H, ld, scale, rng, softmax, st);
   }
+  else if constexpr (NT == 13) {
+    // 9..13 row tiles (level 1, N = 196): 7 waves walk them in two rounds instead of four
+    if (N > 128) return launch_scores_w<T, NT, DP, 7>(q, k, Ps, B, N, D, H, ld, scale, rng, softmax, st);
+    return launch_scores_w<T, NT, DP, 4>(q, k, Ps, B, N, D, H, ld, scale, rng, softmax, st);
+  }
   else return launch_scores_w<T, NT, DP, 4>(q, k, Ps, B, N, D, H, ld, scale, rng, softmax, st);
 }
 
