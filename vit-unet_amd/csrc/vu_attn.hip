@@ -1,484 +1,10 @@
-// Fused re-attention kernels for gfx950.
-//
-// attn_scores_kernel (K6+K7+K8, model.py:155-157): one workgroup = 64 query rows of one (batch,
-// head); the head's whole K (N x d, always 2*P/h bytes = 37.6 KB in bf16 for 224x224x3) is staged
-// in LDS once, each wave computes its 16 x N logits tile with MFMA into registers (N <= 784:
-// 49 accumulator tiles), does the row softmax with 16-lane shuffles, draws the dropout mask from
-// the counter hash and writes the sign-tagged probabilities - the (B,h,N,N) logits never touch
-// HBM.  Algorithmic traffic: one write of the map (E*|T|) + q, k reads.
+// Entry points of the fused scores kernels (vu_attn_scores.h); the four {type} x {form} instantiation sets live in
+// vu_attn_sc_*.hip so that they build in parallel.
 #include <stdlib.h>
-#include <type_traits>
 #include "vu_kernels.h"
 
-namespace {
-
-template <typename T> struct Mma;
-template <> struct Mma<bf16_t> {
-  static constexpr int KS = 32;          // k per MFMA
-  static constexpr int FE = 8;           // elements per lane fragment
-  typedef bf16x8 Frag;
-  static __device__ __forceinline__ Frag zero() { return Frag{0, 0, 0, 0, 0, 0, 0, 0}; }
-  static __device__ __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-  }
-};
-template <> struct Mma<float> {
-  static constexpr int KS = 4;
-  static constexpr int FE = 1;
-  typedef float Frag;
-  static __device__ __forceinline__ Frag zero() { return 0.f; }
-  static __device__ __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-  }
-};
-
-// fragment of a k-contiguous row: FE consecutive elements starting at p (k bounds handled by caller)
-template <typename T>
-__device__ __forceinline__ typename Mma<T>::Frag load_frag(const T* p, int kvalid, bool vec) {
-  typedef typename Mma<T>::Frag Frag;
-  constexpr int FE = Mma<T>::FE;
-  if constexpr (FE == 1) {
-    return kvalid > 0 ? (float)p[0] : 0.f;
-  } else {
-    if (vec && kvalid >= FE) return *reinterpret_cast<const Frag*>(p);
-    Frag f = Mma<T>::zero();
-#pragma unroll
-    for (int e = 0; e < FE; ++e)
-      if (e < kvalid) f[e] = p[e];
-    return f;
-  }
-}
-
-// DP = head dim padded to a multiple of 32 ; NT = max 16-column tiles (N <= 16*NT)
-template <typename T, int NT, int DP, int WAVES, bool EXACT, bool SOFTMAX>
-__global__ __launch_bounds__(WAVES * 64) void attn_scores_kernel(const T* __restrict__ q, const T* __restrict__ k,
-                                                          T* __restrict__ Ps, int N, int D, int H, int d, int ld,
-                                                          float scale, vu_rng rng_in) {
-  typedef Mma<T> MM;
-  typedef typename MM::Frag Frag;
-  constexpr int KSTEPS = DP / MM::KS;
-  constexpr int LDK = DP + (sizeof(T) == 2 ? 8 : 4);   // LDS row stride (elements)
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T* Ks = reinterpret_cast<T*>(smem_raw);
-  const vu_rng rng = vu_rng_resolve(rng_in);
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int l15 = lane & 15, lg = lane >> 4;
-  const int bz = blockIdx.y, b = bz / H, g = bz % H;
-  const T* qb = q + (long long)b * N * D + g * d;
-  const T* kb = k + (long long)b * N * D + g * d;
-  const bool vec = (d % (16 / (int)sizeof(T)) == 0);   // head slices 16-byte aligned
-
-  // ---- stage K_g (N x d, zero-padded to DP columns) in LDS ---------------------------------
-  {
-    constexpr int VE = 16 / sizeof(T);
-    const int chunks_per_row = DP / VE;
-    const int total = N * chunks_per_row;
-    for (int c = tid; c < total; c += WAVES * 64) {
-      const int row = c / chunks_per_row, kc = (c % chunks_per_row) * VE;
-      alignas(16) T tmp[VE];
-      if (vec && kc + VE <= d) {
-        *reinterpret_cast<uint4*>(tmp) = *reinterpret_cast<const uint4*>(kb + (long long)row * D + kc);
-      } else {
-#pragma unroll
-        for (int e = 0; e < VE; ++e) tmp[e] = (kc + e < d) ? kb[(long long)row * D + kc + e] : (T)0.f;
-      }
-      // keys of whole 64-key groups are stored with their two 2-bit index fields exchanged
-      // (key 64u + 16a + 4b + c -> LDS row 64u + 16b + 4a + c): see the tile -> key map below
-      const int lrow = row < (EXACT ? ((NT * 16) >> 6) << 6 : (N >> 6) << 6) ? ((row & ~60) | (((row >> 2) & 3) << 4) | (((row >> 4) & 3) << 2)) : row;
-      *reinterpret_cast<uint4*>(&Ks[lrow * LDK + kc]) = *reinterpret_cast<uint4*>(tmp);
-    }
-  }
-  __syncthreads();
-  // The workgroup staged K_g once; its waves now walk the 16-row query tiles of this (sample, head)
-  // with no further barrier: a wave's stores drain while it multiplies its next tile.
-  const int nrt = (N + 15) >> 4;
-  // the q fragments of the next row tile are fetched while the current tile is multiplied and stored
-  Frag qn[KSTEPS];
-  auto load_q = [&](int rt) {
-    const int row = rt * 16 + l15;
-#pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) {
-      const int k0 = ks * MM::KS + lg * MM::FE;
-      qn[ks] = (rt < nrt && row < N) ? load_frag<T>(qb + (long long)row * D + k0, d - k0, vec) : MM::zero();
-    }
-  };
-  load_q(blockIdx.x * WAVES + wave);
-  for (int rt = blockIdx.x * WAVES + wave; rt < nrt; rt += gridDim.x * WAVES) {
-  const int i0 = rt * 16;
-  Frag qf[KSTEPS];
-#pragma unroll
-  for (int ks = 0; ks < KSTEPS; ++ks) qf[ks] = qn[ks];
-  load_q(rt + gridDim.x * WAVES);
-
-  // Swapped product S^T = K Q^T: the accumulator of tile nt holds, for query i0+l15 (the lane's
-  // column), four consecutive keys j0(nt) + r (r = 0..3), so the row softmax reduces in-lane plus
-  // two shuffles, a dropout hash word serves an in-lane key pair, and the stores are vectors.
-  // Which key an accumulator row stands for is free (it only picks the K row an A-operand lane
-  // reads): whole groups of 4 tiles (64 keys) are dealt so that a lane's 4 tiles hold 16
-  // CONSECUTIVE keys, 64u + 16 lg + 4 s + r - a query row is then written in full 128-byte
-  // segments (4 lanes x 32 B) with 16-byte stores instead of 32-byte segments of 8-byte stores.
-  // The permutation lives in the K staging pass (LDS row order), so fragment reads stay conflict-free.
-  // EXACT: N == 16 * NT - every tile exists and is full, so all tile conditions fold at compile time
-  const int ntiles = EXACT ? NT : (N + 15) >> 4;
-  const int ngt = EXACT ? ((NT * 16) >> 6) << 2 : (N >> 6) << 2;   // tiles in whole (fully valid) groups of 64 keys
-  // (opaque copy of lg: otherwise every per-tile column / hash index is hoisted out of the row-tile loop as a
-  // loop invariant, ~60 live registers that spill - and a scratch reload's vmcnt wait drains the store stream)
-  int lgv = lg;
-  asm volatile("" : "+v"(lgv));
-  auto j0_of = [&](int nt) { return nt < ngt ? ((nt >> 2) << 6) + (lgv << 4) + ((nt & 3) << 2) : nt * 16 + lgv * 4; };
-  f32x4 acc[NT];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (nt < ntiles) {
-      const int key = nt * 16 + l15;       // LDS row (the staging pass applied the group permutation)
-      const bool kv = EXACT || key < N;
-#pragma unroll
-      for (int ks = 0; ks < KSTEPS; ++ks) {
-        Frag kf;
-        if constexpr (MM::FE == 1) kf = kv ? (float)Ks[key * LDK + ks * MM::KS + lg] : 0.f;
-        else kf = kv ? *reinterpret_cast<const Frag*>(&Ks[key * LDK + ks * MM::KS + lg * MM::FE]) : MM::zero();
-        acc[nt] = MM::mma(kf, qf[ks], acc[nt]);
-      }
-    }
-    if constexpr (NT > 16) { if (nt % 7 == 6) __builtin_amdgcn_sched_barrier(0); }   // bound the K fragments in flight
-  }
-  // store tiles nt (and nt+1 when both sit in a whole group: 8 consecutive keys, one 16-byte store for bf16)
-  auto store_tiles = [&](T* prow, int nt, bool pair, const vu_f4& oa, const vu_f4& ob) {
-    const int j0 = j0_of(nt);
-    if constexpr (sizeof(T) == 2) {
-      if (pair) {
-        union { uint4 u; bf16_t h[8]; } pk;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { pk.h[r] = (bf16_t)oa.v[r]; pk.h[4 + r] = (bf16_t)ob.v[r]; }
-        *reinterpret_cast<uint4*>(prow + j0) = pk.u;
-        return;
-      }
-    }
-    if (EXACT || j0 < ld) vu_st4(prow + j0, oa);
-    if (pair) { const int j1 = j0_of(nt + 1); if (EXACT || j1 < ld) vu_st4(prow + j1, ob); }
-  };
-  if constexpr (!SOFTMAX) {   // plain product (dAhat = dO v^T in the backward): scaled vector stores
-    const int i = i0 + l15;
-    if (i < N) {
-      T* prow = Ps + ((long long)bz * N + i) * ld;
-#pragma unroll
-      for (int nt = 0; nt < NT; nt += 2) {
-        if (nt < ntiles) {
-          const bool pair = (nt + 1 < NT) && (nt + 1 < ntiles);
-          vu_f4 oa, ob = {{0.f, 0.f, 0.f, 0.f}};
-          const int ja = j0_of(nt);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) oa.v[r] = (EXACT || ja + r < N) ? acc[nt][r] * scale : 0.f;
-          if (nt + 1 < NT) {
-            const int jb = j0_of(nt + 1);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) ob.v[r] = (EXACT || jb + r < N) ? acc[nt + 1][r] * scale : 0.f;
-          }
-          if (pair && nt + 1 < ngt) store_tiles(prow, nt, true, oa, ob);
-          else { store_tiles(prow, nt, false, oa, oa); if (pair) store_tiles(prow, nt + 1, false, ob, ob); }
-        }
-      }
-    }
-    continue;
-  }
-  // ---- row softmax (logits rounded to the storage type first, like the unfused path) ------------
-  // Only the last key tile can be partial: full tiles take a mask-free path (wave-uniform branch).
-  float mx = -INFINITY;
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    if (nt < ntiles) {
-      const int j0 = j0_of(nt);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float sv = acc[nt][r] * scale;
-        if constexpr (sizeof(T) == 2) sv = (float)(bf16_t)sv;
-        if constexpr (!EXACT) sv = (j0 + r < N) ? sv : -INFINITY;
-        acc[nt][r] = sv;
-        mx = fmaxf(mx, sv);
-      }
-    }
-  }
-  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-  float sum = 0.f;
-  const float mxl = mx * 1.44269504088896341f;
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    if (nt < ntiles) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float e;
-        // fp32 storage: subtract first (exact for nearby floats; large logits would lose bits in x*log2e - m*log2e).
-        // bf16 storage: the logits were just rounded to 8 significant bits, one fma + exp2 is ample.
-        if constexpr (sizeof(T) == 2) e = __builtin_amdgcn_exp2f(fmaf(acc[nt][r], 1.44269504088896341f, -mxl));
-        else e = __expf(acc[nt][r] - mx);          // exp(-inf) = 0 for masked keys
-        acc[nt][r] = e;
-        sum += e;
-      }
-    }
-  }
-  sum += __shfl_xor(sum, 16, 64);
-  sum += __shfl_xor(sum, 32, 64);
-  const float inv = 1.0f / sum;
-  // ---- dropout + sign-tagged store -------------------------------------------------------------
-  // mask index of element (row, j) = row * ld + j with ld even: keys (j0, j0+1) and (j0+2, j0+3)
-  // each share one 32-bit hash word (16 bits per element).
-  const int i = i0 + l15;
-  if (i < N) {
-    const uint64_t rowi = (uint64_t)bz * N + i;
-    T* prow = Ps + rowi * ld;
-    const uint32_t ib32 = (uint32_t)(rowi * (uint64_t)ld);   // launcher guarantees < 2^32 map elements
-    const uint32_t thr = rng.thr;
-    auto tile_out = [&](int nt, const f32x4& a) {
-      const int j0 = j0_of(nt);
-      float o0 = a[0] * inv, o1 = a[1] * inv, o2 = a[2] * inv, o3 = a[3] * inv;
-      if (thr) {
-        // 16-bit lanes of two hash words; (x - thr) is negative exactly when x < thr: its sign
-        // bit is the "dropped" tag, XOR-ed into the sign of the probability
-        const uint32_t wa = vu_hash_word32(rng, ib32 + j0), wb = vu_hash_word32(rng, ib32 + j0 + 2);
-        o0 = __uint_as_float(__float_as_uint(o0) ^ (((wa & 0xffffu) - thr) & 0x80000000u));
-        o1 = __uint_as_float(__float_as_uint(o1) ^ (((wa >> 16) - thr) & 0x80000000u));
-        o2 = __uint_as_float(__float_as_uint(o2) ^ (((wb & 0xffffu) - thr) & 0x80000000u));
-        o3 = __uint_as_float(__float_as_uint(o3) ^ (((wb >> 16) - thr) & 0x80000000u));
-      }
-      if constexpr (!EXACT) {   // zero the padding columns of the partial tile
-        if (j0 + 0 >= N) o0 = 0.f;
-        if (j0 + 1 >= N) o1 = 0.f;
-        if (j0 + 2 >= N) o2 = 0.f;
-        if (j0 + 3 >= N) o3 = 0.f;
-      }
-      const vu_f4 o = {{o0, o1, o2, o3}};
-      return o;
-    };
-#pragma unroll
-    for (int nt = 0; nt < NT; nt += 2) {
-      if (nt < ntiles) {
-        const bool pair = (nt + 1 < NT) && (nt + 1 < ntiles);
-        const vu_f4 oa = tile_out(nt, acc[nt]);
-        vu_f4 ob = oa;
-        if (nt + 1 < NT) { if (pair) ob = tile_out(nt + 1, acc[nt + 1]); }
-        if (pair && nt + 1 < ngt) store_tiles(prow, nt, true, oa, ob);
-        else { store_tiles(prow, nt, false, oa, oa); if (pair) store_tiles(prow, nt + 1, false, ob, ob); }
-      }
-      // keep the tiles' hash / tag / store chains apart: scheduled together they need > 256 registers
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-  }   // row tiles
-}
-
-template <typename T, int NT, int DP, int WAVES>
-int launch_scores_w(const T* q, const T* k, T* Ps, int B, int N, int D, int H, int ld, float scale, vu_rng rng,
-                    bool softmax, hipStream_t st) {
-  const int d = D / H;
-  constexpr int LDK = DP + (sizeof(T) == 2 ? 8 : 4);
-  const size_t lds = (size_t)N * LDK * sizeof(T);
-  const bool full = N == 16 * NT;
-  auto kern = softmax ? (full ? attn_scores_kernel<T, NT, DP, WAVES, true, true> : attn_scores_kernel<T, NT, DP, WAVES, false, true>)
-                      : (full ? attn_scores_kernel<T, NT, DP, WAVES, true, false> : attn_scores_kernel<T, NT, DP, WAVES, false, false>);
-  if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) { vu_set_error("attn_scores: cannot reserve %zu bytes of LDS", lds); return VU_ELAUNCH; }
-  }
-  // one workgroup per (sample, head) stages K once and walks all row tiles; small batches split the
-  // row tiles over several workgroups so that at least ~512 are in flight
-  const int nrt = (N + 15) / 16, maxsplit = (nrt + WAVES - 1) / WAVES;
-  int nsplit = (512 + B * H - 1) / (B * H);
-  if (softmax && N > 208) nsplit = maxsplit;   // VALU-bound form: one tile per wave, finer-grained balance (measured)
-  if (nsplit > maxsplit) nsplit = maxsplit;
-  if (nsplit < 1) nsplit = 1;
-  dim3 grid((unsigned)nsplit, (unsigned)(B * H));
-  hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, st, q, k, Ps, N, D, H, d, ld, scale, rng);
-  if (vu_prof_on()) vu_prof_note(softmax ? "attn_scores_kernel" : "attn_dscores_kernel", 2.0 * B * H * (double)N * N * d,
-                                 ((double)B * H * N * N + 2.0 * B * N * D) * sizeof(T));
-  return vu_check_launch("vu_attn_scores");
-}
-
-template <typename T, int NT, int DP>
-int launch_scores(const T* q, const T* k, T* Ps, int B, int N, int D, int H, int ld, float scale, vu_rng rng,
-                  bool softmax, hipStream_t st) {
-  // long rows (N > 208): 128-row workgroups (8 waves) halve the K re-staging; measured 2.0 ms vs
-  // 3.25 ms per step against 64-row workgroups on Base (profiles/).
-  // long rows: the plain product is store-bound and takes 7 waves (49 row tiles = 7 x 7 at N = 784); the
-  // softmax form is VALU-bound (exp + dropout hash) and wants all 8 wave slots of the CU
-  if constexpr (NT > 13) {
-    if (softmax) return launch_scores_w<T, NT, DP, 8>(q, k, Ps, B, N, D, H, ld, scale, rng, softmax, st);
-    return launch_scores_w<T, NT, DP, 7>(q, k, Ps, B, N, D, H, ld, scale, rng, softmax, st);
-  }
-  else if constexpr (NT == 13) {
-    // 9..13 row tiles (level 1, N = 196): 7 waves walk them in two rounds instead of four
-    if (N > 128) return launch_scores_w<T, NT, DP, 7>(q, k, Ps, B, N, D, H, ld, scale, rng, softmax, st);
-    return launch_scores_w<T, NT, DP, 4>(q, k, Ps, B, N, D, H, ld, scale, rng, softmax, st);
-  }
-  else return launch_scores_w<T, NT, DP, 4>(q, k, Ps, B, N, D, H, ld, scale, rng, softmax, st);
-}
-
-// ---------------------------------------------------------------------------------------------
-// attn_scores_long_kernel: rows too long for the register-resident form (N > 784, d <= 32:
-// Lite level 2 has N = 3136, the 512x512 config N = 4096).  K streams through LDS in chunks of
-// 512 keys; with softmax the kernel sweeps the keys twice - sweep 1 keeps an online (max, sum)
-// per lane, sweep 2 recomputes the logits with MFMA (K = d is tiny) and writes the tagged
-// probabilities - so the logits still never reach HBM.
-// ---------------------------------------------------------------------------------------------
-template <typename T, bool EXACT, bool SOFTMAX>
-__global__ __launch_bounds__(512) void attn_scores_long_kernel(const T* __restrict__ q, const T* __restrict__ k,
-                                                               T* __restrict__ Ps, int N, int D, int H, int d, int ld,
-                                                               float scale, vu_rng rng_in) {
-  typedef Mma<T> MM;
-  typedef typename MM::Frag Frag;
-  constexpr int DP = 32, CH = 512, WAVES = 8;
-  constexpr int KSTEPS = DP / MM::KS;
-  constexpr int LDK = DP + (sizeof(T) == 2 ? 8 : 4);
-  __shared__ __attribute__((aligned(16))) T Ks[CH * LDK];
-  const vu_rng rng = vu_rng_resolve(rng_in);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int l15 = lane & 15, lg = lane >> 4;
-  const int bz = blockIdx.y, b = bz / H, g = bz % H;
-  const T* qb = q + (long long)b * N * D + g * d;
-  const T* kb = k + (long long)b * N * D + g * d;
-  const bool vec = (d % (16 / (int)sizeof(T)) == 0);
-  const int i0 = blockIdx.x * (WAVES * 16) + wave * 16;
-  Frag qf[KSTEPS];
-  {
-    const int row = i0 + l15;
-#pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) {
-      const int k0 = ks * MM::KS + lg * MM::FE;
-      qf[ks] = (row < N) ? load_frag<T>(qb + (long long)row * D + k0, d - k0, vec) : MM::zero();
-    }
-  }
-  const int i = i0 + l15;
-  const uint64_t rowi = (uint64_t)bz * N + (i < N ? i : 0);
-  T* prow = Ps + rowi * ld;
-  const uint32_t ib32 = (uint32_t)(rowi * (uint64_t)ld);
-  const uint32_t thr = rng.thr;
-  float mrun = -INFINITY, srun = 0.f, Mx = 0.f, inv = 0.f;
-  for (int sweep = 0; sweep < (SOFTMAX ? 2 : 1); ++sweep) {
-    for (int c0 = 0; c0 < N; c0 += CH) {
-      __syncthreads();
-      {  // stage keys [c0, c0+CH) (zero-padded to DP columns)
-        constexpr int VE = 16 / sizeof(T);
-        constexpr int cpr = DP / VE;
-        for (int c = tid; c < CH * cpr; c += WAVES * 64) {
-          const int row = c / cpr, kc = (c % cpr) * VE;
-          alignas(16) T tmp[VE];
-          const int key = c0 + row;
-          if (key < N && vec && kc + VE <= d) {
-            *reinterpret_cast<uint4*>(tmp) = *reinterpret_cast<const uint4*>(kb + (long long)key * D + kc);
-          } else {
-#pragma unroll
-            for (int e = 0; e < VE; ++e) tmp[e] = (key < N && kc + e < d) ? kb[(long long)key * D + kc + e] : (T)0.f;
-          }
-          *reinterpret_cast<uint4*>(&Ks[row * LDK + kc]) = *reinterpret_cast<uint4*>(tmp);
-        }
-      }
-      __syncthreads();
-      const int ntl = (N - c0 < CH ? N - c0 : CH);
-      for (int nt = 0; nt * 16 < ntl; ++nt) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        const int key = nt * 16 + l15;
-#pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) {
-          Frag kf;
-          if constexpr (MM::FE == 1) kf = (float)Ks[key * LDK + ks * MM::KS + lg];
-          else kf = *reinterpret_cast<const Frag*>(&Ks[key * LDK + ks * MM::KS + lg * MM::FE]);
-          acc = MM::mma(kf, qf[ks], acc);
-        }
-        const int j0 = c0 + nt * 16 + lg * 4;       // this lane's 4 consecutive keys
-        float x[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float sv = acc[r] * scale;
-          if constexpr (SOFTMAX) {
-            if constexpr (sizeof(T) == 2) sv = (float)(bf16_t)sv;
-            if constexpr (!EXACT) sv = (j0 + r < N) ? sv : -INFINITY;
-          }
-          x[r] = sv;
-        }
-        if constexpr (!SOFTMAX) {
-          if (i < N && (EXACT || j0 < ld)) {
-            vu_f4 o;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o.v[r] = (EXACT || j0 + r < N) ? x[r] : 0.f;
-            vu_st4(prow + j0, o);
-          }
-        } else if (sweep == 0) {
-          const float tm = fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3]));
-          const float mn = fmaxf(mrun, tm);
-          if (mn > -INFINITY) {   // differences first (exact for nearby floats), then the exponential
-            srun = srun * __expf(mrun - mn) + __expf(x[0] - mn) + __expf(x[1] - mn) + __expf(x[2] - mn) + __expf(x[3] - mn);
-            mrun = mn;
-          }
-        } else if (i < N && (EXACT || j0 < ld)) {
-          float o0 = __expf(x[0] - Mx) * inv, o1 = __expf(x[1] - Mx) * inv;
-          float o2 = __expf(x[2] - Mx) * inv, o3 = __expf(x[3] - Mx) * inv;
-          if (thr) {
-            const uint32_t wa = vu_hash_word32(rng, ib32 + j0), wb = vu_hash_word32(rng, ib32 + j0 + 2);
-            o0 = __uint_as_float(__float_as_uint(o0) ^ (((wa & 0xffffu) - thr) & 0x80000000u));
-            o1 = __uint_as_float(__float_as_uint(o1) ^ (((wa >> 16) - thr) & 0x80000000u));
-            o2 = __uint_as_float(__float_as_uint(o2) ^ (((wb & 0xffffu) - thr) & 0x80000000u));
-            o3 = __uint_as_float(__float_as_uint(o3) ^ (((wb >> 16) - thr) & 0x80000000u));
-          }
-          if constexpr (!EXACT) {
-            if (j0 + 0 >= N) o0 = 0.f;
-            if (j0 + 1 >= N) o1 = 0.f;
-            if (j0 + 2 >= N) o2 = 0.f;
-            if (j0 + 3 >= N) o3 = 0.f;
-          }
-          vu_f4 o = {{o0, o1, o2, o3}};
-          vu_st4(prow + j0, o);
-        }
-      }
-    }
-    if (SOFTMAX && sweep == 0) {   // combine the 4 lanes (lg = 0..3) that share a query
-      float M = fmaxf(mrun, __shfl_xor(mrun, 16, 64));
-      M = fmaxf(M, __shfl_xor(M, 32, 64));
-      float sc = (mrun > -INFINITY) ? srun * __expf(mrun - M) : 0.f;
-      sc += __shfl_xor(sc, 16, 64);
-      sc += __shfl_xor(sc, 32, 64);
-      Mx = M;
-      inv = 1.0f / sc;
-    }
-  }
-}
-
-template <typename T>
-int launch_scores_long(const void* q, const void* k, void* Ps, int B, int N, int D, int H, int ld, float scale, vu_rng rng,
-                       bool softmax, hipStream_t st) {
-  const int d = D / H;
-  auto kern = softmax ? ((N % 16 == 0) ? attn_scores_long_kernel<T, true, true> : attn_scores_long_kernel<T, false, true>)
-                      : ((N % 16 == 0) ? attn_scores_long_kernel<T, true, false> : attn_scores_long_kernel<T, false, false>);
-  dim3 grid((unsigned)((N + 127) / 128), (unsigned)(B * H));
-  hipLaunchKernelGGL(kern, grid, dim3(512), 0, st, (const T*)q, (const T*)k, (T*)Ps, N, D, H, d, ld, scale, rng);
-  if (vu_prof_on()) vu_prof_note(softmax ? "attn_scores_long_kernel" : "attn_dscores_long_kernel",
-                                 (softmax ? 4.0 : 2.0) * B * H * (double)N * N * d, ((double)B * H * N * N + 2.0 * B * N * D) * sizeof(T));
-  return vu_check_launch("vu_attn_scores_long");
-}
-
-template <typename T>
-int dispatch_scores(const void* q, const void* k, void* Ps, int B, int N, int D, int H, int ld, float scale, vu_rng rng,
-                    bool softmax, hipStream_t st) {
-  const int d = D / H;
-  const int dp = (d + 31) / 32 * 32;
-  const int nt = (N + 15) / 16;
-#define VU_SC(NTv, DPv) return launch_scores<T, NTv, DPv>((const T*)q, (const T*)k, (T*)Ps, B, N, D, H, ld, scale, rng, softmax, st)
-  if (nt <= 4) {
-    if (dp == 32) VU_SC(4, 32); if (dp == 64) VU_SC(4, 64); if (dp == 96) VU_SC(4, 96); if (dp == 128) VU_SC(4, 128);
-    if (dp == 192) VU_SC(4, 192); if (dp == 384) VU_SC(4, 384);
-  } else if (nt <= 13) {
-    if (dp == 32) VU_SC(13, 32); if (dp == 64) VU_SC(13, 64); if (dp == 96) VU_SC(13, 96); if (dp == 128) VU_SC(13, 128);
-  } else if (nt <= 49) {
-    if (dp == 32) VU_SC(49, 32); if (dp == 64) VU_SC(49, 64);
-  } else if (dp == 32) {
-    return launch_scores_long<T>(q, k, Ps, B, N, D, H, ld, scale, rng, softmax, st);
-  }
-#undef VU_SC
-  return 1;   // shape not covered: the caller falls back to GEMM + softmax kernels
-}
-
-}  // namespace
+#define VU_SC_DECL(name) int name(const void*, const void*, void*, int, int, int, int, int, float, vu_rng, hipStream_t)
+VU_SC_DECL(vu_scores_f32_softmax); VU_SC_DECL(vu_scores_f32_plain); VU_SC_DECL(vu_scores_bf16_softmax); VU_SC_DECL(vu_scores_bf16_plain);
 
 // returns VU_OK, a negative error, or 1 when the shape is not covered by the fused kernel
 int vu_k_attn_scores(int dtype, const void* q, const void* k, void* Ps, int B, int N, int D, int H, int ld, float scale,
@@ -489,8 +15,8 @@ int vu_k_attn_scores(int dtype, const void* q, const void* k, void* Ps, int B, i
   const size_t lds = (size_t)N * (dp + (es == 2 ? 8 : 4)) * es;
   if (lds > 150 * 1024 && !(N > 784 && dp == 32)) return 1;      // (long rows stream K in chunks)
   if ((double)B * H * N * (double)ld >= 4294967295.0) return 1;   // 32-bit mask index in the fused kernel
-  if (dtype == 0) return dispatch_scores<float>(q, k, Ps, B, N, D, H, ld, scale, rng, true, st);
-  return dispatch_scores<bf16_t>(q, k, Ps, B, N, D, H, ld, scale, rng, true, st);
+  if (dtype == 0) return vu_scores_f32_softmax(q, k, Ps, B, N, D, H, ld, scale, rng, st);
+  return vu_scores_bf16_softmax(q, k, Ps, B, N, D, H, ld, scale, rng, st);
 }
 
 // out[b,g,i,j] = scale * sum_t a[b,i,g*d+t] * bmat[b,j,g*d+t]   (dAhat = dO v^T); 1 = shape not covered
@@ -502,1143 +28,7 @@ int vu_k_attn_outer(int dtype, const void* a, const void* bmat, void* out, int B
   const size_t lds = (size_t)N * (dp + (es == 2 ? 8 : 4)) * es;
   if (lds > 150 * 1024 && !(N > 784 && dp == 32)) return 1;
   vu_rng none = vu_make_rng(0, 0, 0.f);
-  if (dtype == 0) return dispatch_scores<float>(a, bmat, out, B, N, D, H, ld, scale, none, false, st);
-  return dispatch_scores<bf16_t>(a, bmat, out, B, N, D, H, ld, scale, none, false, st);
+  if (dtype == 0) return vu_scores_f32_plain(a, bmat, out, B, N, D, H, ld, scale, none, st);
+  return vu_scores_bf16_plain(a, bmat, out, B, N, D, H, ld, scale, none, st);
 }
 
-// =============================================================================================
-// map_bwd_row_kernel: backward of BatchNorm -> head mix -> dropout -> softmax on one map row for
-// ALL heads, with the row held in registers (one read of the tagged probabilities and of dAhat,
-// one write of dS over dAhat).  TPR threads per row, each owning 4 consecutive columns; a block
-// of 256 threads handles 256/TPR rows per iteration and walks the rows persistently so that the
-// head-mix weight gradient (h x h) stays in registers until one final reduction.
-// =============================================================================================
-namespace {
-
-template <typename T, int H, int TPR>
-__global__ __launch_bounds__(256) void map_bwd_row_kernel(const T* __restrict__ Ps, T* dA, const float* __restrict__ W,
-                                                          const float* __restrict__ c, const float* __restrict__ gamma,
-                                                          const float* __restrict__ stats, float* dW, float* dc,
-                                                          long long rows, int N, int ld, float inv_keep, float scale) {
-  constexpr int RPB = 256 / TPR;
-  // W and the backward tables (written by bn_bwd_small_finalize_kernel) come through scalar loads
-  const float* __restrict__ tX = stats + H * H + 5 * H;     // X[H*H], Xc[H], Gs[H]
-  const float* __restrict__ tM = stats + H * H + 3 * H;     // m1[H], m2[H]
-  __shared__ float redd[4][H];
-  __shared__ float red[4][H * H + H];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int rsub = threadIdx.x / TPR, t = threadIdx.x % TPR;
-  const int jc = t * 4;
-  const long long hs = (long long)N * ld;
-  float aW[H * H], ac[H];
-#pragma unroll
-  for (int i = 0; i < H * H; ++i) aW[i] = 0.f;
-#pragma unroll
-  for (int i = 0; i < H; ++i) ac[i] = 0.f;
-  const long long nrow_iters = (rows + RPB - 1) / RPB;
-  for (long long it = blockIdx.x; it < nrow_iters; it += gridDim.x) {
-    const long long row = it * RPB + rsub;
-    const bool live = row < rows && jc < ld;
-    const long long b = live ? row / N : 0;
-    const int i = live ? (int)(row - b * N) : 0;
-    const long long off = (b * H * N + i) * (long long)ld + jc;
-    float pv[H][4], dP[H][4];
-    float delta[H];
-#pragma unroll
-    for (int h = 0; h < H; ++h) delta[h] = 0.f;
-    if (live) {
-      float dAh[H][4];
-#pragma unroll
-      for (int h = 0; h < H; ++h) {
-        const vu_f4 v = vu_ld4(Ps + off + h * hs);
-        const vu_f4 d = vu_ld4(dA + off + h * hs);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { pv[h][e] = v.v[e]; dAh[h][e] = d.v[e]; }
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const bool cv = jc + e < N;
-        float pt[H], dAg[H];
-#pragma unroll
-        for (int h = 0; h < H; ++h) pt[h] = pv[h][e] > 0.f ? pv[h][e] * inv_keep : 0.f;
-#pragma unroll
-        for (int g = 0; g < H; ++g) {
-          float xh = tX[H * H + g];
-#pragma unroll
-          for (int h = 0; h < H; ++h) xh += tX[g * H + h] * pt[h];
-          dAg[g] = cv ? tX[H * H + H + g] * (dAh[g][e] - tM[g] - xh * tM[H + g]) : 0.f;
-          ac[g] += dAg[g];
-#pragma unroll
-          for (int h = 0; h < H; ++h) aW[g * H + h] += dAg[g] * pt[h];
-        }
-#pragma unroll
-        for (int h = 0; h < H; ++h) {
-          float dp = 0.f;
-#pragma unroll
-          for (int g = 0; g < H; ++g) dp += W[g * H + h] * dAg[g];
-          dp = pv[h][e] > 0.f ? dp * inv_keep : 0.f;
-          dP[h][e] = dp;
-          delta[h] += dp * fabsf(pv[h][e]);
-        }
-      }
-    }
-    // delta[h] = sum over the row
-    if constexpr (TPR == 64) {
-#pragma unroll
-      for (int h = 0; h < H; ++h) delta[h] = vu_wave_sum(delta[h]);
-    } else {
-#pragma unroll
-      for (int h = 0; h < H; ++h) {
-        const float v = vu_wave_sum(delta[h]);
-        if (lane == 0) redd[wave][h] = v;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int h = 0; h < H; ++h) delta[h] = redd[0][h] + redd[1][h] + redd[2][h] + redd[3][h];
-      __syncthreads();
-    }
-    if (live) {
-#pragma unroll
-      for (int h = 0; h < H; ++h) {
-        vu_f4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o.v[e] = (jc + e < N) ? fabsf(pv[h][e]) * (dP[h][e] - delta[h]) * scale : 0.f;
-        vu_st4(dA + off + h * hs, o);
-      }
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < H * H; ++i) { const float v = vu_wave_sum(aW[i]); if (lane == 0) red[wave][i] = v; }
-#pragma unroll
-  for (int i = 0; i < H; ++i) { const float v = vu_wave_sum(ac[i]); if (lane == 0) red[wave][H * H + i] = v; }
-  __syncthreads();
-  for (int i = threadIdx.x; i < H * H + H; i += blockDim.x) {
-    const float v = red[0][i] + red[1][i] + red[2][i] + red[3][i];
-    if (i < H * H) atomicAdd(dW + i, v); else atomicAdd(dc + (i - H * H), v);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// map_bwd_mfma_kernel (bf16 storage, one 256-thread block per row, ld <= 1024): as
-// map_bwd_row_kernel, but the head-mix weight gradient dW[g,h] = sum_pos dA_g P~_h is taken off the
-// VALU: every lane drops its dA and P~ values (bf16) into two [16][row] LDS images and the four
-// waves contract them over the row's positions with v_mfma_f32_16x16x32_bf16 (a ones row in the
-// P~ image yields dc = sum dA_g for free).  Without the 64 per-lane accumulators the kernel fits
-// two waves per SIMD.
-// ---------------------------------------------------------------------------------------------
-template <int H, int NWV>
-__global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void map_bwd_mfma_kernel(const bf16_t* __restrict__ Ps, bf16_t* dA,
-                                                              const float* __restrict__ W, const float* __restrict__ c,
-                                                              const float* __restrict__ gamma, const float* __restrict__ stats,
-                                                              float* dW, float* dc, long long rows, int N, int ld,
-                                                              float inv_keep, float scale) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  // W and the backward tables are wave-uniform and indexed with compile-time constants: they
-  // arrive through scalar loads (SGPRs), not through LDS / VGPRs
-  const float* __restrict__ tX0 = stats + H * H + 5 * H;    // X[H*H], Xc[H], Gs[H]
-  const float* __restrict__ tM0 = stats + H * H + 3 * H;    // m1[H], m2[H]
-  __shared__ float redd[NWV][H];
-  __shared__ float red[NWV][256];
-  const int ldk = (ld + 31) / 32 * 32;        // positions rounded up to whole k-steps
-  const int LDP = ldk + 8;                    // image row stride (elements)
-  bf16_t* sA = reinterpret_cast<bf16_t*>(smem_raw);   // [H][LDP]    rows g: dA_g, high bf16 part (MFMA rows >= H read as zero)
-  bf16_t* sL = sA + H * LDP;                          // [H][LDP]    low part: dA = hi + lo keeps 16 significant bits
-  bf16_t* sB = sL + H * LDP;                          // [H+1][LDP]  rows h: P~_h, row H: ones
-  for (int i = threadIdx.x; i < (3 * H + 1) * LDP; i += blockDim.x) {
-    const int r = i / LDP, col = i % LDP;
-    sA[i] = (r == 3 * H && col < N) ? (bf16_t)1.0f : (bf16_t)0.0f;   // sB row H = ones over the valid positions
-  }
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int l15 = lane & 15, lg = lane >> 4;
-  const int jc = threadIdx.x * 4;
-  const long long hs = (long long)N * ld;
-  const int nks = ldk / 32;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
-    const bool live = jc < ld;
-    const long long b = row / N;
-    const int i = (int)(row - b * N);
-    const long long off = (b * H * N + i) * (long long)ld + jc;
-    // (measured: forcing the scalar table loads to stay inside the row loop is slower - 6.3 vs 4.4 ms
-    // per step - than letting the compiler hoist them and spill part of the table to VGPR lanes)
-    const float* tX = tX0; const float* tM = tM0; const float* Wt = W;
-    float pv[H][4], dP[H][4], dAg[H][4], delta[H];
-#pragma unroll
-    for (int h = 0; h < H; ++h) delta[h] = 0.f;
-    if (live) {
-#pragma unroll
-      for (int h = 0; h < H; ++h) {
-        const vu_f4 v = vu_ld4(Ps + off + h * hs);
-        const vu_f4 d = vu_ld4(dA + off + h * hs);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { pv[h][e] = v.v[e]; dAg[h][e] = d.v[e]; }
-      }
-      // two phases so that only one 8x8 table (X, then W) is live in scalar registers at a time
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const bool cv = jc + e < N;
-        float pt[H];
-#pragma unroll
-        for (int h = 0; h < H; ++h) pt[h] = pv[h][e] > 0.f ? pv[h][e] * inv_keep : 0.f;
-#pragma unroll
-        for (int g = 0; g < H; ++g) {
-          float xh = tX[H * H + g];
-#pragma unroll
-          for (int h = 0; h < H; ++h) xh = fmaf(tX[g * H + h], pt[h], xh);
-          dAg[g][e] = cv ? tX[H * H + H + g] * (dAg[g][e] - tM[g] - xh * tM[H + g]) : 0.f;
-        }
-      }
-      asm volatile("" ::: "memory");
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-#pragma unroll
-        for (int h = 0; h < H; ++h) {
-          float dp = 0.f;
-#pragma unroll
-          for (int g = 0; g < H; ++g) dp = fmaf(Wt[g * H + h], dAg[g][e], dp);
-          dp = pv[h][e] > 0.f ? dp * inv_keep : 0.f;
-          dP[h][e] = dp;
-          delta[h] = fmaf(dp, fabsf(pv[h][e]), delta[h]);
-        }
-      }
-      // LDS images for the MFMA contraction (4 consecutive positions per store)
-#pragma unroll
-      for (int h = 0; h < H; ++h) {
-        vu_f4 a4, l4, p4;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          a4.v[e] = dAg[h][e];
-          l4.v[e] = dAg[h][e] - (float)(bf16_t)dAg[h][e];
-          p4.v[e] = pv[h][e] > 0.f ? pv[h][e] * inv_keep : 0.f;
-        }
-        vu_st4(sA + h * LDP + jc, a4);
-        vu_st4(sL + h * LDP + jc, l4);
-        vu_st4(sB + h * LDP + jc, p4);
-      }
-    }
-#pragma unroll
-    for (int h = 0; h < H; ++h) {
-      const float v = vu_wave_sum(delta[h]);
-      if (lane == 0) redd[wave][h] = v;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int h = 0; h < H; ++h) { float dsum = 0.f;
-#pragma unroll
-      for (int q = 0; q < NWV; ++q) dsum += redd[q][h];
-      delta[h] = dsum; }
-    // contraction over the row's positions, k-steps dealt round-robin to the 4 waves
-    for (int ks = wave; ks < nks; ks += NWV) {
-      const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-      const bf16x8 af = l15 < H ? *reinterpret_cast<const bf16x8*>(sA + l15 * LDP + ks * 32 + lg * 8) : zero8;
-      const bf16x8 lf = l15 < H ? *reinterpret_cast<const bf16x8*>(sL + l15 * LDP + ks * 32 + lg * 8) : zero8;
-      const bf16x8 bf = l15 <= H ? *reinterpret_cast<const bf16x8*>(sB + l15 * LDP + ks * 32 + lg * 8) : zero8;
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lf, bf, acc, 0, 0, 0);
-    }
-    if (live) {
-#pragma unroll
-      for (int h = 0; h < H; ++h) {
-        vu_f4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o.v[e] = (jc + e < N) ? fabsf(pv[h][e]) * (dP[h][e] - delta[h]) * scale : 0.f;
-        vu_st4(dA + off + h * hs, o);
-      }
-    }
-    __syncthreads();     // images and redd are rewritten by the next row
-  }
-  // acc: C[row g = lg*4 + r][col = l15]; columns < H are dW[g][h], column H is dc[g]
-#pragma unroll
-  for (int r = 0; r < 4; ++r) red[wave][(lg * 4 + r) * 16 + l15] = acc[r];
-  __syncthreads();
-  if (threadIdx.x < 256) {
-    const int g = threadIdx.x / 16, hcol = threadIdx.x % 16;
-    float v = 0.f;
-#pragma unroll
-    for (int q = 0; q < NWV; ++q) v += red[q][threadIdx.x];
-    if (g < H && hcol < H) atomicAdd(dW + g * H + hcol, v);
-    else if (g < H && hcol == H) atomicAdd(dc + g, v);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// map_bwd_mm_kernel (bf16 storage, H = 8, one 256-thread block per row, ld <= 1024): all three
-// 8x8 head contractions of the map backward run on the matrix cores.
-//   "own" layout    : thread t owns the position quad 4t..4t+3, all 8 heads  (B operand of MFMA #1)
-//   "result" layout : what v_mfma_f32_16x16x32 returns when four position sets (one per 16-lane
-//                     group) are stacked along K with a block-diagonal A operand: lane (l15, lg)
-//                     gets heads 4*(lg&1)..+3 of the quads owned by lanes (l15, lg>>1) ["A"] and
-//                     (l15, 2 + (lg>>1)) ["B"].
-// MFMA #1: xhat pre-activation  = X  (8x8) . P~   -> result layout
-// elementwise (result layout, dAhat / P loaded from HBM directly in that layout):  dA, later dP, dS
-// MFMA #2: dP~ = W^T (8x8) . dA : the accumulators of #1's layout ARE its B operand (k-slot
-//          (lg, 4m+r)), and its output lands in the same result layout - no lane movement.
-// MFMA #3: dW[g,h] = sum_pos dA_g P~_h through two [head][position] LDS images (as
-//          map_bwd_mfma_kernel), dA split hi/lo.
-// ---------------------------------------------------------------------------------------------
-typedef short s16x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-// zero the bf16 halves whose sign bit is set (the dropped probabilities): packed signed-16 max with 0
-__device__ __forceinline__ unsigned keep_pos(unsigned w) {
-  const s16x2 z = {0, 0};
-  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, w), z));
-}
-__device__ __forceinline__ float half_f(unsigned w, int odd) { return __uint_as_float(odd ? (w & 0xffff0000u) : (w << 16)); }
-__device__ __forceinline__ float unpk(const uint2& q, int e) { return half_f(e < 2 ? q.x : q.y, e & 1); }
-__device__ __forceinline__ unsigned pk2(float a, float b) {
-  const bf16x2v v = {(bf16_t)a, (bf16_t)b};
-  return __builtin_bit_cast(unsigned, v);
-}
-// word made of the low (odd = 0) or high (odd = 1) bf16 halves of x (-> low half) and y (-> high half)
-__device__ __forceinline__ unsigned halves(unsigned x, unsigned y, int odd) {
-  return __builtin_amdgcn_perm(y, x, odd ? 0x07060302u : 0x05040100u);
-}
-__device__ __forceinline__ bf16x8 pack8(const float (&v)[8]) {
-  bf16x8 r;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) r[j] = (bf16_t)v[j];
-  return r;
-}
-
-// EXACT: N % 4 == 0, position quads are wholly valid or wholly padding.
-// WPR = waves per map row: 4 (256 < ld <= 1024: the block's four waves share a row) or 1 (ld <= 256: every
-// wave owns a row of its own - its LDS images, its delta reduction and its dW contraction - no barriers).
-template <bool EXACT, int WPR>
-__global__ __launch_bounds__(256, 2) void map_bwd_mm_kernel(const bf16_t* __restrict__ Ps, bf16_t* dA,
-                                                            const float* __restrict__ W, const float* __restrict__ c,
-                                                            const float* __restrict__ gamma, const float* __restrict__ stats,
-                                                            float* dW, float* dc, long long rows, int N, int ld,
-                                                            float inv_keep, float scale) {
-  constexpr int H = 8;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  __shared__ float redd[4][H];
-  __shared__ float red[4][256];
-  const int ldk = (ld + 31) / 32 * 32;
-  const int LDP = ldk + 8;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wsub = WPR == 4 ? wave : 0;               // wave's index within its row
-  bf16_t* sbase = reinterpret_cast<bf16_t*>(smem_raw);
-  bf16_t* sA = sbase + (WPR == 4 ? 0 : wave) * (3 * H + 1) * LDP;   // [H][LDP]   dA hi
-  bf16_t* sL = sA + H * LDP;                          // [H][LDP]   dA lo
-  bf16_t* sB = sL + H * LDP;                          // [H+1][LDP] kept P (without 1/keep), row H = ones
-  for (int i = threadIdx.x; i < (WPR == 4 ? 1 : 4) * (3 * H + 1) * LDP; i += blockDim.x) {
-    const int r = (i / LDP) % (3 * H + 1), col = i % LDP;
-    sbase[i] = (r == 3 * H && col < N) ? (bf16_t)1.0f : (bf16_t)0.0f;
-  }
-  const int l15 = lane & 15, lg = lane >> 4;
-  const float* tX = stats + H * H + 5 * H;     // X[H*H] = W*rstd_g, Xc[H], Gs[H]
-  const float* tM = stats + H * H + 3 * H;     // m1[H], m2[H]
-  // ---- constant A operands (block diagonal over the four lane-group position sets) ------------
-  // #1, MFMA m: row16 = l15 -> (q' = 2m + l15/8, g = l15%8); k-slot (lg, j): X[g][j]/keep if lg == q'
-  // #2, MFMA m2: row16 = l15 -> (q'' = 2m2 + l15/8, h = l15%8); k-slot (lg, j = 4m + r) is
-  //     (q' = 2m + lg/2, g = 4(lg&1) + r): W[g][h] scale/keep if q' == q''
-  bf16x8 A1[2], A2[2];
-#pragma unroll
-  for (int m = 0; m < 2; ++m) {
-    float v1[8], v2[8];
-    const int qrow = 2 * m + (l15 >> 3), hr = l15 & 7;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      v1[j] = (lg == qrow) ? tX[hr * H + j] * inv_keep : 0.f;
-      const int mk = j >> 2, r = j & 3;
-      const int qk = 2 * mk + (lg >> 1), gk = 4 * (lg & 1) + r;
-      v2[j] = (qk == qrow) ? W[gk * H + hr] * (inv_keep * scale) : 0.f;
-    }
-    A1[m] = pack8(v1);
-    A2[m] = pack8(v2);
-  }
-  const int hbase = 4 * (lg & 1);
-  // dA = Gs (dAhat - m1 - (acc + Xc) m2) = Gs dAhat + K1 + K2 acc
-  float Gs4[4], K1[4], K2[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const float gs = tX[H * H + H + hbase + r], xc = tX[H * H + hbase + r];
-    const float m1 = tM[hbase + r], m2 = tM[H + hbase + r];
-    Gs4[r] = gs; K1[r] = -gs * (m1 + xc * m2); K2[r] = -gs * m2;
-  }
-  __syncthreads();
-  const unsigned hs = (unsigned)N * (unsigned)ld;     // launcher guarantees 8 * N * ld < 2^31
-  const int nks = ldk / 32;
-  const int nquads = EXACT ? (N >> 2) : (ld >> 2);
-  const int qown = WPR == 4 ? threadIdx.x : lane;         // own quad
-  const int qA = 64 * wsub + 16 * (lg >> 1) + l15;        // result-layout quads
-  const int qB = qA + 32;
-  f32x4 accw = {0.f, 0.f, 0.f, 0.f};
-
-  uint2 pown[H], PA[4], PB[4], QA[4], QB[4];             // packed bf16 quads: P (own / result layout), dAhat
-  auto load_row = [&](long long row, uint2 (&po)[H], uint2 (&pa)[4], uint2 (&pb)[4], uint2 (&qa)[4], uint2 (&qb)[4]) {
-    const long long b = row / N;
-    const int i = (int)(row - b * N);
-    const long long base = (b * H * N + i) * (long long)ld;
-    const bf16_t* __restrict__ Prow = Ps + base;
-    const bf16_t* Drow = dA + base;
-#pragma unroll
-    for (int h = 0; h < H; ++h) po[h] = make_uint2(0, 0);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { pa[r] = make_uint2(0, 0); pb[r] = make_uint2(0, 0); qa[r] = make_uint2(0, 0); qb[r] = make_uint2(0, 0); }
-    if (qown < nquads) {
-#pragma unroll
-      for (int h = 0; h < H; ++h) po[h] = *reinterpret_cast<const uint2*>(Prow + (h * hs + 4u * qown));
-    }
-    if (qA < nquads) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const unsigned o = (hbase + r) * hs + 4u * qA;
-        pa[r] = *reinterpret_cast<const uint2*>(Prow + o);
-        qa[r] = *reinterpret_cast<const uint2*>(Drow + o);
-      }
-    }
-    if (qB < nquads) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const unsigned o = (hbase + r) * hs + 4u * qB;
-        pb[r] = *reinterpret_cast<const uint2*>(Prow + o);
-        qb[r] = *reinterpret_cast<const uint2*>(Drow + o);
-      }
-    }
-  };
-  const long long row0 = WPR == 4 ? (long long)blockIdx.x : (long long)blockIdx.x * 4 + wave;
-  const long long rstep = WPR == 4 ? (long long)gridDim.x : (long long)gridDim.x * 4;
-  if (row0 < rows) load_row(row0, pown, PA, PB, QA, QB);
-  for (long long row = row0; row < rows; row += rstep) {
-    // ---- own layout: kept probabilities, P image, B operands of #1 -------------------------------
-    unsigned b1w[4][4];
-#pragma unroll
-    for (int h = 0; h < H; ++h) { pown[h].x = keep_pos(pown[h].x); pown[h].y = keep_pos(pown[h].y); }
-    if (qown < nquads) {
-#pragma unroll
-      for (int h = 0; h < H; ++h) *reinterpret_cast<uint2*>(sB + h * LDP + 4 * qown) = pown[h];
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      b1w[0][j] = halves(pown[2 * j].x, pown[2 * j + 1].x, 0);
-      b1w[1][j] = halves(pown[2 * j].x, pown[2 * j + 1].x, 1);
-      b1w[2][j] = halves(pown[2 * j].y, pown[2 * j + 1].y, 0);
-      b1w[3][j] = halves(pown[2 * j].y, pown[2 * j + 1].y, 1);
-    }
-    unsigned hiw[4][4], low[4][4];        // [e][word]: bf16 pairs (r0,r1),(r2,r3) of quad A, then of quad B
-    float dPa[4][4], dPb[4][4], delta[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const u32x4 b1u = {b1w[e][0], b1w[e][1], b1w[e][2], b1w[e][3]};
-      const bf16x8 b1 = __builtin_bit_cast(bf16x8, b1u);
-      f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
-      c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1[0], b1, c0, 0, 0, 0);   // quads of lane groups 0,1
-      c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1[1], b1, c1, 0, 0, 0);   // quads of lane groups 2,3
-      float va[4], vb[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        va[r] = fmaf(K2[r], c0[r], fmaf(Gs4[r], unpk(QA[r], e), K1[r]));
-        vb[r] = fmaf(K2[r], c1[r], fmaf(Gs4[r], unpk(QB[r], e), K1[r]));
-        if (!EXACT) { va[r] = (4 * qA + e < N) ? va[r] : 0.f; vb[r] = (4 * qB + e < N) ? vb[r] : 0.f; }
-      }
-      hiw[e][0] = pk2(va[0], va[1]); hiw[e][1] = pk2(va[2], va[3]);
-      hiw[e][2] = pk2(vb[0], vb[1]); hiw[e][3] = pk2(vb[2], vb[3]);
-      low[e][0] = pk2(va[0] - half_f(hiw[e][0], 0), va[1] - half_f(hiw[e][0], 1));
-      low[e][1] = pk2(va[2] - half_f(hiw[e][1], 0), va[3] - half_f(hiw[e][1], 1));
-      low[e][2] = pk2(vb[0] - half_f(hiw[e][2], 0), vb[1] - half_f(hiw[e][2], 1));
-      low[e][3] = pk2(vb[2] - half_f(hiw[e][3], 0), vb[3] - half_f(hiw[e][3], 1));
-      const u32x4 b2u = {hiw[e][0], hiw[e][1], hiw[e][2], hiw[e][3]};
-      const bf16x8 b2 = __builtin_bit_cast(bf16x8, b2u);
-      f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
-      d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2[0], b2, d0, 0, 0, 0);
-      d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2[1], b2, d1, 0, 0, 0);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float pa = unpk(PA[r], e), pb = unpk(PB[r], e);
-        const float xa = pa > 0.f ? d0[r] : 0.f;        // = dP scale (1/keep and scale sit in A2)
-        const float xb = pb > 0.f ? d1[r] : 0.f;
-        dPa[r][e] = xa; dPb[r][e] = xb;
-        delta[r] = fmaf(xa, fabsf(pa), fmaf(xb, fabsf(pb), delta[r]));
-      }
-    }
-    // ---- LDS images of dA for dW (result layout -> [head][position]) ----------------------------
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int wv = r >> 1, od = r & 1;
-      if (qA < nquads) {
-        *reinterpret_cast<uint2*>(sA + (hbase + r) * LDP + 4 * qA) =
-            make_uint2(halves(hiw[0][wv], hiw[1][wv], od), halves(hiw[2][wv], hiw[3][wv], od));
-        *reinterpret_cast<uint2*>(sL + (hbase + r) * LDP + 4 * qA) =
-            make_uint2(halves(low[0][wv], low[1][wv], od), halves(low[2][wv], low[3][wv], od));
-      }
-      if (qB < nquads) {
-        *reinterpret_cast<uint2*>(sA + (hbase + r) * LDP + 4 * qB) =
-            make_uint2(halves(hiw[0][2 + wv], hiw[1][2 + wv], od), halves(hiw[2][2 + wv], hiw[3][2 + wv], od));
-        *reinterpret_cast<uint2*>(sL + (hbase + r) * LDP + 4 * qB) =
-            make_uint2(halves(low[0][2 + wv], low[1][2 + wv], od), halves(low[2][2 + wv], low[3][2 + wv], od));
-      }
-    }
-    // ---- next row's loads fly during the reduction / contraction / store phase --------------------
-    uint2 nP[4], nPB[4];
-    const long long nrow = row + rstep;
-    if (nrow < rows) load_row(nrow, pown, nP, nPB, QA, QB);
-    // ---- delta_h over the row: lanes with the same (lg & 1) hold the same heads ----------------
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float v = delta[r];
-      v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-      v += __shfl_xor(v, 32, 64);
-      if (WPR == 4) { if (l15 == 0 && lg < 2) redd[wave][4 * lg + r] = v; }
-      else delta[r] = v;                 // one wave = one row: the shuffles already hold the row sum
-    }
-    if (WPR == 4) {
-      __syncthreads();
-#pragma unroll
-      for (int r = 0; r < 4; ++r) delta[r] = redd[0][hbase + r] + redd[1][hbase + r] + redd[2][hbase + r] + redd[3][hbase + r];
-    }
-    for (int ks = wsub; ks < nks; ks += WPR) {
-      const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-      const bf16x8 af = l15 < H ? *reinterpret_cast<const bf16x8*>(sA + l15 * LDP + ks * 32 + lg * 8) : zero8;
-      const bf16x8 lf = l15 < H ? *reinterpret_cast<const bf16x8*>(sL + l15 * LDP + ks * 32 + lg * 8) : zero8;
-      const bf16x8 bf = l15 <= H ? *reinterpret_cast<const bf16x8*>(sB + l15 * LDP + ks * 32 + lg * 8) : zero8;
-      accw = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, accw, 0, 0, 0);
-      accw = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lf, bf, accw, 0, 0, 0);
-    }
-    // ---- dS = |p| (dP - delta) scale, result layout, 4 consecutive positions per store ----------
-    {
-      const long long b = row / N;
-      const int i = (int)(row - b * N);
-      bf16_t* Drow = dA + (b * H * N + i) * (long long)ld;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const unsigned o = (hbase + r) * hs;
-        float oa[4], ob[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          oa[e] = fabsf(unpk(PA[r], e)) * (dPa[r][e] - delta[r]);
-          ob[e] = fabsf(unpk(PB[r], e)) * (dPb[r][e] - delta[r]);
-          if (!EXACT) { oa[e] = (4 * qA + e < N) ? oa[e] : 0.f; ob[e] = (4 * qB + e < N) ? ob[e] : 0.f; }
-        }
-        if (qA < nquads) *reinterpret_cast<uint2*>(Drow + (o + 4u * qA)) = make_uint2(pk2(oa[0], oa[1]), pk2(oa[2], oa[3]));
-        if (qB < nquads) *reinterpret_cast<uint2*>(Drow + (o + 4u * qB)) = make_uint2(pk2(ob[0], ob[1]), pk2(ob[2], ob[3]));
-      }
-      if (EXACT && qown >= nquads && 4 * qown < ld) {      // the padding quad of the row
-#pragma unroll
-        for (int h = 0; h < H; ++h) *reinterpret_cast<uint2*>(Drow + (h * hs + 4u * qown)) = make_uint2(0, 0);
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { PA[r] = nP[r]; PB[r] = nPB[r]; }
-    if (WPR == 4) __syncthreads();       // (WPR = 1: a wave's LDS traffic is ordered by itself)
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) red[wave][(lg * 4 + r) * 16 + l15] = accw[r];
-  __syncthreads();
-  {
-    const int g = threadIdx.x / 16, hcol = threadIdx.x % 16;
-    const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-    if (g < H && hcol < H) atomicAdd(dW + g * H + hcol, v * inv_keep);    // the P image holds kept p, not p/keep
-    else if (g < H && hcol == H) atomicAdd(dc + g, v);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// mix_stats_mm_kernel (bf16 storage, H = 8, 256 < ld <= 1024): the BatchNorm batch statistics of
-// the mixed maps, s1_g = sum (a_g - shift_g), s2_g = sum (a_g - shift_g)^2 with
-// a_g = sum_h W[g,h] P~_h, one 256-thread block per map row.  The 8x8 mix runs on the matrix cores
-// exactly as MFMA #1 of map_bwd_mm_kernel (own-layout B operand, block-diagonal A, result layout
-// out); W/keep enters as a bf16 hi + lo pair (16 significant bits) and -shift_g as the accumulator
-// input, so that the VALU only squares and sums.
-// ---------------------------------------------------------------------------------------------
-template <bool EXACT>
-__global__ __launch_bounds__(256) void mix_stats_mm_kernel(const bf16_t* __restrict__ Ps, const float* __restrict__ W,
-                                                           float* __restrict__ partials, long long rows, int N, int ld,
-                                                           float inv_keep) {
-  constexpr int H = 8;
-  __shared__ float red[4][2 * H];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int l15 = lane & 15, lg = lane >> 4;
-  bf16x8 Ah[2], Al[2];
-#pragma unroll
-  for (int m = 0; m < 2; ++m) {
-    float vh[8], vl[8];
-    const int qrow = 2 * m + (l15 >> 3), hr = l15 & 7;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float v = (lg == qrow) ? W[hr * H + j] * inv_keep : 0.f;
-      vh[j] = (float)(bf16_t)v;
-      vl[j] = v - vh[j];
-    }
-    Ah[m] = pack8(vh);
-    Al[m] = pack8(vl);
-  }
-  const int hbase = 4 * (lg & 1);
-  f32x4 cin;       // -shift_g, shift_g = sum_h W[g,h] / N  (the exact mean without dropout; the bias cancels)
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    float sacc = 0.f;
-#pragma unroll
-    for (int h = 0; h < H; ++h) sacc += W[(hbase + r) * H + h];
-    cin[r] = -sacc / (float)N;
-  }
-  const unsigned hs = (unsigned)N * (unsigned)ld;
-  const int nquads = EXACT ? (N >> 2) : (ld >> 2);
-  const int qown = threadIdx.x;
-  const int qA = 64 * wave + 16 * (lg >> 1) + l15, qB = qA + 32;
-  float mA[4], mB[4];       // validity of the result-layout positions (1 / 0)
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    mA[e] = (EXACT ? qA < nquads : 4 * qA + e < N) ? 1.f : 0.f;
-    mB[e] = (EXACT ? qB < nquads : 4 * qB + e < N) ? 1.f : 0.f;
-  }
-  float s1a[4] = {0.f, 0.f, 0.f, 0.f}, s2a[4] = {0.f, 0.f, 0.f, 0.f}, s1b[4] = {0.f, 0.f, 0.f, 0.f}, s2b[4] = {0.f, 0.f, 0.f, 0.f};
-  uint2 pown[H];
-  auto load_row = [&](long long row) {
-    const long long b = row / N;
-    const int i = (int)(row - b * N);
-    const bf16_t* __restrict__ Prow = Ps + (b * H * N + i) * (long long)ld;
-#pragma unroll
-    for (int h = 0; h < H; ++h) pown[h] = make_uint2(0, 0);
-    if (qown < nquads) {
-#pragma unroll
-      for (int h = 0; h < H; ++h) pown[h] = *reinterpret_cast<const uint2*>(Prow + (h * hs + 4u * qown));
-    }
-  };
-  if ((long long)blockIdx.x < rows) load_row(blockIdx.x);
-  for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
-    unsigned b1w[4][4];
-#pragma unroll
-    for (int h = 0; h < H; ++h) { pown[h].x = keep_pos(pown[h].x); pown[h].y = keep_pos(pown[h].y); }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      b1w[0][j] = halves(pown[2 * j].x, pown[2 * j + 1].x, 0);
-      b1w[1][j] = halves(pown[2 * j].x, pown[2 * j + 1].x, 1);
-      b1w[2][j] = halves(pown[2 * j].y, pown[2 * j + 1].y, 0);
-      b1w[3][j] = halves(pown[2 * j].y, pown[2 * j + 1].y, 1);
-    }
-    const long long nrow = row + gridDim.x;
-    if (nrow < rows) load_row(nrow);          // the next row is in flight during the MFMAs
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const u32x4 b1u = {b1w[e][0], b1w[e][1], b1w[e][2], b1w[e][3]};
-      const bf16x8 b1 = __builtin_bit_cast(bf16x8, b1u);
-      f32x4 c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[0], b1, cin, 0, 0, 0);
-      f32x4 c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[1], b1, cin, 0, 0, 0);
-      c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al[0], b1, c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al[1], b1, c1, 0, 0, 0);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if constexpr (EXACT) {
-          s1a[r] += c0[r]; s2a[r] = fmaf(c0[r], c0[r], s2a[r]);
-          s1b[r] += c1[r]; s2b[r] = fmaf(c1[r], c1[r], s2b[r]);
-        } else {
-          const float a = c0[r] * mA[e], bq = c1[r] * mB[e];
-          s1a[r] += a; s2a[r] = fmaf(a, a, s2a[r]);
-          s1b[r] += bq; s2b[r] = fmaf(bq, bq, s2b[r]);
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    // (EXACT: a lane's two quads are valid or padding for every row - drop the padding sums here)
-    float v1 = EXACT ? s1a[r] * mA[0] + s1b[r] * mB[0] : s1a[r] + s1b[r];
-    float v2 = EXACT ? s2a[r] * mA[0] + s2b[r] * mB[0] : s2a[r] + s2b[r];
-#pragma unroll
-    for (int m = 1; m <= 8; m <<= 1) { v1 += __shfl_xor(v1, m, 64); v2 += __shfl_xor(v2, m, 64); }
-    v1 += __shfl_xor(v1, 32, 64); v2 += __shfl_xor(v2, 32, 64);
-    if (l15 == 0 && lg < 2) { red[wave][4 * lg + r] = v1; red[wave][H + 4 * lg + r] = v2; }
-  }
-  __syncthreads();
-  if (threadIdx.x < 2 * H)
-    partials[blockIdx.x * 2 * H + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-}
-
-// A/B switch for measurements: VU_MAP_BWD_VALU=1 keeps the VALU map-backward kernels (read once)
-inline bool map_bwd_valu_forced() { static const bool v = getenv("VU_MAP_BWD_VALU") != nullptr; return v; }
-
-template <int WPR>
-int launch_map_bwd_mm(const void* Ps, void* dA, const float* W, const float* c, const float* gamma, const float* stats,
-                      float* dW, float* dc, int B, int N, int ld, float inv_keep, float scale, hipStream_t st) {
-  const long long rows = (long long)B * N;
-  const int ldk = (ld + 31) / 32 * 32;
-  const size_t lds = (size_t)(WPR == 4 ? 1 : 4) * (3 * 8 + 1) * (ldk + 8) * 2;
-  auto kern = (N % 4 == 0) ? map_bwd_mm_kernel<true, WPR> : map_bwd_mm_kernel<false, WPR>;
-  if (lds > 40 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) { vu_set_error("map_bwd: cannot reserve %zu bytes of LDS", lds); return VU_ELAUNCH; }
-  }
-  long long grid = WPR == 4 ? rows : (rows + 3) / 4;
-  if (grid > 1024) grid = 1024;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, (const bf16_t*)Ps, (bf16_t*)dA, W, c, gamma, stats, dW, dc,
-                     rows, N, ld, inv_keep, scale);
-  if (vu_prof_on()) vu_prof_note(WPR == 4 ? "map_bwd_mm_kernel" : "map_bwd_mm_kernel<1 wave/row>", 0.0, (double)B * 8 * N * N * 3 * 2.0);
-  return vu_check_launch("vu_map_bwd");
-}
-
-template <typename T, int H>
-int launch_map_bwd_row(const void* Ps, void* dA, const float* W, const float* c, const float* gamma, const float* stats,
-                       float* dW, float* dc, int B, int N, int ld, float inv_keep, float scale, hipStream_t st) {
-  const long long rows = (long long)B * N;
-  if constexpr (H == 8 && sizeof(T) == 2) {
-    if (ld <= 256 && ld >= 64 && !map_bwd_valu_forced())
-      return launch_map_bwd_mm<1>(Ps, dA, W, c, gamma, stats, dW, dc, B, N, ld, inv_keep, scale, st);
-  }
-  if (ld <= 256) {
-    long long grid = (rows + 3) / 4; if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL((map_bwd_row_kernel<T, H, 64>), dim3((unsigned)grid), dim3(256), 0, st, (const T*)Ps, (T*)dA, W, c, gamma,
-                       stats, dW, dc, rows, N, ld, inv_keep, scale);
-    if (vu_prof_on()) vu_prof_note("map_bwd_row_kernel", 0.0, (double)B * H * N * N * 3 * sizeof(T));
-  } else if (sizeof(T) == 2 && (ld <= 1024 || (ld <= 4096 && H <= 4))) {
-    // one block per row: 256 threads (ld <= 1024) or 1024 threads (ld <= 4096; 128-VGPR budget -> H <= 4)
-    const int ldk = (ld + 31) / 32 * 32;
-    const size_t lds = (size_t)(3 * H + 1) * (ldk + 8) * 2;
-    const bool big = ld > 1024;
-    if constexpr (H == 8) {
-      if (!big && !map_bwd_valu_forced()) return launch_map_bwd_mm<4>(Ps, dA, W, c, gamma, stats, dW, dc, B, N, ld, inv_keep, scale, st);
-    }
-    auto kern = big ? map_bwd_mfma_kernel<(H <= 4 ? H : 4), 16> : map_bwd_mfma_kernel<H, 4>;
-    if (lds > 40 * 1024) {
-      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) { vu_set_error("map_bwd: cannot reserve %zu bytes of LDS", lds); return VU_ELAUNCH; }
-    }
-    long long grid = rows; if (grid > 1024) grid = 1024;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(big ? 1024 : 256), lds, st, (const bf16_t*)Ps, (bf16_t*)dA, W, c, gamma,
-                       stats, dW, dc, rows, N, ld, inv_keep, scale);
-    if (vu_prof_on()) vu_prof_note("map_bwd_mfma_kernel", 0.0, (double)B * H * N * N * 3 * sizeof(T));
-  } else if (ld > 1024) {
-    return 1;   // caller falls back to the two-sweep kernel
-  } else {
-    long long grid = rows; if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL((map_bwd_row_kernel<T, H, 256>), dim3((unsigned)grid), dim3(256), 0, st, (const T*)Ps, (T*)dA, W, c, gamma,
-                       stats, dW, dc, rows, N, ld, inv_keep, scale);
-    if (vu_prof_on()) vu_prof_note("map_bwd_row_kernel", 0.0, (double)B * H * N * N * 3 * sizeof(T));
-  }
-  return vu_check_launch("vu_map_bwd");
-}
-
-}  // namespace
-
-int vu_k_map_bwd(int dtype, const void* Ps, void* dAhat_dS, const float* W, const float* c, const float* gamma,
-                 const float* stats, float* dW, float* dc, int B, int H, int N, int ld, float inv_keep, float scale,
-                 hipStream_t st) {
-  if (ld > 4096 || (ld > 1024 && (dtype == 0 || H > 4)))
-    return vu_k_map_bwd_2sweep(dtype, Ps, dAhat_dS, W, c, gamma, stats, dW, dc, B, H, N, ld, inv_keep, scale, st);
-#define VU_MB(Tt, Hh) return launch_map_bwd_row<Tt, Hh>(Ps, dAhat_dS, W, c, gamma, stats, dW, dc, B, N, ld, inv_keep, scale, st)
-  if (dtype == 0) { switch (H) { case 1: VU_MB(float, 1); case 2: VU_MB(float, 2); case 4: VU_MB(float, 4); case 8: VU_MB(float, 8); } }
-  else { switch (H) { case 1: VU_MB(bf16_t, 1); case 2: VU_MB(bf16_t, 2); case 4: VU_MB(bf16_t, 4); case 8: VU_MB(bf16_t, 8); } }
-#undef VU_MB
-  vu_set_error("map_bwd: num_heads %d not supported", H);
-  return VU_EUNSUPPORTED;
-}
-
-// returns VU_OK, a negative error, or 1 when the shape is not covered (the caller uses mix_stats_kernel)
-int vu_k_mix_stats_mm(int dtype, const void* Ps, const float* W, float* partials, int nblocks, int B, int H, int N, int ld,
-                      float inv_keep, hipStream_t st) {
-  if (dtype != 1 || H != 8 || ld <= 256 || ld > 1024 || ld % 8 != 0 || (long long)H * N * ld >= 2147483647LL) return 1;
-  const long long rows = (long long)B * N;
-  if (N % 4 == 0)
-    hipLaunchKernelGGL(mix_stats_mm_kernel<true>, dim3(nblocks), dim3(256), 0, st, (const bf16_t*)Ps, W, partials, rows, N, ld, inv_keep);
-  else
-    hipLaunchKernelGGL(mix_stats_mm_kernel<false>, dim3(nblocks), dim3(256), 0, st, (const bf16_t*)Ps, W, partials, rows, N, ld, inv_keep);
-  if (vu_prof_on()) vu_prof_note("mix_stats_mm_kernel", 0.0, (double)B * H * N * N * 2.0);
-  return vu_check_launch("vu_mix_stats_mm");
-}
-
-// =============================================================================================
-// BatchNorm-backward statistics WITHOUT a pass over the maps.  With dAhat_g = dO_g v_g^T:
-//   s1_g = sum dAhat_g                 = sum_b sum_t (sum_i dO_g[i,t]) (sum_j v_g[j,t])
-//   r_g  = sum dAhat_g * Ahat_g        = sum_{b,i,t} dO_g[i,t] O_g[i,t]        (O = Ahat v, saved)
-// and, because Ahat = gamma*xhat + beta,   s2_g = sum dAhat_g*xhat_g = (r_g - beta_g s1_g) / gamma_g.
-// Reads three (B,N,D) tensors instead of two (B,h,N,N) maps.
-// =============================================================================================
-namespace {
-
-// one block per (sample, head): feature columns side by side, row lanes stacked, LDS combine
-template <typename T>
-__global__ __launch_bounds__(256) void bn_bwd_small_kernel(const T* __restrict__ dO, const T* __restrict__ O,
-                                                           const T* __restrict__ v, float* partials, int N, int D, int H) {
-  __shared__ float sm[16];
-  __shared__ float sdo[4 * 256], sv[4 * 256];
-  const int b = blockIdx.x, g = blockIdx.y, d = D / H;
-  const long long base = (long long)b * N * D + g * d;
-  float s1 = 0.f, r = 0.f;
-  if (d % 4 == 0) {
-    // a thread owns 4 consecutive features (one vector load per tensor and row) of the rows i = rl, rl + RL, ...
-    const int nq = d >> 2;
-    int TQ = 256;                       // feature quads handled side by side (power of two >= min(nq, 256))
-    while (TQ / 2 >= nq) TQ /= 2;
-    const int RL = 256 / TQ;
-    const int tc = threadIdx.x % TQ, rl = threadIdx.x / TQ;
-    for (int q0 = 0; q0 < nq; q0 += TQ) {
-      const int qd = q0 + tc;
-      float cdo[4] = {0.f, 0.f, 0.f, 0.f}, cv[4] = {0.f, 0.f, 0.f, 0.f};
-      if (qd < nq) {
-        const long long cb = base + 4 * qd;
-#pragma unroll 4
-        for (int i = rl; i < N; i += RL) {
-          const vu_f4 a = vu_ld4(dO + cb + (long long)i * D), vv = vu_ld4(v + cb + (long long)i * D), o = vu_ld4(O + cb + (long long)i * D);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { cdo[e] += a.v[e]; cv[e] += vv.v[e]; r = fmaf(a.v[e], o.v[e], r); }
-        }
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { sdo[e * 256 + threadIdx.x] = cdo[e]; sv[e * 256 + threadIdx.x] = cv[e]; }
-      __syncthreads();
-      if (rl == 0 && qd < nq) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float a = 0.f, c = 0.f;
-          for (int q = 0; q < RL; ++q) { a += sdo[e * 256 + q * TQ + tc]; c += sv[e * 256 + q * TQ + tc]; }
-          s1 = fmaf(a, c, s1);
-        }
-      }
-      __syncthreads();
-    }
-  } else {
-    int TCOL = 256;                       // feature columns handled side by side (power of two >= min(d,256))
-    while (TCOL / 2 >= d) TCOL /= 2;
-    const int RL = 256 / TCOL;            // row lanes per column
-    const int tc = threadIdx.x % TCOL, rl = threadIdx.x / TCOL;
-    for (int t0 = 0; t0 < d; t0 += TCOL) {
-      const int t = t0 + tc;
-      float cdo = 0.f, cv = 0.f;
-      if (t < d) {
-        for (int i = rl; i < N; i += RL) {
-          const float a = vu_ld(dO + base + (long long)i * D + t);
-          cdo += a;
-          cv += vu_ld(v + base + (long long)i * D + t);
-          r += a * vu_ld(O + base + (long long)i * D + t);
-        }
-      }
-      sdo[threadIdx.x] = cdo; sv[threadIdx.x] = cv;
-      __syncthreads();
-      if (rl == 0 && t < d) {
-        float a = 0.f, c = 0.f;
-        for (int q = 0; q < RL; ++q) { a += sdo[q * TCOL + tc]; c += sv[q * TCOL + tc]; }
-        s1 += a * c;
-      }
-      __syncthreads();
-    }
-  }
-  s1 = vu_block_sum(s1, sm);
-  r = vu_block_sum(r, sm);
-  if (threadIdx.x == 0) {
-    partials[(long long)b * 2 * H + g] = s1;
-    partials[(long long)b * 2 * H + H + g] = r;
-  }
-}
-
-// stats layout: Wf[H*H] cf[H] mean[H] rstd[H] m1[H] m2[H]
-__global__ void bn_bwd_small_finalize_kernel(const float* partials, int nb, const float* gamma, const float* beta,
-                                             const float* W, const float* c, float* stats, float* dgamma, float* dbeta,
-                                             int H, double count, int training) {
-  // 32 lanes per head (launched with 32 * H threads, H <= 16): strided partial sums, shuffle reduction
-  const int g = threadIdx.x >> 5, sub = threadIdx.x & 31;
-  if (g >= H) return;
-  double s1 = 0.0, r = 0.0;
-  for (int i = sub; i < nb; i += 32) { s1 += (double)partials[i * 2 * H + g]; r += (double)partials[i * 2 * H + H + g]; }
-#pragma unroll
-  for (int m = 16; m >= 1; m >>= 1) { s1 += __shfl_xor(s1, m, 64); r += __shfl_xor(r, m, 64); }
-  if (sub != 0) return;
-  {  // tables read by the map-backward kernels through scalar loads
-    const float rstd = stats[H * H + 2 * H + g];
-    float* X = stats + H * H + 5 * H;
-    for (int h = 0; h < H; ++h) X[g * H + h] = W[g * H + h] * rstd;
-    X[H * H + g] = (c[g] - stats[H * H + H + g]) * rstd;
-    X[H * H + H + g] = gamma[g] * rstd;
-  }
-  const double gm = gamma[g];
-  const double s2 = fabs(gm) > 1e-20 ? (r - (double)beta[g] * s1) / gm : 0.0;
-  dbeta[g] += (float)s1;
-  dgamma[g] += (float)s2;
-  stats[H * H + 3 * H + g] = training ? (float)(s1 / count) : 0.f;
-  stats[H * H + 4 * H + g] = training ? (float)(s2 / count) : 0.f;
-}
-
-}  // namespace
-
-// partials: >= B*2*H floats
-int vu_k_bn_bwd_small(int dtype, const void* dO, const void* O, const void* v, const float* gamma, const float* beta,
-                      const float* W, const float* c, float* stats, float* dgamma, float* dbeta, float* partials, int B, int N, int D, int H,
-                      int training, hipStream_t st) {
-  if (dtype == 0) hipLaunchKernelGGL((bn_bwd_small_kernel<float>), dim3(B, H), dim3(256), 0, st, (const float*)dO, (const float*)O, (const float*)v, partials, N, D, H);
-  else hipLaunchKernelGGL((bn_bwd_small_kernel<bf16_t>), dim3(B, H), dim3(256), 0, st, (const bf16_t*)dO, (const bf16_t*)O, (const bf16_t*)v, partials, N, D, H);
-  hipLaunchKernelGGL(bn_bwd_small_finalize_kernel, dim3(1), dim3(32 * H), 0, st, partials, B, gamma, beta, W, c, stats, dgamma, dbeta, H,
-                     (double)B * N * N, training);
-  if (vu_prof_on()) vu_prof_note("bn_bwd_small(2 kernels)", 0.0, 3.0 * B * N * D * (dtype == 0 ? 4.0 : 2.0));
-  return vu_check_launch("vu_bn_bwd_small");
-}
-
-// =============================================================================================
-// Map x head-slice products for long rows and small head dims (bf16 storage, d <= 32):
-//   rows form: out[b,i,g*d+t] = sum_j M[b,g,i,j] X[b,j,g*d+t]      O = Ahat v ;  dq = dS k
-//   cols form: out[b,j,g*d+t] = sum_i M[b,g,i,j] X[b,i,g*d+t]      dv = Ahat^T dO ;  dk = dS^T q
-// Both stream the (N x N) map of one (sample, head) exactly once, straight from HBM into MFMA
-// operand registers (each lane reads 32 contiguous bytes of a map row, a 16-lane group 128 B): the
-// map never passes through LDS.  The head slice X_g (N x d, a few tens of KB) is staged once per
-// workgroup, transposed, as Xt[t][n], so that its fragments are 16-/8-byte LDS reads.
-// The products are computed transposed (out^T = Xt . M^T) so that a lane ends up with 4
-// consecutive t of one token: 8-byte stores into the token-major (B,N,D) activation.
-// =============================================================================================
-namespace {
-
-// Xt[t][n] = X[n][t] for n < N, t < d; zero elsewhere (t < 16 TT, n < ldk).  LDV = ldk + 8: consecutive
-// rows start 4 banks apart, 16 lanes reading 16 B of 16 different rows cover all 64 banks once.
-template <int TT>
-__device__ __forceinline__ void stage_slice_T(bf16_t* Xt, const bf16_t* __restrict__ Xg, int N, int D, int d, int ldk, int LDV,
-                                              int tid, int nthr) {
-  const bool vec = (d % 8 == 0) && (D % 8 == 0);
-  constexpr int CPT = 2 * TT;          // 8-element chunks per token
-  const int cells = ldk * CPT;
-  for (int c0 = tid; c0 < cells; c0 += 4 * nthr) {      // 4 independent 16-byte loads in flight per thread
-    uint4 x[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int c = c0 + k * nthr;
-      const int n = c / CPT, t0 = (c % CPT) * 8;
-      x[k] = make_uint4(0, 0, 0, 0);
-      if (c < cells && n < N && t0 < d) {
-        if (vec) x[k] = *reinterpret_cast<const uint4*>(Xg + (long long)n * D + t0);
-        else {
-          unsigned w[4] = {0, 0, 0, 0};
-#pragma unroll
-          for (int e = 0; e < 8; ++e)
-            if (t0 + e < d) w[e >> 1] |= (unsigned)__builtin_bit_cast(unsigned short, Xg[(long long)n * D + t0 + e]) << (16 * (e & 1));
-          x[k] = make_uint4(w[0], w[1], w[2], w[3]);
-        }
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int c = c0 + k * nthr;
-      if (c < cells) {
-        const int n = c / CPT, t0 = (c % CPT) * 8;
-        const unsigned w[4] = {x[k].x, x[k].y, x[k].z, x[k].w};
-        unsigned short* dst = reinterpret_cast<unsigned short*>(Xt) + t0 * LDV + n;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) dst[e * LDV] = (unsigned short)(w[e >> 1] >> (16 * (e & 1)));
-      }
-    }
-  }
-}
-
-// 4 consecutive t (t0..t0+3) of token row `orow` (points at the head slice): vector store when whole
-__device__ __forceinline__ void store_t4(bf16_t* orow, int t0, int d, bool vec, const f32x4& a) {
-  if (t0 >= d) return;
-  if (vec && t0 + 4 <= d) {
-    const vu_f4 o = {{a[0], a[1], a[2], a[3]}};
-    vu_st4(orow + t0, o);
-  } else {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) if (t0 + r < d) orow[t0 + r] = (bf16_t)a[r];
-  }
-}
-
-// Both kernels move the map HBM -> registers (a ring a few steps ahead) -> a small wave-private LDS tile ->
-// MFMA fragments.  The detour through LDS is what keeps the global loads whole: a wave instruction reads
-// 8 full 128-byte row segments (lane = 16 B of a line), where loading in fragment shape (16 lanes = 16
-// different rows) costs 8x the cache-line lookups.  A wave only ever touches its own tile, and LDS
-// operations of one wave complete in order, so no barrier is involved.
-constexpr int MP_LDT = 72;     // tile row stride in elements (144 B: 16 rows x 16 B cover all banks once)
-
-template <int WAVES, int TT>
-__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4, 8))) void attn_map_rows_kernel(const bf16_t* __restrict__ M, const bf16_t* __restrict__ X,
-                                                                 bf16_t* __restrict__ out, int N, int D, int H, int d, int ld) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int ldk = (N + 63) & ~63, LDV = ldk + 8;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
-  bf16_t* Xt = reinterpret_cast<bf16_t*>(smem_raw);                       // [16 TT][LDV] (rows >= d stay zero)
-  bf16_t* T = Xt + 16 * TT * LDV + wave * (16 * MP_LDT);                  // this wave's [16][MP_LDT] tile
-  const int bz = blockIdx.y, b = bz / H, g = bz % H;
-  stage_slice_T<TT>(Xt, X + (long long)b * N * D + g * d, N, D, d, ldk, LDV, tid, WAVES * 64);
-  __syncthreads();
-  const bf16_t* Mb = M + (long long)bz * N * ld;
-  const int nrt = (N + 15) >> 4, nsteps = ldk >> 6;
-  const bool vec = (d % 4 == 0) && (D % 4 == 0);
-  const int lrow = lane >> 3, lch = (lane & 7) * 8;                        // load shape: 8 rows x 8 chunks of 16 B
-  const bf16_t* x0 = Xt + l15 * LDV + 16 * lg;
-  for (int rt = blockIdx.x * WAVES + wave; rt < nrt; rt += gridDim.x * WAVES) {
-    // unconditional loads at clamped addresses (rows >= N re-read row N-1, columns >= ld the row's last chunk):
-    // what they return is finite map data that meets zeros of Xt or lands in rows that are never stored.
-    // (Selecting between a load and a zero makes hipcc select between POINTERS and emit serialized flat loads.)
-    const bf16_t* r0 = Mb + (long long)min(rt * 16 + lrow, N - 1) * ld;
-    const bf16_t* r1 = Mb + (long long)min(rt * 16 + 8 + lrow, N - 1) * ld;
-    f32x4 acc[TT];
-#pragma unroll
-    for (int tt = 0; tt < TT; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // (named registers, not an array: hipcc left an indexed ring in scratch memory)
-    uint4 ma0, mb0, ma1, mb1, ma2, mb2, ma3, mb3, ma4, mb4, ma5, mb5;
-    auto fetch = [&](int step, uint4& ma, uint4& mb) {
-      const int j = min(step * 64 + lch, ld - 8);
-      ma = *reinterpret_cast<const uint4*>(r0 + j);
-      mb = *reinterpret_cast<const uint4*>(r1 + j);
-    };
-    auto put = [&](const uint4& ma, const uint4& mb) {
-      *reinterpret_cast<uint4*>(T + lrow * MP_LDT + lch) = ma;
-      *reinterpret_cast<uint4*>(T + (8 + lrow) * MP_LDT + lch) = mb;
-    };
-    auto mult = [&](int sidx) {
-      // B operand: lane (l15 = map row, lg): columns 16 lg + [0,8) and + [8,16) of the step: k-slots of two MFMAs
-      const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(T + l15 * MP_LDT + 16 * lg);
-      const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(T + l15 * MP_LDT + 16 * lg + 8);
-      const bf16_t* xa = x0 + sidx * 64;
-#pragma unroll
-      for (int tt = 0; tt < TT; ++tt) {
-        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(xa + 16 * tt * LDV), b0, acc[tt], 0, 0, 0);
-        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(xa + 16 * tt * LDV + 8), b1, acc[tt], 0, 0, 0);
-      }
-    };
-    auto step = [&](int sidx, uint4& ma, uint4& mb) {
-      put(ma, mb);                      // the tile leaves the ring registers ...
-      fetch(sidx + 6, ma, mb);          // ... which are re-issued at once, 6 steps ahead
-      mult(sidx);
-    };
-    fetch(0, ma0, mb0); fetch(1, ma1, mb1); fetch(2, ma2, mb2); fetch(3, ma3, mb3); fetch(4, ma4, mb4); fetch(5, ma5, mb5);
-    // the main loop is branch-free so that hipcc can count its vmcnt waits (a conditional step makes it drain
-    // the whole ring, vmcnt(0), once per trip); the last nsteps % 6 steps follow
-    const int nfull = nsteps / 6 * 6;
-    for (int s0 = 0; s0 < nfull; s0 += 6) {
-      step(s0, ma0, mb0); step(s0 + 1, ma1, mb1); step(s0 + 2, ma2, mb2);
-      step(s0 + 3, ma3, mb3); step(s0 + 4, ma4, mb4); step(s0 + 5, ma5, mb5);
-    }
-    if (nfull + 0 < nsteps) { put(ma0, mb0); mult(nfull + 0); }
-    if (nfull + 1 < nsteps) { put(ma1, mb1); mult(nfull + 1); }
-    if (nfull + 2 < nsteps) { put(ma2, mb2); mult(nfull + 2); }
-    if (nfull + 3 < nsteps) { put(ma3, mb3); mult(nfull + 3); }
-    if (nfull + 4 < nsteps) { put(ma4, mb4); mult(nfull + 4); }
-    // C[row = t = 4 lg + r (+16)][col = token i]
-    const int i = rt * 16 + l15;
-    if (i < N) {
-      bf16_t* orow = out + ((long long)b * N + i) * D + g * d;
-#pragma unroll
-      for (int tt = 0; tt < TT; ++tt) store_t4(orow, 16 * tt + 4 * lg, d, vec, acc[tt]);
-    }
-  }
-}
-
-// cols form: a wave owns a strip of 64 map columns and walks all rows 32 at a time; the contraction runs
-// over map rows, so the B operand (k = row, n = column) comes out of the row-major tile through the
-// transposing LDS read (ds_read_b64_tr_b16).
-template <int WAVES, int TT>
-__global__ __launch_bounds__(WAVES * 64) void attn_map_cols_kernel(const bf16_t* __restrict__ M, const bf16_t* __restrict__ X,
-                                                                 bf16_t* __restrict__ out, int N, int D, int H, int d, int ld) {
-  typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
-  typedef __attribute__((ext_vector_type(8))) short s16x8;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int ldk = (N + 63) & ~63, LDV = ldk + 8;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
-  bf16_t* Xt = reinterpret_cast<bf16_t*>(smem_raw);                       // [16 TT][LDV]
-  bf16_t* T = Xt + 16 * TT * LDV + wave * (32 * MP_LDT);                  // this wave's [32][MP_LDT] tile
-  const int bz = blockIdx.y, b = bz / H, g = bz % H;
-  stage_slice_T<TT>(Xt, X + (long long)b * N * D + g * d, N, D, d, ldk, LDV, tid, WAVES * 64);
-  __syncthreads();
-  const bf16_t* Mb = M + (long long)bz * N * ld;
-  const bool vec = (d % 4 == 0) && (D % 4 == 0);
-  const int lrow = lane >> 3, lch = (lane & 7) * 8;
-  const int nstrips = (N + 63) >> 6;
-  const int nrows = (N + 31) & ~31;
-  const int q = l15 >> 2, pq = l15 & 3;
-  for (int strip = blockIdx.x * WAVES + wave; strip < nstrips; strip += gridDim.x * WAVES) {
-    const int j0 = strip * 64;
-    const int jc = min(j0 + lch, ld - 8);                // columns >= ld: any finite data, never stored
-    f32x4 acc[4][TT];
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int tt = 0; tt < TT; ++tt) acc[u][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // register ring two 32-row steps (8 x 16 B per lane) ahead; clamped unconditional loads: rows >= N meet zeros of Xt
-    // (named registers, not an array: hipcc left an indexed ring in scratch memory)
-    uint4 p0, p1, p2, p3, q0, q1, q2, q3;
-    auto fetch = [&](int i0, uint4& m0, uint4& m1, uint4& m2, uint4& m3) {
-      m0 = *reinterpret_cast<const uint4*>(Mb + (long long)min(i0 + lrow, N - 1) * ld + jc);
-      m1 = *reinterpret_cast<const uint4*>(Mb + (long long)min(i0 + 8 + lrow, N - 1) * ld + jc);
-      m2 = *reinterpret_cast<const uint4*>(Mb + (long long)min(i0 + 16 + lrow, N - 1) * ld + jc);
-      m3 = *reinterpret_cast<const uint4*>(Mb + (long long)min(i0 + 24 + lrow, N - 1) * ld + jc);
-    };
-    auto put = [&](const uint4& m0, const uint4& m1, const uint4& m2, const uint4& m3) {
-      *reinterpret_cast<uint4*>(T + lrow * MP_LDT + lch) = m0;
-      *reinterpret_cast<uint4*>(T + (8 + lrow) * MP_LDT + lch) = m1;
-      *reinterpret_cast<uint4*>(T + (16 + lrow) * MP_LDT + lch) = m2;
-      *reinterpret_cast<uint4*>(T + (24 + lrow) * MP_LDT + lch) = m3;
-    };
-    auto mult = [&](int i0) {
-      // A operand: Xt rows t, k-slots = map rows i0 + 8 lg + e
-      bf16x8 xa[TT];
-#pragma unroll
-      for (int tt = 0; tt < TT; ++tt) xa[tt] = *reinterpret_cast<const bf16x8*>(Xt + (16 * tt + l15) * LDV + i0 + 8 * lg);
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const bf16_t* tb = T + (8 * lg + q) * MP_LDT + 16 * u + 4 * pq;
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)tb);
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(tb + 4 * MP_LDT));
-        const s16x8 t8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        const bf16x8 bm = __builtin_bit_cast(bf16x8, t8);
-#pragma unroll
-        for (int tt = 0; tt < TT; ++tt) acc[u][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[tt], bm, acc[u][tt], 0, 0, 0);
-      }
-    };
-    auto step = [&](int i0, uint4& m0, uint4& m1, uint4& m2, uint4& m3) {
-      put(m0, m1, m2, m3);
-      fetch(i0 + 64, m0, m1, m2, m3);
-      mult(i0);
-    };
-    fetch(0, p0, p1, p2, p3);
-    fetch(32, q0, q1, q2, q3);
-    // branch-free main loop (counted vmcnt waits), then the odd last step
-    const int nfull = nrows / 64 * 64;
-    for (int i00 = 0; i00 < nfull; i00 += 64) {
-      step(i00, p0, p1, p2, p3);
-      step(i00 + 32, q0, q1, q2, q3);
-    }
-    if (nfull < nrows) { put(p0, p1, p2, p3); mult(nfull); }
-    // C[row = t = 4 lg + r (+16)][col = token j0 + 16 u + l15]
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int j = j0 + 16 * u + l15;
-      if (j < N) {
-        bf16_t* orow = out + ((long long)b * N + j) * D + g * d;
-#pragma unroll
-        for (int tt = 0; tt < TT; ++tt) store_t4(orow, 16 * tt + 4 * lg, d, vec, acc[u][tt]);
-      }
-    }
-  }
-}
-
-template <bool COLS, int WAVES, int TT>
-int launch_map_prod_w(const void* M, const void* X, void* out, int B, int N, int D, int H, int ld, int nsplit, hipStream_t st) {
-  const int d = D / H;
-  const int ldk = (N + 63) & ~63;
-  const size_t lds = (size_t)16 * TT * (ldk + 8) * 2 + (size_t)WAVES * (COLS ? 32 : 16) * MP_LDT * 2;
-  auto kern = COLS ? attn_map_cols_kernel<WAVES, TT> : attn_map_rows_kernel<WAVES, TT>;
-  if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) { vu_set_error("attn_map_prod: cannot reserve %zu bytes of LDS", lds); return VU_ELAUNCH; }
-  }
-  hipLaunchKernelGGL(kern, dim3((unsigned)nsplit, (unsigned)(B * H)), dim3(WAVES * 64), lds, st, (const bf16_t*)M,
-                     (const bf16_t*)X, (bf16_t*)out, N, D, H, d, ld);
-  if (vu_prof_on()) vu_prof_note(COLS ? "attn_map_cols_kernel" : "attn_map_rows_kernel", 2.0 * B * H * (double)N * N * d,
-                                 ((double)B * H * N * ld + 2.0 * B * N * D) * 2.0);
-  return vu_check_launch("vu_attn_map_prod");
-}
-
-template <bool COLS, int TT>
-int launch_map_prod(const void* M, const void* X, void* out, int B, int N, int D, int H, int ld, hipStream_t st) {
-  const int units = COLS ? (N + 63) / 64 : (N + 15) / 16;       // strips / row tiles per (sample, head)
-  // waves per workgroup: as many as there are units, in whole rounds where possible
-  const int waves = units <= 4 ? 4 : ((units % 7 == 0 || (units > 8 && units <= 14)) ? 7 : 8);
-  int nsplit = (512 + B * H - 1) / (B * H);
-  const int maxsplit = (units + waves - 1) / waves;
-  if (nsplit > maxsplit) nsplit = maxsplit;
-  if (nsplit < 1) nsplit = 1;
-  if (waves == 4) return launch_map_prod_w<COLS, 4, TT>(M, X, out, B, N, D, H, ld, nsplit, st);
-  if (waves == 7) return launch_map_prod_w<COLS, 7, TT>(M, X, out, B, N, D, H, ld, nsplit, st);
-  return launch_map_prod_w<COLS, 8, TT>(M, X, out, B, N, D, H, ld, nsplit, st);
-}
-
-}  // namespace
-
-// returns VU_OK, a negative error, or 1 when the shape is not covered (the caller uses the batched GEMM)
-int vu_k_attn_map_prod(int dtype, int cols, const void* M, const void* X, void* out, int B, int N, int D, int H, int ld,
-                       hipStream_t st) {
-  const int d = D / H;
-  if (dtype != 1 || d > 96 || N < 64 || ld % 8 != 0) return 1;
-  const int tt = d <= 32 ? 2 : 6;
-  if ((size_t)16 * tt * (((N + 63) & ~63) + 8) * 2 + 8 * 32 * MP_LDT * 2 > 150 * 1024) return 1;
-  if (tt == 2) return cols ? launch_map_prod<true, 2>(M, X, out, B, N, D, H, ld, st) : launch_map_prod<false, 2>(M, X, out, B, N, D, H, ld, st);
-  return cols ? launch_map_prod<true, 6>(M, X, out, B, N, D, H, ld, st) : launch_map_prod<false, 6>(M, X, out, B, N, D, H, ld, st);
-}
