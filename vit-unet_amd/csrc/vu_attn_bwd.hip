@@ -542,10 +542,14 @@ __global__ __launch_bounds__(256, 2) void map_bwd_mm_kernel(const bf16_t* __rest
 // out); W/keep enters as a bf16 hi + lo pair (16 significant bits) and -shift_g as the accumulator
 // input, so that the VALU only squares and sums.
 // ---------------------------------------------------------------------------------------------
-template <bool EXACT>
+// STORE: also write the centred mixed map  Ac_g = a_g - shift_g  (bf16).  BatchNorm is affine in it,
+// Ahat_g = sc_g Ac_g + kappa_g, and so are the two products that consume Ahat (O = Ahat v, dv = Ahat^T dO):
+// they take Ac and apply (sc, kappa) with a column sum in their epilogue - the normalised map is never
+// written and the separate apply pass (one more read of P) disappears.
+template <bool EXACT, bool STORE>
 __global__ __launch_bounds__(256) void mix_stats_mm_kernel(const bf16_t* __restrict__ Ps, const float* __restrict__ W,
-                                                           float* __restrict__ partials, long long rows, int N, int ld,
-                                                           float inv_keep) {
+                                                           float* __restrict__ partials, bf16_t* __restrict__ Ac,
+                                                           long long rows, int N, int ld, float inv_keep) {
   constexpr int H = 8;
   __shared__ float red[4][2 * H];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -610,6 +614,7 @@ __global__ __launch_bounds__(256) void mix_stats_mm_kernel(const bf16_t* __restr
     }
     const long long nrow = row + gridDim.x;
     if (nrow < rows) load_row(nrow);          // the next row is in flight during the MFMAs
+    float oa[4][4], ob[4][4];                 // [head r][element e] of the two result-layout quads (STORE)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const u32x4 b1u = {b1w[e][0], b1w[e][1], b1w[e][2], b1w[e][3]};
@@ -623,11 +628,28 @@ __global__ __launch_bounds__(256) void mix_stats_mm_kernel(const bf16_t* __restr
         if constexpr (EXACT) {
           s1a[r] += c0[r]; s2a[r] = fmaf(c0[r], c0[r], s2a[r]);
           s1b[r] += c1[r]; s2b[r] = fmaf(c1[r], c1[r], s2b[r]);
+          if constexpr (STORE) { oa[r][e] = c0[r]; ob[r][e] = c1[r]; }
         } else {
           const float a = c0[r] * mA[e], bq = c1[r] * mB[e];
           s1a[r] += a; s2a[r] = fmaf(a, a, s2a[r]);
           s1b[r] += bq; s2b[r] = fmaf(bq, bq, s2b[r]);
+          if constexpr (STORE) { oa[r][e] = a; ob[r][e] = bq; }
         }
+      }
+    }
+    if constexpr (STORE) {
+      const long long b = row / N;
+      const int i = (int)(row - b * N);
+      bf16_t* Arow = Ac + (b * H * N + i) * (long long)ld;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const unsigned o = (hbase + r) * hs;
+        if (qA < nquads) *reinterpret_cast<uint2*>(Arow + (o + 4u * qA)) = make_uint2(pk2(oa[r][0], oa[r][1]), pk2(oa[r][2], oa[r][3]));
+        if (qB < nquads) *reinterpret_cast<uint2*>(Arow + (o + 4u * qB)) = make_uint2(pk2(ob[r][0], ob[r][1]), pk2(ob[r][2], ob[r][3]));
+      }
+      if (EXACT && qown >= nquads && 4 * qown < ld) {      // the padding quad of the row: zeros (consumers clamp, never skip)
+#pragma unroll
+        for (int h = 0; h < H; ++h) *reinterpret_cast<uint2*>(Arow + (h * hs + 4u * qown)) = make_uint2(0, 0);
       }
     }
   }
@@ -724,16 +746,17 @@ int vu_k_map_bwd(int dtype, const void* Ps, void* dAhat_dS, const float* W, cons
   return VU_EUNSUPPORTED;
 }
 
-// returns VU_OK, a negative error, or 1 when the shape is not covered (the caller uses mix_stats_kernel)
-int vu_k_mix_stats_mm(int dtype, const void* Ps, const float* W, float* partials, int nblocks, int B, int H, int N, int ld,
-                      float inv_keep, hipStream_t st) {
+// returns VU_OK, a negative error, or 1 when the shape is not covered (the caller uses mix_stats_kernel).
+// Ac != null: also write the centred mixed map (see mix_stats_mm_kernel).
+int vu_k_mix_stats_mm(int dtype, const void* Ps, const float* W, float* partials, void* Ac, int nblocks, int B, int H, int N,
+                      int ld, float inv_keep, hipStream_t st) {
   if (dtype != 1 || H != 8 || ld <= 256 || ld > 1024 || ld % 8 != 0 || (long long)H * N * ld >= 2147483647LL) return 1;
   const long long rows = (long long)B * N;
-  if (N % 4 == 0)
-    hipLaunchKernelGGL(mix_stats_mm_kernel<true>, dim3(nblocks), dim3(256), 0, st, (const bf16_t*)Ps, W, partials, rows, N, ld, inv_keep);
-  else
-    hipLaunchKernelGGL(mix_stats_mm_kernel<false>, dim3(nblocks), dim3(256), 0, st, (const bf16_t*)Ps, W, partials, rows, N, ld, inv_keep);
-  if (vu_prof_on()) vu_prof_note("mix_stats_mm_kernel", 0.0, (double)B * H * N * N * 2.0);
+  const bool ex = N % 4 == 0;
+  auto kern = Ac ? (ex ? mix_stats_mm_kernel<true, true> : mix_stats_mm_kernel<false, true>)
+                 : (ex ? mix_stats_mm_kernel<true, false> : mix_stats_mm_kernel<false, false>);
+  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), 0, st, (const bf16_t*)Ps, W, partials, (bf16_t*)Ac, rows, N, ld, inv_keep);
+  if (vu_prof_on()) vu_prof_note(Ac ? "mix_center_mm_kernel" : "mix_stats_mm_kernel", 0.0, (double)B * H * N * N * (Ac ? 4.0 : 2.0));
   return vu_check_launch("vu_mix_stats_mm");
 }
 

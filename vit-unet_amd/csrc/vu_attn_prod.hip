@@ -77,7 +77,8 @@ constexpr int MP_LDT = 72;     // tile row stride in elements (144 B: 16 rows x 
 
 template <int WAVES, int TT>
 __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4, 8))) void attn_map_rows_kernel(const bf16_t* __restrict__ M, const bf16_t* __restrict__ X,
-                                                                 bf16_t* __restrict__ out, int N, int D, int H, int d, int ld) {
+                                                                 bf16_t* __restrict__ out, const float* __restrict__ sc, const float* __restrict__ kappa,
+                                                                 int N, int D, int H, int d, int ld) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int ldk = (N + 63) & ~63, LDV = ldk + 8;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
@@ -86,6 +87,26 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4, 8
   const int bz = blockIdx.y, b = bz / H, g = bz % H;
   stage_slice_T<TT>(Xt, X + (long long)b * N * D + g * d, N, D, d, ldk, LDV, tid, WAVES * 64);
   __syncthreads();
+  // affine form (M is the centred mixed map Ac, the product wanted is with Ahat = sc_g Ac + kappa_g):
+  // out = sc_g (Ac . X) + kappa_g * (column sums of X over the tokens), the sums taken from the staged slice
+  __shared__ float colsum_s[16 * TT];
+  float a_sc = 1.f, a_kp = 0.f;
+  if (sc) {
+    a_sc = sc[g]; a_kp = kappa[g];
+    const int part = tid % 16;                         // 16 threads per feature row
+    for (int t = tid / 16; t < 16 * TT; t += WAVES * 4) {
+      float acc_s = 0.f;
+      for (int n = part * 8; n < ldk; n += 128) {
+        const bf16x8 v8 = *reinterpret_cast<const bf16x8*>(Xt + t * LDV + n);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc_s += (float)v8[e];
+      }
+#pragma unroll
+      for (int m = 8; m >= 1; m >>= 1) acc_s += __shfl_xor(acc_s, m, 64);
+      if (part == 0) colsum_s[t] = acc_s;
+    }
+    __syncthreads();
+  }
   const bf16_t* Mb = M + (long long)bz * N * ld;
   const int nrt = (N + 15) >> 4, nsteps = ldk >> 6;
   const bool vec = (d % 4 == 0) && (D % 4 == 0);
@@ -145,7 +166,14 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4, 8
     if (i < N) {
       bf16_t* orow = out + ((long long)b * N + i) * D + g * d;
 #pragma unroll
-      for (int tt = 0; tt < TT; ++tt) store_t4(orow, 16 * tt + 4 * lg, d, vec, acc[tt]);
+      for (int tt = 0; tt < TT; ++tt) {
+        f32x4 o = acc[tt];
+        if (sc) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = fmaf(a_sc, o[r], a_kp * colsum_s[16 * tt + 4 * lg + r]);
+        }
+        store_t4(orow, 16 * tt + 4 * lg, d, vec, o);
+      }
     }
   }
 }
@@ -155,7 +183,8 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4, 8
 // transposing LDS read (ds_read_b64_tr_b16).
 template <int WAVES, int TT>
 __global__ __launch_bounds__(WAVES * 64) void attn_map_cols_kernel(const bf16_t* __restrict__ M, const bf16_t* __restrict__ X,
-                                                                 bf16_t* __restrict__ out, int N, int D, int H, int d, int ld) {
+                                                                 bf16_t* __restrict__ out, const float* __restrict__ sc, const float* __restrict__ kappa,
+                                                                 int N, int D, int H, int d, int ld) {
   typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
   typedef __attribute__((ext_vector_type(8))) short s16x8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -166,6 +195,26 @@ __global__ __launch_bounds__(WAVES * 64) void attn_map_cols_kernel(const bf16_t*
   const int bz = blockIdx.y, b = bz / H, g = bz % H;
   stage_slice_T<TT>(Xt, X + (long long)b * N * D + g * d, N, D, d, ldk, LDV, tid, WAVES * 64);
   __syncthreads();
+  // affine form (M is the centred mixed map Ac, the product wanted is with Ahat = sc_g Ac + kappa_g):
+  // out = sc_g (Ac . X) + kappa_g * (column sums of X over the tokens), the sums taken from the staged slice
+  __shared__ float colsum_s[16 * TT];
+  float a_sc = 1.f, a_kp = 0.f;
+  if (sc) {
+    a_sc = sc[g]; a_kp = kappa[g];
+    const int part = tid % 16;                         // 16 threads per feature row
+    for (int t = tid / 16; t < 16 * TT; t += WAVES * 4) {
+      float acc_s = 0.f;
+      for (int n = part * 8; n < ldk; n += 128) {
+        const bf16x8 v8 = *reinterpret_cast<const bf16x8*>(Xt + t * LDV + n);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc_s += (float)v8[e];
+      }
+#pragma unroll
+      for (int m = 8; m >= 1; m >>= 1) acc_s += __shfl_xor(acc_s, m, 64);
+      if (part == 0) colsum_s[t] = acc_s;
+    }
+    __syncthreads();
+  }
   const bf16_t* Mb = M + (long long)bz * N * ld;
   const bool vec = (d % 4 == 0) && (D % 4 == 0);
   const int lrow = lane >> 3, lch = (lane & 7) * 8;
@@ -232,14 +281,22 @@ __global__ __launch_bounds__(WAVES * 64) void attn_map_cols_kernel(const bf16_t*
       if (j < N) {
         bf16_t* orow = out + ((long long)b * N + j) * D + g * d;
 #pragma unroll
-        for (int tt = 0; tt < TT; ++tt) store_t4(orow, 16 * tt + 4 * lg, d, vec, acc[u][tt]);
+        for (int tt = 0; tt < TT; ++tt) {
+          f32x4 o = acc[u][tt];
+          if (sc) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = fmaf(a_sc, o[r], a_kp * colsum_s[16 * tt + 4 * lg + r]);
+          }
+          store_t4(orow, 16 * tt + 4 * lg, d, vec, o);
+        }
       }
     }
   }
 }
 
 template <bool COLS, int WAVES, int TT>
-int launch_map_prod_w(const void* M, const void* X, void* out, int B, int N, int D, int H, int ld, int nsplit, hipStream_t st) {
+int launch_map_prod_w(const void* M, const void* X, void* out, const float* sc, const float* kappa, int B, int N, int D, int H, int ld,
+                      int nsplit, hipStream_t st) {
   const int d = D / H;
   const int ldk = (N + 63) & ~63;
   const size_t lds = (size_t)16 * TT * (ldk + 8) * 2 + (size_t)WAVES * (COLS ? 32 : 16) * MP_LDT * 2;
@@ -249,14 +306,15 @@ int launch_map_prod_w(const void* M, const void* X, void* out, int B, int N, int
     if (e != hipSuccess) { vu_set_error("attn_map_prod: cannot reserve %zu bytes of LDS", lds); return VU_ELAUNCH; }
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)nsplit, (unsigned)(B * H)), dim3(WAVES * 64), lds, st, (const bf16_t*)M,
-                     (const bf16_t*)X, (bf16_t*)out, N, D, H, d, ld);
+                     (const bf16_t*)X, (bf16_t*)out, sc, kappa, N, D, H, d, ld);
   if (vu_prof_on()) vu_prof_note(COLS ? "attn_map_cols_kernel" : "attn_map_rows_kernel", 2.0 * B * H * (double)N * N * d,
                                  ((double)B * H * N * ld + 2.0 * B * N * D) * 2.0);
   return vu_check_launch("vu_attn_map_prod");
 }
 
 template <bool COLS, int TT>
-int launch_map_prod(const void* M, const void* X, void* out, int B, int N, int D, int H, int ld, hipStream_t st) {
+int launch_map_prod(const void* M, const void* X, void* out, const float* sc, const float* kappa, int B, int N, int D, int H, int ld,
+                    hipStream_t st) {
   const int units = COLS ? (N + 63) / 64 : (N + 15) / 16;       // strips / row tiles per (sample, head)
   // waves per workgroup: as many as there are units, in whole rounds where possible
   const int waves = units <= 4 ? 4 : ((units % 7 == 0 || (units > 8 && units <= 14)) ? 7 : 8);
@@ -264,21 +322,21 @@ int launch_map_prod(const void* M, const void* X, void* out, int B, int N, int D
   const int maxsplit = (units + waves - 1) / waves;
   if (nsplit > maxsplit) nsplit = maxsplit;
   if (nsplit < 1) nsplit = 1;
-  if (waves == 4) return launch_map_prod_w<COLS, 4, TT>(M, X, out, B, N, D, H, ld, nsplit, st);
-  if (waves == 7) return launch_map_prod_w<COLS, 7, TT>(M, X, out, B, N, D, H, ld, nsplit, st);
-  return launch_map_prod_w<COLS, 8, TT>(M, X, out, B, N, D, H, ld, nsplit, st);
+  if (waves == 4) return launch_map_prod_w<COLS, 4, TT>(M, X, out, sc, kappa, B, N, D, H, ld, nsplit, st);
+  if (waves == 7) return launch_map_prod_w<COLS, 7, TT>(M, X, out, sc, kappa, B, N, D, H, ld, nsplit, st);
+  return launch_map_prod_w<COLS, 8, TT>(M, X, out, sc, kappa, B, N, D, H, ld, nsplit, st);
 }
 
 }  // namespace
 
 // returns VU_OK, a negative error, or 1 when the shape is not covered (the caller uses the batched GEMM)
-int vu_k_attn_map_prod(int dtype, int cols, const void* M, const void* X, void* out, int B, int N, int D, int H, int ld,
-                       hipStream_t st) {
+int vu_k_attn_map_prod(int dtype, int cols, const void* M, const void* X, void* out, const float* sc, const float* kappa,
+                       int B, int N, int D, int H, int ld, hipStream_t st) {
   const int d = D / H;
   if (dtype != 1 || d > 96 || N < 64 || ld % 8 != 0) return 1;
   const int tt = d <= 32 ? 2 : 6;
   if ((size_t)16 * tt * (((N + 63) & ~63) + 8) * 2 + 8 * 32 * MP_LDT * 2 > 150 * 1024) return 1;
-  if (tt == 2) return cols ? launch_map_prod<true, 2>(M, X, out, B, N, D, H, ld, st) : launch_map_prod<false, 2>(M, X, out, B, N, D, H, ld, st);
-  return cols ? launch_map_prod<true, 6>(M, X, out, B, N, D, H, ld, st) : launch_map_prod<false, 6>(M, X, out, B, N, D, H, ld, st);
+  if (tt == 2) return cols ? launch_map_prod<true, 2>(M, X, out, sc, kappa, B, N, D, H, ld, st) : launch_map_prod<false, 2>(M, X, out, sc, kappa, B, N, D, H, ld, st);
+  return cols ? launch_map_prod<true, 6>(M, X, out, sc, kappa, B, N, D, H, ld, st) : launch_map_prod<false, 6>(M, X, out, sc, kappa, B, N, D, H, ld, st);
 }
 

@@ -41,19 +41,20 @@ int vu_k_attn_scores(int dtype, const void* q, const void* k, void* Ps, int B, i
                      float scale, vu_rng rng, hipStream_t st);
 
 // map x head-slice products for long rows / small head dims (streaming MFMA kernels); 1 = shape not covered
-int vu_k_attn_map_prod(int dtype, int cols, const void* M, const void* X, void* out, int B, int N, int D, int H, int ld,
-                       hipStream_t st);
+int vu_k_attn_map_prod(int dtype, int cols, const void* M, const void* X, void* out, const float* sc, const float* kappa,
+                       int B, int N, int D, int H, int ld, hipStream_t st);
 int vu_k_attn_outer(int dtype, const void* a, const void* bmat, void* out, int B, int N, int D, int H, int ld,
                     float scale, hipStream_t st);
 
 // K9+K10: head mixing + BatchNorm on sign-tagged maps (B,H,N,ld).
 // stats buffer layout (floats): Wf[H*H] cf[H] mean[H] rstd[H] m1[H] m2[H]
 // backward tables appended: X[H*H] = W*rstd_g, Xc[H] = (c-mean)*rstd, Gs[H] = gamma*rstd
-#define VU_BN_STATS_FLOATS(H) (2 * (H) * (H) + 8 * (H))
+#define VU_BN_STATS_FLOATS(H) (2 * (H) * (H) + 10 * (H))   /* ... + sc[H], kappa[H] of the centred-map form */
+#define VU_BN_STATS_SC(H) (2 * (H) * (H) + 8 * (H))
 int vu_k_mix_stats(int dtype, const void* Ps, const float* W, const float* c, float* partials,
                    int nblocks, int B, int H, int N, int ld, float inv_keep, hipStream_t st);
-int vu_k_mix_stats_mm(int dtype, const void* Ps, const float* W, float* partials, int nblocks, int B, int H, int N, int ld,
-                      float inv_keep, hipStream_t st);   // MFMA form (bf16, H = 8, 256 < ld <= 1024); 1 = not covered
+int vu_k_mix_stats_mm(int dtype, const void* Ps, const float* W, float* partials, void* Ac, int nblocks, int B, int H, int N,
+                      int ld, float inv_keep, hipStream_t st);   // MFMA form (bf16, H = 8, 256 < ld <= 1024); 1 = not covered
 int vu_k_bn_finalize(const float* partials, int nblocks, const float* W, const float* c,
                      const float* gamma, const float* beta, float* run_mean, float* run_var,
                      float* stats, int H, int N, double count, int training, float momentum,

@@ -250,6 +250,12 @@ __global__ void bn_finalize_kernel(const float* partials, int nblocks, const flo
     stats[H * H + 2 * H + g] = rstd;
     stats[H * H + 3 * H + g] = 0.f;
     stats[H * H + 4 * H + g] = 0.f;
+    {  // centred-map form: Ahat_g = sc_g (a_g - shift0_g) + kappa_g with shift0 = sum_h W[g,h] / N
+      float sw = 0.f;
+      for (int h = 0; h < H; ++h) sw += W[g * H + h];
+      stats[VU_BN_STATS_SC(H) + g] = sc;
+      stats[VU_BN_STATS_SC(H) + H + g] = (c[g] - mean) * sc + beta[g] + sc * (sw / (float)N);
+    }
   }
 }
 
@@ -455,7 +461,7 @@ int vu_k_mix_stats(int dtype, const void* Ps, const float* W, const float* c, fl
   VU_REQUIRE(ld % 4 == 0, "mix_stats: ld %% 4");
   VU_REQUIRE((long long)B * N * (ld / 4) < 4294967295LL, "mix kernels: more than 2^32 vector positions");
   {
-    const int mm = vu_k_mix_stats_mm(dtype, Ps, W, partials, nblocks, B, H, N, ld, inv_keep, st);
+    const int mm = vu_k_mix_stats_mm(dtype, Ps, W, partials, nullptr, nblocks, B, H, N, ld, inv_keep, st);
     if (mm <= 0) return mm;
   }
   VU_HEADS(H, VU_DISPATCH_T(dtype, hipLaunchKernelGGL((mix_stats_kernel<T, HH>), dim3(nblocks), dim3(256), 0, st, (const T*)Ps, W, c, partials, B, N, ld, inv_keep);))

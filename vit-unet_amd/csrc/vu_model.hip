@@ -148,7 +148,13 @@ int build_plan(const vu_config& c, Plan& pl) {
 struct AttnBuf { void *q, *k, *v, *Ps, *Ah, *O; float* stats; };
 struct AttnScratch { void *dO, *dq, *dk, *dv, *dA; float* partials; int nblocks; };
 
-struct AttnDims { int dtype, B, N, D, H, C, s, ld; };
+struct AttnDims { int dtype, B, N, D, H, C, s, ld; int centered = 0; };
+// centred-map form (model path only; the stand-alone attention op returns the normalised map itself): the mixed map
+// is stored centred, BatchNorm's affine part is applied inside the two products that consume it.  Needs the MFMA mix
+// kernel and the streaming product kernels to cover the shape.
+inline bool centered_ok(const AttnDims& d) {
+  return d.centered && d.dtype == 1 && d.H == 8 && d.ld > 256 && d.ld <= 1024 && d.ld % 8 == 0 && d.D / d.H <= 96 && d.N >= 64;
+}
 
 inline int stats_blocks(const AttnDims& d) {
   long long t = (long long)d.B * d.N * (d.ld / 4);
@@ -186,11 +192,18 @@ int attn_forward(const AttnDims& d, const vu_attn_params& p, const void* xq, con
     VU_TRY(vu_k_softmax_dropout(dt, a.Ps, (long long)B * H * N, N, ld, ra, st));
   }
   const double count = (double)B * N * N;
-  if (training) VU_TRY(vu_k_mix_stats(dt, a.Ps, p.mix_w, p.mix_b, partials, stats_blocks(d), B, H, N, ld, ra.inv_keep, st));
+  const bool cen = centered_ok(d);
+  if (cen) {   // one pass over P: batch statistics + the centred mixed map (a.Ah holds Ac, not Ahat)
+    const int r = vu_k_mix_stats_mm(dt, a.Ps, p.mix_w, partials, a.Ah, stats_blocks(d), B, H, N, ld, ra.inv_keep, st);
+    if (r != 0) { if (r > 0) vu_set_error("attention: centred-map form not available for this shape"); return r < 0 ? r : VU_EUNSUPPORTED; }
+  } else if (training) VU_TRY(vu_k_mix_stats(dt, a.Ps, p.mix_w, p.mix_b, partials, stats_blocks(d), B, H, N, ld, ra.inv_keep, st));
   VU_TRY(vu_k_bn_finalize(partials, stats_blocks(d), p.mix_w, p.mix_b, p.bn_w, p.bn_b, p.run_mean, p.run_var,
                           a.stats, H, N, count, training, 0.1f, 1e-5f, st));
-  VU_TRY(vu_k_mix_apply(dt, a.Ps, a.Ah, a.stats, B, H, N, ld, ra.inv_keep, st));
-  int mp = vu_k_attn_map_prod(dt, 0, a.Ah, a.v, a.O, B, N, D, H, ld, st);   // streaming kernel for long rows
+  if (!cen) VU_TRY(vu_k_mix_apply(dt, a.Ps, a.Ah, a.stats, B, H, N, ld, ra.inv_keep, st));
+  const float* aff_sc = cen ? a.stats + VU_BN_STATS_SC(H) : nullptr;
+  const float* aff_kp = cen ? a.stats + VU_BN_STATS_SC(H) + H : nullptr;
+  int mp = vu_k_attn_map_prod(dt, 0, a.Ah, a.v, a.O, aff_sc, aff_kp, B, N, D, H, ld, st);   // streaming kernel for long rows
+  if (cen && mp == 1) { vu_set_error("attention: centred-map form needs the streaming product kernel"); return VU_EUNSUPPORTED; }
   if (mp < 0) return mp;
   if (mp == 1) {  // O = Ahat v  (model.py:161)
     vu_gemm_args g;
@@ -253,7 +266,10 @@ int attn_backward(const AttnDims& d, const vu_attn_params& p, const vu_attn_grad
     g.sC1 = (long long)H * N * ld; g.sC2 = (long long)N * ld; g.alpha = 1.f;
     VU_TRY(vu_gemm_launch(dt, 0, g, st));
   }
-  int mp = vu_k_attn_map_prod(dt, 1, a.Ah, sc.dO, sc.dv, B, N, D, H, ld, st);
+  const bool cen = centered_ok(d);
+  int mp = vu_k_attn_map_prod(dt, 1, a.Ah, sc.dO, sc.dv, cen ? a.stats + VU_BN_STATS_SC(H) : nullptr,
+                              cen ? a.stats + VU_BN_STATS_SC(H) + H : nullptr, B, N, D, H, ld, st);
+  if (cen && mp == 1) { vu_set_error("attention: centred-map form needs the streaming product kernel"); return VU_EUNSUPPORTED; }
   if (mp < 0) return mp;
   if (mp == 1) {  // dv = Ahat^T dO
     vu_gemm_args g;
@@ -270,7 +286,7 @@ int attn_backward(const AttnDims& d, const vu_attn_params& p, const vu_attn_grad
   VU_TRY(vu_k_bn_bwd_small(dt, sc.dO, a.O, a.v, p.bn_w, p.bn_b, p.mix_w, p.mix_b, a.stats, gr.bn_w, gr.bn_b, sc.partials, B, N, D, H, training, st));
   VU_TRY(vu_k_map_bwd(dt, a.Ps, sc.dA, p.mix_w, p.mix_b, p.bn_w, a.stats, gr.mix_w, gr.mix_b, B, H, N, ld, inv_keep,
                       1.0f / sqrtf((float)dh), st));
-  mp = vu_k_attn_map_prod(dt, 0, sc.dA, a.k, sc.dq, B, N, D, H, ld, st);
+  mp = vu_k_attn_map_prod(dt, 0, sc.dA, a.k, sc.dq, nullptr, nullptr, B, N, D, H, ld, st);
   if (mp < 0) return mp;
   if (mp == 1) {  // dq = dS k
     vu_gemm_args g;
@@ -281,7 +297,7 @@ int attn_backward(const AttnDims& d, const vu_attn_params& p, const vu_attn_grad
     g.sB1 = (long long)N * D; g.sB2 = dh; g.sC1 = (long long)N * D; g.sC2 = dh; g.alpha = 1.f;
     VU_TRY(vu_gemm_launch(dt, 0, g, st));
   }
-  mp = vu_k_attn_map_prod(dt, 1, sc.dA, a.q, sc.dk, B, N, D, H, ld, st);
+  mp = vu_k_attn_map_prod(dt, 1, sc.dA, a.q, sc.dk, nullptr, nullptr, B, N, D, H, ld, st);
   if (mp < 0) return mp;
   if (mp == 1) {  // dk = dS^T q
     vu_gemm_args g;
@@ -399,7 +415,7 @@ int block_forward(Ctx& cx, const BlockP& bp, BlockBuf& bb, const void* x, uint64
   const Level& L = cx.pl->lv[bp.level];
   const int dt = c.dtype, B = cx.B;
   const long long P = (long long)L.N * L.D;
-  AttnDims d{dt, B, L.N, L.D, c.num_heads, c.num_channels, L.s, L.ld};
+  AttnDims d{dt, B, L.N, L.D, c.num_heads, c.num_channels, L.s, L.ld, 1};
   vu_attn_params ap = attn_params(bp.at, c, cx.prm, cx.shadow, cx.bn);
   VU_TRY(attn_forward(d, ap, x, x, bb.z1, bb.at, cx.w->partials, c.attn_drop, c.proj_drop, cx.training,
                       cx.seed, stream_id, cx.salt, cx.st, x));          // z1 = attn(x) + x
@@ -476,7 +492,7 @@ int block_backward(Ctx& cx, const BlockP& bp, BlockBuf& bb, const void* x, void*
   const bool masked = rp.thr != 0;
   VU_TRY(vu_k_ln_bwd(dt, w.gb, bb.z1, cx.prm + bp.ln1w, bb.ln1s, G + bp.ln1w, G + bp.ln1b, w.lnp2, w.ga,
                      masked ? w.gc : nullptr, rp, B, P, cx.st));
-  AttnDims d{dt, B, L.N, L.D, c.num_heads, c.num_channels, L.s, L.ld};
+  AttnDims d{dt, B, L.N, L.D, c.num_heads, c.num_channels, L.s, L.ld, 1};
   vu_attn_params ap = attn_params(bp.at, c, cx.prm, cx.shadow, cx.bn);
   vu_attn_grads ag = attn_grads(bp.at, G);
   VU_TRY(attn_backward(d, ap, ag, x, x, masked ? w.gc : w.ga, w.ga, nullptr, dx, nullptr, bb.at, w.asc, c.attn_drop,
@@ -516,7 +532,7 @@ int model_forward(Ctx& cx, const float* x, float* y) {
       const int lfrom = pl.dec[i].level, lto = lfrom - 1;
       VU_TRY(vu_k_retile(dt, 0, 0, cur, w.up_out[j], nullptr, B, C, im, pl.lv[lfrom].s, pl.lv[lto].s, cx.st));
       const Level& L = pl.lv[lto];
-      AttnDims d{dt, B, L.N, L.D, c.num_heads, C, L.s, L.ld};
+      AttnDims d{dt, B, L.N, L.D, c.num_heads, C, L.s, L.ld, 1};
       vu_attn_params ap = attn_params(pl.skip[j], c, cx.prm, cx.shadow, cx.bn);
       VU_TRY(attn_forward(d, ap, skips[lto], w.up_out[j], w.skip_out[j], w.skip[j], w.partials, c.attn_drop, c.proj_drop,
                           cx.training, cx.seed, sid++, cx.salt, cx.st));
@@ -566,7 +582,7 @@ int model_backward(Ctx& cx, const float* dy, float* dx, int stage) {
         const uint64_t sid_skip = sid_blk + 1;
         const int lfrom = pl.dec[i].level, lto = lfrom - 1;
         const Level& L = pl.lv[lto];
-        AttnDims d{dt, B, L.N, L.D, c.num_heads, C, L.s, L.ld};
+        AttnDims d{dt, B, L.N, L.D, c.num_heads, C, L.s, L.ld, 1};
         vu_attn_params ap = attn_params(pl.skip[j], c, cx.prm, cx.shadow, cx.bn);
         vu_attn_grads ag = attn_grads(pl.skip[j], G);
         const void* dz = cur;
