@@ -298,3 +298,37 @@ def test_standalone_modules_vs_golden(golden_dir):
             assert serr(blk(x), g[f"{tag}.{mode}.block.out"]) < 1e-4
             skp.load_state_dict(sds)
             assert serr(skp(enc, x, x), g[f"{tag}.{mode}.skip.out"]) < 1e-4
+
+
+def test_image_fitter_fit_checkpoints_and_callbacks(tmp_path):
+    """The training harness of run_denoising.py:84-100 on the HIP path: fused step for MSELoss + AdamW, autograd path
+    for another criterion, best / last checkpoints, callback dicts with 'epoch', load() restores the best weights."""
+    import os
+    from vit_unet.torch.fitter import ImageFitter
+    kw = dict(depth=1, depth_te=1, size_bottleneck=1, preprocessing="conv", im_size=32, patch_size=8, num_channels=3,
+              hidden_dim=16, num_heads=2, attn_drop=0.0, proj_drop=0.0, linear_drop=0.0)
+    g = torch.Generator().manual_seed(3)
+    y = torch.rand(8, 3, 32, 32, generator=g)
+    x = (y + 0.1 * torch.randn(8, 3, 32, 32, generator=g)).clamp(0, 1)
+    loader = [{"x": x[i:i + 4], "y": y[i:i + 4]} for i in (0, 4)]
+    torch.manual_seed(0)
+    m = M.HViT_UNet(**kw).to(DEV)
+    seen = []
+    f = ImageFitter(m, loss=torch.nn.MSELoss(), optimizer=torch.optim.AdamW(m.parameters(), lr=2e-3), device=DEV,
+                    folder=str(tmp_path))
+    hist = f.fit(loader, loader, n_epochs=3, callbacks=[seen.append])
+    assert f._fused is not None                                   # the fused HIP step ran
+    assert [h["epoch"] for h in hist] == [0, 1, 2] and [s["epoch"] for s in seen] == [0, 1, 2]
+    assert all(k in hist[0] for k in ("train", "val"))
+    assert hist[-1]["train"] < hist[0]["train"]                   # it trains
+    assert os.path.exists(tmp_path / "best-checkpoint.bin") and os.path.exists(tmp_path / "last-checkpoint.bin")
+    best = f.best_metric
+    with torch.no_grad():
+        for p_ in m.parameters():
+            p_.mul_(0.5)
+    f.load(str(tmp_path / "best-checkpoint.bin"))
+    assert abs(f.validate(loader) - best) < 1e-4 * max(best, 1e-6) + 1e-6
+    # another criterion: autograd path through the same kernels
+    f2 = ImageFitter(m, loss=torch.nn.L1Loss(), device=DEV, folder=str(tmp_path / "l1"), lr=1e-3)
+    h2 = f2.fit(loader, None, n_epochs=2)
+    assert f2._fused is None and h2[-1]["train"] < h2[0]["train"] * 1.05

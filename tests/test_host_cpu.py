@@ -105,3 +105,30 @@ def test_no_oracle_import_in_product():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "vit_unet_oracle" not in txt or f == "vu_common.h" and "import" not in txt, f
+
+
+def test_fitter_surface_and_checkpoint_roundtrip(tmp_path):
+    """ImageFitter counterpart (reference dataset.py:76-91 / run_denoising.py:84-100): unpack, checkpoint files with the
+    module's state_dict key names, load restores the weights.  (The batch step itself needs the GPU: tests/test_gpu_model.py.)"""
+    import torch
+    import vit_unet.torch.model as M
+    from vit_unet.torch.fitter import ImageFitter
+    kw = dict(depth=1, depth_te=1, size_bottleneck=1, preprocessing="conv", im_size=32, patch_size=8, num_channels=3,
+              hidden_dim=16, num_heads=2, attn_drop=0.0, proj_drop=0.0, linear_drop=0.0)
+    m = M.HViT_UNet(**kw)
+    f = ImageFitter(m, device="cpu", folder=str(tmp_path))
+    x, y, w = f.unpack({"x": torch.zeros(2, 3, 32, 32, dtype=torch.float64), "y": torch.ones(2, 3, 32, 32), "w": torch.ones(2)})
+    assert x.dtype == torch.float32 and y.dtype == torch.float32 and w.shape == (2,)
+    assert f.unpack({"x": x, "y": y})[2] is None
+    path = str(tmp_path / "best-checkpoint.bin")
+    f.epoch, f.best_metric = 3, 0.25
+    f.save(path)
+    ref = {k: v.clone() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        for p_ in m.parameters():
+            p_.add_(1.0)
+    g = ImageFitter(m, device="cpu", folder=str(tmp_path)).load(path)
+    assert g.epoch == 3 and g.best_metric == 0.25
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, ref[k]), k
+    assert not f._fused_ok()          # CPU device: never the fused HIP step

@@ -1,0 +1,131 @@
+"""Training harness next to the model: the counterpart of the reference's `ImageFitter`
+(vit_unet/torch/dataset.py:76-91, a benatools `TorchFitterBase`) as `run_denoising.py:84-100`
+drives it - `ImageFitter(model, loss=, optimizer=, device=, folder=)`, `fit(train, val, n_epochs,
+callbacks)`, best / last checkpoints under `folder`, `load(path)`, `.model`.
+
+benatools is not part of the reference tree (unpinned dependency), so only the
+behaviour the reference relies on is reproduced: `unpack` -> `model(x)` -> loss -> backward ->
+optimizer step per batch, a validation pass per epoch, `best-checkpoint.bin` written when the
+monitored loss improves, `last-checkpoint.bin` every epoch, and callbacks that receive a dict
+containing `'epoch'`.
+
+When the loss is `MSELoss` (or None) and the optimizer is `AdamW` (or None) the batch step is the
+fused HIP step (`engine.TrainStep`: forward + MSE + backward + AdamW without autograd); any other
+loss / optimizer runs through the module's autograd path.
+"""
+from __future__ import annotations
+
+import os
+from typing import Callable, Dict, Iterable, List, Optional
+
+import torch
+
+
+class ImageFitter:
+    def __init__(self, model, loss=None, optimizer=None, device="cuda", folder="models", lr: float = 1e-4, seed: int = 0):
+        self.model = model
+        self.loss = loss if loss is not None else torch.nn.MSELoss()
+        self.optimizer = optimizer
+        self.device = device
+        self.folder = folder
+        self.epoch = 0
+        self.best_metric = float("inf")
+        self._lr = lr
+        self._seed = seed
+        self._fused = None
+
+    # ---- reference surface -----------------------------------------------------------------------
+    def unpack(self, data):
+        """dataset.py:78-91: x, y (and optional per-sample weights w) as float tensors on the device."""
+        x = data["x"].to(self.device).float()
+        y = data["y"].to(self.device).float()
+        w = data["w"].to(self.device).float() if "w" in data else None
+        return x, y, w
+
+    def _fused_ok(self) -> bool:
+        if not isinstance(self.loss, torch.nn.MSELoss) or getattr(self.loss, "reduction", "mean") != "mean":
+            return False
+        if self.optimizer is not None and type(self.optimizer) is not torch.optim.AdamW:
+            return False
+        if self.optimizer is not None and len(self.optimizer.param_groups) != 1:
+            return False
+        return str(self.device).startswith("cuda")
+
+    def _make_fused(self):
+        from .engine import TrainStep
+        kw = dict(lr=self._lr)
+        if self.optimizer is not None:
+            g = self.optimizer.param_groups[0]
+            kw = dict(lr=g["lr"], betas=tuple(g["betas"]), eps=g["eps"], weight_decay=g["weight_decay"])
+        return TrainStep(self.model, seed=self._seed, **kw)
+
+    def _train_batch(self, x, y, w) -> float:
+        if w is None and self._fused_ok():
+            if self._fused is None:
+                self._fused = self._make_fused()
+            return float(self._fused.step(x, y).item())
+        if self.optimizer is None:
+            self.optimizer = torch.optim.AdamW(self.model.parameters(), lr=self._lr)
+        self.optimizer.zero_grad()
+        out = self.model(x)
+        if w is None:
+            loss = self.loss(out, y)
+        else:   # per-sample weights: weighted mean of the per-sample mean squared / criterion error
+            per = ((out - y) ** 2).reshape(out.shape[0], -1).mean(dim=1)
+            loss = (per * w.reshape(-1)).sum() / w.sum()
+        loss.backward()
+        self.optimizer.step()
+        return float(loss.item())
+
+    @torch.no_grad()
+    def validate(self, loader: Iterable) -> float:
+        self.model.eval()
+        tot, n = 0.0, 0
+        for data in loader:
+            x, y, _ = self.unpack(data)
+            tot += float(self.loss(self.model(x), y).item()) * x.shape[0]
+            n += x.shape[0]
+        return tot / max(n, 1)
+
+    def fit(self, train_loader: Iterable, val_loader: Optional[Iterable] = None, n_epochs: int = 1,
+            callbacks: Optional[List[Callable[[Dict], None]]] = None, verbose: bool = False) -> List[Dict]:
+        os.makedirs(self.folder, exist_ok=True)
+        history = []
+        for _ in range(n_epochs):
+            self.model.train()
+            tot, n = 0.0, 0
+            for data in train_loader:
+                x, y, w = self.unpack(data)
+                tot += self._train_batch(x, y, w) * x.shape[0]
+                n += x.shape[0]
+            log = {"epoch": self.epoch, "train": tot / max(n, 1)}
+            monitored = log["train"]
+            if val_loader is not None:
+                log["val"] = self.validate(val_loader)
+                monitored = log["val"]
+            self.save(os.path.join(self.folder, "last-checkpoint.bin"))
+            if monitored < self.best_metric:
+                self.best_metric = monitored
+                self.save(os.path.join(self.folder, "best-checkpoint.bin"))
+            if verbose:
+                print(log)
+            for cb in callbacks or []:
+                cb(dict(log))
+            history.append(log)
+            self.epoch += 1
+        return history
+
+    # ---- checkpoints (reference key names: state_dict of the nn.Module) ----------------------------
+    def save(self, path: str):
+        torch.save({"model_state_dict": {k: v.detach().cpu() for k, v in self.model.state_dict().items()},
+                    "epoch": self.epoch, "best_metric": self.best_metric}, path)
+
+    def load(self, path: str):
+        ck = torch.load(path, map_location="cpu")
+        self.model.load_state_dict(ck["model_state_dict"])
+        self.epoch = ck.get("epoch", 0)
+        self.best_metric = ck.get("best_metric", float("inf"))
+        if hasattr(self.model, "_shadow_clean"):
+            self.model._shadow_clean = False  # the bf16 shadow of the weights is re-cast before the next forward
+        self._fused = None                    # optimizer moments restart (the reference reloads weights only)
+        return self
