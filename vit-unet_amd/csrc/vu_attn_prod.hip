@@ -75,56 +75,63 @@ __device__ __forceinline__ void store_t4(bf16_t* orow, int t0, int d, bool vec, 
 // operations of one wave complete in order, so no barrier is involved.
 constexpr int MP_LDT = 72;     // tile row stride in elements (144 B: 16 rows x 16 B cover all banks once)
 
-template <int WAVES, int TT>
+// CHUNKED (rows longer than one LDS image of X: Lite level 2, N = 3136): the contraction index is cut into chunks of
+// mp_ch(TT) tokens; a workgroup then owns WAVES row tiles (one per wave, accumulators live across chunks) and re-stages
+// the head slice chunk by chunk.
+constexpr int mp_ch(int tt) { return tt <= 2 ? 832 : 256; }     // tokens per staged chunk (image = 16 tt rows x chunk)
+
+template <int WAVES, int TT, bool CHUNKED>
 __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4, 8))) void attn_map_rows_kernel(const bf16_t* __restrict__ M, const bf16_t* __restrict__ X,
                                                                  bf16_t* __restrict__ out, const float* __restrict__ sc, const float* __restrict__ kappa,
                                                                  int N, int D, int H, int d, int ld) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int ldk = (N + 63) & ~63, LDV = ldk + 8;
+  const int ldk = CHUNKED ? mp_ch(TT) : ((N + 63) & ~63), LDV = ldk + 8;     // tokens per staged image
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
   bf16_t* Xt = reinterpret_cast<bf16_t*>(smem_raw);                       // [16 TT][LDV] (rows >= d stay zero)
   bf16_t* T = Xt + 16 * TT * LDV + wave * (16 * MP_LDT);                  // this wave's [16][MP_LDT] tile
   const int bz = blockIdx.y, b = bz / H, g = bz % H;
-  stage_slice_T<TT>(Xt, X + (long long)b * N * D + g * d, N, D, d, ldk, LDV, tid, WAVES * 64);
-  __syncthreads();
+  const bf16_t* Xg = X + (long long)b * N * D + g * d;
   // affine form (M is the centred mixed map Ac, the product wanted is with Ahat = sc_g Ac + kappa_g):
   // out = sc_g (Ac . X) + kappa_g * (column sums of X over the tokens), the sums taken from the staged slice
   __shared__ float colsum_s[16 * TT];
   float a_sc = 1.f, a_kp = 0.f;
-  if (sc) {
-    a_sc = sc[g]; a_kp = kappa[g];
-    const int part = tid % 16;                         // 16 threads per feature row
-    for (int t = tid / 16; t < 16 * TT; t += WAVES * 4) {
-      float acc_s = 0.f;
-      for (int n = part * 8; n < ldk; n += 128) {
-        const bf16x8 v8 = *reinterpret_cast<const bf16x8*>(Xt + t * LDV + n);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc_s += (float)v8[e];
-      }
-#pragma unroll
-      for (int m = 8; m >= 1; m >>= 1) acc_s += __shfl_xor(acc_s, m, 64);
-      if (part == 0) colsum_s[t] = acc_s;
-    }
+  if (sc) { a_sc = sc[g]; a_kp = kappa[g]; }
+  if (tid < 16 * TT) colsum_s[tid] = 0.f;
+  auto stage = [&](int n0) {       // tokens [n0, n0 + ldk) of the slice -> Xt, column sums accumulated (affine form)
+    stage_slice_T<TT>(Xt, Xg + (long long)n0 * D, min(N - n0, ldk), D, d, ldk, LDV, tid, WAVES * 64);
     __syncthreads();
-  }
+    if (sc) {
+      const int part = tid % 16;                         // 16 threads per feature row
+      for (int t = tid / 16; t < 16 * TT; t += WAVES * 4) {
+        float acc_s = 0.f;
+        for (int n = part * 8; n < ldk; n += 128) {
+          const bf16x8 v8 = *reinterpret_cast<const bf16x8*>(Xt + t * LDV + n);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc_s += (float)v8[e];
+        }
+#pragma unroll
+        for (int m = 8; m >= 1; m >>= 1) acc_s += __shfl_xor(acc_s, m, 64);
+        if (part == 0) colsum_s[t] += acc_s;
+      }
+      __syncthreads();
+    }
+  };
   const bf16_t* Mb = M + (long long)bz * N * ld;
-  const int nrt = (N + 15) >> 4, nsteps = ldk >> 6;
+  const int nrt = (N + 15) >> 4;
   const bool vec = (d % 4 == 0) && (D % 4 == 0);
   const int lrow = lane >> 3, lch = (lane & 7) * 8;                        // load shape: 8 rows x 8 chunks of 16 B
   const bf16_t* x0 = Xt + l15 * LDV + 16 * lg;
-  for (int rt = blockIdx.x * WAVES + wave; rt < nrt; rt += gridDim.x * WAVES) {
+  // one row tile against the staged tokens: map columns cbase + [0, 64 nsteps)
+  auto run = [&](int rt, int cbase, int nsteps, f32x4 (&acc)[TT]) {
     // unconditional loads at clamped addresses (rows >= N re-read row N-1, columns >= ld the row's last chunk):
     // what they return is finite map data that meets zeros of Xt or lands in rows that are never stored.
     // (Selecting between a load and a zero makes hipcc select between POINTERS and emit serialized flat loads.)
     const bf16_t* r0 = Mb + (long long)min(rt * 16 + lrow, N - 1) * ld;
     const bf16_t* r1 = Mb + (long long)min(rt * 16 + 8 + lrow, N - 1) * ld;
-    f32x4 acc[TT];
-#pragma unroll
-    for (int tt = 0; tt < TT; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
     // (named registers, not an array: hipcc left an indexed ring in scratch memory)
     uint4 ma0, mb0, ma1, mb1, ma2, mb2, ma3, mb3, ma4, mb4, ma5, mb5;
     auto fetch = [&](int step, uint4& ma, uint4& mb) {
-      const int j = min(step * 64 + lch, ld - 8);
+      const int j = min(cbase + step * 64 + lch, ld - 8);
       ma = *reinterpret_cast<const uint4*>(r0 + j);
       mb = *reinterpret_cast<const uint4*>(r1 + j);
     };
@@ -161,7 +168,9 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4, 8
     if (nfull + 2 < nsteps) { put(ma2, mb2); mult(nfull + 2); }
     if (nfull + 3 < nsteps) { put(ma3, mb3); mult(nfull + 3); }
     if (nfull + 4 < nsteps) { put(ma4, mb4); mult(nfull + 4); }
-    // C[row = t = 4 lg + r (+16)][col = token i]
+  };
+  // C[row = t = 4 lg + r (+16)][col = token i]
+  auto finish = [&](int rt, f32x4 (&acc)[TT]) {
     const int i = rt * 16 + l15;
     if (i < N) {
       bf16_t* orow = out + ((long long)b * N + i) * D + g * d;
@@ -175,68 +184,89 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4, 8
         store_t4(orow, 16 * tt + 4 * lg, d, vec, o);
       }
     }
+  };
+  if constexpr (!CHUNKED) {
+    __syncthreads();
+    stage(0);
+    __syncthreads();
+    for (int rt = blockIdx.x * WAVES + wave; rt < nrt; rt += gridDim.x * WAVES) {
+      f32x4 acc[TT];
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      run(rt, 0, ldk >> 6, acc);
+      finish(rt, acc);
+    }
+  } else {
+    const int rt = blockIdx.x * WAVES + wave;       // one row tile per wave; every wave takes part in the staging
+    f32x4 acc[TT];
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int n0 = 0; n0 < N; n0 += mp_ch(TT)) {
+      __syncthreads();                               // the previous chunk's fragments have been read
+      stage(n0);
+      __syncthreads();
+      if (rt < nrt) run(rt, n0, (min(N - n0, mp_ch(TT)) + 63) >> 6, acc);
+    }
+    if (rt < nrt) finish(rt, acc);
   }
 }
 
 // cols form: a wave owns a strip of 64 map columns and walks all rows 32 at a time; the contraction runs
 // over map rows, so the B operand (k = row, n = column) comes out of the row-major tile through the
 // transposing LDS read (ds_read_b64_tr_b16).
-template <int WAVES, int TT>
+template <int WAVES, int TT, bool CHUNKED>
 __global__ __launch_bounds__(WAVES * 64) void attn_map_cols_kernel(const bf16_t* __restrict__ M, const bf16_t* __restrict__ X,
                                                                  bf16_t* __restrict__ out, const float* __restrict__ sc, const float* __restrict__ kappa,
                                                                  int N, int D, int H, int d, int ld) {
   typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
   typedef __attribute__((ext_vector_type(8))) short s16x8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int ldk = (N + 63) & ~63, LDV = ldk + 8;
+  const int ldk = CHUNKED ? mp_ch(TT) : ((N + 63) & ~63), LDV = ldk + 8;     // tokens (= map rows here) per staged image
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
   bf16_t* Xt = reinterpret_cast<bf16_t*>(smem_raw);                       // [16 TT][LDV]
   bf16_t* T = Xt + 16 * TT * LDV + wave * (32 * MP_LDT);                  // this wave's [32][MP_LDT] tile
   const int bz = blockIdx.y, b = bz / H, g = bz % H;
-  stage_slice_T<TT>(Xt, X + (long long)b * N * D + g * d, N, D, d, ldk, LDV, tid, WAVES * 64);
-  __syncthreads();
-  // affine form (M is the centred mixed map Ac, the product wanted is with Ahat = sc_g Ac + kappa_g):
-  // out = sc_g (Ac . X) + kappa_g * (column sums of X over the tokens), the sums taken from the staged slice
+  const bf16_t* Xg = X + (long long)b * N * D + g * d;
+  // affine form: see the rows kernel
   __shared__ float colsum_s[16 * TT];
   float a_sc = 1.f, a_kp = 0.f;
-  if (sc) {
-    a_sc = sc[g]; a_kp = kappa[g];
-    const int part = tid % 16;                         // 16 threads per feature row
-    for (int t = tid / 16; t < 16 * TT; t += WAVES * 4) {
-      float acc_s = 0.f;
-      for (int n = part * 8; n < ldk; n += 128) {
-        const bf16x8 v8 = *reinterpret_cast<const bf16x8*>(Xt + t * LDV + n);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc_s += (float)v8[e];
-      }
-#pragma unroll
-      for (int m = 8; m >= 1; m >>= 1) acc_s += __shfl_xor(acc_s, m, 64);
-      if (part == 0) colsum_s[t] = acc_s;
-    }
+  if (sc) { a_sc = sc[g]; a_kp = kappa[g]; }
+  if (tid < 16 * TT) colsum_s[tid] = 0.f;
+  auto stage = [&](int n0) {
+    stage_slice_T<TT>(Xt, Xg + (long long)n0 * D, min(N - n0, ldk), D, d, ldk, LDV, tid, WAVES * 64);
     __syncthreads();
-  }
+    if (sc) {
+      const int part = tid % 16;                         // 16 threads per feature row
+      for (int t = tid / 16; t < 16 * TT; t += WAVES * 4) {
+        float acc_s = 0.f;
+        for (int n = part * 8; n < ldk; n += 128) {
+          const bf16x8 v8 = *reinterpret_cast<const bf16x8*>(Xt + t * LDV + n);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc_s += (float)v8[e];
+        }
+#pragma unroll
+        for (int m = 8; m >= 1; m >>= 1) acc_s += __shfl_xor(acc_s, m, 64);
+        if (part == 0) colsum_s[t] += acc_s;
+      }
+      __syncthreads();
+    }
+  };
   const bf16_t* Mb = M + (long long)bz * N * ld;
   const bool vec = (d % 4 == 0) && (D % 4 == 0);
   const int lrow = lane >> 3, lch = (lane & 7) * 8;
   const int nstrips = (N + 63) >> 6;
-  const int nrows = (N + 31) & ~31;
   const int q = l15 >> 2, pq = l15 & 3;
-  for (int strip = blockIdx.x * WAVES + wave; strip < nstrips; strip += gridDim.x * WAVES) {
-    const int j0 = strip * 64;
-    const int jc = min(j0 + lch, ld - 8);                // columns >= ld: any finite data, never stored
-    f32x4 acc[4][TT];
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int tt = 0; tt < TT; ++tt) acc[u][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // one strip of 64 map columns against the staged rows: map rows rbase + [0, nrows), nrows a multiple of 32
+  auto run = [&](int strip, int rbase, int nrows, f32x4 (&acc)[4][TT]) {
+    const int jc = min(strip * 64 + lch, ld - 8);        // columns >= ld: any finite data, never stored
     // register ring two 32-row steps (8 x 16 B per lane) ahead; clamped unconditional loads: rows >= N meet zeros of Xt
     // (named registers, not an array: hipcc left an indexed ring in scratch memory)
     uint4 p0, p1, p2, p3, q0, q1, q2, q3;
     auto fetch = [&](int i0, uint4& m0, uint4& m1, uint4& m2, uint4& m3) {
-      m0 = *reinterpret_cast<const uint4*>(Mb + (long long)min(i0 + lrow, N - 1) * ld + jc);
-      m1 = *reinterpret_cast<const uint4*>(Mb + (long long)min(i0 + 8 + lrow, N - 1) * ld + jc);
-      m2 = *reinterpret_cast<const uint4*>(Mb + (long long)min(i0 + 16 + lrow, N - 1) * ld + jc);
-      m3 = *reinterpret_cast<const uint4*>(Mb + (long long)min(i0 + 24 + lrow, N - 1) * ld + jc);
+      m0 = *reinterpret_cast<const uint4*>(Mb + (long long)min(rbase + i0 + lrow, N - 1) * ld + jc);
+      m1 = *reinterpret_cast<const uint4*>(Mb + (long long)min(rbase + i0 + 8 + lrow, N - 1) * ld + jc);
+      m2 = *reinterpret_cast<const uint4*>(Mb + (long long)min(rbase + i0 + 16 + lrow, N - 1) * ld + jc);
+      m3 = *reinterpret_cast<const uint4*>(Mb + (long long)min(rbase + i0 + 24 + lrow, N - 1) * ld + jc);
     };
     auto put = [&](const uint4& m0, const uint4& m1, const uint4& m2, const uint4& m3) {
       *reinterpret_cast<uint4*>(T + lrow * MP_LDT + lch) = m0;
@@ -245,7 +275,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_map_cols_kernel(const bf16_t*
       *reinterpret_cast<uint4*>(T + (24 + lrow) * MP_LDT + lch) = m3;
     };
     auto mult = [&](int i0) {
-      // A operand: Xt rows t, k-slots = map rows i0 + 8 lg + e
+      // A operand: Xt rows t, k-slots = staged rows i0 + 8 lg + e
       bf16x8 xa[TT];
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt) xa[tt] = *reinterpret_cast<const bf16x8*>(Xt + (16 * tt + l15) * LDV + i0 + 8 * lg);
@@ -274,10 +304,12 @@ __global__ __launch_bounds__(WAVES * 64) void attn_map_cols_kernel(const bf16_t*
       step(i00 + 32, q0, q1, q2, q3);
     }
     if (nfull < nrows) { put(p0, p1, p2, p3); mult(nfull); }
-    // C[row = t = 4 lg + r (+16)][col = token j0 + 16 u + l15]
+  };
+  // C[row = t = 4 lg + r (+16)][col = token j0 + 16 u + l15]
+  auto finish = [&](int strip, f32x4 (&acc)[4][TT]) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int j = j0 + 16 * u + l15;
+      const int j = strip * 64 + 16 * u + l15;
       if (j < N) {
         bf16_t* orow = out + ((long long)b * N + j) * D + g * d;
 #pragma unroll
@@ -291,16 +323,44 @@ __global__ __launch_bounds__(WAVES * 64) void attn_map_cols_kernel(const bf16_t*
         }
       }
     }
+  };
+  if constexpr (!CHUNKED) {
+    __syncthreads();
+    stage(0);
+    __syncthreads();
+    for (int strip = blockIdx.x * WAVES + wave; strip < nstrips; strip += gridDim.x * WAVES) {
+      f32x4 acc[4][TT];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) acc[u][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      run(strip, 0, (N + 31) & ~31, acc);
+      finish(strip, acc);
+    }
+  } else {
+    const int strip = blockIdx.x * WAVES + wave;    // one strip per wave; every wave takes part in the staging
+    f32x4 acc[4][TT];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) acc[u][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int n0 = 0; n0 < N; n0 += mp_ch(TT)) {
+      __syncthreads();
+      stage(n0);
+      __syncthreads();
+      if (strip < nstrips) run(strip, n0, (min(N - n0, mp_ch(TT)) + 31) & ~31, acc);
+    }
+    if (strip < nstrips) finish(strip, acc);
   }
 }
 
-template <bool COLS, int WAVES, int TT>
+template <bool COLS, int WAVES, int TT, bool CHUNKED>
 int launch_map_prod_w(const void* M, const void* X, void* out, const float* sc, const float* kappa, int B, int N, int D, int H, int ld,
                       int nsplit, hipStream_t st) {
   const int d = D / H;
-  const int ldk = (N + 63) & ~63;
+  const int ldk = CHUNKED ? mp_ch(TT) : ((N + 63) & ~63);
   const size_t lds = (size_t)16 * TT * (ldk + 8) * 2 + (size_t)WAVES * (COLS ? 32 : 16) * MP_LDT * 2;
-  auto kern = COLS ? attn_map_cols_kernel<WAVES, TT> : attn_map_rows_kernel<WAVES, TT>;
+  auto kern = COLS ? attn_map_cols_kernel<WAVES, TT, CHUNKED> : attn_map_rows_kernel<WAVES, TT, CHUNKED>;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { vu_set_error("attn_map_prod: cannot reserve %zu bytes of LDS", lds); return VU_ELAUNCH; }
@@ -316,15 +376,19 @@ template <bool COLS, int TT>
 int launch_map_prod(const void* M, const void* X, void* out, const float* sc, const float* kappa, int B, int N, int D, int H, int ld,
                     hipStream_t st) {
   const int units = COLS ? (N + 63) / 64 : (N + 15) / 16;       // strips / row tiles per (sample, head)
+  if ((size_t)16 * TT * (((N + 63) & ~63) + 8) * 2 + 8 * 32 * MP_LDT * 2 > 150 * 1024) {
+    // the head slice does not fit one LDS image: chunked form, one unit per wave, 7 waves per workgroup
+    return launch_map_prod_w<COLS, 7, TT, true>(M, X, out, sc, kappa, B, N, D, H, ld, (units + 6) / 7, st);
+  }
   // waves per workgroup: as many as there are units, in whole rounds where possible
   const int waves = units <= 4 ? 4 : ((units % 7 == 0 || (units > 8 && units <= 14)) ? 7 : 8);
   int nsplit = (512 + B * H - 1) / (B * H);
   const int maxsplit = (units + waves - 1) / waves;
   if (nsplit > maxsplit) nsplit = maxsplit;
   if (nsplit < 1) nsplit = 1;
-  if (waves == 4) return launch_map_prod_w<COLS, 4, TT>(M, X, out, sc, kappa, B, N, D, H, ld, nsplit, st);
-  if (waves == 7) return launch_map_prod_w<COLS, 7, TT>(M, X, out, sc, kappa, B, N, D, H, ld, nsplit, st);
-  return launch_map_prod_w<COLS, 8, TT>(M, X, out, sc, kappa, B, N, D, H, ld, nsplit, st);
+  if (waves == 4) return launch_map_prod_w<COLS, 4, TT, false>(M, X, out, sc, kappa, B, N, D, H, ld, nsplit, st);
+  if (waves == 7) return launch_map_prod_w<COLS, 7, TT, false>(M, X, out, sc, kappa, B, N, D, H, ld, nsplit, st);
+  return launch_map_prod_w<COLS, 8, TT, false>(M, X, out, sc, kappa, B, N, D, H, ld, nsplit, st);
 }
 
 }  // namespace
@@ -335,8 +399,6 @@ int vu_k_attn_map_prod(int dtype, int cols, const void* M, const void* X, void* 
   const int d = D / H;
   if (dtype != 1 || d > 96 || N < 64 || ld % 8 != 0) return 1;
   const int tt = d <= 32 ? 2 : 6;
-  if ((size_t)16 * tt * (((N + 63) & ~63) + 8) * 2 + 8 * 32 * MP_LDT * 2 > 150 * 1024) return 1;
   if (tt == 2) return cols ? launch_map_prod<true, 2>(M, X, out, sc, kappa, B, N, D, H, ld, st) : launch_map_prod<false, 2>(M, X, out, sc, kappa, B, N, D, H, ld, st);
   return cols ? launch_map_prod<true, 6>(M, X, out, sc, kappa, B, N, D, H, ld, st) : launch_map_prod<false, 6>(M, X, out, sc, kappa, B, N, D, H, ld, st);
 }
-
