@@ -173,6 +173,7 @@ GRAD_KEYS = ["reatten_matrix.weight", "reatten_matrix.bias", "var_norm.weight", 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("N,Cn,s,H", [(49, 3, 8, 4), (16, 3, 4, 4), (196, 1, 8, 2), (64, 3, 8, 8),
+                                      (64, 3, 16, 4), (16, 3, 32, 4),    # wide patches with cross inputs (MFMA weight gradients, edge pixels)
                                       (784, 3, 8, 8), (196, 3, 16, 8), (49, 3, 32, 8), (400, 1, 8, 4), (1156, 3, 4, 4), (1024, 1, 8, 8), (1024, 1, 16, 8),
                                       (225, 3, 8, 8), (289, 3, 8, 8),    # ragged rows (N % 4 != 0) through the MFMA map kernels
                                       (3136, 3, 4, 4)])                  # Lite level 2: long rows (chunked map products, long-row scores)
