@@ -73,8 +73,8 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const TI* __restrict__ in
       }
       TO* op = o == 0 ? o0 : (o == 1 ? o1 : o2);
       const float* __restrict__ wp = o == 0 ? w0 : (o == 1 ? w1 : w2);
-#pragma unroll
-      for (int co = 0; co < C; ++co) {
+#pragma unroll 1
+      for (int co = 0; co < C; ++co) {     // (rolled: 27 weights live at a time; unrolled, the 81 of a convolution sit in VGPRs)
         vu_f4 acc;
         const float b0 = bias ? bias[co] : 0.f;
 #pragma unroll
