@@ -143,7 +143,7 @@ __device__ __forceinline__ void vu_epilogue_swapped(const vu_gemm_args& g, const
 }
 
 template <typename T, typename TC, bool TA, bool TB, int BM, int BN, int BK>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void vu_gemm_kernel(const vu_gemm_args g) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 2 ? 3 : 1, 8))) void vu_gemm_kernel(const vu_gemm_args g) {
   constexpr int VEC = vu_vec<T>::N;            // elements per 16 B
   constexpr bool IS_BF16 = sizeof(T) == 2;
   constexpr int PADK = IS_BF16 ? 8 : 4;        // [row][k] images: row stride 80 B / 144 B
