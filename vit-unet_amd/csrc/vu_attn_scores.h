@@ -88,9 +88,10 @@ __global__ __launch_bounds__(WAVES * 64) void attn_scores_kernel(const T* __rest
 #pragma unroll
         for (int e = 0; e < VE; ++e) tmp[e] = (kc + e < d) ? kb[(long long)row * D + kc + e] : (T)0.f;
       }
-      // keys of whole 64-key groups are stored with their two 2-bit index fields exchanged
-      // (key 64u + 16a + 4b + c -> LDS row 64u + 16b + 4a + c): see the tile -> key map below
-      const int lrow = row < (EXACT ? ((NT * 16) >> 6) << 6 : (N >> 6) << 6) ? ((row & ~60) | (((row >> 2) & 3) << 4) | (((row >> 4) & 3) << 2)) : row;
+      // keys of whole 64-key groups are stored permuted (key 64u + 32 s1 + 8 a + 4 s0 + c -> LDS row
+      // 64u + 16 (2 s1 + s0) + 4 a + c): see the tile -> key map below
+      const int lrow = row < (EXACT ? ((NT * 16) >> 6) << 6 : (N >> 6) << 6)
+                           ? ((row & ~31) | (((row >> 2) & 1) << 4) | (((row >> 3) & 3) << 2) | (row & 3)) : row;
       *reinterpret_cast<uint4*>(&Ks[lrow * LDK + kc]) = *reinterpret_cast<uint4*>(tmp);
     }
   }
@@ -121,7 +122,8 @@ __global__ __launch_bounds__(WAVES * 64) void attn_scores_kernel(const T* __rest
   // two shuffles, a dropout hash word serves an in-lane key pair, and the stores are vectors.
   // Which key an accumulator row stands for is free (it only picks the K row an A-operand lane
   // reads): whole groups of 4 tiles (64 keys) are dealt so that a lane's 4 tiles hold 16
-  // CONSECUTIVE keys, 64u + 16 lg + 4 s + r - a query row is then written in full 128-byte
+  // CONSECUTIVE keys per tile pair, 64u + 32 (s >> 1) + 8 lg + 4 (s & 1) + r - one 16-byte store per pair, the
+  // four lane groups of a row side by side (64 contiguous bytes per instruction), a query row in full 128-byte
   // segments (4 lanes x 32 B) with 16-byte stores instead of 32-byte segments of 8-byte stores.
   // The permutation lives in the K staging pass (LDS row order), so fragment reads stay conflict-free.
   // EXACT: N == 16 * NT - every tile exists and is full, so all tile conditions fold at compile time
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_scores_kernel(const T* __rest
   // loop invariant, ~60 live registers that spill - and a scratch reload's vmcnt wait drains the store stream)
   int lgv = lg;
   asm volatile("" : "+v"(lgv));
-  auto j0_of = [&](int nt) { return nt < ngt ? ((nt >> 2) << 6) + (lgv << 4) + ((nt & 3) << 2) : nt * 16 + lgv * 4; };
+  auto j0_of = [&](int nt) { return nt < ngt ? ((nt >> 2) << 6) + ((nt & 2) << 4) + (lgv << 3) + ((nt & 1) << 2) : nt * 16 + lgv * 4; };
   f32x4 acc[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
