@@ -56,7 +56,7 @@ __device__ __forceinline__ typename Mma<T>::Frag load_frag(const T* p, int kvali
 
 // DP = head dim padded to a multiple of 32 ; NT = max 16-column tiles (N <= 16*NT)
 template <typename T, int NT, int DP, int WAVES, bool EXACT, bool SOFTMAX>
-__global__ __launch_bounds__(WAVES * 64) void attn_scores_kernel(const T* __restrict__ q, const T* __restrict__ k,
+__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu((!SOFTMAX && NT > 26) ? 4 : 1, 8))) void attn_scores_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                           T* __restrict__ Ps, int N, int D, int H, int d, int ld,
                                                           float scale, vu_rng rng_in) {
   typedef Mma<T> MM;
@@ -134,23 +134,29 @@ __global__ __launch_bounds__(WAVES * 64) void attn_scores_kernel(const T* __rest
   int lgv = lg;
   asm volatile("" : "+v"(lgv));
   auto j0_of = [&](int nt) { return nt < ngt ? ((nt >> 2) << 6) + ((nt & 2) << 4) + (lgv << 3) + ((nt & 1) << 2) : nt * 16 + lgv * 4; };
-  f32x4 acc[NT];
+  // accumulators: the softmax form needs the whole row (NT tiles); the plain product has no row-wide dependency and
+  // is done in two column halves for long rows - half the accumulator registers, twice the waves per SIMD
+  constexpr bool HALVES = !SOFTMAX && NT > 26;
+  constexpr int NTA = HALVES ? 26 : NT;            // tiles per pass (even: tile pairs never straddle a pass)
+  f32x4 acc[NTA];
+  auto compute = [&](int t0) {
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (nt < ntiles) {
-      const int key = nt * 16 + l15;       // LDS row (the staging pass applied the group permutation)
-      const bool kv = EXACT || key < N;
+    for (int nt = 0; nt < NTA; ++nt) {
+      acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (t0 + nt < ntiles) {
+        const int key = (t0 + nt) * 16 + l15;       // LDS row (the staging pass applied the group permutation)
+        const bool kv = EXACT || key < N;
 #pragma unroll
-      for (int ks = 0; ks < KSTEPS; ++ks) {
-        Frag kf;
-        if constexpr (MM::FE == 1) kf = kv ? (float)Ks[key * LDK + ks * MM::KS + lg] : 0.f;
-        else kf = kv ? *reinterpret_cast<const Frag*>(&Ks[key * LDK + ks * MM::KS + lg * MM::FE]) : MM::zero();
-        acc[nt] = MM::mma(kf, qf[ks], acc[nt]);
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+          Frag kf;
+          if constexpr (MM::FE == 1) kf = kv ? (float)Ks[key * LDK + ks * MM::KS + lg] : 0.f;
+          else kf = kv ? *reinterpret_cast<const Frag*>(&Ks[key * LDK + ks * MM::KS + lg * MM::FE]) : MM::zero();
+          acc[nt] = MM::mma(kf, qf[ks], acc[nt]);
+        }
       }
+      if constexpr (NT > 16) { if (nt % 7 == 6) __builtin_amdgcn_sched_barrier(0); }   // bound the K fragments in flight
     }
-    if constexpr (NT > 16) { if (nt % 7 == 6) __builtin_amdgcn_sched_barrier(0); }   // bound the K fragments in flight
-  }
+  };
   // store tiles nt (and nt+1 when both sit in a whole group: 8 consecutive keys, one 16-byte store for bf16)
   auto store_tiles = [&](T* prow, int nt, bool pair, const vu_f4& oa, const vu_f4& ob) {
     const int j0 = j0_of(nt);
@@ -168,28 +174,34 @@ __global__ __launch_bounds__(WAVES * 64) void attn_scores_kernel(const T* __rest
   };
   if constexpr (!SOFTMAX) {   // plain product (dAhat = dO v^T in the backward): scaled vector stores
     const int i = i0 + l15;
-    if (i < N) {
-      T* prow = Ps + ((long long)bz * N + i) * ld;
+    T* prow = Ps + ((long long)bz * N + (i < N ? i : 0)) * ld;
 #pragma unroll
-      for (int nt = 0; nt < NT; nt += 2) {
-        if (nt < ntiles) {
-          const bool pair = (nt + 1 < NT) && (nt + 1 < ntiles);
-          vu_f4 oa, ob = {{0.f, 0.f, 0.f, 0.f}};
-          const int ja = j0_of(nt);
+    for (int t0 = 0; t0 < NT; t0 += NTA) {
+      compute(t0);
+      if (i < N) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) oa.v[r] = (EXACT || ja + r < N) ? acc[nt][r] * scale : 0.f;
-          if (nt + 1 < NT) {
-            const int jb = j0_of(nt + 1);
+        for (int nt = 0; nt < NTA; nt += 2) {
+          const int gt = t0 + nt;                   // global tile index
+          if (gt < ntiles && gt < NT) {
+            const bool pair = (nt + 1 < NTA) && (gt + 1 < NT) && (gt + 1 < ntiles);
+            vu_f4 oa, ob = {{0.f, 0.f, 0.f, 0.f}};
+            const int ja = j0_of(gt);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ob.v[r] = (EXACT || jb + r < N) ? acc[nt + 1][r] * scale : 0.f;
+            for (int r = 0; r < 4; ++r) oa.v[r] = (EXACT || ja + r < N) ? acc[nt][r] * scale : 0.f;
+            if (nt + 1 < NTA) {
+              const int jb = j0_of(gt + 1);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) ob.v[r] = (EXACT || jb + r < N) ? acc[nt + 1][r] * scale : 0.f;
+            }
+            if (pair && gt + 1 < ngt) store_tiles(prow, gt, true, oa, ob);
+            else { store_tiles(prow, gt, false, oa, oa); if (pair) store_tiles(prow, gt + 1, false, ob, ob); }
           }
-          if (pair && nt + 1 < ngt) store_tiles(prow, nt, true, oa, ob);
-          else { store_tiles(prow, nt, false, oa, oa); if (pair) store_tiles(prow, nt + 1, false, ob, ob); }
         }
       }
     }
     continue;
   }
+  compute(0);
   // ---- row softmax (logits rounded to the storage type first, like the unfused path) ------------
   // Only the last key tile can be partial: full tiles take a mask-free path (wave-uniform branch).
   float mx = -INFINITY;
