@@ -47,6 +47,8 @@ static int launch_one(const vu_gemm_args& g, hipStream_t st) {
 
 template <typename T, typename TC, bool TA, bool TB>
 static int launch_tiles(const vu_gemm_args& g, hipStream_t st) {
+  static const int force = getenv("VU_GEMM_TILE") ? atoi(getenv("VU_GEMM_TILE")) : 0;     // measurement switch
+  if (force == 12864) return launch_one<T, TC, TA, TB, 128, 64>(g, st);
   if (g.N <= 32) return launch_one<T, TC, TA, TB, 128, 32>(g, st);
   if (g.M <= 64) return launch_one<T, TC, TA, TB, 64, 64>(g, st);
   if (g.N <= 64) return launch_one<T, TC, TA, TB, 128, 64>(g, st);
