@@ -180,6 +180,19 @@ GRAD_KEYS = ["reatten_matrix.weight", "reatten_matrix.bias", "var_norm.weight", 
 @pytest.mark.parametrize("mode", ["eval", "train", "train_drop"])
 @pytest.mark.parametrize("cross", [False, True])
 def test_attention_fwd_bwd(dt, N, Cn, s, H, mode, cross):
+    _attention_fwd_bwd(dt, N, Cn, s, H, mode, cross, centered=False)
+
+
+@pytest.mark.parametrize("N,Cn,s,H", [(784, 3, 8, 8), (289, 3, 8, 8)])
+@pytest.mark.parametrize("mode", ["train", "train_drop"])
+def test_attention_centred_map_form(N, Cn, s, H, mode, monkeypatch):
+    """The model path's centred-map form (mix + statistics in one pass, BatchNorm's affine part inside the PV / dv
+    products) against the same oracle and tolerances as the plain form; VU_ATTN_CENTERED switches the stand-alone op."""
+    monkeypatch.setenv("VU_ATTN_CENTERED", "1")
+    _attention_fwd_bwd(torch.bfloat16, N, Cn, s, H, mode, False, centered=True)
+
+
+def _attention_fwd_bwd(dt, N, Cn, s, H, mode, cross, centered):
     if dt == torch.bfloat16 and mode == "eval":
         pytest.skip("eval with tiny running_var amplifies bf16 rounding by 100x; covered in fp32")
     if N * Cn * s * s > 50000 and (mode == "eval" or cross):
@@ -216,13 +229,14 @@ def test_attention_fwd_bwd(dt, N, Cn, s, H, mode, cross):
     nbytes = L.vu_attn_workspace_bytes(code, B, N, D, H)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
     y = torch.empty_like(xqd)
-    amap = torch.empty(B, H, N, N, dtype=dt, device=DEV)
+    amap = None if centered else torch.empty(B, H, N, N, dtype=dt, device=DEV)    # (the centred form never forms the map)
     check(L.vu_attn_forward(code, C.byref(prm), ptr(xqd), ptr(xkvd), ptr(y), ptr(amap), ptr(ws), nbytes, B, N, D, H, Cn,
                             ad, pd, int(training), seed, sid, st()))
     ft, bt = TOL[dt]
     if dt == torch.float32:
         ft, bt = 1e-4, 1e-3      # softmax/BN chains: fp32 noise amplified by 1/sqrt(var) ~ 100
-    assert serr(amap, mapr) < ft, "attention map"
+    if not centered:
+        assert serr(amap, mapr) < ft, "attention map"
     assert serr(y, yr) < ft, "attention output"
     if training:    # running statistics updated in place (momentum 0.1, unbiased variance)
         assert serr(d["var_norm.running_mean"], pr["var_norm.running_mean"]) < 1e-4

@@ -11,6 +11,7 @@
 #include <string>
 
 #include "../../include/vit_unet_amd.h"
+#include <stdlib.h>
 #include "vu_kernels.h"
 
 const char* vu_get_error();
@@ -752,6 +753,8 @@ int vu_attn_forward(int dtype, const vu_attn_params* prm, const void* xq, const 
   AttnBuf a; AttnScratch sc; void* dz;
   carve_attn_ws(bp, d, a, sc, &dz);
   if (bp.off > ws_bytes) { vu_set_error("attention workspace too small"); return VU_EWORKSPACE; }
+  // test switch: the stand-alone op in the model path's centred-map form (only when the map itself is not asked for)
+  d.centered = (!map_out && getenv("VU_ATTN_CENTERED")) ? 1 : 0;
   VU_TRY(attn_forward(d, *prm, xq, xkv, y, a, sc.partials, attn_drop, proj_drop, training, seed, stream_id, nullptr,
                       (hipStream_t)stream));
   if (map_out) {  // the attn_next tensor of model.py:160 as (B,H,N,N) without row padding
@@ -771,6 +774,7 @@ int vu_attn_backward(int dtype, const vu_attn_params* prm, const vu_attn_grads* 
   AttnBuf a; AttnScratch sc; void* dzb;
   carve_attn_ws(bp, d, a, sc, &dzb);
   if (bp.off > ws_bytes) { vu_set_error("attention workspace too small"); return VU_EWORKSPACE; }
+  d.centered = getenv("VU_ATTN_CENTERED") ? 1 : 0;      // must match what the forward call used (test switch)
   const void* dz = dy;
   vu_rng rp = vu_make_rng(seed, 2 * stream_id + 1, training ? proj_drop : 0.f);
   if (rp.thr != 0) { VU_TRY(vu_k_dropout(dtype, dy, dzb, (long long)B * N * D, rp, (hipStream_t)stream)); dz = dzb; }
