@@ -305,7 +305,6 @@ int launch_scores_w(const T* q, const T* k, T* Ps, int B, int N, int D, int H, i
   // row tiles over several workgroups so that at least ~512 are in flight
   const int nrt = (N + 15) / 16, maxsplit = (nrt + WAVES - 1) / WAVES;
   int nsplit = (512 + B * H - 1) / (B * H);
-  if (softmax && N > 208) nsplit = maxsplit;   // VALU-bound form: one tile per wave, finer-grained balance (measured)
   if (nsplit > maxsplit) nsplit = maxsplit;
   if (nsplit < 1) nsplit = 1;
   dim3 grid((unsigned)nsplit, (unsigned)(B * H));
@@ -320,10 +319,12 @@ int launch_scores(const T* q, const T* k, T* Ps, int B, int N, int D, int H, int
                   hipStream_t st) {
   // long rows (N > 208): 128-row workgroups (8 waves) halve the K re-staging; measured 2.0 ms vs
   // 3.25 ms per step against 64-row workgroups on Base (profiles/).
-  // long rows: the plain product is store-bound and takes 7 waves (49 row tiles = 7 x 7 at N = 784); the
-  // softmax form is VALU-bound (exp + dropout hash) and wants all 8 wave slots of the CU
+  // long rows: the plain product is store-bound and takes 7 waves (49 row tiles = 7 x 7 at N = 784); the softmax
+  // form is VALU-bound (exp + dropout hash, 232 VGPRs = 2 waves per SIMD): 4-wave workgroups, two per CU from
+  // different (sample, head) pairs, so that one multiplies while the other stages its K (measured per step at
+  // Base: 8 waves x 7 splits 1.53 ms, 4 waves x 2 splits 1.36, 4 waves x 1 split 1.27)
   if constexpr (NT > 13) {
-    if constexpr (SOFTMAX) return launch_scores_w<T, NT, DP, 8, true>(q, k, Ps, B, N, D, H, ld, scale, rng, st);
+    if constexpr (SOFTMAX) return launch_scores_w<T, NT, DP, 4, true>(q, k, Ps, B, N, D, H, ld, scale, rng, st);
     else return launch_scores_w<T, NT, DP, 7, false>(q, k, Ps, B, N, D, H, ld, scale, rng, st);
   }
   else if constexpr (NT == 13) {
