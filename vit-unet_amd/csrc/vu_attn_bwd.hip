@@ -683,7 +683,8 @@ int launch_map_bwd_mm(const void* Ps, void* dA, const float* W, const float* c, 
     if (e != hipSuccess) { vu_set_error("map_bwd: cannot reserve %zu bytes of LDS", lds); return VU_ELAUNCH; }
   }
   long long grid = WPR == 4 ? rows : (rows + 3) / 4;
-  if (grid > 1024) grid = 1024;
+  const long long cap = WPR == 4 ? 1024 : 512;     // (measured: 512 blocks of 4 one-wave rows beat 1024 at N = 196)
+  if (grid > cap) grid = cap;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, (const bf16_t*)Ps, (bf16_t*)dA, W, c, gamma, stats, dW, dc,
                      rows, N, ld, inv_keep, scale);
   if (vu_prof_on()) vu_prof_note(WPR == 4 ? "map_bwd_mm_kernel" : "map_bwd_mm_kernel<1 wave/row>", 0.0, (double)B * 8 * N * N * 3 * 2.0);
