@@ -141,6 +141,28 @@ int vu_adamw(float* params, const float* grads, float* m, float* v, void* shadow
              const float* hyper, int* step, float grad_scale, void* stream);
 int vu_cast_bf16(const float* in, void* out, long long n, void* stream);
 
+/* Dice loss with its gradient (README.md:91-101: smooth = 1, flattened,
+ * 1 - (2 sum(p t) + 1) / (sum p + sum t + 1)).  apply_sigmoid != 0: p = sigmoid(logits) (the
+ * segmentation head of BASELINE config 5 - the reference has none) and dlogits is the
+ * gradient w.r.t. the logits; dlogits may be NULL (loss only).  partials: >=
+ * vu_dice_partials_floats() floats.  Operands 16-byte aligned. */
+size_t vu_dice_partials_floats(void);
+int vu_dice_loss(const float* logits, const float* target, float* dlogits, float* loss,
+                 float* partials, long long n, int apply_sigmoid, float grad_scale, void* stream);
+/* Per-image PSNR = 10 log10(R^2 / mean((target-out)^2)) over P elements per image
+ * (vit_unet/torch/functions.py:7-19, skimage.metrics.peak_signal_noise_ratio per image);
+ * psnr: B floats; partials: >= vu_psnr_partials_floats(B) floats. */
+size_t vu_psnr_partials_floats(int B);
+int vu_psnr(const float* target, const float* out, float* psnr, float* partials, int B, long long P,
+            float data_range, void* stream);
+/* Per-image mean SSIM of (B,C,H,W) float images, averaged over channels (README.md:85-89;
+ * scikit-image structural_similarity defaults: uniform win x win window (7), K1 = 0.01,
+ * K2 = 0.03, sample covariance, (win-1)/2 border cropped).  ssim: B floats; partials: >=
+ * vu_ssim_partials_floats(...) floats. */
+size_t vu_ssim_partials_floats(int B, int C, int H, int W, int win);
+int vu_ssim(const float* target, const float* out, float* ssim, float* partials, int B, int C, int H,
+            int W, int win, float data_range, void* stream);
+
 /* In-process launch profiler (bench.py's roofline leg): after vu_prof_enable(stream) an event is
  * recorded behind every launch; vu_prof_report() stops, waits, and returns a JSON object
  * {"<kernel tag>": {"count","ms","flops","bytes"}} with ALGORITHMIC flops / bytes per tag. */

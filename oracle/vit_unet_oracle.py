@@ -29,7 +29,7 @@ __all__ = [
     "Config", "retile", "patchify", "unpatchify", "downsample", "upsample",
     "conv3x3_per_patch", "reattention", "te_block", "skip_block", "forward",
     "param_shapes", "param_count", "make_weights", "keep_mask", "mse_loss", "psnr",
-    "dice_loss", "adamw_step", "PRESETS",
+    "ssim", "dice_loss", "adamw_step", "PRESETS",
 ]
 
 
@@ -441,6 +441,36 @@ def psnr(target, out, data_range: float = 1.0):
     B = target.shape[0]
     mse = ((target.double() - out.double()) ** 2).reshape(B, -1).mean(dim=1)
     return 10.0 * torch.log10(data_range ** 2 / mse)
+
+
+def ssim(target, out, data_range: float = 1.0, win: int = 7, K1: float = 0.01, K2: float = 0.03):
+    """Per-image mean SSIM, channels averaged (README.md:85-89 names the metric; the reference has
+    no implementation).  Third-party algorithm restated: scikit-image (unpinned in
+    requirements.txt, absent here) `structural_similarity(im1, im2, data_range=R, channel_axis=0)`
+    with its defaults - `scipy.ndimage.uniform_filter(size=win)` local moments, sample covariance
+    (N/(N-1)), S = (2 ux uy + C1)(2 vxy + C2) / ((ux^2 + uy^2 + C1)(vx + vy + C2)), C1 = (K1 R)^2,
+    C2 = (K2 R)^2, mean of S in float64 after cropping (win-1)//2 on every side.  PARITY UNPINNED
+    (no reference fixture exists for it); float64 throughout."""
+    from scipy.ndimage import uniform_filter
+    X = np.asarray(target, dtype=np.float64)
+    Y = np.asarray(out, dtype=np.float64)
+    B, C = X.shape[:2]
+    NP = win * win
+    cov_norm = NP / (NP - 1.0)
+    C1, C2 = (K1 * data_range) ** 2, (K2 * data_range) ** 2
+    pad = (win - 1) // 2
+    res = np.zeros(B)
+    for b in range(B):
+        acc = 0.0
+        for c in range(C):
+            x, y = X[b, c], Y[b, c]
+            ux, uy = uniform_filter(x, size=win), uniform_filter(y, size=win)
+            uxx, uyy, uxy = uniform_filter(x * x, size=win), uniform_filter(y * y, size=win), uniform_filter(x * y, size=win)
+            vx, vy, vxy = cov_norm * (uxx - ux * ux), cov_norm * (uyy - uy * uy), cov_norm * (uxy - ux * uy)
+            S = ((2 * ux * uy + C1) * (2 * vxy + C2)) / ((ux ** 2 + uy ** 2 + C1) * (vx + vy + C2))
+            acc += S[pad:S.shape[0] - pad, pad:S.shape[1] - pad].mean()
+        res[b] = acc / C
+    return torch.from_numpy(res)
 
 
 def adamw_step(p, g, m, v, step: int, lr=1e-4, b1=0.9, b2=0.999, eps=1e-8, wd=1e-2):

@@ -140,3 +140,33 @@ def test_keep_mask_statistics():
     # neighbouring pairs are not correlated
     a, b = m[0::2].float(), m[1::2].float()
     assert abs(((a - a.mean()) * (b - b.mean())).mean().item()) < 2e-3
+
+
+def test_metric_oracles_hand_values():
+    """PSNR / Dice / SSIM restatements against hand-computed values (the reference holds no fixtures
+    for them: functions.py:7-19 defers to scikit-image, README.md:85-101 is prose)."""
+    y = torch.full((2, 1, 9, 9), 0.5)
+    x = y + 0.1
+    assert torch.allclose(O.psnr(y, x), torch.full((2,), 20.0, dtype=torch.float64), atol=1e-5)   # 10 log10(1/0.01)
+    # Dice, README snippet: 1 - (2*I + 1)/(S + T + 1)
+    a, b = torch.tensor([1.0, 0.0, 1.0, 1.0]), torch.tensor([1.0, 1.0, 0.0, 1.0])
+    assert abs(O.dice_loss(a, b).item() - (1 - 5.0 / 7.0)) < 1e-7
+    # SSIM of constant images: variances vanish, S = (2ab + C1)/(a^2 + b^2 + C1)
+    s = O.ssim(y.numpy(), x.numpy())
+    c1 = 0.01 ** 2
+    assert torch.allclose(s, torch.full((2,), (2 * 0.5 * 0.6 + c1) / (0.25 + 0.36 + c1), dtype=torch.float64), atol=1e-9)
+    # brute-force windows on a small random pair
+    g = torch.Generator().manual_seed(5)
+    p, q = torch.rand(1, 2, 10, 12, generator=g).double().numpy(), torch.rand(1, 2, 10, 12, generator=g).double().numpy()
+    win, tot = 7, 0.0
+    for c in range(2):
+        vals = []
+        for i in range(10 - win + 1):
+            for j in range(12 - win + 1):
+                u, v = p[0, c, i:i + win, j:j + win].ravel(), q[0, c, i:i + win, j:j + win].ravel()
+                cov = np.cov(u, v, ddof=1)
+                vals.append(((2 * u.mean() * v.mean() + c1) * (2 * cov[0, 1] + 0.03 ** 2))
+                            / ((u.mean() ** 2 + v.mean() ** 2 + c1) * (cov[0, 0] + cov[1, 1] + 0.03 ** 2)))
+        tot += np.mean(vals)
+    assert abs(O.ssim(p, q).item() - tot / 2) < 1e-10
+    assert abs(O.ssim(p, p).item() - 1.0) < 1e-12

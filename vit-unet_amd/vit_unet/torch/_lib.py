@@ -76,6 +76,12 @@ SIGNATURES = {
     "vu_mse_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _f, _vp]),
     "vu_adamw": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _vp, _vp, _f, _vp]),
     "vu_cast_bf16": (_i, [_vp, _vp, _ll, _vp]),
+    "vu_dice_partials_floats": (_sz, []),
+    "vu_dice_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _i, _f, _vp]),
+    "vu_psnr_partials_floats": (_sz, [_i]),
+    "vu_psnr": (_i, [_vp, _vp, _vp, _vp, _i, _ll, _f, _vp]),
+    "vu_ssim_partials_floats": (_sz, [_i, _i, _i, _i, _i]),
+    "vu_ssim": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "vu_prof_enable": (_i, [_vp]),
     "vu_prof_report": (C.c_char_p, []),
 }

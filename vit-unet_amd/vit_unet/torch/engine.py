@@ -48,7 +48,12 @@ def allreduce_bucket(flat: torch.Tensor, lo: int, hi: int, group=None):
 
 class TrainStep:
     def __init__(self, model, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
-                 process_group=None, seed: int = 0, overlap: bool = True):
+                 process_group=None, seed: int = 0, overlap: bool = True, loss: str = "mse"):
+        """`loss`: "mse" (run_denoising.py:80) or "dice" (README.md:91-101 on sigmoid(model output),
+        the segmentation configuration of BASELINE config 5)."""
+        if loss not in ("mse", "dice"):
+            raise ValueError(f"loss must be 'mse' or 'dice', got {loss!r}")
+        self.loss_kind = loss
         model._ensure_flat()
         self.model = model
         dev = model._arena.device
@@ -59,7 +64,7 @@ class TrainStep:
         self.hyper = torch.tensor([lr, betas[0], betas[1], eps, weight_decay], dtype=torch.float32, device=dev)
         self.step_count = torch.zeros(1, dtype=torch.int32, device=dev)      # device-side (graph replay safe)
         self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
-        self.partials = torch.zeros(2048, dtype=torch.float32, device=dev)
+        self.partials = torch.zeros(max(2048, lib().vu_dice_partials_floats()), dtype=torch.float32, device=dev)
         self.seed = seed
         self.pg = process_group
         self.world = 1
@@ -91,8 +96,12 @@ class TrainStep:
         m._garena.zero_()
         check(L.vu_model_forward(cfg, ptr(m._arena), ptr(m._shadow), ptr(m._bn), ptr(x), ptr(out), ptr(ws), ws.numel(),
                                  B, 1, self.seed, ptr(salt), st), "vu_model_forward")
-        check(L.vu_mse_loss(ptr(out), ptr(y), ptr(dout), ptr(self.loss), ptr(self.partials), out.numel(), 1.0, st),
-              "vu_mse_loss")
+        if self.loss_kind == "mse":
+            check(L.vu_mse_loss(ptr(out), ptr(y), ptr(dout), ptr(self.loss), ptr(self.partials), out.numel(), 1.0, st),
+                  "vu_mse_loss")
+        else:
+            check(L.vu_dice_loss(ptr(out), ptr(y), ptr(dout), ptr(self.loss), ptr(self.partials), out.numel(), 1, 1.0,
+                                 st), "vu_dice_loss")
         cur = torch.cuda.current_stream(self.dev)
         for stage, (lo, hi) in zip((1, 2, 3), self._buckets):
             check(L.vu_model_backward(cfg, ptr(m._arena), ptr(m._shadow), ptr(m._bn), ptr(m._garena), ptr(dout), None,
