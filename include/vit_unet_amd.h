@@ -163,6 +163,19 @@ size_t vu_ssim_partials_floats(int B, int C, int H, int W, int win);
 int vu_ssim(const float* target, const float* out, float* ssim, float* partials, int B, int C, int H,
             int W, int win, float data_range, void* stream);
 
+/* Device-side input pipeline of the denoising runs: DenoisingDataset.__getitem__
+ * (vit_unet/torch/dataset.py:52-71) + the albumentations transforms of run_denoising.py:52-59 for
+ * a whole batch.  noisy / clean: (B,Hs,Ws,channels) uint8 HWC as decoded; x / y: (B,channels,im,im)
+ * float32.  Steps: cv2.resize to im x im (skipped when Hs == Ws == im) -> warpAffine with the
+ * per-image INVERSE 2x3 matrices inv_affine (B x 6 doubles, device memory; NULL = validation
+ * transform, no warp; bilinear for noisy, nearest for clean, constant border 0) -> Normalize
+ * ((v - 255 mean) / (255 std)) on noisy only -> /255 on both -> CHW.  A pair may be omitted
+ * (noisy == x == NULL or clean == y == NULL).  scratch: >= vu_denoise_prepare_scratch_bytes. */
+size_t vu_denoise_prepare_scratch_bytes(int B, int im, int channels);
+int vu_denoise_prepare(const uint8_t* noisy, const uint8_t* clean, float* x, float* y,
+                       uint8_t* scratch, size_t scratch_bytes, const double* inv_affine, int B,
+                       int Hs, int Ws, int channels, int im, float mean, float std, void* stream);
+
 /* In-process launch profiler (bench.py's roofline leg): after vu_prof_enable(stream) an event is
  * recorded behind every launch; vu_prof_report() stops, waits, and returns a JSON object
  * {"<kernel tag>": {"count","ms","flops","bytes"}} with ALGORITHMIC flops / bytes per tag. */

@@ -29,7 +29,8 @@ __all__ = [
     "Config", "retile", "patchify", "unpatchify", "downsample", "upsample",
     "conv3x3_per_patch", "reattention", "te_block", "skip_block", "forward",
     "param_shapes", "param_count", "make_weights", "keep_mask", "mse_loss", "psnr",
-    "ssim", "dice_loss", "adamw_step", "PRESETS",
+    "ssim", "dice_loss", "resize_u8", "warp_affine_u8", "invert_affine", "shift_scale_rotate_matrix",
+    "denoise_prepare", "adamw_step", "PRESETS",
 ]
 
 
@@ -471,6 +472,117 @@ def ssim(target, out, data_range: float = 1.0, win: int = 7, K1: float = 0.01, K
             acc += S[pad:S.shape[0] - pad, pad:S.shape[1] - pad].mean()
         res[b] = acc / C
     return torch.from_numpy(res)
+
+
+# --------------------------------------------------------------------------------------------
+# f3: host-side input pipeline (dataset.py:52-71 + run_denoising.py:52-59), third-party arithmetic
+# restated: OpenCV (`cv2`, unpinned in requirements.txt, absent here) 8-bit resize / warpAffine
+# fixed-point schemes and albumentations' Normalize / ShiftScaleRotate.  PARITY UNPINNED against
+# cv2 / albumentations themselves (neither can be run here and the reference holds no fixture).
+# --------------------------------------------------------------------------------------------
+def _lin_coef(dsize: int, ssize: int):
+    """cv2 resize INTER_LINEAR tables for 8-bit images: tap pair and 11-bit coefficient pair."""
+    d = np.arange(dsize, dtype=np.float64)
+    f = ((d + 0.5) * (ssize / dsize) - 0.5).astype(np.float32)
+    s = np.floor(f).astype(np.int64)
+    f = (f - s.astype(np.float32)).astype(np.float32)
+    lo, hi = s < 0, s >= ssize - 1
+    f[lo] = 0.0
+    s[lo] = 0
+    f[hi] = 0.0
+    s[hi] = ssize - 1
+    s1 = np.minimum(s + 1, ssize - 1)
+    a0 = np.rint((np.float32(1.0) - f) * np.float32(2048.0)).astype(np.int64)
+    a1 = np.rint(f * np.float32(2048.0)).astype(np.int64)
+    return s, s1, a0, a1
+
+
+def resize_u8(img: np.ndarray, im: int) -> np.ndarray:
+    """cv2.resize(img, (im, im)) for an (H,W,C) uint8 image, default INTER_LINEAR (dataset.py:55-56):
+    two-pass 11-bit fixed point; an exact 2x reduction is the 2x2 box mean (OpenCV switches
+    INTER_LINEAR to its fast INTER_AREA there)."""
+    H, W, C = img.shape
+    if H == im and W == im:
+        return img.copy()
+    v = img.astype(np.int64)
+    if H == 2 * im and W == 2 * im:
+        return ((v[0::2, 0::2] + v[0::2, 1::2] + v[1::2, 0::2] + v[1::2, 1::2] + 2) >> 2).astype(np.uint8)
+    x0, x1, a0, a1 = _lin_coef(im, W)
+    y0, y1, b0, b1 = _lin_coef(im, H)
+    S = v[:, x0, :] * a0[None, :, None] + v[:, x1, :] * a1[None, :, None]        # (H, im, C)
+    S0, S1 = S[y0], S[y1]
+    out = (((b0[:, None, None] * (S0 >> 4)) >> 16) + ((b1[:, None, None] * (S1 >> 4)) >> 16) + 2) >> 2
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
+def shift_scale_rotate_matrix(im: int, angle: float, scale: float, dx: float, dy: float) -> np.ndarray:
+    """albumentations ShiftScaleRotate's forward 2x3 matrix: cv2.getRotationMatrix2D(center, angle,
+    scale) with center = (w/2 - 0.5, h/2 - 0.5), then the shift (dx*w, dy*h) added."""
+    cx = cy = im / 2.0 - 0.5
+    a = scale * math.cos(math.radians(angle))
+    b = scale * math.sin(math.radians(angle))
+    return np.array([[a, b, (1 - a) * cx - b * cy + dx * im], [-b, a, b * cx + (1 - a) * cy + dy * im]], dtype=np.float64)
+
+
+def invert_affine(M: np.ndarray) -> np.ndarray:
+    """The inversion cv2.warpAffine applies to a forward matrix."""
+    M = np.asarray(M, dtype=np.float64).reshape(2, 3)
+    D = M[0, 0] * M[1, 1] - M[0, 1] * M[1, 0]
+    D = 1.0 / D if D != 0 else 0.0
+    A11, A22 = M[1, 1] * D, M[0, 0] * D
+    i00, i01, i10, i11 = A11, M[0, 1] * (-D), M[1, 0] * (-D), A22
+    b1 = -i00 * M[0, 2] - i01 * M[1, 2]
+    b2 = -i10 * M[0, 2] - i11 * M[1, 2]
+    return np.array([[i00, i01, b1], [i10, i11, b2]], dtype=np.float64)
+
+
+def warp_affine_u8(img: np.ndarray, Minv: np.ndarray, nearest: bool) -> np.ndarray:
+    """cv2.warpAffine(img, M, (w,h), INTER_LINEAR | INTER_NEAREST, BORDER_CONSTANT, 0) for a square
+    (im,im,C) uint8 image, given the INVERSE matrix: 10-bit fixed-point coordinates; bilinear at 1/32
+    sub-pixel with integer weights (sum 1024, round half up); taps outside the image are 0."""
+    im, _, C = img.shape
+    xs = np.arange(im, dtype=np.float64)
+    ys = np.arange(im, dtype=np.float64)
+    adx = np.rint(Minv[0, 0] * xs * 1024.0).astype(np.int64)[None, :]
+    ady = np.rint(Minv[1, 0] * xs * 1024.0).astype(np.int64)[None, :]
+    X0 = np.rint((Minv[0, 1] * ys + Minv[0, 2]) * 1024.0).astype(np.int64)[:, None]
+    Y0 = np.rint((Minv[1, 1] * ys + Minv[1, 2]) * 1024.0).astype(np.int64)[:, None]
+    pad = np.zeros((im + 2, im + 2, C), dtype=np.int64)
+    pad[1:-1, 1:-1] = img
+
+    def tap(yy, xx):
+        ok = (yy >= 0) & (yy < im) & (xx >= 0) & (xx < im)
+        return pad[np.where(ok, yy, -1) + 1, np.where(ok, xx, -1) + 1]
+    if nearest:
+        return tap((Y0 + 512 + ady) >> 10, (X0 + 512 + adx) >> 10).astype(np.uint8)
+    X, Y = (X0 + 16 + adx) >> 5, (Y0 + 16 + ady) >> 5
+    sx, sy, ax, ay = X >> 5, Y >> 5, (X & 31)[..., None], (Y & 31)[..., None]
+    acc = ((32 - ax) * (32 - ay) * tap(sy, sx) + ax * (32 - ay) * tap(sy, sx + 1)
+           + (32 - ax) * ay * tap(sy + 1, sx) + ax * ay * tap(sy + 1, sx + 1) + 512) >> 10
+    return acc.astype(np.uint8)
+
+
+def denoise_prepare(noisy: np.ndarray, clean: np.ndarray, im: int, fwd: Optional[np.ndarray] = None,
+                    mean: float = 0.456, std: float = 0.224):
+    """One batch of DenoisingDataset items (dataset.py:52-71) under run_denoising.py's train
+    (`fwd` = (B,2,3) ShiftScaleRotate matrices) or validation (`fwd=None`) transform.
+    noisy / clean: (B,H,W,C) uint8 -> x, y: (B,C,im,im) float32 torch tensors.
+    Normalize (albumentations, float32): (v - mean*255) * (1 / (std*255)) on the image only; the
+    "mask" (clean) is warped with nearest interpolation and not normalised; then both `/255.`."""
+    B = noisy.shape[0]
+    m255 = np.float32(mean) * np.float32(255.0)
+    rden = np.float32(1.0) / (np.float32(std) * np.float32(255.0))
+    xs, ys = [], []
+    for b in range(B):
+        n, c = resize_u8(noisy[b], im), resize_u8(clean[b], im)
+        if fwd is not None:
+            Minv = invert_affine(fwd[b])
+            n, c = warp_affine_u8(n, Minv, nearest=False), warp_affine_u8(c, Minv, nearest=True)
+        xn = ((n.astype(np.float32) - m255) * rden) / np.float32(255.0)
+        yc = (c / 255.0).astype(np.float32)
+        xs.append(xn.transpose(2, 0, 1))
+        ys.append(yc.transpose(2, 0, 1))
+    return torch.from_numpy(np.stack(xs)), torch.from_numpy(np.stack(ys))
 
 
 def adamw_step(p, g, m, v, step: int, lr=1e-4, b1=0.9, b2=0.999, eps=1e-8, wd=1e-2):
