@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="N=1: launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-host-input", action="store_true", help="skip the PCIe-inclusive legs (N=1 only)")
     ap.add_argument("--profile-steps", type=int, default=2)
     ap.add_argument("--dump-profile", default=None, help="write the full per-kernel table (JSON) here")
     return ap.parse_args()
@@ -148,6 +149,40 @@ def main():
     images = a.batch * world * a.steps
     value = images / dt_s
 
+    # PCIe-inclusive rates (never `value`): the same step fed from pinned host memory, (a) as the float32
+    # CHW batch ImageFitter.unpack moves (dataset.py:78-91), (b) as decoded uint8 HWC images that the
+    # device-side input pipeline (vu_denoise_prepare, train transform) turns into the batch
+    host_in = None
+    if rank == 0 and world == 1 and not a.no_host_input:
+        from vit_unet.torch.dataset import DenoisingBatchTransform
+        n_h = max(3, min(a.steps, 10))
+        hx, hy = x.cpu().pin_memory(), y.cpu().pin_memory()
+        hu = (y.cpu() * 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous().pin_memory()
+        prep = DenoisingBatchTransform(224, train=True, seed=0)
+        gx, gy = (ts._gx, ts._gy) if use_graph else (x, y)
+
+        def step_f32():
+            gx.copy_(hx, non_blocking=True)
+            gy.copy_(hy, non_blocking=True)
+            step()
+
+        def step_u8():
+            b = prep(hu, hu)
+            gx.copy_(b["x"])
+            gy.copy_(b["y"])
+            step()
+        host_in = {}
+        for key, fn in (("float32_chw", step_f32), ("uint8_hwc_device_pipeline", step_u8)):
+            fn()
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(n_h):
+                fn()
+            fence()
+            host_in[key] = a.batch * n_h / (time.perf_counter() - t1)
+        host_in["unit"] = "images/s"
+        host_in["steps"] = n_h
+
     roof = None
     if rank == 0 and not a.no_roofline:
         L = _lib.lib()
@@ -207,7 +242,7 @@ def main():
                                       f"AdamW on synthetic SIDD-style 224x224x3 noisy/clean pairs, random-init weights",
                           "per_gpu_batch": a.batch, "global_batch": a.batch * world, "parallelism": f"dp{world}",
                           "hip_graph": use_graph, "final_loss": loss},
-               "roofline": roof, "cpu_baseline": cpu}
+               "roofline": roof, "cpu_baseline": cpu, "host_input": host_in}
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -138,3 +138,52 @@ def test_denoise_prepare_extreme_affine_and_errors():
     assert L.vu_denoise_prepare(_lib.ptr(z), _lib.ptr(z), _lib.ptr(f), _lib.ptr(f), None, 0, None, 1, 2, 2, 2, 2, 0.456, 0.224, st) < 0  # channels
     assert L.vu_denoise_prepare(_lib.ptr(z), _lib.ptr(z), _lib.ptr(f), _lib.ptr(f), None, 0, None, 1, 4, 4, 1, 2, 0.456, 0.224, st) < 0  # scratch
     assert L.vu_denoise_prepare(_lib.ptr(z), _lib.ptr(z), _lib.ptr(f), _lib.ptr(f), None, 0, None, 0, 2, 2, 1, 2, 0.456, 0.224, st) < 0  # empty
+
+
+# ---------------------------------------------------------------- K-fold driver (run_denoising.py:16-122)
+def test_kfold_indices_partition():
+    from vit_unet.torch.run import kfold_indices
+    seen = []
+    for tr, te in kfold_indices(11, 3, seed=1):
+        assert len(set(tr) & set(te)) == 0 and len(tr) + len(te) == 11
+        assert sorted(te) == list(te)
+        seen.extend(te.tolist())
+    assert sorted(seen) == list(range(11))                     # every sample is tested exactly once
+    assert [len(te) for _, te in kfold_indices(11, 3, seed=1)] == [4, 4, 3]   # sklearn's fold sizes
+    with pytest.raises(AssertionError):
+        list(kfold_indices(3, 5))
+
+
+@pytest.mark.gpu
+def test_run_denoising_kfold_end_to_end(tmp_path):
+    """Two folds of the Lite preset on a handful of synthetic uint8 pairs: decode-free loader ->
+    device pipeline -> fused HIP train step -> checkpoints -> reload best -> per-image PSNR."""
+    from vit_unet.torch.run import run_denoising
+    noisy, clean = _batch(6, 96, 80, 3, seed=21)
+    seen = []
+    res = run_denoising(noisy, clean, n_epochs=2, folds=2, model_string="lite", lr=1e-4, batch_size=2, im_size=224,
+                        folder=str(tmp_path / "models"), seed=3, callbacks=[lambda fold, log: seen.append((fold, log["epoch"]))])
+    assert [len(p) for p in res["psnr"]] == [3, 3]
+    assert all(np.isfinite(p).all() for p in res["psnr"]) and np.isfinite(res["psnr_mean"])
+    assert seen == [(0, 0), (0, 1), (1, 0), (1, 1)]
+    assert all("train" in h and "val" in h for hist in res["history"] for h in hist)
+    assert (tmp_path / "models" / "best-checkpoint.bin").exists() and (tmp_path / "models" / "last-checkpoint.bin").exists()
+    with pytest.raises(AssertionError):
+        run_denoising(noisy, clean[:5])
+
+
+@pytest.mark.gpu
+def test_image_fitter_fused_dice(tmp_path):
+    """ImageFitter with functions.DiceLoss() takes the fused HIP step (TrainStep(loss='dice'))."""
+    from vit_unet.torch import functions as Fn, model as M
+    from vit_unet.torch.fitter import ImageFitter
+    m = M.HViT_UNet(depth=1, depth_te=1, size_bottleneck=1, preprocessing="conv", im_size=64, patch_size=16,
+                    num_channels=1, hidden_dim=16, num_heads=2, attn_drop=0.0, proj_drop=0.0, linear_drop=0.0).to(DEV)
+    g = torch.Generator().manual_seed(0)
+    data = [{"x": torch.rand(4, 1, 64, 64, generator=g), "y": (torch.rand(4, 1, 64, 64, generator=g) < 0.1).float()}] * 3
+    f = ImageFitter(m, loss=Fn.DiceLoss(), device=DEV, folder=str(tmp_path), lr=1e-3)
+    hist = f.fit(data, data, n_epochs=3)
+    assert f._fused is not None and f._fused.loss_kind == "dice"
+    assert hist[-1]["train"] < hist[0]["train"] and np.isfinite(hist[-1]["val"])
+    g2 = ImageFitter(m, loss=Fn.DiceLoss(apply_sigmoid=False), device=DEV, folder=str(tmp_path))
+    assert g2._fused_kind() is None        # plain Dice on raw outputs: autograd path

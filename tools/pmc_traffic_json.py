@@ -1,0 +1,24 @@
+"""profiles/<tag>_pmc_traffic.json from the FETCH_SIZE / WRITE_SIZE summaries tools/gpu_pmc.sh leaves in
+gpurun_out/ (usage: python tools/pmc_traffic_json.py r01k)."""
+import csv
+import json
+import shutil
+import sys
+
+tag = sys.argv[1]
+k = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    shutil.copy(f"gpurun_out/pmc_{c}_summary.csv", f"profiles/{tag}_pmc_{c}_summary.csv")
+    for r in csv.DictReader(open(f"gpurun_out/pmc_{c}_summary.csv")):
+        k.setdefault(r["kernel"], {})[c] = float(r["avg_per_launch"])
+out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/gpu_pmc.sh), KB per launch averaged over "
+               "all launches of the symbol (a symbol that runs at several token levels averages over them); "
+               "traffic_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: on gfx950 FETCH_SIZE counts half the bytes of wide "
+               "coalesced reads (MI355X_MICROARCH.md, HBM)",
+       "kernels": {}}
+for name, v in sorted(k.items()):
+    f, w = v.get("FETCH_SIZE"), v.get("WRITE_SIZE")
+    out["kernels"][name] = {"FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w,
+                            "traffic_bytes": (2 * f + w) * 1024 if f is not None and w is not None else None}
+json.dump(out, open(f"profiles/{tag}_pmc_traffic.json", "w"), indent=1)
+print(json.dumps({n: r["traffic_bytes"] for n, r in out["kernels"].items() if "map_bwd_mm" in n}))

@@ -9,9 +9,9 @@ optimizer step per batch, a validation pass per epoch, `best-checkpoint.bin` wri
 monitored loss improves, `last-checkpoint.bin` every epoch, and callbacks that receive a dict
 containing `'epoch'`.
 
-When the loss is `MSELoss` (or None) and the optimizer is `AdamW` (or None) the batch step is the
-fused HIP step (`engine.TrainStep`: forward + MSE + backward + AdamW without autograd); any other
-loss / optimizer runs through the module's autograd path.
+When the loss is `MSELoss` (or None) or `functions.DiceLoss()` and the optimizer is `AdamW` (or None)
+the batch step is the fused HIP step (`engine.TrainStep`: forward + loss + backward + AdamW without
+autograd); any other loss / optimizer runs through the module's autograd path.
 """
 from __future__ import annotations
 
@@ -42,8 +42,16 @@ class ImageFitter:
         w = data["w"].to(self.device).float() if "w" in data else None
         return x, y, w
 
+    def _fused_kind(self) -> Optional[str]:
+        from .functions import DiceLoss
+        if isinstance(self.loss, torch.nn.MSELoss) and getattr(self.loss, "reduction", "mean") == "mean":
+            return "mse"
+        if isinstance(self.loss, DiceLoss) and self.loss.apply_sigmoid:
+            return "dice"
+        return None
+
     def _fused_ok(self) -> bool:
-        if not isinstance(self.loss, torch.nn.MSELoss) or getattr(self.loss, "reduction", "mean") != "mean":
+        if self._fused_kind() is None:
             return False
         if self.optimizer is not None and type(self.optimizer) is not torch.optim.AdamW:
             return False
@@ -57,7 +65,7 @@ class ImageFitter:
         if self.optimizer is not None:
             g = self.optimizer.param_groups[0]
             kw = dict(lr=g["lr"], betas=tuple(g["betas"]), eps=g["eps"], weight_decay=g["weight_decay"])
-        return TrainStep(self.model, seed=self._seed, **kw)
+        return TrainStep(self.model, seed=self._seed, loss=self._fused_kind(), **kw)
 
     def _train_batch(self, x, y, w) -> float:
         if w is None and self._fused_ok():

@@ -89,3 +89,16 @@ def dice_loss(input: torch.Tensor, target: torch.Tensor, apply_sigmoid: bool = F
     BASELINE config 5: `input` are the model's logits."""
     assert input.numel() == target.numel(), "dice_loss: input and target sizes differ"
     return _Dice.apply(input, target, apply_sigmoid)
+
+
+class DiceLoss(torch.nn.Module):
+    """Criterion object for `ImageFitter(model, loss=DiceLoss())`: Dice on sigmoid(model output) (the
+    segmentation configuration, BASELINE config 5).  With `apply_sigmoid=True` the fitter runs the
+    fused HIP step (`TrainStep(loss="dice")`)."""
+
+    def __init__(self, apply_sigmoid: bool = True):
+        super().__init__()
+        self.apply_sigmoid = bool(apply_sigmoid)
+
+    def forward(self, input, target):
+        return dice_loss(input, target, apply_sigmoid=self.apply_sigmoid)
