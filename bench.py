@@ -27,7 +27,7 @@ sys.path.insert(0, os.path.join(ROOT, "vit-unet_amd"))
 
 import torch  # noqa: E402
 
-TRAIN_GFLOP_PER_IMG = {"lite": 27.93, "base": 23.27, "large": 42.43}
+TRAIN_GFLOP_PER_IMG = {"lite": 27.93, "base": 23.27, "large": 42.43, "seg512": 107.71}
 MFMA_PEAK_TFLOPS = 2500.0      # dense bf16, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 
@@ -37,7 +37,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--model", default="base", choices=["lite", "base", "large"])
+    ap.add_argument("--model", default="base", choices=["lite", "base", "large", "seg512"],
+                    help="seg512 = BASELINE config 5 shape: Base ctor at 512x512x1, Dice loss on a sigmoid head")
     ap.add_argument("--batch", type=int, default=64, help="images per GPU")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-graph", action="store_true", help="N=1: launch eagerly instead of replaying a hipGraph")
@@ -114,12 +115,19 @@ def main():
 
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     torch.manual_seed(0)                                   # identical initial weights on every rank
-    model = M.get_vit_unet(a.model, dtype=dt).to(dev).train()
-    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
-    y = torch.rand(a.batch, 3, 224, 224, generator=g)
-    x = (y + 0.1 * torch.randn(y.shape, generator=g)).clamp(0, 1)
+    seg = a.model == "seg512"
+    if seg:
+        model = M.get_vit_unet("base", dtype=dt, im_size=512, num_channels=1).to(dev).train()
+        g = torch.Generator(device="cpu").manual_seed(4321 + rank)
+        x = torch.rand(a.batch, 1, 512, 512, generator=g)
+        y = (torch.rand(a.batch, 1, 512, 512, generator=g) < 0.1).float()
+    else:
+        model = M.get_vit_unet(a.model, dtype=dt).to(dev).train()
+        g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+        y = torch.rand(a.batch, 3, 224, 224, generator=g)
+        x = (y + 0.1 * torch.randn(y.shape, generator=g)).clamp(0, 1)
     x, y = x.to(dev), y.to(dev)
-    ts = TrainStep(model, lr=1e-4, seed=1234 + rank)
+    ts = TrainStep(model, lr=1e-4, seed=1234 + rank, loss="dice" if seg else "mse")
     use_graph = world == 1 and not a.no_graph
     if use_graph:
         ts.capture(x, y)
@@ -153,7 +161,7 @@ def main():
     # CHW batch ImageFitter.unpack moves (dataset.py:78-91), (b) as decoded uint8 HWC images that the
     # device-side input pipeline (vu_denoise_prepare, train transform) turns into the batch
     host_in = None
-    if rank == 0 and world == 1 and not a.no_host_input:
+    if rank == 0 and world == 1 and not a.no_host_input and not seg:
         from vit_unet.torch.dataset import DenoisingBatchTransform
         n_h = max(3, min(a.steps, 10))
         hx, hy = x.cpu().pin_memory(), y.cpu().pin_memory()
@@ -230,16 +238,19 @@ def main():
                                   "GBs": (v["bytes"] / (v["ms"] * 1e-3) / 1e9) if v["bytes"] else None}
                                  for k, v in top[:8]]})
     cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and not seg:
         cpu = cpu_baseline(a.model, host_cores())
 
     if rank == 0:
-        out = {"metric": f"images/sec (224x224x3) ViT_UNet-{a.model.capitalize()} train step",
+        shape, lossn = ("512x512x1", "Dice(sigmoid)") if seg else ("224x224x3", "MSELoss")
+        mname = "Base@512" if seg else a.model.capitalize()
+        out = {"metric": f"images/sec ({shape}) ViT_UNet-{mname} train step",
                "value": value, "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": dt_s / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-               "config": {"workload": f"ViT_UNet-{a.model.capitalize()} train step: forward + MSELoss + backward + "
-                                      f"AdamW on synthetic SIDD-style 224x224x3 noisy/clean pairs, random-init weights",
+               "config": {"workload": f"ViT_UNet-{mname} train step: forward + {lossn} + backward + "
+                                      f"AdamW on synthetic " + ("CT-style 512x512x1 image/mask pairs" if seg else
+                                                                "SIDD-style 224x224x3 noisy/clean pairs") + ", random-init weights",
                           "per_gpu_batch": a.batch, "global_batch": a.batch * world, "parallelism": f"dp{world}",
                           "hip_graph": use_graph, "final_loss": loss},
                "roofline": roof, "cpu_baseline": cpu, "host_input": host_in}
