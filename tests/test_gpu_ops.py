@@ -176,7 +176,8 @@ GRAD_KEYS = ["reatten_matrix.weight", "reatten_matrix.bias", "var_norm.weight", 
                                       (64, 3, 16, 4), (16, 3, 32, 4),    # wide patches with cross inputs (MFMA weight gradients, edge pixels)
                                       (784, 3, 8, 8), (196, 3, 16, 8), (49, 3, 32, 8), (400, 1, 8, 4), (1156, 3, 4, 4), (1024, 1, 8, 8), (1024, 1, 16, 8),
                                       (225, 3, 8, 8), (289, 3, 8, 8),    # ragged rows (N % 4 != 0) through the MFMA map kernels
-                                      (3136, 3, 4, 4)])                  # Lite level 2: long rows (chunked map products, long-row scores)
+                                      (3136, 3, 4, 4),                   # Lite level 2: long rows (chunked map products, long-row scores)
+                                      (1089, 1, 8, 8), (1225, 3, 4, 2), (1090, 1, 8, 8)])   # rows > 1024 through the two-sweep map backward (8 heads: 2 columns per lane; ragged N)
 @pytest.mark.parametrize("mode", ["eval", "train", "train_drop"])
 @pytest.mark.parametrize("cross", [False, True])
 def test_attention_fwd_bwd(dt, N, Cn, s, H, mode, cross):

@@ -364,8 +364,64 @@ __global__ void bn_bwd_finalize_kernel(const float* partials, int nblocks, float
 }
 
 // backward pass 2 (one wave per (b,i) row, all heads): dAhat -> dA -> dP~ -> dP -> dS, in place.
+// Rows of any length: two sweeps over the row (the softmax backward needs the row-wide sum
+// delta_h = sum_j dP_h P_h before the first dS can be written); a lane owns V consecutive columns
+// per trip (V = 4, or 2 for 8 heads), loads run one trip ahead of the arithmetic, the second sweep
+// re-reads a row the wave has just streamed.  (Measured on the 512x512x1 configuration, N = 4096,
+// 8 heads: scalar loads 13.0 ms per launch; vector loads 9.9; two waves per SIMD 7.9; loads one
+// trip ahead 6.8.  Leaving dP in HBM after sweep 1 to make sweep 2 element-wise was slower, 8.0.)
+template <int V> struct vu_fv { float v[V]; };
+template <int V> __device__ __forceinline__ vu_fv<V> ld_vec(const float* p) {
+  vu_fv<V> r;
+  if constexpr (V == 4) { const float4 t = *reinterpret_cast<const float4*>(p); r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w; }
+  else { const float2 t = *reinterpret_cast<const float2*>(p); r.v[0] = t.x; r.v[1] = t.y; }
+  return r;
+}
+template <int V> __device__ __forceinline__ vu_fv<V> ld_vec(const bf16_t* p) {
+  vu_fv<V> r;
+  if constexpr (V == 4) {
+    const uint2 t = *reinterpret_cast<const uint2*>(p);
+    r.v[0] = __uint_as_float(t.x << 16); r.v[1] = __uint_as_float(t.x & 0xffff0000u);
+    r.v[2] = __uint_as_float(t.y << 16); r.v[3] = __uint_as_float(t.y & 0xffff0000u);
+  } else {
+    const uint32_t t = *reinterpret_cast<const uint32_t*>(p);
+    r.v[0] = __uint_as_float(t << 16); r.v[1] = __uint_as_float(t & 0xffff0000u);
+  }
+  return r;
+}
+template <int V> __device__ __forceinline__ void st_vec(float* p, const vu_fv<V>& a) {
+  if constexpr (V == 4) *reinterpret_cast<float4*>(p) = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]);
+  else *reinterpret_cast<float2*>(p) = make_float2(a.v[0], a.v[1]);
+}
+template <int V> __device__ __forceinline__ void st_vec(bf16_t* p, const vu_fv<V>& a) {
+  if constexpr (V == 4) { bf16x4 t = {(bf16_t)a.v[0], (bf16_t)a.v[1], (bf16_t)a.v[2], (bf16_t)a.v[3]}; *reinterpret_cast<bf16x4*>(p) = t; }
+  else { typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_; bf16x2_ t = {(bf16_t)a.v[0], (bf16_t)a.v[1]}; *reinterpret_cast<bf16x2_*>(p) = t; }
+}
+
+template <typename T, int V> struct vu_raw { uint32_t w[sizeof(T) * V / 4]; };
+template <typename T, int V> __device__ __forceinline__ vu_raw<T, V> ld_raw(const T* p) {
+  vu_raw<T, V> r;
+  constexpr int NW = sizeof(T) * V / 4;
+  if constexpr (NW == 1) r.w[0] = *reinterpret_cast<const uint32_t*>(p);
+  else if constexpr (NW == 2) { const uint2 t = *reinterpret_cast<const uint2*>(p); r.w[0] = t.x; r.w[1] = t.y; }
+  else { const uint4 t = *reinterpret_cast<const uint4*>(p); r.w[0] = t.x; r.w[1] = t.y; r.w[2] = t.z; r.w[3] = t.w; }
+  return r;
+}
+template <int V> __device__ __forceinline__ vu_fv<V> cvt_raw(const vu_raw<float, V>& a) {
+  vu_fv<V> r;
+#pragma unroll
+  for (int q = 0; q < V; ++q) r.v[q] = __uint_as_float(a.w[q]);
+  return r;
+}
+template <int V> __device__ __forceinline__ vu_fv<V> cvt_raw(const vu_raw<bf16_t, V>& a) {
+  vu_fv<V> r;
+#pragma unroll
+  for (int q = 0; q < V; ++q) r.v[q] = (q & 1) ? __uint_as_float(a.w[q >> 1] & 0xffff0000u) : __uint_as_float(a.w[q >> 1] << 16);
+  return r;
+}
+
 template <typename T, int H>
-__global__ __launch_bounds__(256) void map_bwd_kernel(const T* __restrict__ Ps, T* dA, const float* __restrict__ W,
+__global__ __launch_bounds__(256, 2) void map_bwd_kernel(const T* __restrict__ Ps, T* dA, const float* __restrict__ W,
                                                       const float* __restrict__ c, const float* __restrict__ gamma,
                                                       const float* __restrict__ stats, float* dW, float* dc,
                                                       long long rows, int N, int ld, float inv_keep, float scale) {
@@ -383,6 +439,8 @@ __global__ __launch_bounds__(256) void map_bwd_kernel(const T* __restrict__ Ps, 
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long hs = (long long)N * ld;
+  constexpr int V = H >= 8 ? 2 : 4;
+  const int n4 = (N + V - 1) / V * V;   // ld is a multiple of 8 >= N: a group starting below N lies inside the row
   float aW[H * H], ac[H];
 #pragma unroll
   for (int i = 0; i < H * H; ++i) aW[i] = 0.f;
@@ -396,39 +454,76 @@ __global__ __launch_bounds__(256) void map_bwd_kernel(const T* __restrict__ Ps, 
     float delta[H];
 #pragma unroll
     for (int h = 0; h < H; ++h) delta[h] = 0.f;
+#pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
-      for (int j = lane; j < N; j += 64) {
-        float pt[H], pa[H], dAg[H];
-        bool kept[H];
+      vu_raw<T, V> np_[H], nd_[H];      // the next trip's operands, loaded one trip ahead
+      if (lane * V < N) {
+#pragma unroll
+        for (int h = 0; h < H; ++h) { np_[h] = ld_raw<T, V>(Ps + off + h * hs + lane * V); nd_[h] = ld_raw<T, V>(dA + off + h * hs + lane * V); }
+      }
+#pragma unroll 1
+      for (int j = lane * V; j < N; j += 64 * V) {
+        vu_raw<T, V> cp_[H], cd_[H];
+#pragma unroll
+        for (int h = 0; h < H; ++h) { cp_[h] = np_[h]; cd_[h] = nd_[h]; }
+        if (j + 64 * V < N) {
+#pragma unroll
+          for (int h = 0; h < H; ++h) {
+            np_[h] = ld_raw<T, V>(Ps + off + h * hs + j + 64 * V);
+            nd_[h] = ld_raw<T, V>(dA + off + h * hs + j + 64 * V);
+          }
+        }
+        asm volatile("" ::: "memory");   // keep the 8x8 constants in LDS: hoisted into registers they cost the second wave per SIMD
+        float pt[H][V], pa[H][V], dAg[H][V];
+        bool ok[V];
+#pragma unroll
+        for (int q = 0; q < V; ++q) ok[q] = j + q < N;
 #pragma unroll
         for (int h = 0; h < H; ++h) {
-          const float v = vu_ld(Ps + off + h * hs + j);
-          pa[h] = fabsf(v); kept[h] = v > 0.f; pt[h] = kept[h] ? v * inv_keep : 0.f;
+          const vu_fv<V> v = cvt_raw<V>(cp_[h]);
+#pragma unroll
+          for (int q = 0; q < V; ++q) {
+            const float x = ok[q] ? v.v[q] : 0.f;
+            pa[h][q] = fabsf(x);
+            pt[h][q] = x > 0.f ? x * inv_keep : 0.f;     // pt > 0 <=> kept
+          }
         }
 #pragma unroll
         for (int g = 0; g < H; ++g) {
-          float xh = sX[H * H + g];
+          const vu_fv<V> d = cvt_raw<V>(cd_[g]);
+          const float x0 = sX[H * H + g], g0 = sG[g], m1 = sG[H + g], m2 = sG[2 * H + g];
 #pragma unroll
-          for (int h = 0; h < H; ++h) xh += sX[g * H + h] * pt[h];
-          const float d = vu_ld(dA + off + g * hs + j);
-          dAg[g] = sG[g] * (d - sG[H + g] - xh * sG[2 * H + g]);
+          for (int q = 0; q < V; ++q) {
+            float xh = x0;
+#pragma unroll
+            for (int h = 0; h < H; ++h) xh += sX[g * H + h] * pt[h][q];
+            dAg[g][q] = ok[q] ? g0 * (d.v[q] - m1 - xh * m2) : 0.f;
+          }
         }
         if (pass == 0) {
 #pragma unroll
           for (int g = 0; g < H; ++g) {
-            ac[g] += dAg[g];
 #pragma unroll
-            for (int h = 0; h < H; ++h) aW[g * H + h] += dAg[g] * pt[h];
+            for (int q = 0; q < V; ++q) ac[g] += dAg[g][q];
+#pragma unroll
+            for (int h = 0; h < H; ++h)
+#pragma unroll
+              for (int q = 0; q < V; ++q) aW[g * H + h] += dAg[g][q] * pt[h][q];
           }
         }
 #pragma unroll
         for (int h = 0; h < H; ++h) {
-          float dp = 0.f;
+          vu_fv<V> o;
 #pragma unroll
-          for (int g = 0; g < H; ++g) dp += sW[g * H + h] * dAg[g];
-          dp = kept[h] ? dp * inv_keep : 0.f;
-          if (pass == 0) delta[h] += dp * pa[h];
-          else vu_st(dA + off + h * hs + j, pa[h] * (dp - delta[h]) * scale);
+          for (int q = 0; q < V; ++q) {
+            float dp = 0.f;
+#pragma unroll
+            for (int g = 0; g < H; ++g) dp += sW[g * H + h] * dAg[g][q];
+            dp = pt[h][q] > 0.f ? dp * inv_keep : 0.f;
+            if (pass == 0) delta[h] += dp * pa[h][q];
+            else o.v[q] = pa[h][q] * (dp - delta[h]) * scale;
+          }
+          if (pass == 1) st_vec<V>(dA + off + h * hs + j, o);
         }
       }
       if (pass == 0) {
@@ -436,7 +531,7 @@ __global__ __launch_bounds__(256) void map_bwd_kernel(const T* __restrict__ Ps, 
         for (int h = 0; h < H; ++h) delta[h] = vu_wave_sum(delta[h]);
       }
     }
-    for (int j = N + lane; j < ld; j += 64)
+    for (int j = n4 + lane; j < ld; j += 64)
 #pragma unroll
       for (int h = 0; h < H; ++h) vu_st(dA + off + h * hs + j, 0.f);
   }
