@@ -177,7 +177,7 @@ GRAD_KEYS = ["reatten_matrix.weight", "reatten_matrix.bias", "var_norm.weight", 
                                       (784, 3, 8, 8), (196, 3, 16, 8), (49, 3, 32, 8), (400, 1, 8, 4), (1156, 3, 4, 4), (1024, 1, 8, 8), (1024, 1, 16, 8),
                                       (225, 3, 8, 8), (289, 3, 8, 8),    # ragged rows (N % 4 != 0) through the MFMA map kernels
                                       (3136, 3, 4, 4),                   # Lite level 2: long rows (chunked map products, long-row scores)
-                                      (1089, 1, 8, 8), (1225, 3, 4, 2), (1090, 1, 8, 8)])   # rows > 1024 through the two-sweep map backward (8 heads: 2 columns per lane; ragged N)
+                                      (1089, 1, 8, 8), (1225, 3, 4, 2), (1090, 1, 8, 8), (1156, 1, 8, 8), (2116, 1, 8, 8)])   # rows > 1024: chunked MFMA map backward (bf16, 8 heads) / two-sweep VALU kernel (fp32, other head counts); ragged and exact N
 @pytest.mark.parametrize("mode", ["eval", "train", "train_drop"])
 @pytest.mark.parametrize("cross", [False, True])
 def test_attention_fwd_bwd(dt, N, Cn, s, H, mode, cross):
@@ -325,3 +325,47 @@ def test_mse_and_adamw_and_cast():
     c = torch.empty(m, dtype=torch.bfloat16, device=DEV)
     check(L.vu_cast_bf16(ptr(pd), ptr(c), m, st()))
     assert torch.equal(c, sh)
+
+
+def _hip_attention(dt, p, xq, dy, N, D, H, Cn, ad, pd, seed=1234, sid=3):
+    """Self-attention forward + backward through the C ABI; returns (y, dxq, grads) as float CPU tensors."""
+    code = _lib.DTYPE_CODE[dt]
+    L = lib()
+    B = xq.shape[0]
+    d = {k: dev(v) for k, v in p.items()}
+    pw = dev(p["proj.weight"], dt)
+    prm = _lib.vu_attn_params(*[d[k].data_ptr() for k in GRAD_KEYS[:7]], pw.data_ptr(), d["proj.bias"].data_ptr(),
+                              d["var_norm.running_mean"].data_ptr(), d["var_norm.running_var"].data_ptr())
+    xqd, dyd = dev(xq, dt), dev(dy, dt)
+    nbytes = L.vu_attn_workspace_bytes(code, B, N, D, H)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    y = torch.empty_like(xqd)
+    check(L.vu_attn_forward(code, C.byref(prm), ptr(xqd), ptr(xqd), ptr(y), None, ptr(ws), nbytes, B, N, D, H, Cn,
+                            ad, pd, 1, seed, sid, st()))
+    grads = [torch.zeros_like(d[k]) for k in GRAD_KEYS]
+    gs = _lib.vu_attn_grads(*[g.data_ptr() for g in grads])
+    dxq = torch.empty_like(xqd)
+    check(L.vu_attn_backward(code, C.byref(prm), C.byref(gs), ptr(xqd), ptr(xqd), ptr(dyd), ptr(dxq), None, ptr(ws),
+                             nbytes, B, N, D, H, Cn, ad, pd, 1, seed, sid, st()))
+    torch.cuda.synchronize()
+    return y.float().cpu(), dxq.float().cpu(), {k: g.float().cpu() for k, g in zip(GRAD_KEYS, grads)}
+
+
+@pytest.mark.parametrize("drop", [0.0, 0.2])
+def test_long_rows_4096_bf16_tracks_fp32(drop):
+    """The 512x512 level-2 shape (N = 4096, 8 heads, four full 1024-column chunks) is too large for the
+    CPU oracle in a test; the bf16 path (chunked MFMA map backward) is held to the bf16 tolerance
+    against the fp32 path (two-sweep VALU kernel), which the oracle pins at N <= 3136 above."""
+    N, Cn, s, H = 4096, 1, 8, 8
+    p, xq, _, dy, D = _attn_case(N, Cn, s, H, B=1, seed=31)
+    xq_r, dy_r = xq.to(torch.bfloat16).float(), dy.to(torch.bfloat16).float()
+    pr = dict(p, **{"proj.weight": p["proj.weight"].to(torch.bfloat16).float()})
+    y32, dx32, g32 = _hip_attention(torch.float32, pr, xq_r, dy_r, N, D, H, Cn, drop, drop)
+    y16, dx16, g16 = _hip_attention(torch.bfloat16, p, xq, dy, N, D, H, Cn, drop, drop)
+    ft, bt = TOL[torch.bfloat16]
+    assert serr(y16, y32) < ft, "attention output"
+    assert serr(dx16, dx32) < bt, "dxq"
+    for k in GRAD_KEYS:
+        if k == "reatten_matrix.bias":
+            continue
+        assert serr(g16[k], g32[k]) < bt, k

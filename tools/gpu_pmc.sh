@@ -4,7 +4,7 @@ cd $GRAFT_REPO_ROOT
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$C -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph --no-roofline > $GRAFT_REPO_ROOT/gpurun_out/pmc_$C.log 2>&1
+  timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$C -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-host-input --no-graph --no-roofline > $GRAFT_REPO_ROOT/gpurun_out/pmc_$C.log 2>&1
   tail -c 200 $GRAFT_REPO_ROOT/gpurun_out/pmc_$C.log
 done
 cd $GRAFT_REPO_ROOT

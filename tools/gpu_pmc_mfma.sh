@@ -1,7 +1,7 @@
 # MFMA utilisation per kernel: SQ_VALU_MFMA_BUSY_CYCLES (cycles, summed over SIMDs) against
 # GRBM_GUI_ACTIVE (sum over the 8 XCDs) - one --pmc pass, kernel-trace only.
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_WAVES --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_mfma -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-graph --no-roofline > $GRAFT_REPO_ROOT/gpurun_out/pmc_mfma.log 2>&1
+timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_WAVES --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_mfma -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-host-input --no-graph --no-roofline > $GRAFT_REPO_ROOT/gpurun_out/pmc_mfma.log 2>&1
 tail -c 200 $GRAFT_REPO_ROOT/gpurun_out/pmc_mfma.log
 cd $GRAFT_REPO_ROOT
 python - <<'PY'

@@ -1,6 +1,6 @@
 # SQ counters for the dominant kernels (one --pmc pass, kernel-trace only)
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_sq -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-graph --no-roofline > $GRAFT_REPO_ROOT/gpurun_out/pmc_sq.log 2>&1
+timeout 600 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_sq -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-host-input --no-graph --no-roofline > $GRAFT_REPO_ROOT/gpurun_out/pmc_sq.log 2>&1
 tail -c 200 $GRAFT_REPO_ROOT/gpurun_out/pmc_sq.log
 cd $GRAFT_REPO_ROOT
 python - <<'PY'

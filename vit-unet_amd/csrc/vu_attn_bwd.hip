@@ -535,6 +535,249 @@ __global__ __launch_bounds__(256, 2) void map_bwd_mm_kernel(const bf16_t* __rest
 }
 
 // ---------------------------------------------------------------------------------------------
+// map_bwd_mm_long_kernel (bf16 storage, H = 8, ld > 1024: the 512x512 inputs, N = 4096): the MFMA
+// stages of map_bwd_mm_kernel applied to CHUNKS of 1024 columns of a row, one 256-thread block per
+// row, in two sweeps - the softmax backward needs delta_h = sum_j dP_h P_h over the WHOLE row:
+//   sweep 1, per chunk: xhat (MFMA #1) -> dA -> dP (MFMA #2) -> delta partial; dA / P images -> dW (MFMA #3)
+//   sweep 2, per chunk: the same two MFMAs again -> dS = |p| (dP - delta) scale, written over dAhat
+// (5 map passes instead of 3; the second read of a row comes right after the first).  The loads of
+// the next chunk fly during the reduction / contraction / store phase of the current one.
+// ---------------------------------------------------------------------------------------------
+template <bool EXACT>
+__global__ __launch_bounds__(256, 2) void map_bwd_mm_long_kernel(const bf16_t* __restrict__ Ps, bf16_t* dA,
+                                                                 const float* __restrict__ W, const float* __restrict__ c,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ stats,
+                                                                 float* dW, float* dc, long long rows, int N, int ld,
+                                                                 float inv_keep, float scale) {
+  constexpr int H = 8, CW = 1024, CQ = CW / 4, LDP = CW + 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __shared__ float redd[4][H];
+  __shared__ float red[4][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  bf16_t* sA = reinterpret_cast<bf16_t*>(smem_raw);   // [H][LDP]   dA hi
+  bf16_t* sL = sA + H * LDP;                          // [H][LDP]   dA lo
+  bf16_t* sB = sL + H * LDP;                          // [H+1][LDP] kept P (without 1/keep), row H = ones over the valid columns
+  for (int i = threadIdx.x; i < (3 * H + 1) * LDP; i += blockDim.x) sA[i] = (bf16_t)0.0f;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const float* tX = stats + H * H + 5 * H;     // X[H*H] = W*rstd_g, Xc[H], Gs[H]
+  const float* tM = stats + H * H + 3 * H;     // m1[H], m2[H]
+  bf16x8 A1[2], A2[2];                         // constant A operands: see map_bwd_mm_kernel
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    float v1[8], v2[8];
+    const int qrow = 2 * m + (l15 >> 3), hr = l15 & 7;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      v1[j] = (lg == qrow) ? tX[hr * H + j] * inv_keep : 0.f;
+      const int mk = j >> 2, r = j & 3;
+      const int qk = 2 * mk + (lg >> 1), gk = 4 * (lg & 1) + r;
+      v2[j] = (qk == qrow) ? W[gk * H + hr] * (inv_keep * scale) : 0.f;
+    }
+    A1[m] = pack8(v1);
+    A2[m] = pack8(v2);
+  }
+  const int hbase = 4 * (lg & 1);
+  float Gs4[4], K1[4], K2[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float gs = tX[H * H + H + hbase + r], xc = tX[H * H + hbase + r];
+    const float m1 = tM[hbase + r], m2 = tM[H + hbase + r];
+    Gs4[r] = gs; K1[r] = -gs * (m1 + xc * m2); K2[r] = -gs * m2;
+  }
+  __syncthreads();
+  const unsigned hs = (unsigned)N * (unsigned)ld;     // launcher guarantees 8 * N * ld < 2^31
+  const int nquads = EXACT ? (N >> 2) : (ld >> 2);    // quads of a row that are loaded
+  const int nch = (ld + CW - 1) / CW;                 // chunks per row
+  const int qown = threadIdx.x;                       // own quad within the chunk
+  const int qA = 64 * wave + 16 * (lg >> 1) + l15;    // result-layout quads within the chunk
+  const int qB = qA + 32;
+  f32x4 accw = {0.f, 0.f, 0.f, 0.f};
+
+  uint2 pown[H], PA[4], PB[4], QA[4], QB[4];
+  auto load_chunk = [&](long long row, int ch, uint2 (&po)[H], uint2 (&pa)[4], uint2 (&pb)[4], uint2 (&qa)[4], uint2 (&qb)[4]) {
+    const long long b = row / N;
+    const int i = (int)(row - b * N);
+    const long long base = (b * H * N + i) * (long long)ld + (long long)ch * CW;
+    const bf16_t* __restrict__ Prow = Ps + base;
+    const bf16_t* Drow = dA + base;
+    const int nq = nquads - ch * CQ;                  // quads of this chunk (may exceed CQ: the q's are < CQ)
+#pragma unroll
+    for (int h = 0; h < H; ++h) po[h] = make_uint2(0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { pa[r] = make_uint2(0, 0); pb[r] = make_uint2(0, 0); qa[r] = make_uint2(0, 0); qb[r] = make_uint2(0, 0); }
+    if (qown < nq) {
+#pragma unroll
+      for (int h = 0; h < H; ++h) po[h] = *reinterpret_cast<const uint2*>(Prow + (h * hs + 4u * qown));
+    }
+    if (qA < nq) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const unsigned o = (hbase + r) * hs + 4u * qA;
+        pa[r] = *reinterpret_cast<const uint2*>(Prow + o);
+        qa[r] = *reinterpret_cast<const uint2*>(Drow + o);
+      }
+    }
+    if (qB < nq) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const unsigned o = (hbase + r) * hs + 4u * qB;
+        pb[r] = *reinterpret_cast<const uint2*>(Prow + o);
+        qb[r] = *reinterpret_cast<const uint2*>(Drow + o);
+      }
+    }
+  };
+  // work items in order: (row, sweep, chunk)
+  long long row = blockIdx.x;
+  int sweep = 0, ch = 0;
+  float dtot[4] = {0.f, 0.f, 0.f, 0.f};
+  if (row < rows) load_chunk(row, 0, pown, PA, PB, QA, QB);
+  while (row < rows) {
+    const int c0 = ch * CW;                           // first column of the chunk
+    const int nq = nquads - ch * CQ;
+    // ---- own layout: kept probabilities, P image (sweep 1 only), B operands of #1 ----------------
+    unsigned b1w[4][4];
+#pragma unroll
+    for (int h = 0; h < H; ++h) { pown[h].x = keep_pos(pown[h].x); pown[h].y = keep_pos(pown[h].y); }
+    if (sweep == 0) {
+#pragma unroll
+      for (int h = 0; h < H; ++h) *reinterpret_cast<uint2*>(sB + h * LDP + 4 * qown) = pown[h];   // zero where not loaded
+      const int cq = c0 + 4 * qown;
+      const unsigned w0 = (cq < N ? 0x3f80u : 0u) | (cq + 1 < N ? 0x3f800000u : 0u);
+      const unsigned w1 = (cq + 2 < N ? 0x3f80u : 0u) | (cq + 3 < N ? 0x3f800000u : 0u);
+      *reinterpret_cast<uint2*>(sB + H * LDP + 4 * qown) = make_uint2(w0, w1);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      b1w[0][j] = halves(pown[2 * j].x, pown[2 * j + 1].x, 0);
+      b1w[1][j] = halves(pown[2 * j].x, pown[2 * j + 1].x, 1);
+      b1w[2][j] = halves(pown[2 * j].y, pown[2 * j + 1].y, 0);
+      b1w[3][j] = halves(pown[2 * j].y, pown[2 * j + 1].y, 1);
+    }
+    unsigned hiw[4][4], low[4][4];
+    float dPa[4][4], dPb[4][4], delta[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const u32x4 b1u = {b1w[e][0], b1w[e][1], b1w[e][2], b1w[e][3]};
+      const bf16x8 b1 = __builtin_bit_cast(bf16x8, b1u);
+      f32x4 c0v = {0.f, 0.f, 0.f, 0.f}, c1v = {0.f, 0.f, 0.f, 0.f};
+      c0v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1[0], b1, c0v, 0, 0, 0);
+      c1v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1[1], b1, c1v, 0, 0, 0);
+      float va[4], vb[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        va[r] = fmaf(K2[r], c0v[r], fmaf(Gs4[r], unpk(QA[r], e), K1[r]));
+        vb[r] = fmaf(K2[r], c1v[r], fmaf(Gs4[r], unpk(QB[r], e), K1[r]));
+        if (!EXACT) { va[r] = (c0 + 4 * qA + e < N) ? va[r] : 0.f; vb[r] = (c0 + 4 * qB + e < N) ? vb[r] : 0.f; }
+      }
+      hiw[e][0] = pk2(va[0], va[1]); hiw[e][1] = pk2(va[2], va[3]);
+      hiw[e][2] = pk2(vb[0], vb[1]); hiw[e][3] = pk2(vb[2], vb[3]);
+      if (sweep == 0) {
+        low[e][0] = pk2(va[0] - half_f(hiw[e][0], 0), va[1] - half_f(hiw[e][0], 1));
+        low[e][1] = pk2(va[2] - half_f(hiw[e][1], 0), va[3] - half_f(hiw[e][1], 1));
+        low[e][2] = pk2(vb[0] - half_f(hiw[e][2], 0), vb[1] - half_f(hiw[e][2], 1));
+        low[e][3] = pk2(vb[2] - half_f(hiw[e][3], 0), vb[3] - half_f(hiw[e][3], 1));
+      }
+      const u32x4 b2u = {hiw[e][0], hiw[e][1], hiw[e][2], hiw[e][3]};
+      const bf16x8 b2 = __builtin_bit_cast(bf16x8, b2u);
+      f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+      d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2[0], b2, d0, 0, 0, 0);
+      d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2[1], b2, d1, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pa = unpk(PA[r], e), pb = unpk(PB[r], e);
+        const float xa = pa > 0.f ? d0[r] : 0.f;        // = dP scale (1/keep and scale sit in A2)
+        const float xb = pb > 0.f ? d1[r] : 0.f;
+        dPa[r][e] = xa; dPb[r][e] = xb;
+        delta[r] = fmaf(xa, fabsf(pa), fmaf(xb, fabsf(pb), delta[r]));
+      }
+    }
+    if (sweep == 0) {
+      // ---- LDS images of dA for dW (result layout -> [head][position]); zero where the chunk has no quad
+      const bool okA = qA < nq, okB = qB < nq;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int wv = r >> 1, od = r & 1;
+        *reinterpret_cast<uint2*>(sA + (hbase + r) * LDP + 4 * qA) =
+            okA ? make_uint2(halves(hiw[0][wv], hiw[1][wv], od), halves(hiw[2][wv], hiw[3][wv], od)) : make_uint2(0, 0);
+        *reinterpret_cast<uint2*>(sL + (hbase + r) * LDP + 4 * qA) =
+            okA ? make_uint2(halves(low[0][wv], low[1][wv], od), halves(low[2][wv], low[3][wv], od)) : make_uint2(0, 0);
+        *reinterpret_cast<uint2*>(sA + (hbase + r) * LDP + 4 * qB) =
+            okB ? make_uint2(halves(hiw[0][2 + wv], hiw[1][2 + wv], od), halves(hiw[2][2 + wv], hiw[3][2 + wv], od)) : make_uint2(0, 0);
+        *reinterpret_cast<uint2*>(sL + (hbase + r) * LDP + 4 * qB) =
+            okB ? make_uint2(halves(low[0][2 + wv], low[1][2 + wv], od), halves(low[2][2 + wv], low[3][2 + wv], od)) : make_uint2(0, 0);
+      }
+    }
+    // ---- the next item's loads fly during the reduction / contraction / store phase ----------------
+    long long nrow = row; int nsweep = sweep, nchk = ch + 1;
+    if (nchk == nch) { nchk = 0; if (++nsweep == 2) { nsweep = 0; nrow = row + gridDim.x; } }
+    uint2 nP[4], nPB[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { nP[r] = make_uint2(0, 0); nPB[r] = make_uint2(0, 0); }
+    if (nrow < rows) load_chunk(nrow, nchk, pown, nP, nPB, QA, QB);
+    if (sweep == 0) {
+      // ---- delta_h over the chunk, added to the row's total --------------------------------------
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = delta[r];
+        v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (l15 == 0 && lg < 2) redd[wave][4 * lg + r] = v;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dtot[r] += redd[0][hbase + r] + redd[1][hbase + r] + redd[2][hbase + r] + redd[3][hbase + r];
+      for (int ks = wave; ks < CW / 32; ks += 4) {
+        const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+        const bf16x8 af = l15 < H ? *reinterpret_cast<const bf16x8*>(sA + l15 * LDP + ks * 32 + lg * 8) : zero8;
+        const bf16x8 lf = l15 < H ? *reinterpret_cast<const bf16x8*>(sL + l15 * LDP + ks * 32 + lg * 8) : zero8;
+        const bf16x8 bf = l15 <= H ? *reinterpret_cast<const bf16x8*>(sB + l15 * LDP + ks * 32 + lg * 8) : zero8;
+        accw = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, accw, 0, 0, 0);
+        accw = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lf, bf, accw, 0, 0, 0);
+      }
+      __syncthreads();     // images and redd are rewritten by the next chunk
+    } else {
+      // ---- dS = |p| (dP - delta) scale, result layout, 4 consecutive positions per store ----------
+      const long long b = row / N;
+      const int i = (int)(row - b * N);
+      bf16_t* Drow = dA + (b * H * N + i) * (long long)ld + c0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const unsigned o = (hbase + r) * hs;
+        float oa[4], ob[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          oa[e] = fabsf(unpk(PA[r], e)) * (dPa[r][e] - dtot[r]);
+          ob[e] = fabsf(unpk(PB[r], e)) * (dPb[r][e] - dtot[r]);
+          if (!EXACT) { oa[e] = (c0 + 4 * qA + e < N) ? oa[e] : 0.f; ob[e] = (c0 + 4 * qB + e < N) ? ob[e] : 0.f; }
+        }
+        if (qA < nq) *reinterpret_cast<uint2*>(Drow + (o + 4u * qA)) = make_uint2(pk2(oa[0], oa[1]), pk2(oa[2], oa[3]));
+        if (qB < nq) *reinterpret_cast<uint2*>(Drow + (o + 4u * qB)) = make_uint2(pk2(ob[0], ob[1]), pk2(ob[2], ob[3]));
+      }
+      if (EXACT && qown >= nq && c0 + 4 * qown < ld) {      // the padding quad of the row
+#pragma unroll
+        for (int h = 0; h < H; ++h) *reinterpret_cast<uint2*>(Drow + (h * hs + 4u * qown)) = make_uint2(0, 0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { PA[r] = nP[r]; PB[r] = nPB[r]; }
+    if (nsweep == 0 && nchk == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dtot[r] = 0.f;
+    }
+    row = nrow; sweep = nsweep; ch = nchk;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[wave][(lg * 4 + r) * 16 + l15] = accw[r];
+  __syncthreads();
+  {
+    const int g = threadIdx.x / 16, hcol = threadIdx.x % 16;
+    const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (g < H && hcol < H) atomicAdd(dW + g * H + hcol, v * inv_keep);    // the P image holds kept p, not p/keep
+    else if (g < H && hcol == H) atomicAdd(dc + g, v);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // mix_stats_mm_kernel (bf16 storage, H = 8, 256 < ld <= 1024): the BatchNorm batch statistics of
 // the mixed maps, s1_g = sum (a_g - shift_g), s2_g = sum (a_g - shift_g)^2 with
 // a_g = sum_h W[g,h] P~_h, one 256-thread block per map row.  The 8x8 mix runs on the matrix cores
@@ -691,6 +934,20 @@ int launch_map_bwd_mm(const void* Ps, void* dA, const float* W, const float* c, 
   return vu_check_launch("vu_map_bwd");
 }
 
+int launch_map_bwd_mm_long(const void* Ps, void* dA, const float* W, const float* c, const float* gamma, const float* stats,
+                           float* dW, float* dc, int B, int N, int ld, float inv_keep, float scale, hipStream_t st) {
+  const long long rows = (long long)B * N;
+  const size_t lds = (size_t)(3 * 8 + 1) * (1024 + 8) * 2;
+  auto kern = (N % 4 == 0) ? map_bwd_mm_long_kernel<true> : map_bwd_mm_long_kernel<false>;
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) { vu_set_error("map_bwd: cannot reserve %zu bytes of LDS", lds); return VU_ELAUNCH; }
+  long long grid = rows; if (grid > 512) grid = 512;     // two blocks per CU (236 VGPRs, 51.6 KB of images each), persistent
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, (const bf16_t*)Ps, (bf16_t*)dA, W, c, gamma, stats, dW, dc,
+                     rows, N, ld, inv_keep, scale);
+  if (vu_prof_on()) vu_prof_note("map_bwd_mm_long_kernel", 0.0, (double)B * 8 * N * N * 3 * 2.0);
+  return vu_check_launch("vu_map_bwd");
+}
+
 template <typename T, int H>
 int launch_map_bwd_row(const void* Ps, void* dA, const float* W, const float* c, const float* gamma, const float* stats,
                        float* dW, float* dc, int B, int N, int ld, float inv_keep, float scale, hipStream_t st) {
@@ -737,6 +994,8 @@ int launch_map_bwd_row(const void* Ps, void* dA, const float* W, const float* c,
 int vu_k_map_bwd(int dtype, const void* Ps, void* dAhat_dS, const float* W, const float* c, const float* gamma,
                  const float* stats, float* dW, float* dc, int B, int H, int N, int ld, float inv_keep, float scale,
                  hipStream_t st) {
+  if (dtype == 1 && H == 8 && ld > 1024 && 8LL * N * ld < 2147483647LL && !map_bwd_valu_forced())
+    return launch_map_bwd_mm_long(Ps, dAhat_dS, W, c, gamma, stats, dW, dc, B, N, ld, inv_keep, scale, st);
   if (ld > 4096 || (ld > 1024 && (dtype == 0 || H > 4)))
     return vu_k_map_bwd_2sweep(dtype, Ps, dAhat_dS, W, c, gamma, stats, dW, dc, B, H, N, ld, inv_keep, scale, st);
 #define VU_MB(Tt, Hh) return launch_map_bwd_row<Tt, Hh>(Ps, dAhat_dS, W, c, gamma, stats, dW, dc, B, N, ld, inv_keep, scale, st)
