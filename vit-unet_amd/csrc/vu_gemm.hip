@@ -52,9 +52,11 @@ static int launch_tiles(const vu_gemm_args& g, hipStream_t st) {
   if (g.N <= 32) return launch_one<T, TC, TA, TB, 128, 32>(g, st);
   if (g.M <= 64) return launch_one<T, TC, TA, TB, 64, 64>(g, st);
   if (g.N <= 64) return launch_one<T, TC, TA, TB, 128, 64>(g, st);
-  // few big tiles and a long K (the 3072 -> 128 feed-forward layers of level 0: 25 tiles of 128x128): quarter tiles
+  // fewer big tiles than CUs and a long K (the 3072 -> 128 feed-forward layers of level 0: 25 tiles of 128x128; the 3072 x 3072
+  // projections at 16 images per GPU: 168 tiles): quarter tiles
   // put 4x the blocks on the chip (measured 77 -> see tools/gemm_bench.py); split-K is not available for bf16 outputs
-  if (sizeof(TC) == 2 && g.K >= 1024 && (long long)vu_cdiv(g.M, 128) * vu_cdiv(g.N, 128) * g.Z1 * g.Z2 < 64)
+  static const int quarter_below = getenv("VU_GEMM_QUARTER_BELOW") ? atoi(getenv("VU_GEMM_QUARTER_BELOW")) : 200;   // measurement switch (64 -> 200: +3 % on the 16-image-per-GPU steps of Base / Large, whose 3072-wide linears have 168 tiles)
+  if (sizeof(TC) == 2 && g.K >= 1024 && (long long)vu_cdiv(g.M, 128) * vu_cdiv(g.N, 128) * g.Z1 * g.Z2 < quarter_below)
     return launch_one<T, TC, TA, TB, 64, 64>(g, st);
   return launch_one<T, TC, TA, TB, 128, 128>(g, st);
 }
