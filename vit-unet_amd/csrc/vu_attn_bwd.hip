@@ -996,7 +996,10 @@ int vu_k_map_bwd(int dtype, const void* Ps, void* dAhat_dS, const float* W, cons
                  hipStream_t st) {
   if (dtype == 1 && H == 8 && ld > 1024 && 8LL * N * ld < 2147483647LL && !map_bwd_valu_forced())
     return launch_map_bwd_mm_long(Ps, dAhat_dS, W, c, gamma, stats, dW, dc, B, N, ld, inv_keep, scale, st);
-  if (ld > 4096 || (ld > 1024 && (dtype == 0 || H > 4)))
+  // rows > 1024 with <= 4 heads (Lite level 2): the two-sweep kernel (two waves per SIMD, loads one trip ahead) beats the
+  // one-row-per-1024-thread-block MFMA form, 4.3 vs 4.9 ms per launch at N = 3136; VU_MAP_BWD_ONE_SWEEP=1 restores the latter
+  static const bool one_sweep = getenv("VU_MAP_BWD_ONE_SWEEP") != nullptr;
+  if (ld > 4096 || (ld > 1024 && (dtype == 0 || H > 4 || !one_sweep)))
     return vu_k_map_bwd_2sweep(dtype, Ps, dAhat_dS, W, c, gamma, stats, dW, dc, B, H, N, ld, inv_keep, scale, st);
 #define VU_MB(Tt, Hh) return launch_map_bwd_row<Tt, Hh>(Ps, dAhat_dS, W, c, gamma, stats, dW, dc, B, N, ld, inv_keep, scale, st)
   if (dtype == 0) { switch (H) { case 1: VU_MB(float, 1); case 2: VU_MB(float, 2); case 4: VU_MB(float, 4); case 8: VU_MB(float, 8); } }
