@@ -105,7 +105,8 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} needs torchrun with {a.gpus} ranks (WORLD_SIZE={world})")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    dp = world > 1 or bool(os.environ.get("VU_DP_FORCE"))     # VU_DP_FORCE=1: the RCCL path on one rank (under torchrun)
+    if dp:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.distributed.init_process_group("nccl", device_id=dev)
 
@@ -128,7 +129,7 @@ def main():
         x = (y + 0.1 * torch.randn(y.shape, generator=g)).clamp(0, 1)
     x, y = x.to(dev), y.to(dev)
     ts = TrainStep(model, lr=1e-4, seed=1234 + rank, loss="dice" if seg else "mse")
-    use_graph = world == 1 and not a.no_graph
+    use_graph = not dp and not a.no_graph
     if use_graph:
         ts.capture(x, y)
         step = lambda: ts.replay()                          # noqa: E731  (inputs stay resident)
@@ -137,7 +138,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if dp:
             torch.distributed.barrier()
         torch.cuda.synchronize(dev)
 
@@ -149,7 +150,7 @@ def main():
         step()
     fence()
     dt_s = time.perf_counter() - t0
-    if world > 1:
+    if dp:
         t = torch.tensor([dt_s], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt_s = t.item()
@@ -161,7 +162,7 @@ def main():
     # CHW batch ImageFitter.unpack moves (dataset.py:78-91), (b) as decoded uint8 HWC images that the
     # device-side input pipeline (vu_denoise_prepare, train transform) turns into the batch
     host_in = None
-    if rank == 0 and world == 1 and not a.no_host_input and not seg:
+    if rank == 0 and not dp and not a.no_host_input and not seg:
         from vit_unet.torch.dataset import DenoisingBatchTransform
         n_h = max(3, min(a.steps, 10))
         hx, hy = x.cpu().pin_memory(), y.cpu().pin_memory()
@@ -192,15 +193,24 @@ def main():
         host_in["steps"] = n_h
 
     roof = None
-    if rank == 0 and not a.no_roofline:
+    rep = None
+    if not a.no_roofline:
+        # extra instrumented steps: every rank runs them (they contain the gradient all-reduce), rank 0 with one HIP
+        # event behind every launch on its compute stream
         L = _lib.lib()
         st = torch.cuda.current_stream(dev)
         torch.cuda.synchronize(dev)
-        if world == 1:
+        if rank == 0:
             L.vu_prof_enable(_lib.C.c_void_p(st.cuda_stream))
-            for _ in range(a.profile_steps):
-                ts.step(x, y)
+        for _ in range(a.profile_steps):
+            ts.step(x, y)
+        torch.cuda.synchronize(dev)
+        if rank == 0:
             rep = json.loads(L.vu_prof_report().decode())
+        if dp:
+            torch.distributed.barrier()
+    if rank == 0 and rep is not None:
+        if True:
             if a.dump_profile:
                 with open(a.dump_profile, "w") as f:
                     json.dump({k: dict(v, ms_per_step=v["ms"] / a.profile_steps) for k, v in
@@ -231,7 +241,7 @@ def main():
             roof.update({"traffic": traffic, "traffic_source": tsrc, "kernel": name, "avg_launch_us": avg_s * 1e6,
                          "launches_per_step": d["count"] / a.profile_steps,
                          "share_of_step": d["ms"] / tot_ms,
-                         "step_mfma_frac": value * TRAIN_GFLOP_PER_IMG[a.model] / 1e3 / MFMA_PEAK_TFLOPS,
+                         "step_mfma_frac": value / world * TRAIN_GFLOP_PER_IMG[a.model] / 1e3 / MFMA_PEAK_TFLOPS,
                          "top": [{"kernel": k, "ms_per_step": v["ms"] / a.profile_steps,
                                   "launches_per_step": v["count"] / a.profile_steps,
                                   "TFLOPs": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["flops"] else None,
@@ -251,11 +261,11 @@ def main():
                "config": {"workload": f"ViT_UNet-{mname} train step: forward + {lossn} + backward + "
                                       f"AdamW on synthetic " + ("CT-style 512x512x1 image/mask pairs" if seg else
                                                                 "SIDD-style 224x224x3 noisy/clean pairs") + ", random-init weights",
-                          "per_gpu_batch": a.batch, "global_batch": a.batch * world, "parallelism": f"dp{world}",
+                          "per_gpu_batch": a.batch, "global_batch": a.batch * world, "parallelism": f"dp{world}", "rccl_path": dp,
                           "hip_graph": use_graph, "final_loss": loss},
                "roofline": roof, "cpu_baseline": cpu, "host_input": host_in}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dp:
         torch.distributed.destroy_process_group()
 
 

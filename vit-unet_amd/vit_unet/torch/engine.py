@@ -12,6 +12,7 @@ collective overlaps the remaining backward; the 1/world average is folded into A
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -70,8 +71,12 @@ class TrainStep:
         self.world = 1
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(process_group)
-        self.overlap = overlap and self.world > 1
-        self.comm_stream = torch.cuda.Stream(device=dev) if self.world > 1 else None
+        # data-parallel path: more than one rank - or VU_DP_FORCE=1 with an initialised process group, which runs the
+        # same bucketed all-reduce / side-stream choreography on ONE rank (how the RCCL path is exercised on a 1-GPU box)
+        self.dp = self.world > 1 or (bool(os.environ.get("VU_DP_FORCE")) and torch.distributed.is_available()
+                                     and torch.distributed.is_initialized())
+        self.overlap = overlap and self.dp
+        self.comm_stream = torch.cuda.Stream(device=dev) if self.dp else None
         self._graph = None
         self._gx = self._gy = self._gout = self._dout = None
         self._buckets = self._make_buckets()
@@ -106,14 +111,14 @@ class TrainStep:
         for stage, (lo, hi) in zip((1, 2, 3), self._buckets):
             check(L.vu_model_backward(cfg, ptr(m._arena), ptr(m._shadow), ptr(m._bn), ptr(m._garena), ptr(dout), None,
                                       ptr(ws), ws.numel(), B, 1, self.seed, ptr(salt), stage, st), "vu_model_backward")
-            if self.world > 1 and hi > lo:
+            if self.dp and hi > lo:
                 if self.overlap:
                     self.comm_stream.wait_stream(cur)
                     with torch.cuda.stream(self.comm_stream):
                         allreduce_bucket(m._garena, lo, hi, self.pg)
                 else:
                     allreduce_bucket(m._garena, lo, hi, self.pg)
-        if self.world > 1 and self.overlap:
+        if self.dp and self.overlap:
             cur.wait_stream(self.comm_stream)
         check(L.vu_adamw(ptr(m._arena), ptr(m._garena), ptr(self.m), ptr(self.v), ptr(m._shadow), m._arena.numel(),
                          ptr(self.hyper), ptr(self.step_count), 1.0 / self.world, st), "vu_adamw")
@@ -135,7 +140,7 @@ class TrainStep:
         """Capture one step into a hipGraph (static input buffers); `replay(x, y)` then copies the
         batch into the static buffers and launches the graph.  Single-GPU only: the collective is
         launched eagerly in DP runs."""
-        assert self.world == 1, "graph capture is used for the single-GPU path"
+        assert not self.dp, "graph capture is used for the single-GPU path"
         self._gx, self._gy = x.float().contiguous().clone(), y.float().contiguous().clone()
         self._gout, self._dout = torch.empty_like(self._gx), torch.empty_like(self._gx)
         self.model._workspace(x.shape[0])
