@@ -1,0 +1,78 @@
+"""Two-rank rehearsal of the data-parallel train step on ONE GPU (gloo moves the CUDA buckets; RCCL cannot put two
+ranks on one device).  Launch from a shell that has not touched the GPU:
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 tools/dp_rehearsal.py
+
+Checks, after 3 fused steps with per-rank batches: (1) every rank holds bit-identical parameters (the three bucketed
+all-reduces cover the whole gradient arena and AdamW applies the same 1/world average everywhere); (2) rank 0's parameters
+equal a single-process reference that back-propagates both ranks' batches through the autograd path, averages the
+gradients and steps torch.optim.AdamW (BatchNorm statistics per replica, as in the DP run)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vit-unet_amd"))
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+dist.init_process_group("gloo")
+from vit_unet.torch import model as M  # noqa: E402
+from vit_unet.torch.engine import TrainStep  # noqa: E402
+
+kw = dict(depth=1, depth_te=1, size_bottleneck=1, preprocessing="conv", im_size=32, patch_size=8, num_channels=3,
+          hidden_dim=16, num_heads=2, attn_drop=0.0, proj_drop=0.0, linear_drop=0.0)
+
+
+def build():
+    torch.manual_seed(0)
+    return M.HViT_UNet(**kw).to("cuda").train()
+
+
+def batch(r, step):
+    g = torch.Generator().manual_seed(100 * step + r)
+    y = torch.rand(4, 3, 32, 32, generator=g)
+    return (y + 0.1 * torch.randn(y.shape, generator=g)).clamp(0, 1).cuda(), y.cuda()
+
+
+m = build()
+ts = TrainStep(m, lr=1e-3, seed=7 + rank)
+assert ts.dp and ts.world == world
+for step in range(3):
+    ts.step(*batch(rank, step))
+torch.cuda.synchronize()
+arena = m._arena.detach().clone()
+gathered = [torch.empty_like(arena) for _ in range(world)]
+dist.all_gather(gathered, arena)
+ok_same = all(torch.equal(gathered[0], t) for t in gathered)
+ok_ref, err = True, 0.0
+if rank == 0:
+    ref = build()
+    opt = torch.optim.AdamW(ref.parameters(), lr=1e-3)
+    bn0 = {k: v.clone() for k, v in ref.state_dict().items() if "running" in k or "num_batches" in k}
+    for step in range(3):
+        grads = None
+        for r in range(world):
+            if r > 0:    # BatchNorm running statistics are per replica: rank 0's model only sees rank 0's batches
+                saved = {k: v.clone() for k, v in ref.state_dict().items() if k in bn0}
+            opt.zero_grad()
+            x, y = batch(r, step)
+            torch.nn.MSELoss()(ref(x), y).backward()
+            if r > 0:
+                ref.load_state_dict(saved, strict=False)
+            gs = [p.grad.detach().clone() for p in ref.parameters()]
+            grads = gs if grads is None else [a + b for a, b in zip(grads, gs)]
+        for p, gsum in zip(ref.parameters(), grads):
+            p.grad = gsum / world
+        opt.step()
+    for (k, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+        if k.endswith("reatten_matrix.bias"):
+            continue      # exact gradient 0 under train-mode BatchNorm: Adam turns rounding noise into +-lr steps
+        e = ((p.detach() - q.detach()).abs().max() / (q.detach().abs().max() + 1e-30)).item()
+        err = max(err, e)
+    ok_ref = err < 2e-4
+print(f"rank {rank}: identical parameters across ranks: {ok_same}; vs single-process reference: {ok_ref} (max scaled err {err:.2e})",
+      flush=True)
+dist.barrier()
+dist.destroy_process_group()
+sys.exit(0 if (ok_same and ok_ref) else 1)
