@@ -332,3 +332,36 @@ def test_image_fitter_fit_checkpoints_and_callbacks(tmp_path):
     f2 = ImageFitter(m, loss=torch.nn.L1Loss(), device=DEV, folder=str(tmp_path / "l1"), lr=1e-3)
     h2 = f2.fit(loader, None, n_epochs=2)
     assert f2._fused is None and h2[-1]["train"] < h2[0]["train"] * 1.05
+
+
+def test_dp_path_one_rank_rccl_matches_single_gpu_step(golden_dir, monkeypatch):
+    """The data-parallel choreography (NCCL process group, three bucketed all-reduces on the side stream, 1/world
+    folded into AdamW) on ONE rank (VU_DP_FORCE=1) must reproduce the plain single-GPU fused step."""
+    import socket
+    import torch.distributed as dist
+    man, g = load_case(golden_dir, "tiny_c")
+    kw = dict(man["cases"]["tiny_c"]["config"], attn_drop=0.2, proj_drop=0.2, linear_drop=0.0)
+    w = O.make_weights(O.Config(**kw), seed=7)
+    x, y = torch.from_numpy(g["x"]).to(DEV), torch.from_numpy(g["y"]).to(DEV)
+    ma, mb = build(kw, w).train(), build(kw, w).train()
+    ta = TrainStep(ma, lr=1e-3, seed=5)
+    assert not ta.dp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    monkeypatch.setenv("VU_DP_FORCE", "1")
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", torch.cuda.current_device()))
+    try:
+        tb = TrainStep(mb, lr=1e-3, seed=5)
+        assert tb.dp and tb.world == 1 and tb.comm_stream is not None
+        for _ in range(3):
+            la, lb = ta.step(x, y).item(), tb.step(x, y).item()
+            assert abs(la - lb) < 1e-4 * abs(la)
+        torch.cuda.synchronize()
+        for (k, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+            if k.endswith("reatten_matrix.bias"):
+                continue
+            assert serr(pa, pb) < 1e-4, k
+    finally:
+        dist.destroy_process_group()
