@@ -125,6 +125,19 @@ int vu_add_layernorm_fwd(int dtype, const void* a, const void* x, void* z, const
 int vu_layernorm_bwd(int dtype, const void* dy, const void* z, const float* w, const float* stats,
                      float* dw, float* db, float* ws, void* dz, int B, long long P, void* stream);
 
+/* FeedForward.forward (model.py:95-110): y = Dropout(Linear(Dropout(GELU(Linear(x))))) on (rows, D) tokens; w1 (hid,D),
+ * w2 (D,hid) in the storage dtype, biases fp32.  hpre / hact (rows,hid) keep the GELU pre-activation and the (dropped)
+ * activation for the backward.  vu_ff_backward accumulates dw1 (hid,D), db1, dw2 (D,hid), db2 (fp32) and writes dx;
+ * scratch >= vu_ff_scratch_bytes.  Dropout sites replay from (seed, stream_id) as in vu_attn_forward. */
+size_t vu_ff_scratch_bytes(int dtype, long long rows, int D, int hid);
+int vu_ff_forward(int dtype, const void* x, const void* w1, const float* b1, const void* w2, const float* b2,
+                  void* hpre, void* hact, void* y, long long rows, int D, int hid, float linear_drop,
+                  int training, uint64_t seed, uint64_t stream_id, void* stream);
+int vu_ff_backward(int dtype, const void* x, const void* w1, const void* w2, const void* hpre, const void* hact,
+                   const void* dy, void* dx, float* dw1, float* db1, float* dw2, float* db2, void* scratch,
+                   long long rows, int D, int hid, float linear_drop, int training, uint64_t seed,
+                   uint64_t stream_id, void* stream);
+
 /* strided batched GEMM C = alpha * A * B (+bias) used for every contraction on the path;
  * strides in elements; exactly one of (sAm,sAk) and one of (sBk,sBn) must be 1. */
 int vu_gemm(int dtype, int c_float, const void* A, const void* Bm, void* C, int M, int N, int K,

@@ -27,7 +27,7 @@ import torch.nn.functional as F
 
 __all__ = [
     "Config", "retile", "patchify", "unpatchify", "downsample", "upsample",
-    "conv3x3_per_patch", "reattention", "te_block", "skip_block", "forward",
+    "conv3x3_per_patch", "reattention", "feed_forward", "te_block", "skip_block", "forward",
     "param_shapes", "param_count", "make_weights", "keep_mask", "mse_loss", "psnr",
     "ssim", "dice_loss", "resize_u8", "warp_affine_u8", "invert_affine", "shift_scale_rotate_matrix",
     "denoise_prepare", "adamw_step", "PRESETS",
@@ -254,11 +254,23 @@ def te_block(x, p, pre: str, cfg: Config, *, training: bool, seed=None, stream: 
                     attn_drop=cfg.attn_drop, proj_drop=cfg.proj_drop, seed=seed, stream=stream, storage=st,
                     round_out=False)
     x = _r(_layernorm_nd(_r(a + x, st), p[pre + "LN1.weight"], p[pre + "LN1.bias"]), st)
-    hdn = _r(F.gelu(F.linear(x, _r(p[pre + "FeedForward.net.0.weight"], st), p[pre + "FeedForward.net.0.bias"])), st)
-    # linear_drop is 0 in every preset (model.py:451,467,483); Dropout(0) is the identity.
-    assert cfg.linear_drop == 0.0 or not training, "oracle: linear_drop>0 in train mode not restated"
-    f = F.linear(hdn, _r(p[pre + "FeedForward.net.3.weight"], st), p[pre + "FeedForward.net.3.bias"])
+    f = feed_forward(x, p, pre + "FeedForward.", training=training, linear_drop=cfg.linear_drop, seed=seed, stream=stream,
+                     storage=st)
     return _r(_layernorm_nd(_r(f + x, st), p[pre + "LN2.weight"], p[pre + "LN2.bias"]), st)
+
+
+FF_STREAM = 1 << 32   # dropout streams of the two FeedForward sites: FF_STREAM + 2*stream (+1)  (csrc/vu_model.hip)
+
+
+def feed_forward(x, p, pre: str, *, training: bool, linear_drop: float = 0.0, seed=None, stream: int = 0, storage=None):
+    """FeedForward.forward (model.py:95-110): Linear -> GELU (exact erf) -> Dropout -> Linear -> Dropout.
+    (linear_drop is 0 in every preset, model.py:451,467,483.)  The result is NOT rounded: inside a block the HIP
+    epilogue adds the residual before storing."""
+    st = storage
+    hdn = F.gelu(F.linear(x, _r(p[pre + "net.0.weight"], st), p[pre + "net.0.bias"]))
+    hdn = _r(_dropout(hdn, linear_drop, training, seed, FF_STREAM + 2 * stream), st)
+    f = F.linear(hdn, _r(p[pre + "net.3.weight"], st), p[pre + "net.3.bias"])
+    return _dropout(f, linear_drop, training, seed, FF_STREAM + 2 * stream + 1)
 
 
 def skip_block(enc, dec, p, pre: str, cfg: Config, *, training: bool, seed=None, stream: int = 0, storage=None):
@@ -281,7 +293,11 @@ def forward(p: Dict[str, torch.Tensor], cfg: Config, X: torch.Tensor, *, trainin
     x = _r(patchify(X, cfg.patch_size) + p["PE.position_embedding.weight"].unsqueeze(0), storage)
     stream = 0
     skips: List[torch.Tensor] = []
+    def tap_block(pre, xin, lvl):
+        if taps is not None:   # teacher-forcing hooks for the tests: every block's input, level and dropout stream
+            taps.setdefault("blocks", []).append((pre, xin.detach(), lvl, stream))
     for i in range(cfg.depth * cfg.depth_te):                          # :388-392
+        tap_block(f"Encoders.{i}.", x, i // cfg.depth_te)
         x = te_block(x, p, f"Encoders.{i}.", cfg, training=training, seed=seed, stream=stream, storage=storage)
         stream += 1
         if (i + 1) % cfg.depth_te == 0:
@@ -290,11 +306,13 @@ def forward(p: Dict[str, torch.Tensor], cfg: Config, X: torch.Tensor, *, trainin
     if taps is not None:
         taps["after_encoders"] = x
     for i in range(cfg.size_bottleneck):                               # :400-401
+        tap_block(f"BottleNeck.{i}.", x, cfg.depth)
         x = te_block(x, p, f"BottleNeck.{i}.", cfg, training=training, seed=seed, stream=stream, storage=storage)
         stream += 1
     if taps is not None:
         taps["after_bottleneck"] = x
     for i in range(cfg.depth * cfg.depth_te):                          # :410-418
+        tap_block(f"Decoders.{i}.", x, cfg.depth - i // cfg.depth_te)
         x = te_block(x, p, f"Decoders.{i}.", cfg, training=training, seed=seed, stream=stream, storage=storage)
         stream += 1
         if (i + 1) % cfg.depth_te == 0:
@@ -302,6 +320,9 @@ def forward(p: Dict[str, torch.Tensor], cfg: Config, X: torch.Tensor, *, trainin
             x = upsample(x, C)
             enc = skips[cfg.depth - j]
             assert enc.shape == x.shape                                # :417
+            if taps is not None:
+                taps.setdefault("skips", []).append((f"SkipConnections.{j - 1}.", enc.detach(), x.detach(),
+                                                     cfg.depth - j, stream))
             x = skip_block(enc, x, p, f"SkipConnections.{j - 1}.", cfg, training=training,
                            seed=seed, stream=stream, storage=storage)
             stream += 1

@@ -65,8 +65,8 @@ int validate(const vu_config& c) {
   const int dl = c.num_channels * (c.patch_size >> c.depth) * (c.patch_size >> c.depth);
   VU_REQUIRE(dl % c.num_heads == 0, "num_heads must divide the projection size at every level");
   VU_REQUIRE((c.hidden_dim >> c.depth) >= 1, "hidden_dim too small for depth");
-  VU_REQUIRE(c.linear_drop == 0.f, "linear_drop > 0 is not implemented (0 in every reference preset)");
-  VU_REQUIRE(c.attn_drop >= 0.f && c.attn_drop < 1.f && c.proj_drop >= 0.f && c.proj_drop < 1.f, "dropout must be in [0,1)");
+  VU_REQUIRE(c.attn_drop >= 0.f && c.attn_drop < 1.f && c.proj_drop >= 0.f && c.proj_drop < 1.f && c.linear_drop >= 0.f && c.linear_drop < 1.f,
+             "dropout must be in [0,1)");
   VU_REQUIRE(c.dtype == 0 || c.dtype == 1, "dtype must be 0 (fp32) or 1 (bf16)");
   return VU_OK;
 }
@@ -411,6 +411,85 @@ struct Ctx {
   int training; uint64_t seed; const uint32_t* salt; hipStream_t st; ModelWS* w;
 };
 
+// ---------------------------------------------------------------------------------------------
+// FeedForward (model.py:95-110): Linear(D,hid) -> GELU -> Dropout(linear_drop) -> Linear(hid,D) -> Dropout(linear_drop).
+// hpre keeps the GELU pre-activation, hact the (dropped) activation.  The two dropout sites draw from the streams
+// VU_FF_STREAM(stream_id, 0 / 1), which do not collide with the attention-map / projection streams 2 sid, 2 sid + 1.
+// ---------------------------------------------------------------------------------------------
+#define VU_FF_STREAM(sid, k) ((1ull << 32) + 2 * (uint64_t)(sid) + (k))
+struct FFDims { int dtype; long long rows; int D, hid; };
+
+int ff_forward(const FFDims& f, const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* hpre,
+               void* hact, void* y, const void* resid, float linear_drop, int training, uint64_t seed, uint64_t stream_id,
+               const uint32_t* salt, hipStream_t st) {
+  {  // hact = dropout(gelu(x W1^T + b1))  (model.py:102-105)
+    vu_gemm_args g;
+    memset(&g, 0, sizeof(g));
+    g.A = x; g.B = w1; g.C = hact; g.aux = hpre;
+    g.M = (int)f.rows; g.N = f.hid; g.K = f.D; g.sAm = f.D; g.sAk = 1; g.sBk = 1; g.sBn = f.D; g.ldc = f.hid;
+    g.Z1 = 1; g.Z2 = 1; g.alpha = 1.f; g.bias = b1; g.act = VU_ACT_GELU;
+    g.rng = vu_make_rng(seed, VU_FF_STREAM(stream_id, 0), training ? linear_drop : 0.f);
+    g.rng.salt = salt;
+    g.dropout = g.rng.thr != 0;
+    VU_TRY(vu_gemm_launch(f.dtype, 0, g, st));
+  }
+  {  // y = dropout(hact W2^T + b2) (+ resid)  (model.py:106-107)
+    vu_gemm_args g;
+    memset(&g, 0, sizeof(g));
+    g.A = hact; g.B = w2; g.C = y;
+    g.M = (int)f.rows; g.N = f.D; g.K = f.hid; g.sAm = f.hid; g.sAk = 1; g.sBk = 1; g.sBn = f.hid; g.ldc = f.D;
+    g.Z1 = 1; g.Z2 = 1; g.alpha = 1.f; g.bias = b2; g.addend = resid;
+    g.rng = vu_make_rng(seed, VU_FF_STREAM(stream_id, 1), training ? linear_drop : 0.f);
+    g.rng.salt = salt;
+    g.dropout = g.rng.thr != 0;
+    VU_TRY(vu_gemm_launch(f.dtype, 0, g, st));
+  }
+  return VU_OK;
+}
+
+// dy: gradient wrt the module output; dym: the same with the output dropout mask applied (== dy when linear_drop is
+// off).  dx = dh W1 (+ addend).  gh: scratch (rows, hid).  Weight gradients are accumulated.
+int ff_backward(const FFDims& f, const void* x, const void* w1, const void* w2, const void* hpre, const void* hact,
+                const void* dym, const void* addend, void* dx, float* dw1, float* db1, float* dw2, float* db2, void* gh,
+                float linear_drop, int training, uint64_t seed, uint64_t stream_id, const uint32_t* salt, hipStream_t st) {
+  {  // dW2 += dym^T hact ; db2 += column sums of dym
+    vu_gemm_args g;
+    memset(&g, 0, sizeof(g));
+    g.A = dym; g.B = hact; g.C = dw2; g.M = f.D; g.N = f.hid; g.K = (int)f.rows;
+    g.sAm = 1; g.sAk = f.D; g.sBk = f.hid; g.sBn = 1; g.ldc = f.hid; g.Z1 = 1; g.Z2 = 1; g.alpha = 1.f; g.accumulate = 1;
+    g.colsum = db2; g.colsum_side = 1;
+    VU_TRY(vu_gemm_launch(f.dtype, 1, g, st));
+  }
+  {  // dh = dropout-mask * (dym W2) * gelu'(hpre)
+    vu_gemm_args g;
+    memset(&g, 0, sizeof(g));
+    g.A = dym; g.B = w2; g.C = gh; g.aux = (void*)hpre;
+    g.M = (int)f.rows; g.N = f.hid; g.K = f.D; g.sAm = f.D; g.sAk = 1; g.sBk = f.hid; g.sBn = 1; g.ldc = f.hid;
+    g.Z1 = 1; g.Z2 = 1; g.alpha = 1.f; g.act = VU_ACT_DGELU;
+    g.rng = vu_make_rng(seed, VU_FF_STREAM(stream_id, 0), training ? linear_drop : 0.f);
+    g.rng.salt = salt;
+    g.dropout = g.rng.thr != 0;
+    VU_TRY(vu_gemm_launch(f.dtype, 0, g, st));
+  }
+  {  // dW1 += dh^T x ; db1 += column sums of dh
+    vu_gemm_args g;
+    memset(&g, 0, sizeof(g));
+    g.A = gh; g.B = x; g.C = dw1; g.M = f.hid; g.N = f.D; g.K = (int)f.rows;
+    g.sAm = 1; g.sAk = f.hid; g.sBk = f.D; g.sBn = 1; g.ldc = f.D; g.Z1 = 1; g.Z2 = 1; g.alpha = 1.f; g.accumulate = 1;
+    g.colsum = db1; g.colsum_side = 1;
+    VU_TRY(vu_gemm_launch(f.dtype, 1, g, st));
+  }
+  {  // dx = dh W1 (+ addend)
+    vu_gemm_args g;
+    memset(&g, 0, sizeof(g));
+    g.A = gh; g.B = w1; g.C = dx; g.addend = addend;
+    g.M = (int)f.rows; g.N = f.D; g.K = f.hid; g.sAm = f.hid; g.sAk = 1; g.sBk = f.D; g.sBn = 1; g.ldc = f.D;
+    g.Z1 = 1; g.Z2 = 1; g.alpha = 1.f;
+    VU_TRY(vu_gemm_launch(f.dtype, 0, g, st));
+  }
+  return VU_OK;
+}
+
 int block_forward(Ctx& cx, const BlockP& bp, BlockBuf& bb, const void* x, uint64_t stream_id) {
   const vu_config& c = cx.pl->cfg;
   const Level& L = cx.pl->lv[bp.level];
@@ -422,22 +501,9 @@ int block_forward(Ctx& cx, const BlockP& bp, BlockBuf& bb, const void* x, uint64
                       cx.seed, stream_id, cx.salt, cx.st, x));          // z1 = attn(x) + x
   VU_TRY(vu_k_add_ln_fwd(dt, bb.z1, nullptr, bb.z1, cx.prm + bp.ln1w, cx.prm + bp.ln1b, bb.x1, cx.w->lnp, bb.ln1s,
                          B, P, 1e-5f, cx.st));
-  {  // hact = gelu(x1 W1^T + b1)  (model.py:102-104)
-    vu_gemm_args g;
-    memset(&g, 0, sizeof(g));
-    g.A = bb.x1; g.B = wptr(c, cx.prm, cx.shadow, bp.w1); g.C = bb.hact; g.aux = bb.hpre;
-    g.M = B * L.N; g.N = L.hid; g.K = L.D; g.sAm = L.D; g.sAk = 1; g.sBk = 1; g.sBn = L.D; g.ldc = L.hid;
-    g.Z1 = 1; g.Z2 = 1; g.alpha = 1.f; g.bias = cx.prm + bp.b1; g.act = VU_ACT_GELU;
-    VU_TRY(vu_gemm_launch(dt, 0, g, cx.st));
-  }
-  {  // f = hact W2^T + b2  (model.py:106)
-    vu_gemm_args g;
-    memset(&g, 0, sizeof(g));
-    g.A = bb.hact; g.B = wptr(c, cx.prm, cx.shadow, bp.w2); g.C = bb.z2;
-    g.M = B * L.N; g.N = L.D; g.K = L.hid; g.sAm = L.hid; g.sAk = 1; g.sBk = 1; g.sBn = L.hid; g.ldc = L.D;
-    g.Z1 = 1; g.Z2 = 1; g.alpha = 1.f; g.bias = cx.prm + bp.b2; g.addend = bb.x1;   // z2 = FF(x1) + x1
-    VU_TRY(vu_gemm_launch(dt, 0, g, cx.st));
-  }
+  FFDims fd{dt, (long long)B * L.N, L.D, L.hid};
+  VU_TRY(ff_forward(fd, bb.x1, wptr(c, cx.prm, cx.shadow, bp.w1), cx.prm + bp.b1, wptr(c, cx.prm, cx.shadow, bp.w2), cx.prm + bp.b2,
+                    bb.hpre, bb.hact, bb.z2, bb.x1, c.linear_drop, cx.training, cx.seed, stream_id, cx.salt, cx.st));   // z2 = FF(x1) + x1
   VU_TRY(vu_k_add_ln_fwd(dt, bb.z2, nullptr, bb.z2, cx.prm + bp.ln2w, cx.prm + bp.ln2b, bb.out, cx.w->lnp, bb.ln2s,
                          B, P, 1e-5f, cx.st));
   return VU_OK;
@@ -451,42 +517,16 @@ int block_backward(Ctx& cx, const BlockP& bp, BlockBuf& bb, const void* x, void*
   const long long P = (long long)L.N * L.D, rows = (long long)B * L.N;
   ModelWS& w = *cx.w;
   float* G = cx.grads;
-  vu_rng none = vu_make_rng(0, 0, 0.f);
-  // LN2 backward: dz2 -> ga
-  VU_TRY(vu_k_ln_bwd(dt, dout, bb.z2, cx.prm + bp.ln2w, bb.ln2s, G + bp.ln2w, G + bp.ln2b, w.lnp2, w.ga, nullptr, none, B, P, cx.st));
-  // FeedForward backward
-  {  // dW2 += dz2^T hact ; db2 += column sums of dz2
-    vu_gemm_args g;
-    memset(&g, 0, sizeof(g));
-    g.A = w.ga; g.B = bb.hact; g.C = G + bp.w2; g.M = L.D; g.N = L.hid; g.K = (int)rows;
-    g.sAm = 1; g.sAk = L.D; g.sBk = L.hid; g.sBn = 1; g.ldc = L.hid; g.Z1 = 1; g.Z2 = 1; g.alpha = 1.f; g.accumulate = 1;
-    g.colsum = G + bp.b2; g.colsum_side = 1;
-    VU_TRY(vu_gemm_launch(dt, 1, g, cx.st));
-  }
-  {  // dh = (dz2 W2) * gelu'(hpre)
-    vu_gemm_args g;
-    memset(&g, 0, sizeof(g));
-    g.A = w.ga; g.B = wptr(c, cx.prm, cx.shadow, bp.w2); g.C = w.gh; g.aux = bb.hpre;
-    g.M = (int)rows; g.N = L.hid; g.K = L.D; g.sAm = L.D; g.sAk = 1; g.sBk = L.hid; g.sBn = 1; g.ldc = L.hid;
-    g.Z1 = 1; g.Z2 = 1; g.alpha = 1.f; g.act = VU_ACT_DGELU;
-    VU_TRY(vu_gemm_launch(dt, 0, g, cx.st));
-  }
-  {  // dW1 += dh^T x1 ; db1 += column sums of dh
-    vu_gemm_args g;
-    memset(&g, 0, sizeof(g));
-    g.A = w.gh; g.B = bb.x1; g.C = G + bp.w1; g.M = L.hid; g.N = L.D; g.K = (int)rows;
-    g.sAm = 1; g.sAk = L.hid; g.sBk = L.D; g.sBn = 1; g.ldc = L.D; g.Z1 = 1; g.Z2 = 1; g.alpha = 1.f; g.accumulate = 1;
-    g.colsum = G + bp.b1; g.colsum_side = 1;
-    VU_TRY(vu_gemm_launch(dt, 1, g, cx.st));
-  }
-  {  // dx1 = dh W1 + dz2  -> gb
-    vu_gemm_args g;
-    memset(&g, 0, sizeof(g));
-    g.A = w.gh; g.B = wptr(c, cx.prm, cx.shadow, bp.w1); g.C = w.gb; g.addend = w.ga;
-    g.M = (int)rows; g.N = L.D; g.K = L.hid; g.sAm = L.hid; g.sAk = 1; g.sBk = L.D; g.sBn = 1; g.ldc = L.D;
-    g.Z1 = 1; g.Z2 = 1; g.alpha = 1.f;
-    VU_TRY(vu_gemm_launch(dt, 0, g, cx.st));
-  }
+  // LN2 backward: dz2 -> ga ; with linear_drop, the copy masked by the FF output dropout -> gc
+  vu_rng rf = vu_make_rng(cx.seed, VU_FF_STREAM(stream_id, 1), cx.training ? c.linear_drop : 0.f);
+  rf.salt = cx.salt;
+  const bool ffmasked = rf.thr != 0;
+  VU_TRY(vu_k_ln_bwd(dt, dout, bb.z2, cx.prm + bp.ln2w, bb.ln2s, G + bp.ln2w, G + bp.ln2b, w.lnp2, w.ga, ffmasked ? w.gc : nullptr, rf, B, P, cx.st));
+  // FeedForward backward: dx1 = dh W1 + dz2 -> gb
+  FFDims fd{dt, rows, L.D, L.hid};
+  VU_TRY(ff_backward(fd, bb.x1, wptr(c, cx.prm, cx.shadow, bp.w1), wptr(c, cx.prm, cx.shadow, bp.w2), bb.hpre, bb.hact,
+                     ffmasked ? w.gc : w.ga, w.ga, w.gb, G + bp.w1, G + bp.b1, G + bp.w2, G + bp.b2, w.gh, c.linear_drop, cx.training,
+                     cx.seed, stream_id, cx.salt, cx.st));
   // LN1 backward: dz1 -> ga ; masked copy (projection dropout backward) -> gc
   vu_rng rp = vu_make_rng(cx.seed, 2 * stream_id + 1, cx.training ? c.proj_drop : 0.f);
   rp.salt = cx.salt;
@@ -792,6 +832,33 @@ int vu_layernorm_bwd(int dtype, const void* dy, const void* z, const float* w, c
                      float* ws, void* dz, int B, long long P, void* stream) {
   vu_rng none = vu_make_rng(0, 0, 0.f);
   return vu_k_ln_bwd(dtype, dy, z, w, stats, dw, db, ws, dz, nullptr, none, B, P, (hipStream_t)stream);
+}
+
+int vu_ff_forward(int dtype, const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* hpre,
+                  void* hact, void* y, long long rows, int D, int hid, float linear_drop, int training, uint64_t seed,
+                  uint64_t stream_id, void* stream) {
+  VU_REQUIRE(x && w1 && b1 && w2 && b2 && hpre && hact && y && rows > 0 && D > 0 && hid > 0, "vu_ff_forward: bad argument");
+  VU_REQUIRE(linear_drop >= 0.f && linear_drop < 1.f, "dropout must be in [0,1)");
+  FFDims f{dtype, rows, D, hid};
+  return ff_forward(f, x, w1, b1, w2, b2, hpre, hact, y, nullptr, linear_drop, training, seed, stream_id, nullptr, (hipStream_t)stream);
+}
+int vu_ff_backward(int dtype, const void* x, const void* w1, const void* w2, const void* hpre, const void* hact, const void* dy,
+                   void* dx, float* dw1, float* db1, float* dw2, float* db2, void* scratch, long long rows, int D, int hid,
+                   float linear_drop, int training, uint64_t seed, uint64_t stream_id, void* stream) {
+  VU_REQUIRE(x && w1 && w2 && hpre && hact && dy && dx && dw1 && db1 && dw2 && db2 && scratch, "vu_ff_backward: null argument");
+  FFDims f{dtype, rows, D, hid};
+  const size_t es = esize(dtype);
+  char* sc = (char*)scratch;
+  void* gh = sc;                                             // (rows, hid)
+  void* dym = sc + vu_align_up((size_t)rows * hid * es, 256);  // (rows, D): dy under the output dropout mask
+  const void* dyu = dy;
+  vu_rng rf = vu_make_rng(seed, VU_FF_STREAM(stream_id, 1), training ? linear_drop : 0.f);
+  if (rf.thr != 0) { VU_TRY(vu_k_dropout(dtype, dy, dym, rows * D, rf, (hipStream_t)stream)); dyu = dym; }
+  return ff_backward(f, x, w1, w2, hpre, hact, dyu, nullptr, dx, dw1, db1, dw2, db2, gh, linear_drop, training, seed, stream_id,
+                     nullptr, (hipStream_t)stream);
+}
+size_t vu_ff_scratch_bytes(int dtype, long long rows, int D, int hid) {
+  return vu_align_up((size_t)rows * hid * esize(dtype), 256) + vu_align_up((size_t)rows * D * esize(dtype), 256);
 }
 
 int vu_gemm(int dtype, int c_float, const void* A, const void* Bm, void* C, int M, int N, int K, long long sAm,

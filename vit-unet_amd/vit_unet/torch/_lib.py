@@ -73,6 +73,10 @@ SIGNATURES = {
     "vu_layernorm_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _ll, _vp]),
     "vu_gemm": (_i, [_i, _i, _vp, _vp, _vp, _i, _i, _i, _ll, _ll, _ll, _ll, _ll, _i, _i,
                      _ll, _ll, _ll, _ll, _ll, _ll, _f, _vp, _i, _vp]),
+    "vu_ff_scratch_bytes": (_sz, [_i, _ll, _i, _i]),
+    "vu_ff_forward": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _f, _i, _u64, _u64, _vp]),
+    "vu_ff_backward": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _f, _i, _u64, _u64,
+                            _vp]),
     "vu_mse_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _f, _vp]),
     "vu_adamw": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _vp, _vp, _f, _vp]),
     "vu_cast_bf16": (_i, [_vp, _vp, _ll, _vp]),
@@ -123,6 +127,10 @@ def ptr(t: Optional[torch.Tensor]):
         raise VuError("the ViT-UNet HIP path needs GPU tensors (got a CPU tensor); there is no CPU fallback")
     if not t.is_contiguous():
         raise VuError("non-contiguous tensor passed to the HIP path")
+    if t.device.index != torch.cuda.current_device():
+        # launches and events target the CURRENT HIP device: a tensor on another card would get a foreign stream
+        raise VuError(f"tensor on {t.device} but the current device is cuda:{torch.cuda.current_device()}: "
+                      "wrap the call in `with torch.cuda.device(tensor.device):` (or torch.cuda.set_device)")
     return C.c_void_p(t.data_ptr())
 
 

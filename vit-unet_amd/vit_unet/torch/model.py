@@ -251,17 +251,20 @@ class PatchEncoder(nn.Module):
 
 
 class FeedForward(nn.Module):
-    """Linear -> GELU -> Dropout -> Linear -> Dropout   (model.py:95-110); parameter container.
-    Executed inside the block / model executors (fused GELU epilogue)."""
+    """Linear -> GELU -> Dropout -> Linear -> Dropout   (model.py:95-110) on vu_ff_forward / vu_ff_backward: two MFMA
+    GEMMs with the bias + exact-erf GELU (+ dropout) and bias (+ dropout) epilogues fused; the backward multiplies by
+    GELU' in the epilogue of dh = dy W2.  Inside HViT_UNet the model executor runs the same two launches."""
 
     def __init__(self, projection_dim: int, hidden_dim: int, dropout: float):
         super().__init__()
         self.net = nn.Sequential(nn.Linear(projection_dim, hidden_dim), nn.GELU(), nn.Dropout(dropout),
                                  nn.Linear(hidden_dim, projection_dim), nn.Dropout(dropout))
 
-    def forward(self, x):
-        raise NotImplementedError("FeedForward runs fused inside ReAttentionTransformerEncoder / HViT_UNet "
-                                  "on the HIP path; call the enclosing module")
+    def forward(self, x, seed=None, stream_id=0):
+        p = float(self.net[2].p)
+        seed = _next_seed() if (seed is None and self.training and p > 0) else (seed or 0)
+        return _FeedForwardFn.apply(x, self.net[0].weight, self.net[0].bias, self.net[3].weight, self.net[3].bias,
+                                    p, self.training, seed, stream_id)
 
 
 class ReAttention(nn.Module):
@@ -317,8 +320,7 @@ class ReAttentionTransformerEncoder(nn.Module):
         seed = _next_seed() if (seed is None and self.training) else (seed or 0)
         a = _AttnFn.apply(x, x, self.ReAttn, self.training, seed, stream_id, False, *self.ReAttn._params())
         x1 = _AddLayerNormFn.apply(a, x, self.LN1.weight, self.LN1.bias)
-        f = _FeedForwardFn.apply(x1, self.FeedForward.net[0].weight, self.FeedForward.net[0].bias,
-                                 self.FeedForward.net[3].weight, self.FeedForward.net[3].bias)
+        f = self.FeedForward(x1, seed=seed, stream_id=stream_id)
         return _AddLayerNormFn.apply(f, x1, self.LN2.weight, self.LN2.bias)
 
 
@@ -354,45 +356,41 @@ class SkipConnection(nn.Module):
 
 
 class _FeedForwardFn(torch.autograd.Function):
-    """FeedForward for the stand-alone block path, on vu_gemm (GELU applied by torch on the tiny
-    hidden tensor).  The model executor uses the fused-epilogue C path instead."""
+    """FeedForward through vu_ff_forward / vu_ff_backward (no torch arithmetic)."""
 
     @staticmethod
-    def _gemm(dt, A, Bm, M, N, K, sAm, sAk, sBk, sBn, bias=None):
-        out = torch.empty(M, N, dtype=dt, device=A.device)
-        check(lib().vu_gemm(_lib.DTYPE_CODE[dt], 0, ptr(A), ptr(Bm), ptr(out), M, N, K, sAm, sAk, sBk, sBn, N, 1, 1,
-                            0, 0, 0, 0, 0, 0, 1.0, ptr(bias), 0, stream_ptr(A.device)), "vu_gemm")
-        return out
-
-    @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2):
+    def forward(ctx, x, w1, b1, w2, b2, p, training, seed, stream_id):
         dt = x.dtype
+        code = _lib.DTYPE_CODE[dt]
         B, N, D = x.shape
         hid = w1.shape[0]
-        xc = x.contiguous().view(B * N, D)
+        xc = x.contiguous()
         w1c, w2c = w1.detach().to(dt).contiguous(), w2.detach().to(dt).contiguous()
-        hpre = _FeedForwardFn._gemm(dt, xc, w1c, B * N, hid, D, D, 1, 1, D, b1.detach().float().contiguous())
-        hact = torch.nn.functional.gelu(hpre.float()).to(dt)
-        y = _FeedForwardFn._gemm(dt, hact, w2c, B * N, D, hid, hid, 1, 1, hid, b2.detach().float().contiguous())
-        ctx.saved = (xc, w1c, w2c, hpre, hact, (B, N, D, hid))
-        return y.view(B, N, D)
+        b1c, b2c = b1.detach().float().contiguous(), b2.detach().float().contiguous()
+        hpre = torch.empty(B * N, hid, dtype=dt, device=x.device)
+        hact = torch.empty_like(hpre)
+        y = torch.empty_like(xc)
+        check(lib().vu_ff_forward(code, ptr(xc), ptr(w1c), ptr(b1c), ptr(w2c), ptr(b2c), ptr(hpre), ptr(hact), ptr(y),
+                                  B * N, D, hid, p, 1 if training else 0, seed, stream_id, stream_ptr(x.device)),
+              "vu_ff_forward")
+        ctx.saved = (xc, w1c, w2c, hpre, hact, (B, N, D, hid), p, training, seed, stream_id)
+        return y
 
     @staticmethod
     def backward(ctx, dy):
-        xc, w1c, w2c, hpre, hact, (B, N, D, hid) = ctx.saved
+        xc, w1c, w2c, hpre, hact, (B, N, D, hid), p, training, seed, stream_id = ctx.saved
         dt = xc.dtype
-        g = dy.contiguous().view(B * N, D)
-        R = B * N
-        dw2 = _FeedForwardFn._gemm(dt, g, hact, D, hid, R, 1, D, hid, 1).float()
-        db2 = g.float().sum(0)
-        dh = _FeedForwardFn._gemm(dt, g, w2c, R, hid, D, D, 1, hid, 1)
-        hp = hpre.float()
-        dh = (dh.float() * (0.5 * (1 + torch.erf(hp / math.sqrt(2))) +
-                            hp * torch.exp(-0.5 * hp * hp) / math.sqrt(2 * math.pi))).to(dt)
-        dw1 = _FeedForwardFn._gemm(dt, dh, xc, hid, D, R, 1, hid, D, 1).float()
-        db1 = dh.float().sum(0)
-        dx = _FeedForwardFn._gemm(dt, dh, w1c, R, D, hid, hid, 1, D, 1)
-        return dx.view(B, N, D), dw1, db1, dw2, db2
+        code = _lib.DTYPE_CODE[dt]
+        L = lib()
+        dev = xc.device
+        dx = torch.empty_like(xc)
+        dw1, db1 = torch.zeros(hid, D, device=dev), torch.zeros(hid, device=dev)
+        dw2, db2 = torch.zeros(D, hid, device=dev), torch.zeros(D, device=dev)
+        scratch = torch.empty(L.vu_ff_scratch_bytes(code, B * N, D, hid), dtype=torch.uint8, device=dev)
+        check(L.vu_ff_backward(code, ptr(xc), ptr(w1c), ptr(w2c), ptr(hpre), ptr(hact), ptr(dy.contiguous().to(dt)),
+                               ptr(dx), ptr(dw1), ptr(db1), ptr(dw2), ptr(db2), ptr(scratch), B * N, D, hid, p,
+                               1 if training else 0, seed, stream_id, stream_ptr(dev)), "vu_ff_backward")
+        return dx, dw1, db1, dw2, db2, None, None, None, None
 
 
 # ---------------------------------------------------------------------------------------------
