@@ -6,6 +6,7 @@ Tolerances (scaled max error = max|got-ref| / max|ref|):
 Re-tiling is a permutation: bit-exact.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -174,7 +175,8 @@ GRAD_KEYS = ["reatten_matrix.weight", "reatten_matrix.bias", "var_norm.weight", 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("N,Cn,s,H", [(49, 3, 8, 4), (16, 3, 4, 4), (196, 1, 8, 2), (64, 3, 8, 8),
                                       (64, 3, 16, 4), (16, 3, 32, 4),    # wide patches with cross inputs (MFMA weight gradients, edge pixels)
-                                      (784, 3, 8, 8), (196, 3, 16, 8), (49, 3, 32, 8), (400, 1, 8, 4), (1156, 3, 4, 4), (1024, 1, 8, 8), (1024, 1, 16, 8),
+                                      (784, 3, 8, 8), (196, 3, 16, 8), (49, 3, 32, 8), (400, 1, 8, 4),
+                                      (196, 3, 16, 4), (784, 3, 8, 4),   # Lite levels 0 and 1 (4 heads, d = 192 / 48) (1156, 3, 4, 4), (1024, 1, 8, 8), (1024, 1, 16, 8),
                                       (225, 3, 8, 8), (289, 3, 8, 8),    # ragged rows (N % 4 != 0) through the MFMA map kernels
                                       (3136, 3, 4, 4),                   # Lite level 2: long rows (chunked map products, long-row scores)
                                       (1089, 1, 8, 8), (1225, 3, 4, 2), (1090, 1, 8, 8), (1156, 1, 8, 8), (2116, 1, 8, 8)])   # rows > 1024: chunked MFMA map backward (bf16, 8 heads) / two-sweep VALU kernel (fp32, other head counts); ragged and exact N
@@ -193,8 +195,21 @@ def test_attention_centred_map_form(N, Cn, s, H, mode, monkeypatch):
     _attention_fwd_bwd(torch.bfloat16, N, Cn, s, H, mode, False, centered=True)
 
 
-def _attention_fwd_bwd(dt, N, Cn, s, H, mode, cross, centered):
-    if dt == torch.bfloat16 and mode == "eval":
+@pytest.mark.parametrize("N,Cn,s,H", [(784, 3, 8, 8), (1024, 1, 8, 8), (1024, 1, 16, 8), (256, 2, 8, 4), (272, 3, 8, 8)])
+@pytest.mark.parametrize("mode", ["eval", "train", "train_drop"])
+@pytest.mark.parametrize("cross", [False, True])
+def test_attention_flash_form(N, Cn, s, H, mode, cross, monkeypatch):
+    """The non-materialising form (csrc/vu_flash.hip: no (B,h,N,N) map in HBM, everything recomputed per pass from
+    q, k, v) against the same oracle and tolerances as the materialised forms; VU_ATTN_FLASH switches the stand-alone op.
+    Shapes: Base / Large level 2 (N = 784, d = 24), the 512x512 levels (d = 8, d = 32), 4 heads, an odd tile count."""
+    monkeypatch.setenv("VU_ATTN_FLASH", "1")
+    if cross and N != 784:
+        pytest.skip("cross inputs: one shape")
+    _attention_fwd_bwd(torch.bfloat16, N, Cn, s, H, mode, cross, centered=True, flash=True)
+
+
+def _attention_fwd_bwd(dt, N, Cn, s, H, mode, cross, centered, flash=False):
+    if dt == torch.bfloat16 and mode == "eval" and not flash:
         pytest.skip("eval with tiny running_var amplifies bf16 rounding by 100x; covered in fp32")
     if N * Cn * s * s > 50000 and (mode == "eval" or cross):
         pytest.skip("full-size levels: train / train_drop self-attention only (CPU oracle time)")
@@ -236,12 +251,16 @@ def _attention_fwd_bwd(dt, N, Cn, s, H, mode, cross, centered):
     ft, bt = TOL[dt]
     if dt == torch.float32:
         ft, bt = 1e-4, 1e-3      # softmax/BN chains: fp32 noise amplified by 1/sqrt(var) ~ 100
+    if flash and os.environ.get("VU_FLASH_FWD_ONLY"):
+        print(f"flash fwd N={N} H={H} d={D // H} {mode}: scaled err {serr(y, yr):.3e}")
     if not centered:
         assert serr(amap, mapr) < ft, "attention map"
     assert serr(y, yr) < ft, "attention output"
     if training:    # running statistics updated in place (momentum 0.1, unbiased variance)
         assert serr(d["var_norm.running_mean"], pr["var_norm.running_mean"]) < 1e-4
         assert serr(d["var_norm.running_var"], pr["var_norm.running_var"]) < 1e-3
+    if flash and os.environ.get("VU_FLASH_FWD_ONLY"):
+        return
     grads = [torch.zeros_like(d[k]) for k in GRAD_KEYS]
     gs = _lib.vu_attn_grads(*[g.data_ptr() for g in grads])
     dxq = torch.empty_like(xqd)

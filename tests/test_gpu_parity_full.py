@@ -1,0 +1,437 @@
+"""Parity of what bench.py measures: FULL-SIZE train steps (Lite / Base / Large), fp32 and bf16 storage.
+
+What is asserted, and why in this form.  The reference's full-depth train-mode model is ill-conditioned in float32:
+driven UNMODIFIED in float32 and in float64 on the same weights it disagrees with itself (tests/golden/manifest.json,
+`full_train.*.ref32`): Lite 7e-6 in the output (well conditioned), Base 2e-2 / gradient cosine 0.89, Large 1.2 /
+cosine -0.53 (chaotic: twenty BatchNorms over attention maps).  So
+
+  * the reference driven in FLOAT64 is the truth (full_train.npz); the CPU oracle reproduces it to 1e-7 in float64
+    (tests/test_oracle_golden.py), which pins the algorithm at full size;
+  * Lite is held to tight float32 tolerances on the loss, the output and ALL gradients (with and without dropout);
+  * Base is held to a multiple of the reference's own float32 deviation, gradient by gradient against the float64
+    oracle, and tightly on the well-conditioned last layers;
+  * every transformer block and every skip module of Lite / Base / Large is checked at FULL dimensions, teacher-forced:
+    it is fed the oracle's input for that block and compared - output, input gradient, every parameter gradient - with
+    the oracle following the same bf16 rounding points (3e-2 forward / 5e-2 backward, scaled max error).  One block
+    is well conditioned, so this is where a kernel error would show; the blocks run through the MODEL EXECUTOR
+    (vu_model_forward / vu_model_backward of a one-block model of that level's shape), i.e. the benchmarked code path;
+  * the bf16 and fp32 train steps are run side by side for 50 optimizer steps on one batch: the loss curves must agree.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import vit_unet_oracle as O
+from vit_unet.torch import model as M
+from vit_unet.torch.engine import TrainStep
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def serr(got, ref):
+    got = torch.as_tensor(np.asarray(got.detach().cpu() if torch.is_tensor(got) else got)).double()
+    ref = torch.as_tensor(np.asarray(ref.detach().cpu() if torch.is_tensor(ref) else ref)).double()
+    return ((got - ref).abs().max() / (ref.abs().max() + 1e-30)).item()
+
+
+def cosine(a, b):
+    a, b = a.detach().double().cpu().reshape(-1), b.detach().double().cpu().reshape(-1)
+    return (a @ b / (a.norm() * b.norm() + 1e-300)).item()
+
+
+def load_full_train(golden_dir):
+    with open(os.path.join(golden_dir, "manifest.json")) as f:
+        man = json.load(f)
+    return man["full_train"], dict(np.load(os.path.join(golden_dir, "full_train.npz")))
+
+
+def build(kw, weights, dtype=torch.float32):
+    m = M.HViT_UNet(dtype=dtype, **kw)
+    r = m.load_state_dict({k: v.clone().float() for k, v in weights.items()}, strict=True)
+    assert not r.missing_keys and not r.unexpected_keys
+    return m.to(DEV)
+
+
+# ------------------------------------------------------------------------------------------------
+# (a) fp32 HIP train step against the reference's float64 run (golden) + the float64 oracle for ALL gradients
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["lite", "base", "large"])
+def test_full_config_train_fp32_vs_reference(golden_dir, name):
+    meta, g = load_full_train(golden_dir)
+    meta = meta[name]
+    r32 = meta["ref32"]
+    kw = dict(O.PRESETS[name], attn_drop=0.0, proj_drop=0.0)
+    cfg = O.Config(**kw)
+    w = O.make_weights(cfg, seed=meta["weights_seed"])
+    x, y = O.make_batch(cfg, B=meta["B"], seed=meta["batch_seed"])
+    m = build(kw, w).train()
+    out = m(x.to(DEV))
+    loss = torch.nn.MSELoss()(out, y.to(DEV))
+    loss.backward()
+    assert torch.isfinite(out).all()
+    sd = dict(m.named_parameters())
+    got_out = out.detach().reshape(-1)[torch.from_numpy(g[f"{name}.out_idx"]).to(DEV)].double().cpu().numpy()
+    out_err = np.abs(got_out - g[f"{name}.out_sample"]).max() / float(g[f"{name}.out_absmax"])
+    loss_rel = abs(loss.item() - meta["loss"]) / abs(meta["loss"])
+    names = [k for k, _ in O.param_shapes(cfg)]
+
+    def sampled_err(pname):
+        got = sd[pname].grad.reshape(-1)[torch.from_numpy(g[f"{name}.grad_idx.{pname}"]).to(DEV)].double().cpu().numpy()
+        return np.abs(got - g[f"{name}.grad.{pname}"]).max() / (float(g[f"{name}.gradmax.{pname}"]) + 1e-30)
+    sampled = [k[len(f"{name}.grad."):] for k in g if k.startswith(f"{name}.grad.")]
+    print(f"full train fp32 {name}: loss_rel {loss_rel:.3e} (ref32 {r32['loss_rel']:.3e}) out_err {out_err:.3e} (ref32 {r32['out_err']:.3e})")
+    if name == "lite":                      # well conditioned: tight float32 statement on everything in the fixture
+        assert loss_rel < 1e-4 and out_err < 5e-4, (loss_rel, out_err)
+        for p in sampled:
+            if not p.endswith("reatten_matrix.bias"):
+                assert sampled_err(p) < 5e-3, p
+        gabs = np.array([float(sd[k].grad.double().abs().sum()) for k in names])
+        sel = np.array([not k.endswith("reatten_matrix.bias") for k in names])
+        np.testing.assert_allclose(gabs[sel], g[f"{name}.gradabs"][sel], rtol=2e-2, atol=5e-5 * g[f"{name}.gradabs"].max())
+        for k in g:
+            if k.startswith(f"{name}.buf."):
+                np.testing.assert_allclose(dict(m.named_buffers())[k[len(f"{name}.buf."):]].cpu().numpy(), g[k], rtol=2e-3)
+        return
+    if name == "large":                     # chaotic in the reference itself (ref32: output error 1.2, loss 18 % off, gradient
+        assert r32["out_err"] > 0.1         # cosine -0.53): nothing but finiteness can be asserted on the whole model; the
+        assert np.isfinite(loss.item())     # per-block statement for Large is the teacher-forced test below
+        for k, p in sd.items():
+            assert torch.isfinite(p.grad).all(), k
+        return
+    # base: a multiple of the reference's own float32 deviation
+    assert loss_rel < 5e-2, (loss_rel, r32["loss_rel"])
+    assert out_err < 8 * r32["out_err"], (out_err, r32["out_err"])
+    # all gradients against the float64 oracle
+    w64 = O.make_weights(cfg, seed=meta["weights_seed"], dtype=torch.float64)
+    for k in names:
+        w64[k].requires_grad_(True)
+    o64 = O.forward(w64, cfg, x.double(), training=True)
+    O.mse_loss(o64, y.double()).backward()
+    assert abs(float(O.mse_loss(o64, y.double())) - meta["loss"]) < 1e-8 * meta["loss"]
+    ga = torch.cat([sd[k].grad.double().cpu().reshape(-1) for k in names if not k.endswith("reatten_matrix.bias")])
+    gb = torch.cat([w64[k].grad.reshape(-1) for k in names if not k.endswith("reatten_matrix.bias")])
+    call = cosine(ga, gb)
+    cmin = min(cosine(sd[k].grad, w64[k].grad) for k in names if not k.endswith("reatten_matrix.bias"))
+    print(f"full train fp32 base: gradient cosine vs float64 oracle: all {call:.4f} (ref32 {r32['grad_cos_all']:.4f}), worst tensor {cmin:.4f}")
+    assert call > r32["grad_cos_all"] - 0.3, (call, r32["grad_cos_all"])
+    assert cmin > 0.3, cmin                 # every tensor points the right way (reference float32: 0.84 .. 1.0)
+    for k in ("conv2d.weight", "conv2d.bias", "SkipConnections.1.proj.weight", "SkipConnections.1.proj.bias"):
+        assert cosine(sd[k].grad, w64[k].grad) > 0.995, k      # well-conditioned last layers (reference float32: 0.9998+)
+
+
+# ------------------------------------------------------------------------------------------------
+# (b) full-size fp32 train step WITH dropout (hash replayed by the oracle), all gradients
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["lite", "base"])
+def test_full_config_train_dropout_fp32_vs_oracle(name):
+    B = 1 if name == "lite" else 2
+    kw = dict(O.PRESETS[name])                       # attn_drop = proj_drop = 0.2 as the presets have it
+    cfg = O.Config(**kw)
+    dt = torch.float32 if name == "lite" else torch.float64
+    w = O.make_weights(cfg, seed=0)
+    x, y = O.make_batch(cfg, B=B, seed=1234)
+    m = build(kw, w).train()
+    m._step_seed = 2024
+    out = m(x.to(DEV))
+    loss = torch.nn.MSELoss()(out, y.to(DEV))
+    loss.backward()
+    wr = O.make_weights(cfg, seed=0, dtype=dt)
+    names = [k for k, _ in O.param_shapes(cfg)]
+    for k in names:
+        wr[k].requires_grad_(True)
+    ref = O.forward(wr, cfg, x.to(dt), training=True, seed=2024)
+    lr = O.mse_loss(ref, y.to(dt))
+    lr.backward()
+    sd = dict(m.named_parameters())
+    print(f"full train dropout {name}: out err {serr(out, ref):.3e} loss rel {abs(loss.item() - lr.item()) / abs(lr.item()):.3e}")
+    if name == "lite":
+        assert serr(out, ref) < 5e-4 and abs(loss.item() - lr.item()) < 1e-4 * abs(lr.item())
+        for k in names:
+            if not k.endswith("reatten_matrix.bias"):
+                assert serr(sd[k].grad, wr[k].grad) < 1e-2, k
+        return
+    # base (float64 oracle): the float32 deviation bounds of the dropout-free fixture apply (same conditioning)
+    assert serr(out, ref) < 0.15 and abs(loss.item() - lr.item()) < 5e-3 * abs(lr.item())
+    ga = torch.cat([sd[k].grad.double().cpu().reshape(-1) for k in names if not k.endswith("reatten_matrix.bias")])
+    gb = torch.cat([wr[k].grad.reshape(-1) for k in names if not k.endswith("reatten_matrix.bias")])
+    print(f"full train dropout base: gradient cosine vs float64 oracle {cosine(ga, gb):.4f}")
+    assert cosine(ga, gb) > 0.3, cosine(ga, gb)
+    for k in ("conv2d.weight", "conv2d.bias", "SkipConnections.1.proj.weight"):
+        assert cosine(sd[k].grad, wr[k].grad) > 0.995, k
+
+
+# ------------------------------------------------------------------------------------------------
+# (c) teacher-forced blocks at full dimensions, bf16 storage, through the model executor
+# ------------------------------------------------------------------------------------------------
+BLOCK_KEYS = ["ReAttn.reatten_matrix.weight", "ReAttn.reatten_matrix.bias", "ReAttn.var_norm.weight", "ReAttn.var_norm.bias",
+              "ReAttn.qconv2d.weight", "ReAttn.kconv2d.weight", "ReAttn.vconv2d.weight", "ReAttn.proj.weight", "ReAttn.proj.bias",
+              "LN1.weight", "LN1.bias", "LN2.weight", "LN2.bias", "FeedForward.net.0.weight", "FeedForward.net.0.bias",
+              "FeedForward.net.3.weight", "FeedForward.net.3.bias"]
+BN_BUFS = ["ReAttn.var_norm.running_mean", "ReAttn.var_norm.running_var"]
+
+
+def _taps(cfg, B, seed):
+    w = O.make_weights(cfg, seed=0)
+    x, _ = O.make_batch(cfg, B=B, seed=1234)
+    taps = {}
+    with torch.no_grad():
+        O.forward({k: v.clone() for k, v in w.items()}, cfg, x, training=True, seed=seed, taps=taps)
+    return w, taps
+
+
+def _one_block_model(cfg, lvl, dtype):
+    N, D, hid, s = cfg.level(lvl)
+    return M.HViT_UNet(depth=0, depth_te=1, size_bottleneck=1, preprocessing="none", im_size=cfg.im_size, patch_size=s,
+                       num_channels=cfg.num_channels, hidden_dim=hid, num_heads=cfg.num_heads, attn_drop=cfg.attn_drop,
+                       proj_drop=cfg.proj_drop, linear_drop=0.0, dtype=dtype).to(DEV).train()
+
+
+@pytest.mark.parametrize("name", ["base", "large", "lite"])
+def test_teacher_forced_blocks_bf16_full_size(name):
+    B = 1 if name == "lite" else 2
+    cfg = O.Config(**O.PRESETS[name])                # dropout 0.2 / 0.2 as benchmarked
+    seed = 777
+    w, taps = _taps(cfg, B, seed)
+    C_ = cfg.num_channels
+    models = {}
+    gen = torch.Generator().manual_seed(5)
+    worst = {"fwd": 0.0, "bwd": 0.0}
+    for pre, xin, lvl, _stream in taps["blocks"]:
+        N, D, hid, s = cfg.level(lvl)
+        if lvl not in models:
+            models[lvl] = _one_block_model(cfg, lvl, torch.bfloat16)
+        m = models[lvl]
+        sdict = {"PE.position_embedding.weight": torch.zeros(N, D)}
+        for k in BLOCK_KEYS + BN_BUFS:
+            sdict["BottleNeck.0." + k] = w[pre + k].clone()
+        sdict["BottleNeck.0.ReAttn.var_norm.num_batches_tracked"] = torch.zeros((), dtype=torch.int64)
+        r = m.load_state_dict(sdict, strict=True)
+        assert not r.missing_keys and not r.unexpected_keys
+        m.zero_grad(set_to_none=False)
+        m._shadow_clean = False
+        m._step_seed = seed
+        G = torch.randn(B, N, D, generator=gen).to(torch.bfloat16).float()
+        X = O.unpatchify(xin, C_).to(DEV).requires_grad_(True)
+        out = m(X)
+        out.backward(O.unpatchify(G, C_).to(DEV))
+        torch.cuda.synchronize()
+        # oracle: same input (as stored: bf16), same rounding points, the executor's dropout stream 0
+        wr = {pre + k: w[pre + k].clone().requires_grad_(True) for k in BLOCK_KEYS}
+        for k in BN_BUFS:
+            wr[pre + k] = w[pre + k].clone()
+        xr = xin.to(torch.bfloat16).float().requires_grad_(True)
+        ref = O.te_block(xr, wr, pre, cfg, training=True, seed=seed, stream=0, storage=torch.bfloat16)
+        (ref * G).sum().backward()
+        ef = serr(O.patchify(out.detach().cpu(), s), ref)
+        assert ef < 3e-2, (pre, "out", ef)
+        eb = serr(O.patchify(X.grad.cpu(), s), xr.grad)
+        assert eb < 5e-2, (pre, "dx", eb)
+        sd = dict(m.named_parameters())
+        for k in BLOCK_KEYS:
+            if k.endswith("reatten_matrix.bias"):
+                continue                                    # analytically zero in train mode (rounding noise only)
+            e = serr(sd["BottleNeck.0." + k].grad, wr[pre + k].grad)
+            assert e < 5e-2, (pre, k, e)
+            eb = max(eb, e)
+        # reatten_matrix.bias: |g| stays at the rounding-noise level of the mixing-matrix gradient
+        gb = sd["BottleNeck.0.ReAttn.reatten_matrix.bias"].grad.abs().max().item()
+        gw = sd["BottleNeck.0.ReAttn.reatten_matrix.weight"].grad.abs().max().item()
+        assert gb < 2.0 * gw + 1e-6, (pre, gb, gw)
+        bufs = dict(m.named_buffers())
+        assert serr(bufs["BottleNeck.0.ReAttn.var_norm.running_var"], wr[pre + "ReAttn.var_norm.running_var"]) < 2e-2, pre
+        worst["fwd"], worst["bwd"] = max(worst["fwd"], ef), max(worst["bwd"], eb)
+    print(f"teacher-forced {name}: {len(taps['blocks'])} blocks, worst scaled error fwd {worst['fwd']:.3e} bwd {worst['bwd']:.3e}")
+
+
+ATTN_KEYS = ["reatten_matrix.weight", "reatten_matrix.bias", "var_norm.weight", "var_norm.bias", "qconv2d.weight",
+             "kconv2d.weight", "vconv2d.weight", "proj.weight", "proj.bias"]
+
+
+@pytest.mark.parametrize("name", ["base", "lite"])
+def test_teacher_forced_skips_bf16_full_size(name):
+    """The two SkipConnection modules at full dimensions (cross re-attention, q from the encoder), stand-alone module
+    on bf16 tensors against the oracle with the same rounding points."""
+    B = 1 if name == "lite" else 2
+    cfg = O.Config(**O.PRESETS[name])
+    seed = 778
+    w, taps = _taps(cfg, B, seed)
+    gen = torch.Generator().manual_seed(6)
+    for pre, enc, dec, lvl, _stream in taps["skips"]:
+        N, D, _, _ = cfg.level(lvl)
+        skp = M.SkipConnection(dim=D, num_channels=cfg.num_channels, num_heads=cfg.num_heads, attn_drop=cfg.attn_drop,
+                               proj_drop=cfg.proj_drop)
+        sd = {k: w[pre + k].clone() for k in ATTN_KEYS}
+        sd.update({"var_norm.running_mean": w[pre + "var_norm.running_mean"].clone(),
+                   "var_norm.running_var": w[pre + "var_norm.running_var"].clone(),
+                   "var_norm.num_batches_tracked": torch.zeros((), dtype=torch.int64)})
+        skp.load_state_dict(sd)
+        skp.to(DEV).train()
+        G = torch.randn(B, N, D, generator=gen).to(torch.bfloat16)
+        e16 = enc.to(torch.bfloat16).to(DEV).requires_grad_(True)
+        d16 = dec.to(torch.bfloat16).to(DEV).requires_grad_(True)
+        out = skp(e16, d16, d16, seed=seed, stream_id=3)
+        out.backward(G.to(DEV))
+        wr = {pre + k: w[pre + k].clone().requires_grad_(True) for k in ATTN_KEYS}
+        wr[pre + "var_norm.running_mean"] = w[pre + "var_norm.running_mean"].clone()
+        wr[pre + "var_norm.running_var"] = w[pre + "var_norm.running_var"].clone()
+        er = enc.to(torch.bfloat16).float().requires_grad_(True)
+        dr = dec.to(torch.bfloat16).float().requires_grad_(True)
+        ref = O.skip_block(er, dr, wr, pre, cfg, training=True, seed=seed, stream=3, storage=torch.bfloat16)
+        (ref * G.float()).sum().backward()
+        assert serr(out.float(), ref) < 3e-2, pre
+        assert serr(e16.grad.float(), er.grad) < 5e-2 and serr(d16.grad.float(), dr.grad) < 5e-2, pre
+        ps = dict(skp.named_parameters())
+        for k in ATTN_KEYS:
+            if not k.endswith("reatten_matrix.bias"):
+                assert serr(ps[k].grad, wr[pre + k].grad) < 5e-2, (pre, k)
+
+
+# ------------------------------------------------------------------------------------------------
+# (d) bf16 against fp32 over an optimisation trajectory (Base, 8 images, 50 fused steps on one batch)
+# ------------------------------------------------------------------------------------------------
+def test_bf16_vs_fp32_loss_trajectory_base():
+    torch.manual_seed(0)
+    m32 = M.get_vit_unet("base", dtype=torch.float32)
+    m16 = M.get_vit_unet("base", dtype=torch.bfloat16)
+    m16.load_state_dict(m32.state_dict())
+    m32, m16 = m32.to(DEV).train(), m16.to(DEV).train()
+    cfg = O.Config(**O.PRESETS["base"])
+    x, y = O.make_batch(cfg, B=8, seed=99)
+    x, y = x.to(DEV), y.to(DEV)
+    t32, t16 = TrainStep(m32, lr=1e-3, seed=11), TrainStep(m16, lr=1e-3, seed=11)
+    l32, l16 = [], []
+    for _ in range(50):
+        l32.append(t32.step(x, y).item())
+        l16.append(t16.step(x, y).item())
+    l32, l16 = np.array(l32), np.array(l16)
+    rel = np.abs(l16 - l32) / l32
+    print("trajectory fp32", np.round(l32, 3).tolist(), "\nbf16", np.round(l16, 3).tolist(), "\nmax rel diff", rel.max())
+    assert np.isfinite(l16).all() and np.isfinite(l32).all()
+    assert rel[0] < 0.1, rel[0]                        # the first step sees identical weights (full depth: chaotic forward)
+    assert l32[-1] < 0.35 * l32[0] and l16[-1] < 0.35 * l16[0]   # both train
+    w32, w16 = l32.reshape(5, 10).mean(axis=1), l16.reshape(5, 10).mean(axis=1)
+    assert np.abs(np.log(w16 / w32)).max() < 0.3, (w32, w16)     # and along the same curve, window by window
+
+
+# ------------------------------------------------------------------------------------------------
+# (e) surface that round 1 left untested: FeedForward alone, preprocessing='none', the ViT_UNet(...) alias
+# ------------------------------------------------------------------------------------------------
+def test_feedforward_module_vs_golden(golden_dir):
+    g = dict(np.load(os.path.join(golden_dir, "ops.npz")))
+    for tag, (N, C_, s, h, hid) in {"n49": (49, 3, 8, 4, 16), "d12": (16, 3, 4, 4, 8)}.items():
+        D = C_ * s * s
+        ff = M.FeedForward(D, hid, 0.0)
+        ff.load_state_dict({k[len(f"{tag}.blk.FeedForward."):]: torch.from_numpy(v.copy()) for k, v in g.items()
+                            if k.startswith(f"{tag}.blk.FeedForward.")})
+        ff.to(DEV)
+        x = torch.from_numpy(g[f"{tag}.x"]).to(DEV).requires_grad_(True)
+        out = ff(x)
+        assert serr(out, g[f"{tag}.ff.out"]) < 2e-5
+        # backward against torch autograd on the same weights (CPU)
+        ffc = torch.nn.Sequential(torch.nn.Linear(D, hid), torch.nn.GELU(), torch.nn.Dropout(0.0), torch.nn.Linear(hid, D),
+                                  torch.nn.Dropout(0.0))
+        ffc.load_state_dict({k: v.detach().cpu() for k, v in ff.net.state_dict().items()})
+        xc = x.detach().cpu().requires_grad_(True)
+        dy = torch.randn(out.shape, generator=torch.Generator().manual_seed(1))
+        ffc(xc).backward(dy)
+        out.backward(dy.to(DEV))
+        assert serr(x.grad, xc.grad) < 2e-4
+        for (k, p), (_, pc) in zip(ff.net.named_parameters(), ffc.named_parameters()):
+            assert serr(p.grad, pc.grad) < 2e-4, k
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_feedforward_linear_drop_vs_oracle(dt):
+    """linear_drop > 0 (model.py:102-108; 0 in every preset): both dropout sites replayed by the oracle."""
+    B, N, D, hid = 2, 49, 192, 16
+    gen = torch.Generator().manual_seed(8)
+    ff = M.FeedForward(D, hid, 0.3).to(DEV).train()
+    x = torch.randn(B, N, D, generator=gen)
+    dy = torch.randn(B, N, D, generator=gen).to(dt)
+    xd = x.to(dt).to(DEV).requires_grad_(True)
+    out = ff(xd, seed=5, stream_id=2)
+    out.backward(dy.to(DEV))
+    p = {"net.0.weight": ff.net[0].weight.detach().cpu().to(dt).float().requires_grad_(True),
+         "net.0.bias": ff.net[0].bias.detach().cpu().clone().requires_grad_(True),
+         "net.3.weight": ff.net[3].weight.detach().cpu().to(dt).float().requires_grad_(True),
+         "net.3.bias": ff.net[3].bias.detach().cpu().clone().requires_grad_(True)}
+    xr = x.to(dt).float().requires_grad_(True)
+    ref = O.feed_forward(xr, p, "", training=True, linear_drop=0.3, seed=5, stream=2, storage=dt)
+    ref.backward(dy.float())
+    ft, bt = (2e-5, 2e-4) if dt == torch.float32 else (3e-2, 5e-2)
+    assert serr(out.float(), ref) < ft
+    assert (out == 0).float().mean().item() > 0.2                      # the output dropout really dropped
+    assert serr(xd.grad.float(), xr.grad) < bt
+    for (k, q) in ff.net.named_parameters():
+        assert serr(q.grad, p["net." + k].grad) < bt, k
+
+
+def test_model_linear_drop_vs_oracle(golden_dir):
+    """A whole (tiny) model with all three dropouts on: element-for-element against the oracle's replay."""
+    with open(os.path.join(golden_dir, "manifest.json")) as f:
+        man = json.load(f)
+    g = dict(np.load(os.path.join(golden_dir, "tiny_a.npz")))
+    kw = dict(man["cases"]["tiny_a"]["config"], attn_drop=0.2, proj_drop=0.1, linear_drop=0.25)
+    cfg = O.Config(**kw)
+    w = O.make_weights(cfg, seed=7)
+    m = build(kw, w).train()
+    x, y = torch.from_numpy(g["x"]).to(DEV), torch.from_numpy(g["y"]).to(DEV)
+    m._step_seed = 99
+    out = m(x)
+    torch.nn.MSELoss()(out, y).backward()
+    wr = {k: v.clone() for k, v in w.items()}
+    for k, _ in O.param_shapes(cfg):
+        wr[k].requires_grad_(True)
+    ref = O.forward(wr, cfg, x.cpu(), training=True, seed=99)
+    O.mse_loss(ref, y.cpu()).backward()
+    assert serr(out, ref) < 2e-4
+    sd = dict(m.named_parameters())
+    for k, _ in O.param_shapes(cfg):
+        if not k.endswith("reatten_matrix.bias"):
+            assert serr(sd[k].grad, wr[k].grad) < 5e-3, k
+
+
+def test_preprocessing_none_and_readme_alias(golden_dir):
+    """preprocessing='none' (model.py:425: no output conv) and the README constructor `ViT_UNet(..., num_patches=...)`
+    (README.md:18-31) run on the GPU against the oracle."""
+    kw = dict(depth=1, depth_te=1, size_bottleneck=1, preprocessing="none", im_size=32, patch_size=8, num_channels=3,
+              hidden_dim=16, num_heads=2, attn_drop=0.0, proj_drop=0.0, linear_drop=0.0)
+    cfg = O.Config(**kw)
+    w = O.make_weights(cfg, seed=3)
+    assert "conv2d.weight" not in w
+    x, y = O.make_batch(cfg, B=2, seed=4)
+    for training in (False, True):
+        m = build(kw, w).train(training)
+        xd = x.to(DEV).requires_grad_(True)
+        out = m(xd)
+        torch.nn.MSELoss()(out, y.to(DEV)).backward()
+        wr = {k: v.clone() for k, v in w.items()}
+        for k, _ in O.param_shapes(cfg):
+            wr[k].requires_grad_(True)
+        xr = x.clone().requires_grad_(True)
+        ref = O.forward(wr, cfg, xr, training=training)
+        O.mse_loss(ref, y).backward()
+        assert serr(out, ref) < 2e-4
+        assert serr(xd.grad, xr.grad) < 5e-3
+        sd = dict(m.named_parameters())
+        for k, _ in O.param_shapes(cfg):
+            if not (training and k.endswith("reatten_matrix.bias")):
+                assert serr(sd[k].grad, wr[k].grad) < 5e-3, k
+    # README alias: num_patches instead of im_size; same arithmetic as HViT_UNet
+    kc = dict(kw, preprocessing="conv")
+    cfgc = O.Config(**kc)
+    wc = O.make_weights(cfgc, seed=3)
+    alias = M.ViT_UNet(depth=1, depth_te=1, size_bottleneck=1, preprocessing="conv", num_patches=16, patch_size=8,
+                       num_channels=3, hidden_dim=16, num_heads=2, attn_drop=0.0, proj_drop=0.0, linear_drop=0.0,
+                       dtype=torch.float32)
+    assert isinstance(alias, M.HViT_UNet) and alias.im_size == 32
+    alias.load_state_dict({k: v.clone() for k, v in wc.items()})
+    alias.to(DEV).eval()
+    with torch.no_grad():
+        out = alias(x.to(DEV))
+        ref = O.forward(wc, cfgc, x, training=False)
+    assert serr(out, ref) < 2e-4

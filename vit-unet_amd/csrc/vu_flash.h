@@ -1,0 +1,27 @@
+// Non-materialising re-attention (vu_flash.hip): host-side launchers.
+#pragma once
+#include "vu_common.h"
+
+struct vu_flash_args {
+  int B, N, D, H;
+  float scale;                 // d^-0.5 (model.py:131)
+  int training;                // 1: batch statistics + dropout (rng); 0: running statistics
+  vu_rng rng;                  // attention-map dropout stream (thr == 0: no dropout)
+  const void *q, *k, *v;       // (B,N,D) bf16
+  void* O;                     // (B,N,D) bf16: A^ v, heads re-concatenated (model.py:161)
+  float* lse2;                 // (B,H,N): log2-domain log-sum-exp of the scaled logits, kept for the backward
+  float* partials;             // >= vu_flash_partials_floats()
+  float* stats;                // VU_BN_STATS_FLOATS(H): folded tables (vu_kernels.h)
+  const float *mix_w, *mix_b, *bn_w, *bn_b;
+  float *run_mean, *run_var;
+  // backward only
+  const void* dO;              // (B,N,D) bf16
+  void *dq, *dk, *dv;          // (B,N,D) bf16
+  float* delta;                // (B,H,N)
+  float *d_mix_w, *d_mix_b;    // accumulated
+};
+
+bool vu_flash_ok(int dtype, int B, int N, int D, int H);
+size_t vu_flash_partials_floats(int B, int N, int H);
+int vu_k_flash_forward(const vu_flash_args& a, hipStream_t st);
+int vu_k_flash_backward(const vu_flash_args& a, hipStream_t st);

@@ -1,0 +1,971 @@
+// Non-materialising re-attention (model.py:155-161) for long rows and small head dims: bf16 storage, N % 16 == 0,
+// head dim a multiple of 8 and <= 32, 4 or 8 heads (Base / Large level 2: N = 784, d = 24; 512x512 inputs: d = 8 / 32).
+//
+// The (B,h,N,N) attention maps never exist in HBM.  BatchNorm over the head-mixed maps needs batch statistics of
+// A_g = sum_h W[g,h] P~_h + c_g BEFORE the PV product (SURVEY 7 hard part 1), so the forward is two recompute passes:
+//   stats pass   per 16-query tile: QK^T on MFMA for ALL heads, row max / row sum (two sweeps over the keys) ->
+//                lse2[b,h,i] (log2 domain); a third sweep recomputes P~ = dropout(P) and accumulates the first moments
+//                sum (P~_h - 1/N) and the h x h cross moments sum (P~_h - 1/N)(P~_h' - 1/N); var(A_g) = W_g^T Cov W_g
+//                in the fp64 finalize.  No map write.
+//   apply pass   recompute P~ from lse2, mix the heads in registers with the folded table (gamma rstd W / keep, folded
+//                bias), round A^ to bf16 as the B operand of O^T = V^T A^^T.  No map read.
+// and the backward is recompute sweeps of the same tile body (row term delta_h = sum_j P dP first, then dq; dk / dv in a
+// key-major sweep), with the BatchNorm-backward means taken from dO, O, v (vu_k_bn_bwd_small).
+//
+// Tile body (all sweeps): the SWAPPED product S^T = K Q^T with v_mfma_f32_16x16x32_bf16: accumulator row = key
+// 4 (lane >> 4) + r, column = query (lane & 15).  Since d <= 32 one MFMA is the whole k-loop of a (head, tile), so a wave
+// holds the 16 x 16 tile of ALL heads in 4 H registers and the 8 x 8 head mix is lane-local VALU work in fp32
+// (exactly the reference's arithmetic; no bf16 rounding of the probabilities at all).  Reductions over keys are
+// in-lane sums plus two shuffles; products that contract over keys (PV, dq) take the accumulators of two tiles as the
+// B operand with no lane movement, their A operands come out of the row-major K / V chunk through ds_read_b64_tr_b16.
+// Algorithmic HBM traffic: q, k, v, O (+ dO, dq, dk, dv) only: ~10 B N D per module instead of 11 E.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "vu_kernels.h"
+#include "vu_flash.h"
+
+#define VU_TRY(expr)              \
+  do {                            \
+    int _rc = (expr);             \
+    if (_rc != VU_OK) return _rc; \
+  } while (0)
+
+namespace {
+
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+template <int H, int DH> struct FC {
+  static constexpr int D = H * DH;
+  static constexpr int PITCH = D + 8;            // LDS row pitch of a (token x feature) chunk, elements: 16 B of (zeroed) pad
+  static constexpr int KS = DH / 8;              // valid 8-feature k-slots of the QK^T MFMA (k = 32 >= DH)
+  static constexpr int DT = (DH + 15) / 16;      // 16-row tiles of the head dim in the transposed products
+  static constexpr int VPR = D / 8;              // 16-byte vectors per row
+  static constexpr int NMOM = H + H * (H + 1) / 2;
+};
+
+__device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// rows [0, nrows) of a row-major (., D) bf16 matrix -> LDS chunk with pitch PITCH.  Four independent 16-byte loads in
+// flight per thread (named registers and clamped unconditional loads: an indexed array or a load-or-skip select ends up
+// in scratch memory / serialized loads with hipcc).
+template <int H, int DH>
+__device__ __forceinline__ void load_chunk(bf16_t* dst, const bf16_t* __restrict__ src, int nrows, int tid, int nthr) {
+  typedef FC<H, DH> C;
+  const int total = nrows * C::VPR;
+  auto src_of = [&](int v) { const int vv = v < total ? v : total - 1; const int r = vv / C::VPR, c = vv - r * C::VPR; return src + (long long)r * C::D + c * 8; };
+  auto put = [&](int v, const uint4& x) { if (v < total) { const int r = v / C::VPR, c = v - r * C::VPR; *reinterpret_cast<uint4*>(dst + r * C::PITCH + c * 8) = x; } };
+  for (int v0 = tid; v0 < total; v0 += 4 * nthr) {
+    const uint4 x0 = *reinterpret_cast<const uint4*>(src_of(v0));
+    const uint4 x1 = *reinterpret_cast<const uint4*>(src_of(v0 + nthr));
+    const uint4 x2 = *reinterpret_cast<const uint4*>(src_of(v0 + 2 * nthr));
+    const uint4 x3 = *reinterpret_cast<const uint4*>(src_of(v0 + 3 * nthr));
+    put(v0, x0); put(v0 + nthr, x1); put(v0 + 2 * nthr, x2); put(v0 + 3 * nthr, x3);
+  }
+}
+template <int H, int DH>
+__device__ __forceinline__ void zero_pads(bf16_t* dst, int rows, int tid, int nthr) {
+  typedef FC<H, DH> C;
+  for (int r = tid; r < rows; r += nthr) *reinterpret_cast<uint4*>(dst + r * C::PITCH + C::D) = make_uint4(0, 0, 0, 0);
+}
+
+// B operand of the logits product for one 16-token tile held in registers: lane (token l15, k-slot g4) has features
+// h DH + 8 g4 .. + 7 of its token, zero where 8 g4 >= DH (so whatever the other operand holds there is multiplied by 0).
+template <int H, int DH>
+__device__ __forceinline__ void load_stationary(bf16x8 (&f)[H], const bf16_t* __restrict__ rowp, int g4) {
+  typedef FC<H, DH> C;
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    if (g4 < C::KS) f[h] = *reinterpret_cast<const bf16x8*>(rowp + h * DH + 8 * g4);
+    else f[h] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  }
+}
+
+// S^T tile of every head: A = chunk rows (tokens 16 kc + l15 of the chunk), B = stationary fragments.
+template <int H, int DH>
+__device__ __forceinline__ void tile_logits(f32x4 (&acc)[H], const bf16_t* Kc, int kc, const bf16x8 (&qf)[H], int l15, int g4) {
+  typedef FC<H, DH> C;
+  const int gk = g4 < C::KS ? g4 : C::KS - 1;                 // slots >= KS meet zeros: re-read a valid slot (finite data)
+  const bf16_t* krow = Kc + (kc * 16 + l15) * C::PITCH + 8 * gk;
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(krow + h * DH);
+    acc[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[h], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+  }
+}
+
+// transposed A operand of v_mfma_f32_16x16x16_bf16 (rows = 16 features f0 .. f0+15 of the chunk, k = 16 tokens): k-slot
+// 4 g4 + j <- token row0 + 4 g4 + j, which is the order of ONE accumulator tile used as the B operand (register r = key
+// 4 g4 + r): the products that contract over keys take a logits-shaped tile as it stands, tile by tile.
+template <int PITCH>
+__device__ __forceinline__ s16x4 tr_operand(const bf16_t* Xc, int row0, int f0, int l15, int g4) {
+  const int qq = l15 >> 2, pp = l15 & 3;
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(Xc + (row0 + 4 * g4 + qq) * PITCH + f0 + 4 * pp));
+}
+__device__ __forceinline__ f32x4 mfma16(const s16x4& a, const s16x4& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ s16x4 pack4s(const f32x4& a) {
+  const bf16x4 t = {(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3]};
+  return __builtin_bit_cast(s16x4, t);
+}
+
+__device__ __forceinline__ bf16x4 pack4(const f32x4& a) { return bf16x4{(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3]}; }
+__device__ __forceinline__ bf16x8 join8(const bf16x4& a, const bf16x4& b) { return bf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
+
+// dropout keep bits of the 4 consecutive keys j0 .. j0+3 of one map row (vu_keep of element row * N + j: one hash word
+// serves a key pair, 16 bits each); w0 = word index of (row, j0).
+struct keep4_t { bool k0, k1, k2, k3; };
+__device__ __forceinline__ keep4_t keep4(const vu_rng& rng, uint32_t w0) {
+  keep4_t kp = {true, true, true, true};
+  if (rng.thr) {
+    const uint32_t x0 = vu_mix32(w0 ^ rng.k0) + rng.k1, x1 = vu_mix32((w0 + 1) ^ rng.k0) + rng.k1;
+    kp.k0 = (x0 & 0xffffu) >= rng.thr; kp.k1 = (x0 >> 16) >= rng.thr;
+    kp.k2 = (x1 & 0xffffu) >= rng.thr; kp.k3 = (x1 >> 16) >= rng.thr;
+  }
+  return kp;
+}
+__device__ __forceinline__ bool kept(const keep4_t& kp, int r) { return r == 0 ? kp.k0 : r == 1 ? kp.k1 : r == 2 ? kp.k2 : kp.k3; }
+
+// XCD-aware work order: the workgroups of one sample stream the same K / V from L2, so they are dealt to one XCD
+// (blocks id and id + 8 share an XCD) when the sample count is a multiple of 8.  Speed only.
+__device__ __forceinline__ void work_item(int id, int B, int per, int& b, int& g) {
+  if ((B & 7) == 0) { const int x = id & 7, r = id >> 3; b = x + 8 * (r / per); g = r % per; }
+  else { b = id / per; g = id % per; }
+}
+
+// =============================================================================================
+// stats pass
+// =============================================================================================
+template <int H, int DH, int WPB, int CK>
+__global__ __launch_bounds__(WPB * 64) void flash_stats_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                               float* __restrict__ lse2, float* __restrict__ partials, int B, int N,
+                                                               float c, vu_rng rng_in, int want_moments) {
+  typedef FC<H, DH> C;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* Kc = reinterpret_cast<bf16_t*>(smem_raw);                       // [CK*16][PITCH]
+  float* red = reinterpret_cast<float*>(Kc + CK * 16 * C::PITCH);        // [WPB][NMOM]
+  const vu_rng rng = vu_rng_resolve(rng_in);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
+  const int ntiles = N >> 4, per = (ntiles + WPB - 1) / WPB;
+  int b, grp;
+  work_item(blockIdx.x, B, per, b, grp);
+  const int t = grp * WPB + wave;
+  const bool active = t < ntiles;
+  const int tq = active ? t : ntiles - 1;
+  const int qrow = tq * 16 + l15;
+  const bf16_t* kb = k + (long long)b * N * C::D;
+  bf16x8 qf[H];
+  load_stationary<H, DH>(qf, q + ((long long)b * N + qrow) * C::D, g4);
+  zero_pads<H, DH>(Kc, CK * 16, tid, WPB * 64);
+  const int nchunks = (ntiles + CK - 1) / CK;
+
+  float mx[H], sm[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) { mx[h] = -3.0e38f; sm[h] = 0.f; }
+  // sweep 1: row maxima of the raw logits
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const int nt = min(CK, ntiles - ch * CK);
+    __syncthreads();
+    load_chunk<H, DH>(Kc, kb + (long long)ch * CK * 16 * C::D, nt * 16, tid, WPB * 64);
+    __syncthreads();
+    if (active)
+      for (int kc = 0; kc < nt; ++kc) {
+        f32x4 acc[H];
+        tile_logits<H, DH>(acc, Kc, kc, qf, l15, g4);
+#pragma unroll
+        for (int h = 0; h < H; ++h) mx[h] = fmaxf(fmaxf(mx[h], fmaxf(acc[h][0], acc[h][1])), fmaxf(acc[h][2], acc[h][3]));
+      }
+  }
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    mx[h] = fmaxf(mx[h], __shfl_xor(mx[h], 16, 64));
+    mx[h] = fmaxf(mx[h], __shfl_xor(mx[h], 32, 64));
+    mx[h] *= c;                                                   // c > 0: max and scale commute
+  }
+  // sweep 2: row sums of exp2(c s - max)
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const int nt = min(CK, ntiles - ch * CK);
+    __syncthreads();
+    load_chunk<H, DH>(Kc, kb + (long long)ch * CK * 16 * C::D, nt * 16, tid, WPB * 64);
+    __syncthreads();
+    if (active)
+      for (int kc = 0; kc < nt; ++kc) {
+        f32x4 acc[H];
+        tile_logits<H, DH>(acc, Kc, kc, qf, l15, g4);
+#pragma unroll
+        for (int h = 0; h < H; ++h)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sm[h] += fexp2(fmaf(acc[h][r], c, -mx[h]));
+      }
+  }
+  float lse[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    sm[h] += __shfl_xor(sm[h], 16, 64);
+    sm[h] += __shfl_xor(sm[h], 32, 64);
+    lse[h] = mx[h] + log2f(sm[h]);
+    if (active && g4 == 0) lse2[((long long)b * H + h) * N + qrow] = lse[h];
+  }
+  if (!want_moments) return;                                      // (uniform: eval mode needs the row statistics only)
+
+  // sweep 3: first and cross moments of the centred dropped probabilities u_h = P~_h - 1/N
+  float s1[H], s2[H * (H + 1) / 2];
+#pragma unroll
+  for (int h = 0; h < H; ++h) s1[h] = 0.f;
+#pragma unroll
+  for (int i = 0; i < H * (H + 1) / 2; ++i) s2[i] = 0.f;
+  const float cen = 1.0f / (float)N;
+  const uint32_t hstride = (uint32_t)(((unsigned long long)N * N) >> 1);
+  const uint32_t wlane = (uint32_t)(((((unsigned long long)b * H) * N + qrow) * (unsigned long long)N) >> 1) + 2u * g4;
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const int nt = min(CK, ntiles - ch * CK);
+    __syncthreads();
+    load_chunk<H, DH>(Kc, kb + (long long)ch * CK * 16 * C::D, nt * 16, tid, WPB * 64);
+    __syncthreads();
+    if (active)
+      for (int kc = 0; kc < nt; ++kc) {
+        f32x4 acc[H];
+        tile_logits<H, DH>(acc, Kc, kc, qf, l15, g4);
+        const uint32_t wt = wlane + 8u * (uint32_t)(ch * CK + kc);
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+          const keep4_t kp = keep4(rng, wt + (uint32_t)h * hstride);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float p = fexp2(fmaf(acc[h][r], c, -lse[h]));
+            acc[h][r] = kept(kp, r) ? fmaf(p, rng.inv_keep, -cen) : -cen;
+          }
+        }
+        int idx = 0;
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+          s1[h] += (acc[h][0] + acc[h][1]) + (acc[h][2] + acc[h][3]);
+#pragma unroll
+          for (int h2 = 0; h2 <= h; ++h2, ++idx)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s2[idx] = fmaf(acc[h][r], acc[h2][r], s2[idx]);
+        }
+      }
+  }
+  // wave -> workgroup -> one partial row per workgroup
+  __syncthreads();
+#pragma unroll
+  for (int h = 0; h < H; ++h) { const float v = vu_wave_sum(active ? s1[h] : 0.f); if (lane == 0) red[wave * C::NMOM + h] = v; }
+#pragma unroll
+  for (int i = 0; i < H * (H + 1) / 2; ++i) { const float v = vu_wave_sum(active ? s2[i] : 0.f); if (lane == 0) red[wave * C::NMOM + H + i] = v; }
+  __syncthreads();
+  for (int i = tid; i < C::NMOM; i += WPB * 64) {
+    float a = 0.f;
+#pragma unroll
+    for (int w = 0; w < WPB; ++w) a += red[w * C::NMOM + i];
+    partials[(long long)blockIdx.x * C::NMOM + i] = a;
+  }
+}
+
+// fp64 finalize: moments -> BatchNorm statistics of the mixed maps, running statistics, folded tables.
+// stats layout: vu_kernels.h (VU_BN_STATS_*), extended by FWk = gamma rstd W / keep and XK = rstd W / keep.
+__global__ void flash_bn_finalize_kernel(const float* __restrict__ partials, int nblocks, const float* __restrict__ W,
+                                         const float* __restrict__ cb, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                         float* run_mean, float* run_var, float* stats, int H, int N, double count, int training,
+                                         float momentum, float eps, float inv_keep) {
+  __shared__ double mom[64];
+  const int NM = H + H * (H + 1) / 2;
+  const int tid = threadIdx.x;          // 256 threads: 4 lanes per moment column when NM <= 64
+  if (training) {
+    const int col = tid >> 2, sub = tid & 3;
+    double a = 0.0;
+    if (col < NM) for (int i = sub; i < nblocks; i += 4) a += (double)partials[(long long)i * NM + col];
+    a += __shfl_xor(a, 1, 64);
+    a += __shfl_xor(a, 2, 64);
+    if (col < NM && sub == 0) mom[col] = a / count;
+  }
+  __syncthreads();
+  if (tid < H) {
+    const int g = tid;
+    double mean, var;
+    if (training) {
+      const double cen = 1.0 / (double)N;
+      double mu = (double)cb[g], vv = 0.0;
+      for (int h = 0; h < H; ++h) mu += (double)W[g * H + h] * (mom[h] + cen);
+      for (int h = 0; h < H; ++h)
+        for (int h2 = 0; h2 < H; ++h2) {
+          const int hi = h > h2 ? h : h2, lo = h > h2 ? h2 : h;
+          const double cov = mom[H + hi * (hi + 1) / 2 + lo] - mom[h] * mom[h2];
+          vv += (double)W[g * H + h] * (double)W[g * H + h2] * cov;
+        }
+      mean = mu; var = vv > 0.0 ? vv : 0.0;
+      const double unb = count > 1.0 ? count / (count - 1.0) : 1.0;
+      run_mean[g] = (1.f - momentum) * run_mean[g] + momentum * (float)mean;
+      run_var[g] = (1.f - momentum) * run_var[g] + momentum * (float)(var * unb);
+    } else {
+      mean = run_mean[g]; var = run_var[g];
+    }
+    const float rstd = rsqrtf((float)var + eps);
+    const float sc = gamma[g] * rstd;
+    for (int h = 0; h < H; ++h) {
+      stats[g * H + h] = W[g * H + h] * sc;
+      stats[VU_BN_STATS_FWK(H) + g * H + h] = W[g * H + h] * sc * inv_keep;
+      stats[VU_BN_STATS_XK(H) + g * H + h] = W[g * H + h] * rstd * inv_keep;
+    }
+    stats[H * H + g] = (cb[g] - (float)mean) * sc + beta[g];
+    stats[H * H + H + g] = (float)mean;
+    stats[H * H + 2 * H + g] = rstd;
+    stats[H * H + 3 * H + g] = 0.f;
+    stats[H * H + 4 * H + g] = 0.f;
+    stats[VU_BN_STATS_SC(H) + g] = sc;
+    stats[VU_BN_STATS_SC(H) + H + g] = (cb[g] - (float)mean) * sc + beta[g];
+  }
+}
+
+// =============================================================================================
+// apply pass: O = A^ v
+// =============================================================================================
+template <int H, int DH, int WPB, int CK>
+__global__ __launch_bounds__(WPB * 64, 2) void flash_apply_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, const float* __restrict__ lse2,
+    const float* __restrict__ stats, bf16_t* __restrict__ O, int B, int N, float c, vu_rng rng_in) {
+  typedef FC<H, DH> C;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* Kc = reinterpret_cast<bf16_t*>(smem_raw);                       // [CK*16][PITCH]
+  bf16_t* Vc = Kc + CK * 16 * C::PITCH;
+  const vu_rng rng = vu_rng_resolve(rng_in);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
+  const int ntiles = N >> 4, per = (ntiles + WPB - 1) / WPB;
+  int b, grp;
+  work_item(blockIdx.x, B, per, b, grp);
+  const int t = grp * WPB + wave;
+  const bool active = t < ntiles;
+  const int tq = active ? t : ntiles - 1;
+  const int qrow = tq * 16 + l15;
+  const bf16_t* kb = k + (long long)b * N * C::D;
+  const bf16_t* vb = v + (long long)b * N * C::D;
+  bf16x8 qf[H];
+  load_stationary<H, DH>(qf, q + ((long long)b * N + qrow) * C::D, g4);
+  float lse[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) lse[h] = lse2[((long long)b * H + h) * N + qrow];
+  zero_pads<H, DH>(Kc, 2 * CK * 16, tid, WPB * 64);
+  float* tab = reinterpret_cast<float*>(Vc + CK * 16 * C::PITCH);       // [H*H] gamma rstd W / keep, [H] folded bias
+  for (int i = tid; i < H * H + H; i += WPB * 64) tab[i] = i < H * H ? stats[VU_BN_STATS_FWK(H) + i] : stats[H * H + (i - H * H)];
+  f32x4 oacc[H][C::DT];
+#pragma unroll
+  for (int h = 0; h < H; ++h)
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt) oacc[h][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const uint32_t hstride = (uint32_t)(((unsigned long long)N * N) >> 1);
+  const uint32_t wlane = (uint32_t)(((((unsigned long long)b * H) * N + qrow) * (unsigned long long)N) >> 1) + 2u * g4;
+  const int nchunks = (ntiles + CK - 1) / CK;
+
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const int nt = min(CK, ntiles - ch * CK);
+    __syncthreads();
+    load_chunk<H, DH>(Kc, kb + (long long)ch * CK * 16 * C::D, nt * 16, tid, WPB * 64);
+    load_chunk<H, DH>(Vc, vb + (long long)ch * CK * 16 * C::D, nt * 16, tid, WPB * 64);
+    __syncthreads();
+    if (active)
+      for (int kc = 0; kc < nt; ++kc) {
+        f32x4 acc[H];
+        tile_logits<H, DH>(acc, Kc, kc, qf, l15, g4);
+        const uint32_t wt = wlane + 8u * (uint32_t)(ch * CK + kc);
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+          const keep4_t kp = keep4(rng, wt + (uint32_t)h * hstride);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float p = fexp2(fmaf(acc[h][r], c, -lse[h]));
+            acc[h][r] = kept(kp, r) ? p : 0.f;
+          }
+        }
+        asm volatile("" ::: "memory");      // keep the table in LDS: hoisted out of the key loop it would cost the second wave per SIMD
+#pragma unroll
+        for (int g = 0; g < H; ++g) {       // A^_g = folded bias + sum_h (gamma rstd W / keep)[g,h] P^_h, then O_g^T += V_g^T A^_g^T
+          float wg[H];
+#pragma unroll
+          for (int h4 = 0; h4 < H; h4 += 4) {
+            const f32x4 w4 = *reinterpret_cast<const f32x4*>(tab + g * H + h4);
+            wg[h4] = w4[0]; wg[h4 + 1] = w4[1]; wg[h4 + 2] = w4[2]; wg[h4 + 3] = w4[3];
+          }
+          const float cg = tab[H * H + g];
+          f32x4 a;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float x = cg;
+#pragma unroll
+            for (int h = 0; h < H; ++h) x = fmaf(wg[h], acc[h][r], x);
+            a[r] = x;
+          }
+          const s16x4 bop = pack4s(a);
+#pragma unroll
+          for (int dt = 0; dt < C::DT; ++dt)
+            oacc[g][dt] = mfma16(tr_operand<C::PITCH>(Vc, kc * 16, g * DH + 16 * dt, l15, g4), bop, oacc[g][dt]);
+        }
+      }
+  }
+  if (active) {
+    bf16_t* orow = O + ((long long)b * N + qrow) * C::D;
+#pragma unroll
+    for (int h = 0; h < H; ++h)
+#pragma unroll
+      for (int dt = 0; dt < C::DT; ++dt) {
+        const int f = 16 * dt + 4 * g4;                               // accumulator row = head feature
+        if (f < DH) *reinterpret_cast<bf16x4*>(orow + h * DH + f) = pack4(oacc[h][dt]);
+      }
+  }
+}
+
+// =============================================================================================
+// backward: recompute sweeps.  With P^ = mask * P (p~ = P^ / keep), x^_g = Xc_g + sum_h XK[g,h] P^_h,
+//   e_g  = dA^_g - m1_g - m2_g x^_g                (dA_g = gamma_g rstd_g e_g; m1 = mean dA^, m2 = mean dA^ x^: bn_bwd_small)
+//   dP_h = sum_g FWk[g,h] e_g                       (= dL/dP~_h / keep)
+//   delta_h = sum_j P^_h dP_h ;  dS_h = P^_h dP_h - P_h delta_h ;  dq = scale dS k ; dk = scale dS^T q ; dv = A^^T dO
+//   dW[g,h] = gamma_g rstd_g / keep * sum e_g P^_h ; dc_g = gamma_g rstd_g sum e_g
+// dA^ = dO v^T is recomputed per tile as a second logits-shaped MFMA product (A = V rows, B = dO fragments) whose
+// accumulator starts at -m1_g - m2_g Xc_g, so that e_g is reached by accumulating -m2_g XK[g,h] P^_h onto it head by head.
+// The probabilities are kept sign-tagged in the logits registers (+p kept, -p dropped): P^ = max(tag, 0), P = |tag|.
+// =============================================================================================
+template <int H> struct BwdTab {
+  float XK2T[H * H];   // [h][g] = -m2_g rstd_g W[g,h] / keep
+  float FWkT[H * H];   // [h][g] = gamma_g rstd_g W[g,h] / keep
+  float cin[H];        // -m1_g - m2_g Xc_g
+};
+template <int H>
+__device__ __forceinline__ void load_bwd_tab(BwdTab<H>* tb, const float* __restrict__ stats, int tid, int nthr) {
+  for (int i = tid; i < H * H; i += nthr) {
+    const int h = i / H, g = i % H;
+    const float m2 = stats[H * H + 4 * H + g];
+    tb->XK2T[i] = -m2 * stats[VU_BN_STATS_XK(H) + g * H + h];
+    tb->FWkT[i] = stats[VU_BN_STATS_FWK(H) + g * H + h];
+  }
+  for (int g = tid; g < H; g += nthr)
+    tb->cin[g] = -stats[H * H + 3 * H + g] - stats[H * H + 4 * H + g] * stats[2 * H * H + 5 * H + g];
+}
+
+// logits-shaped MFMA product with a per-head constant as the initial accumulator; STREAM_A: the LDS chunk is the A
+// operand (q-major sweeps: rows = keys) else the B operand (key-major sweeps: columns = queries).  The stationary
+// operand (the wave's own 16 tokens) is either a register array `sf` or, to keep the register budget of the backward
+// sweeps at two waves per SIMD, the wave's 16-row LDS image `sl` (k-slots >= DH / 8 zeroed after the read).
+template <int H, int DH, bool STREAM_A>
+__device__ __forceinline__ void tile_prod(f32x4 (&acc)[H], const bf16_t* Xc, int kc, const bf16x8* sf, const bf16_t* sl, const float* cin,
+                                          int l15, int g4) {
+  typedef FC<H, DH> C;
+  const int gk = g4 < C::KS ? g4 : C::KS - 1;
+  const bf16_t* xrow = Xc + (kc * 16 + l15) * C::PITCH + 8 * gk;
+  const bf16_t* srow = sl ? sl + l15 * C::PITCH + 8 * gk : nullptr;
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xrow + h * DH);
+    bf16x8 st;
+    if (sl) {
+      st = *reinterpret_cast<const bf16x8*>(srow + h * DH);
+      if (C::KS < 4 && g4 >= C::KS) st = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    } else st = sf[h];
+    const float ci = cin ? cin[h] : 0.f;
+    const f32x4 c0 = {ci, ci, ci, ci};
+    acc[h] = STREAM_A ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, st, c0, 0, 0, 0)
+                      : __builtin_amdgcn_mfma_f32_16x16x32_bf16(st, xf, c0, 0, 0, 0);
+  }
+}
+// the wave's own 16 token rows -> its LDS image [16][PITCH] (wave-private: no barrier, LDS operations of a wave are ordered)
+template <int H, int DH>
+__device__ __forceinline__ void stage_own_rows(bf16_t* dst, const bf16_t* __restrict__ src, int lane) {
+  typedef FC<H, DH> C;
+  for (int v = lane; v < 16 * C::VPR; v += 64) {
+    const int r = v / C::VPR, c = v - r * C::VPR;
+    *reinterpret_cast<uint4*>(dst + r * C::PITCH + c * 8) = *reinterpret_cast<const uint4*>(src + (long long)r * C::D + c * 8);
+  }
+}
+
+// logits -> sign-tagged probabilities, in place
+template <int H>
+__device__ __forceinline__ void tag_probs(f32x4 (&S)[H], const float (&lse)[H], float c, const vu_rng& rng, uint32_t wt, uint32_t hstride) {
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    const keep4_t kp = keep4(rng, wt + (uint32_t)h * hstride);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float p = fexp2(fmaf(S[h][r], c, -lse[h]));
+      S[h][r] = kept(kp, r) ? p : -p;
+    }
+  }
+}
+// dA^' (accumulator started at cin) -> e, in place: e_g += sum_h XK2T[h][g] P^_h
+template <int H>
+__device__ __forceinline__ void mix_to_e(f32x4 (&E)[H], const f32x4 (&S)[H], const BwdTab<H>* tb) {
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    asm volatile("" ::: "memory");       // one table row at a time: hoisted, the 64 + 64 table values cost the second wave per SIMD
+    float w[H];
+#pragma unroll
+    for (int g4_ = 0; g4_ < H; g4_ += 4) {
+      const f32x4 w4 = *reinterpret_cast<const f32x4*>(tb->XK2T + h * H + g4_);
+      w[g4_] = w4[0]; w[g4_ + 1] = w4[1]; w[g4_ + 2] = w4[2]; w[g4_ + 3] = w4[3];
+    }
+    f32x4 ph;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ph[r] = fmaxf(S[h][r], 0.f);
+#pragma unroll
+    for (int g = 0; g < H; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) E[g][r] = fmaf(w[g], ph[r], E[g][r]);
+  }
+}
+template <int H>
+__device__ __forceinline__ f32x4 mix_back(const f32x4 (&E)[H], const BwdTab<H>* tb, int h) {
+  asm volatile("" ::: "memory");
+  float w[H];
+#pragma unroll
+  for (int g4_ = 0; g4_ < H; g4_ += 4) {
+    const f32x4 w4 = *reinterpret_cast<const f32x4*>(tb->FWkT + h * H + g4_);
+    w[g4_] = w4[0]; w[g4_ + 1] = w4[1]; w[g4_ + 2] = w4[2]; w[g4_ + 3] = w4[3];
+  }
+  f32x4 dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int g = 0; g < H; ++g)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dp[r] = fmaf(w[g], E[g][r], dp[r]);
+  return dp;
+}
+
+// ---- sweep 1 (q-major): delta_h[i] and the head-mix gradient sums ---------------------------------------------------
+template <int H, int DH, int WPB, int CK>
+__global__ __launch_bounds__(WPB * 64, 2) void flash_bwd_delta_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, const bf16_t* __restrict__ dO,
+    const float* __restrict__ lse2, const float* __restrict__ stats, float* __restrict__ delta, float* __restrict__ partials,
+    int B, int N, float c, vu_rng rng_in) {
+  typedef FC<H, DH> C;
+  constexpr int NT = H * H + H;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* Kc = reinterpret_cast<bf16_t*>(smem_raw);
+  bf16_t* Vc = Kc + CK * 16 * C::PITCH;
+  bf16_t* Qs = Vc + CK * 16 * C::PITCH + (threadIdx.x >> 6) * 32 * C::PITCH;             // this wave's q rows, then its dO rows
+  bf16_t* dOs = Qs + 16 * C::PITCH;
+  BwdTab<H>* tb = reinterpret_cast<BwdTab<H>*>(Vc + CK * 16 * C::PITCH + WPB * 32 * C::PITCH);
+  float* red = reinterpret_cast<float*>(tb + 1);                          // [WPB][NT]
+  const vu_rng rng = vu_rng_resolve(rng_in);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
+  const int ntiles = N >> 4, per = (ntiles + WPB - 1) / WPB;
+  int b, grp;
+  work_item(blockIdx.x, B, per, b, grp);
+  const int t = grp * WPB + wave;
+  const bool active = t < ntiles;
+  const int tq = active ? t : ntiles - 1;
+  const int qrow = tq * 16 + l15;
+  const bf16_t* kb = k + (long long)b * N * C::D;
+  const bf16_t* vb = v + (long long)b * N * C::D;
+  stage_own_rows<H, DH>(Qs, q + ((long long)b * N + tq * 16) * C::D, lane);
+  stage_own_rows<H, DH>(dOs, dO + ((long long)b * N + tq * 16) * C::D, lane);
+  float lse[H], dl[H], Tc[H], T[H * H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) { lse[h] = lse2[((long long)b * H + h) * N + qrow]; dl[h] = 0.f; Tc[h] = 0.f; }
+#pragma unroll
+  for (int i = 0; i < H * H; ++i) T[i] = 0.f;
+  zero_pads<H, DH>(Kc, 2 * CK * 16 + WPB * 32, tid, WPB * 64);
+  load_bwd_tab<H>(tb, stats, tid, WPB * 64);
+  const uint32_t hstride = (uint32_t)(((unsigned long long)N * N) >> 1);
+  const uint32_t wlane = (uint32_t)(((((unsigned long long)b * H) * N + qrow) * (unsigned long long)N) >> 1) + 2u * g4;
+  const int nchunks = (ntiles + CK - 1) / CK;
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const int nt = min(CK, ntiles - ch * CK);
+    __syncthreads();
+    load_chunk<H, DH>(Kc, kb + (long long)ch * CK * 16 * C::D, nt * 16, tid, WPB * 64);
+    load_chunk<H, DH>(Vc, vb + (long long)ch * CK * 16 * C::D, nt * 16, tid, WPB * 64);
+    __syncthreads();
+    if (active)
+      for (int kc = 0; kc < nt; ++kc) {
+        f32x4 S[H], E[H];
+        tile_prod<H, DH, true>(S, Kc, kc, nullptr, Qs, nullptr, l15, g4);
+        asm volatile("" ::: "memory");
+        tile_prod<H, DH, true>(E, Vc, kc, nullptr, dOs, tb->cin, l15, g4);
+        tag_probs<H>(S, lse, c, rng, wlane + 8u * (uint32_t)(ch * CK + kc), hstride);
+        mix_to_e<H>(E, S, tb);
+#pragma unroll
+        for (int g = 0; g < H; ++g) Tc[g] += (E[g][0] + E[g][1]) + (E[g][2] + E[g][3]);
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+          const f32x4 dp = mix_back<H>(E, tb, h);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float ph = fmaxf(S[h][r], 0.f);
+            dl[h] = fmaf(ph, dp[r], dl[h]);
+#pragma unroll
+            for (int g = 0; g < H; ++g) T[g * H + h] = fmaf(E[g][r], ph, T[g * H + h]);
+          }
+        }
+      }
+  }
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    dl[h] += __shfl_xor(dl[h], 16, 64);
+    dl[h] += __shfl_xor(dl[h], 32, 64);
+    if (active && g4 == 0) delta[((long long)b * H + h) * N + qrow] = dl[h];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < H * H; ++i) { const float x = vu_wave_sum(active ? T[i] : 0.f); if (lane == 0) red[wave * NT + i] = x; }
+#pragma unroll
+  for (int g = 0; g < H; ++g) { const float x = vu_wave_sum(active ? Tc[g] : 0.f); if (lane == 0) red[wave * NT + H * H + g] = x; }
+  __syncthreads();
+  for (int i = tid; i < NT; i += WPB * 64) {
+    float a = 0.f;
+#pragma unroll
+    for (int w = 0; w < WPB; ++w) a += red[w * NT + i];
+    partials[(long long)blockIdx.x * NT + i] = a;
+  }
+}
+
+// head-mix gradients from the sweep-1 partial sums
+__global__ void flash_bwd_mix_finalize_kernel(const float* __restrict__ partials, int nblocks, const float* __restrict__ stats,
+                                              float* dW, float* dc, int H, float inv_keep) {
+  const int NT = H * H + H;
+  const int col = threadIdx.x >> 2, sub = threadIdx.x & 3;      // 4 lanes per column (NT <= 72 -> 288 threads)
+  double a = 0.0;
+  if (col < NT) for (int i = sub; i < nblocks; i += 4) a += (double)partials[(long long)i * NT + col];
+  a += __shfl_xor(a, 1, 64);
+  a += __shfl_xor(a, 2, 64);
+  if (col < NT && sub == 0) {
+    const int g = col < H * H ? col / H : col - H * H;
+    const float gs = stats[2 * H * H + 6 * H + g];               // gamma rstd
+    if (col < H * H) dW[col] += (float)(a * gs * inv_keep); else dc[g] += (float)(a * gs);
+  }
+}
+
+// ---- sweep 2 (q-major): dq ------------------------------------------------------------------------------------------
+template <int H, int DH, int WPB, int CK>
+__global__ __launch_bounds__(WPB * 64, 2) void flash_bwd_dq_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, const bf16_t* __restrict__ dO,
+    const float* __restrict__ lse2, const float* __restrict__ delta, const float* __restrict__ stats, bf16_t* __restrict__ dq,
+    int B, int N, float c, float scale, vu_rng rng_in) {
+  typedef FC<H, DH> C;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* Kc = reinterpret_cast<bf16_t*>(smem_raw);
+  bf16_t* Vc = Kc + CK * 16 * C::PITCH;
+  bf16_t* Qs = Vc + CK * 16 * C::PITCH + (threadIdx.x >> 6) * 32 * C::PITCH;             // this wave's q rows, then its dO rows
+  bf16_t* dOs = Qs + 16 * C::PITCH;
+  BwdTab<H>* tb = reinterpret_cast<BwdTab<H>*>(Vc + CK * 16 * C::PITCH + WPB * 32 * C::PITCH);
+  const vu_rng rng = vu_rng_resolve(rng_in);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
+  const int ntiles = N >> 4, per = (ntiles + WPB - 1) / WPB;
+  int b, grp;
+  work_item(blockIdx.x, B, per, b, grp);
+  const int t = grp * WPB + wave;
+  const bool active = t < ntiles;
+  const int tq = active ? t : ntiles - 1;
+  const int qrow = tq * 16 + l15;
+  const bf16_t* kb = k + (long long)b * N * C::D;
+  const bf16_t* vb = v + (long long)b * N * C::D;
+  stage_own_rows<H, DH>(Qs, q + ((long long)b * N + tq * 16) * C::D, lane);
+  stage_own_rows<H, DH>(dOs, dO + ((long long)b * N + tq * 16) * C::D, lane);
+  // row constants of the wave's 16 queries: [2][H][16] floats, wave-private, re-read per tile (16 registers saved)
+  float* rowc = reinterpret_cast<float*>(tb + 1) + wave * (2 * H * 16);
+  for (int i = lane; i < 2 * H * 16; i += 64) {
+    const int which = i / (H * 16), h = (i / 16) % H, j = i & 15;
+    rowc[i] = (which ? delta : lse2)[((long long)b * H + h) * N + tq * 16 + j];
+  }
+  zero_pads<H, DH>(Kc, 2 * CK * 16 + WPB * 32, tid, WPB * 64);
+  load_bwd_tab<H>(tb, stats, tid, WPB * 64);
+  f32x4 dqa[H][C::DT];
+#pragma unroll
+  for (int h = 0; h < H; ++h)
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt) dqa[h][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const uint32_t hstride = (uint32_t)(((unsigned long long)N * N) >> 1);
+  const uint32_t wlane = (uint32_t)(((((unsigned long long)b * H) * N + qrow) * (unsigned long long)N) >> 1) + 2u * g4;
+  const int nchunks = (ntiles + CK - 1) / CK;
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const int nt = min(CK, ntiles - ch * CK);
+    __syncthreads();
+    load_chunk<H, DH>(Kc, kb + (long long)ch * CK * 16 * C::D, nt * 16, tid, WPB * 64);
+    load_chunk<H, DH>(Vc, vb + (long long)ch * CK * 16 * C::D, nt * 16, tid, WPB * 64);
+    __syncthreads();
+    if (active)
+      for (int kc = 0; kc < nt; ++kc) {
+        f32x4 S[H], E[H];
+        tile_prod<H, DH, true>(S, Kc, kc, nullptr, Qs, nullptr, l15, g4);
+        asm volatile("" ::: "memory");
+        tile_prod<H, DH, true>(E, Vc, kc, nullptr, dOs, tb->cin, l15, g4);
+        {
+          float lse[H];
+#pragma unroll
+          for (int h = 0; h < H; ++h) lse[h] = rowc[h * 16 + l15];
+          tag_probs<H>(S, lse, c, rng, wlane + 8u * (uint32_t)(ch * CK + kc), hstride);
+        }
+        mix_to_e<H>(E, S, tb);
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+          const f32x4 dp = mix_back<H>(E, tb, h);
+          const float dlh = rowc[(H + h) * 16 + l15];
+          f32x4 ds;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ds[r] = fmaf(fmaxf(S[h][r], 0.f), dp[r], -fabsf(S[h][r]) * dlh);
+          const s16x4 bop = pack4s(ds);
+#pragma unroll
+          for (int dt = 0; dt < C::DT; ++dt)       // dq_h^T += K_h^T dS_h^T
+            dqa[h][dt] = mfma16(tr_operand<C::PITCH>(Kc, kc * 16, h * DH + 16 * dt, l15, g4), bop, dqa[h][dt]);
+        }
+      }
+  }
+  if (active) {
+    bf16_t* orow = dq + ((long long)b * N + qrow) * C::D;
+#pragma unroll
+    for (int h = 0; h < H; ++h)
+#pragma unroll
+      for (int dt = 0; dt < C::DT; ++dt) {
+        const int f = 16 * dt + 4 * g4;
+        if (f < DH) {
+          f32x4 o = dqa[h][dt];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] *= scale;
+          *reinterpret_cast<bf16x4*>(orow + h * DH + f) = pack4(o);
+        }
+      }
+  }
+}
+
+// ---- sweeps 3 / 4 (key-major loop, same tile orientation): dk, dv ---------------------------------------------------
+// A wave owns 16 keys (fragments in registers as the A operand) and walks every query tile (Q / dO chunks in LDS as
+// the B operand), so the accumulator still has the query on the lane and 4 consecutive keys in its registers, and the
+// tile body is the one of the q-major sweeps.  dk^T = Q^T dS and dv^T = dO^T A^ contract over the QUERY (lane) index:
+// the packed tile goes through a 512-byte wave-private LDS image [query][key] and comes back through the transposing
+// read as the B operand (k = query, column = key); the A operand is the transposing read of the Q / dO chunk.
+template <int H, int DH, int WPB, int CK, bool DV>
+__global__ __launch_bounds__(WPB * 64, 2) void flash_bwd_dkv_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, const bf16_t* __restrict__ dO,
+    const float* __restrict__ lse2, const float* __restrict__ delta, const float* __restrict__ stats, bf16_t* __restrict__ out,
+    int B, int N, float c, float scale, vu_rng rng_in) {
+  typedef FC<H, DH> C;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* Qc = reinterpret_cast<bf16_t*>(smem_raw);
+  bf16_t* Dc = Qc + CK * 16 * C::PITCH;                                   // dO chunk
+  bf16_t* Ks = Dc + CK * 16 * C::PITCH + (threadIdx.x >> 6) * 32 * C::PITCH;             // dk form: this wave's k rows, then its v rows
+  bf16_t* Vs = Ks + 16 * C::PITCH;
+  float* lsec = reinterpret_cast<float*>(Dc + CK * 16 * C::PITCH + (DV ? 0 : WPB * 32 * C::PITCH));       // [H][CK*16]
+  float* dlc = lsec + H * CK * 16;                                        // [H][CK*16]
+  BwdTab<H>* tb = reinterpret_cast<BwdTab<H>*>(dlc + H * CK * 16);
+  float* ftab = reinterpret_cast<float*>(tb + 1);                        // DV: FWk [g][h] (H*H), cf[H]
+  bf16_t* img = reinterpret_cast<bf16_t*>(ftab + H * H + H) + (threadIdx.x >> 6) * 256;     // this wave's [16 q][16 keys]
+  const vu_rng rng = vu_rng_resolve(rng_in);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
+  const int ntiles = N >> 4, per = (ntiles + WPB - 1) / WPB;
+  int b, grp;
+  work_item(blockIdx.x, B, per, b, grp);
+  const int t = grp * WPB + wave;
+  const bool active = t < ntiles;
+  const int tk = active ? t : ntiles - 1;
+  const int krow = tk * 16 + l15;
+  const bf16_t* qb = q + (long long)b * N * C::D;
+  const bf16_t* dob = dO + (long long)b * N * C::D;
+  bf16x8 kf[H];
+  if (DV) load_stationary<H, DH>(kf, k + ((long long)b * N + krow) * C::D, g4);
+  else {
+    stage_own_rows<H, DH>(Ks, k + ((long long)b * N + tk * 16) * C::D, lane);
+    stage_own_rows<H, DH>(Vs, v + ((long long)b * N + tk * 16) * C::D, lane);
+  }
+  zero_pads<H, DH>(Qc, 2 * CK * 16 + (DV ? 0 : WPB * 32), tid, WPB * 64);
+  load_bwd_tab<H>(tb, stats, tid, WPB * 64);
+  for (int i = tid; i < H * H + H; i += WPB * 64) ftab[i] = i < H * H ? stats[VU_BN_STATS_FWK(H) + i] : stats[H * H + (i - H * H)];
+  f32x4 oa[H][C::DT];
+#pragma unroll
+  for (int h = 0; h < H; ++h)
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt) oa[h][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const uint32_t hstride = (uint32_t)(((unsigned long long)N * N) >> 1);
+  // word index of map element (row = (b H + h) N + query, key 16 tk + 4 g4): the query part is added per tile
+  const uint32_t wkey = (uint32_t)((((unsigned long long)b * H) * N * (unsigned long long)N) >> 1) + 8u * (uint32_t)tk + 2u * g4;
+  const uint32_t wq = (uint32_t)(N >> 1);                                  // words per map row
+  const int nchunks = (ntiles + CK - 1) / CK;
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const int nt = min(CK, ntiles - ch * CK);
+    __syncthreads();
+    load_chunk<H, DH>(Qc, qb + (long long)ch * CK * 16 * C::D, nt * 16, tid, WPB * 64);
+    load_chunk<H, DH>(Dc, dob + (long long)ch * CK * 16 * C::D, nt * 16, tid, WPB * 64);
+    for (int i = tid; i < H * nt * 16; i += WPB * 64) {
+      const int h = i / (nt * 16), j = i - h * (nt * 16);
+      lsec[h * CK * 16 + j] = lse2[((long long)b * H + h) * N + ch * CK * 16 + j];
+      dlc[h * CK * 16 + j] = delta ? delta[((long long)b * H + h) * N + ch * CK * 16 + j] : 0.f;
+    }
+    __syncthreads();
+    if (active)
+      for (int qc = 0; qc < nt; ++qc) {
+        float lse[H], dl[H];
+#pragma unroll
+        for (int h = 0; h < H; ++h) { lse[h] = lsec[h * CK * 16 + qc * 16 + l15]; dl[h] = dlc[h * CK * 16 + qc * 16 + l15]; }
+        f32x4 S[H];
+        tile_prod<H, DH, false>(S, Qc, qc, DV ? kf : nullptr, DV ? nullptr : Ks, nullptr, l15, g4);
+        const uint32_t wt = wkey + (uint32_t)((ch * CK + qc) * 16 + l15) * wq;
+        tag_probs<H>(S, lse, c, rng, wt, hstride);
+        if constexpr (DV) {
+          asm volatile("" ::: "memory");
+#pragma unroll
+          for (int g = 0; g < H; ++g) {       // A^_g, then dv_g^T += dO_g^T A^_g
+            float wg[H];
+#pragma unroll
+            for (int h4 = 0; h4 < H; h4 += 4) {
+              const f32x4 w4 = *reinterpret_cast<const f32x4*>(ftab + g * H + h4);
+              wg[h4] = w4[0]; wg[h4 + 1] = w4[1]; wg[h4 + 2] = w4[2]; wg[h4 + 3] = w4[3];
+            }
+            const float cg = ftab[H * H + g];
+            f32x4 a;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float x = cg;
+#pragma unroll
+              for (int h = 0; h < H; ++h) x = fmaf(wg[h], fmaxf(S[h][r], 0.f), x);
+              a[r] = x;
+            }
+            *reinterpret_cast<s16x4*>(img + l15 * 16 + 4 * g4) = pack4s(a);
+            const s16x4 bop = tr_operand<16>(img, 0, 0, l15, g4);
+#pragma unroll
+            for (int dt = 0; dt < C::DT; ++dt)
+              oa[g][dt] = mfma16(tr_operand<C::PITCH>(Dc, qc * 16, g * DH + 16 * dt, l15, g4), bop, oa[g][dt]);
+          }
+        } else {
+          f32x4 E[H];
+          asm volatile("" ::: "memory");
+          tile_prod<H, DH, false>(E, Dc, qc, nullptr, Vs, tb->cin, l15, g4);
+          mix_to_e<H>(E, S, tb);
+#pragma unroll
+          for (int h = 0; h < H; ++h) {
+            const f32x4 dp = mix_back<H>(E, tb, h);
+            f32x4 ds;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ds[r] = fmaf(fmaxf(S[h][r], 0.f), dp[r], -fabsf(S[h][r]) * dl[h]);
+            *reinterpret_cast<s16x4*>(img + l15 * 16 + 4 * g4) = pack4s(ds);
+            const s16x4 bop = tr_operand<16>(img, 0, 0, l15, g4);
+#pragma unroll
+            for (int dt = 0; dt < C::DT; ++dt)       // dk_h^T += Q_h^T dS_h
+              oa[h][dt] = mfma16(tr_operand<C::PITCH>(Qc, qc * 16, h * DH + 16 * dt, l15, g4), bop, oa[h][dt]);
+          }
+        }
+      }
+  }
+  if (active) {
+    bf16_t* orow = out + ((long long)b * N + krow) * C::D;
+#pragma unroll
+    for (int h = 0; h < H; ++h)
+#pragma unroll
+      for (int dt = 0; dt < C::DT; ++dt) {
+        const int f = 16 * dt + 4 * g4;
+        if (f < DH) {
+          f32x4 o = oa[h][dt];
+          if (!DV) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] *= scale;
+          }
+          *reinterpret_cast<bf16x4*>(orow + h * DH + f) = pack4(o);
+        }
+      }
+  }
+}
+
+template <typename K>
+int reserve_lds(K kern, size_t lds) {
+  if (lds > 48 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    vu_set_error("flash attention: cannot reserve %zu bytes of LDS", lds);
+    return VU_ELAUNCH;
+  }
+  return VU_OK;
+}
+
+template <int H, int DH>
+int launch_backward(const vu_flash_args& a, hipStream_t st) {
+  typedef FC<H, DH> C;
+  constexpr int WPB = 4, CK = 4, CK2 = 2, NT = H * H + H;     // CK2: sweeps that keep BOTH stationary tiles in LDS
+  const int ntiles = a.N >> 4, per = (ntiles + WPB - 1) / WPB;
+  const int nblk = a.B * per;
+  const float c = a.scale * 1.44269504088896340736f;
+  const size_t rowb = (size_t)16 * C::PITCH * 2;                                      // one 16-row image
+  const size_t lds1 = (2 * CK2 + 2 * WPB) * rowb + sizeof(BwdTab<H>) + (size_t)WPB * NT * 4;
+  const size_t lds2 = (2 * CK2 + 2 * WPB) * rowb + sizeof(BwdTab<H>) + (size_t)WPB * 2 * H * 16 * 4;
+  const size_t lds3 = (2 * CK2 + 2 * WPB) * rowb + (size_t)2 * H * CK2 * 16 * 4 + sizeof(BwdTab<H>) + (size_t)(H * H + H) * 4 + (size_t)WPB * 512;
+  const size_t lds4 = (2 * CK) * rowb + (size_t)2 * H * CK * 16 * 4 + sizeof(BwdTab<H>) + (size_t)(H * H + H) * 4 + (size_t)WPB * 512;
+  auto k1 = flash_bwd_delta_kernel<H, DH, WPB, CK2>;
+  auto k2 = flash_bwd_dq_kernel<H, DH, WPB, CK2>;
+  auto k3 = flash_bwd_dkv_kernel<H, DH, WPB, CK2, false>;
+  auto k4 = flash_bwd_dkv_kernel<H, DH, WPB, CK, true>;
+  VU_TRY(reserve_lds(k1, lds1)); VU_TRY(reserve_lds(k2, lds2)); VU_TRY(reserve_lds(k3, lds3)); VU_TRY(reserve_lds(k4, lds4));
+  const double E = (double)a.B * H * a.N * a.N, act = (double)a.B * a.N * C::D * 2.0;
+  const bf16_t *q = (const bf16_t*)a.q, *k = (const bf16_t*)a.k, *v = (const bf16_t*)a.v, *dO = (const bf16_t*)a.dO;
+  hipLaunchKernelGGL(k1, dim3(nblk), dim3(WPB * 64), lds1, st, q, k, v, dO, a.lse2, a.stats, a.delta, a.partials, a.B, a.N, c, a.rng);
+  if (vu_prof_on()) vu_prof_note("flash_bwd_delta_kernel", 4.0 * E * DH + 6.0 * E * H, 4.0 * act);
+  VU_TRY(vu_check_launch("flash_bwd_delta"));
+  hipLaunchKernelGGL(flash_bwd_mix_finalize_kernel, dim3(1), dim3(320), 0, st, a.partials, nblk, a.stats, a.d_mix_w, a.d_mix_b, H, a.rng.inv_keep);
+  VU_TRY(vu_check_launch("flash_bwd_mix_finalize"));
+  hipLaunchKernelGGL(k2, dim3(nblk), dim3(WPB * 64), lds2, st, q, k, v, dO, a.lse2, a.delta, a.stats, (bf16_t*)a.dq, a.B, a.N, c, a.scale, a.rng);
+  if (vu_prof_on()) vu_prof_note("flash_bwd_dq_kernel", 6.0 * E * DH + 4.0 * E * H, 5.0 * act);
+  VU_TRY(vu_check_launch("flash_bwd_dq"));
+  hipLaunchKernelGGL(k3, dim3(nblk), dim3(WPB * 64), lds3, st, q, k, v, dO, a.lse2, a.delta, a.stats, (bf16_t*)a.dk, a.B, a.N, c, a.scale, a.rng);
+  if (vu_prof_on()) vu_prof_note("flash_bwd_dk_kernel", 6.0 * E * DH + 4.0 * E * H, 5.0 * act);
+  VU_TRY(vu_check_launch("flash_bwd_dk"));
+  hipLaunchKernelGGL(k4, dim3(nblk), dim3(WPB * 64), lds4, st, q, k, v, dO, a.lse2, (const float*)nullptr, a.stats, (bf16_t*)a.dv, a.B, a.N, c, a.scale, a.rng);
+  if (vu_prof_on()) vu_prof_note("flash_bwd_dv_kernel", 4.0 * E * DH + 2.0 * E * H, 4.0 * act);
+  return vu_check_launch("flash_bwd_dv");
+}
+
+template <int H, int DH>
+int launch_forward(const vu_flash_args& a, hipStream_t st) {
+  typedef FC<H, DH> C;
+  constexpr int WPB = 4, CK = 4;
+  const int ntiles = a.N >> 4, per = (ntiles + WPB - 1) / WPB;
+  const int nblk = a.B * per;
+  const float c = a.scale * 1.44269504088896340736f;
+  const size_t lds1 = (size_t)CK * 16 * C::PITCH * 2 + (size_t)WPB * C::NMOM * 4;
+  const size_t lds2 = (size_t)2 * CK * 16 * C::PITCH * 2 + (size_t)(H * H + H) * 4;
+  auto k1 = flash_stats_kernel<H, DH, WPB, CK>;
+  auto k2 = flash_apply_kernel<H, DH, WPB, CK>;
+  if (lds1 > 48 * 1024 && hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1) != hipSuccess) {
+    vu_set_error("flash attention: cannot reserve %zu bytes of LDS", lds1); return VU_ELAUNCH;
+  }
+  if (lds2 > 48 * 1024 && hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess) {
+    vu_set_error("flash attention: cannot reserve %zu bytes of LDS", lds2); return VU_ELAUNCH;
+  }
+  const double E = (double)a.B * H * a.N * a.N, act = (double)a.B * a.N * C::D * 2.0;
+  hipLaunchKernelGGL(k1, dim3(nblk), dim3(WPB * 64), lds1, st, (const bf16_t*)a.q, (const bf16_t*)a.k, a.lse2, a.partials, a.B, a.N, c,
+                     a.rng, a.training);
+  if (vu_prof_on()) vu_prof_note("flash_stats_kernel", (a.training ? 3.0 : 2.0) * 2.0 * E * DH, 2.0 * act);
+  VU_TRY(vu_check_launch("flash_stats"));
+  hipLaunchKernelGGL(flash_bn_finalize_kernel, dim3(1), dim3(256), 0, st, a.partials, nblk, a.mix_w, a.mix_b, a.bn_w, a.bn_b, a.run_mean,
+                     a.run_var, a.stats, H, a.N, (double)a.B * a.N * a.N, a.training, 0.1f, 1e-5f, a.rng.inv_keep);
+  VU_TRY(vu_check_launch("flash_bn_finalize"));
+  hipLaunchKernelGGL(k2, dim3(nblk), dim3(WPB * 64), lds2, st, (const bf16_t*)a.q, (const bf16_t*)a.k, (const bf16_t*)a.v, a.lse2,
+                     a.stats, (bf16_t*)a.O, a.B, a.N, c, a.rng);
+  if (vu_prof_on()) vu_prof_note("flash_apply_kernel", 4.0 * E * DH + 2.0 * E * H, 4.0 * act);
+  return vu_check_launch("flash_apply");
+}
+
+}  // namespace
+
+#define VU_FLASH_DISPATCH(FN, ...)                                                     \
+  do {                                                                                 \
+    const int dh_ = a.D / a.H;                                                         \
+    if (a.H == 8 && dh_ == 24) return FN<8, 24>(__VA_ARGS__);                         \
+    if (a.H == 8 && dh_ == 8) return FN<8, 8>(__VA_ARGS__);                           \
+    if (a.H == 8 && dh_ == 32) return FN<8, 32>(__VA_ARGS__);                         \
+    if (a.H == 4 && dh_ == 32) return FN<4, 32>(__VA_ARGS__);                         \
+    vu_set_error("flash attention: shape H=%d d=%d not instantiated", a.H, dh_);      \
+    return VU_EUNSUPPORTED;                                                            \
+  } while (0)
+
+bool vu_flash_ok(int dtype, int B, int N, int D, int H) {
+  if (dtype != 1 || H <= 0 || D % H != 0) return false;
+  const int dh = D / H;
+  const bool inst = (H == 8 && (dh == 24 || dh == 8 || dh == 32)) || (H == 4 && dh == 32);
+  // the dropout word index of a map element must fit 32 bits: B H N N < 2^33
+  return inst && N % 16 == 0 && N >= 256 && (double)B * H * N * N < 8589934592.0;
+}
+
+size_t vu_flash_partials_floats(int B, int N, int H) {
+  const int ntiles = N >> 4, per = (ntiles + 3) / 4;
+  return (size_t)B * per * (H * H + H) + 64;          // forward: H + H (H + 1) / 2 moments; backward: H H + H mix-gradient sums
+}
+
+int vu_k_flash_forward(const vu_flash_args& a, hipStream_t st) {
+  VU_REQUIRE(vu_flash_ok(1, a.B, a.N, a.D, a.H), "flash attention: shape not covered");
+  VU_FLASH_DISPATCH(launch_forward, a, st);
+}
+
+int vu_k_flash_backward(const vu_flash_args& a, hipStream_t st) {
+  VU_REQUIRE(vu_flash_ok(1, a.B, a.N, a.D, a.H), "flash attention: shape not covered");
+  VU_FLASH_DISPATCH(launch_backward, a, st);
+}

@@ -49,8 +49,12 @@ int vu_k_attn_outer(int dtype, const void* a, const void* bmat, void* out, int B
 // K9+K10: head mixing + BatchNorm on sign-tagged maps (B,H,N,ld).
 // stats buffer layout (floats): Wf[H*H] cf[H] mean[H] rstd[H] m1[H] m2[H]
 // backward tables appended: X[H*H] = W*rstd_g, Xc[H] = (c-mean)*rstd, Gs[H] = gamma*rstd
-#define VU_BN_STATS_FLOATS(H) (2 * (H) * (H) + 10 * (H))   /* ... + sc[H], kappa[H] of the centred-map form */
+// then sc[H], kappa[H] of the centred-map form, then the tables of the non-materialising form (vu_flash.hip):
+// FWk[H*H] = gamma rstd W / keep, XK[H*H] = rstd W / keep
+#define VU_BN_STATS_FLOATS(H) (4 * (H) * (H) + 10 * (H))
 #define VU_BN_STATS_SC(H) (2 * (H) * (H) + 8 * (H))
+#define VU_BN_STATS_FWK(H) (2 * (H) * (H) + 10 * (H))
+#define VU_BN_STATS_XK(H) (3 * (H) * (H) + 10 * (H))
 int vu_k_mix_stats(int dtype, const void* Ps, const float* W, const float* c, float* partials,
                    int nblocks, int B, int H, int N, int ld, float inv_keep, hipStream_t st);
 int vu_k_mix_stats_mm(int dtype, const void* Ps, const float* W, float* partials, void* Ac, int nblocks, int B, int H, int N,

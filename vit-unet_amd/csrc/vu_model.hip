@@ -13,6 +13,7 @@
 #include "../../include/vit_unet_amd.h"
 #include <stdlib.h>
 #include "vu_kernels.h"
+#include "vu_flash.h"
 
 const char* vu_get_error();
 
@@ -146,10 +147,13 @@ int build_plan(const vu_config& c, Plan& pl) {
 // ---------------------------------------------------------------------------------------------
 // ReAttention / SkipConnection
 // ---------------------------------------------------------------------------------------------
-struct AttnBuf { void *q, *k, *v, *Ps, *Ah, *O; float* stats; };
+struct AttnBuf { void *q, *k, *v, *Ps, *Ah, *O; float* stats; float *lse2, *delta; };
 struct AttnScratch { void *dO, *dq, *dk, *dv, *dA; float* partials; int nblocks; };
 
-struct AttnDims { int dtype, B, N, D, H, C, s, ld; int centered = 0; };
+struct AttnDims { int dtype, B, N, D, H, C, s, ld; int centered = 0; int flash = 0; };
+// non-materialising form (vu_flash.hip): the maps are recomputed from q, k (and v, dO) in every pass
+inline bool flash_on(const AttnDims& d) { return d.flash && vu_flash_ok(d.dtype, d.B, d.N, d.D, d.H); }
+inline int flash_switch() { const char* e = getenv("VU_ATTN_FLASH"); return e && e[0] != '0'; }
 // centred-map form (model path only; the stand-alone attention op returns the normalised map itself): the mixed map
 // is stored centred, BatchNorm's affine part is applied inside the two products that consume it.  Needs the MFMA mix
 // kernel and the streaming product kernels to cover the shape.
@@ -168,6 +172,17 @@ void carve_attn(Bump& bp, const AttnDims& d, AttnBuf& a) {
   a.q = bp.take(act); a.k = bp.take(act); a.v = bp.take(act); a.O = bp.take(act);
   a.Ps = bp.take(map); a.Ah = bp.take(map);
   a.stats = bp.takef(VU_BN_STATS_FLOATS(d.H));
+  a.lse2 = bp.takef((size_t)d.B * d.H * d.N);
+  a.delta = bp.takef((size_t)d.B * d.H * d.N);
+}
+inline size_t attn_partials_floats(const AttnDims& d) {
+  return std::max((size_t)std::max(stats_blocks(d), d.B) * 2 * d.H + 1024, vu_flash_partials_floats(d.B, d.N, d.H));
+}
+void fill_flash_args(vu_flash_args& fa, const AttnDims& d, const vu_attn_params& p, AttnBuf& a, float* partials, vu_rng ra, int training) {
+  memset(&fa, 0, sizeof(fa));
+  fa.B = d.B; fa.N = d.N; fa.D = d.D; fa.H = d.H; fa.scale = 1.0f / sqrtf((float)(d.D / d.H)); fa.training = training; fa.rng = ra;
+  fa.q = a.q; fa.k = a.k; fa.v = a.v; fa.O = a.O; fa.lse2 = a.lse2; fa.delta = a.delta; fa.partials = partials; fa.stats = a.stats;
+  fa.mix_w = p.mix_w; fa.mix_b = p.mix_b; fa.bn_w = p.bn_w; fa.bn_b = p.bn_b; fa.run_mean = p.run_mean; fa.run_var = p.run_var;
 }
 
 int attn_forward(const AttnDims& d, const vu_attn_params& p, const void* xq, const void* xkv, void* y,
@@ -179,6 +194,11 @@ int attn_forward(const AttnDims& d, const vu_attn_params& p, const void* xq, con
   VU_TRY(vu_k_conv3x3_qkv_fwd(dt, xq, xkv, p.wq, p.wk, p.wv, a.q, a.k, a.v, npatch, d.C, d.s, st));
   vu_rng ra = vu_make_rng(seed, 2 * stream_id, training ? attn_drop : 0.f);
   ra.salt = salt;
+  if (flash_on(d)) {   // O = A^ v without ever forming a map
+    vu_flash_args fa;
+    fill_flash_args(fa, d, p, a, partials, ra, training);
+    VU_TRY(vu_k_flash_forward(fa, st));
+  } else {
   int fused = vu_k_attn_scores(dt, a.q, a.k, a.Ps, B, N, D, H, ld, 1.0f / sqrtf((float)dh), ra, st);
   if (fused < 0) return fused;
   if (fused == 1) {  // shape outside the fused kernel: S = scale * q k^T (model.py:155), then softmax + dropout
@@ -216,6 +236,7 @@ int attn_forward(const AttnDims& d, const vu_attn_params& p, const void* xq, con
     g.alpha = 1.f;
     VU_TRY(vu_gemm_launch(dt, 0, g, st));
   }
+  }
   {  // y = dropout(O Wp^T + bp)  (model.py:162-163)
     vu_gemm_args g;
     memset(&g, 0, sizeof(g));
@@ -236,7 +257,8 @@ int attn_forward(const AttnDims& d, const vu_attn_params& p, const void* xq, con
 // If dxkv == nullptr the module is self-attention (xq == xkv) and everything lands in dxq.
 int attn_backward(const AttnDims& d, const vu_attn_params& p, const vu_attn_grads& gr, const void* xq,
                   const void* xkv, const void* dz, const void* add_q, const void* add_kv, void* dxq, void* dxkv,
-                  AttnBuf& a, AttnScratch& sc, float attn_drop, int training, hipStream_t st) {
+                  AttnBuf& a, AttnScratch& sc, float attn_drop, int training, uint64_t seed, uint64_t stream_id,
+                  const uint32_t* salt, hipStream_t st) {
   const int dt = d.dtype, B = d.B, N = d.N, D = d.D, H = d.H, ld = d.ld;
   const int dh = D / H;
   const long long npatch = (long long)B * N, rows = (long long)B * N;
@@ -255,6 +277,18 @@ int attn_backward(const AttnDims& d, const vu_attn_params& p, const vu_attn_grad
     g.A = dz; g.B = p.proj_w; g.C = sc.dO; g.M = (int)rows; g.N = D; g.K = D;
     g.sAm = D; g.sAk = 1; g.sBk = D; g.sBn = 1; g.ldc = D; g.Z1 = 1; g.Z2 = 1; g.alpha = 1.f;
     VU_TRY(vu_gemm_launch(dt, 0, g, st));
+  }
+  if (flash_on(d)) {   // recompute sweeps: no map is read or written (vu_flash.hip)
+    VU_TRY(vu_k_bn_bwd_small(dt, sc.dO, a.O, a.v, p.bn_w, p.bn_b, p.mix_w, p.mix_b, a.stats, gr.bn_w, gr.bn_b, sc.partials, B, N, D, H, training, st));
+    vu_rng ra = vu_make_rng(seed, 2 * stream_id, training ? attn_drop : 0.f);
+    ra.salt = salt;
+    vu_flash_args fa;
+    fill_flash_args(fa, d, p, a, sc.partials, ra, training);
+    fa.dO = sc.dO; fa.dq = sc.dq; fa.dk = sc.dk; fa.dv = sc.dv; fa.d_mix_w = gr.mix_w; fa.d_mix_b = gr.mix_b;
+    VU_TRY(vu_k_flash_backward(fa, st));
+    VU_TRY(vu_k_conv3x3_qkv_wgrad(dt, sc.dq, sc.dk, sc.dv, xq, xkv, gr.wq, gr.wk, gr.wv, npatch, d.C, d.s, st));
+    VU_TRY(vu_k_conv3x3_qkv_dgrad(dt, sc.dq, sc.dk, sc.dv, p.wq, p.wk, p.wv, add_q, add_kv, dxq, dxkv, npatch, d.C, d.s, st));
+    return VU_OK;
   }
   int fo = vu_k_attn_outer(dt, sc.dO, a.v, sc.dA, B, N, D, H, ld, 1.0f, st);   // dAhat = dO v^T (fused, vector stores)
   if (fo < 0) return fo;
@@ -366,20 +400,21 @@ void carve_model(const Plan& pl, int B, char* base, ModelWS& w) {
   w.img = bp.take(act);
   w.y_attn = bp.take(act); w.f_ff = bp.take(act);
   w.gx0 = bp.take(act); w.gx1 = bp.take(act); w.ga = bp.take(act); w.gb = bp.take(act); w.gc = bp.take(act);
-  size_t hh = 0, map = 0;
+  size_t hh = 0, map = 0, npart = 0;
   int nb = 1;
   for (const Level& L : pl.lv) {
     hh = std::max(hh, (size_t)B * L.N * L.hid * esize(dt));
     map = std::max(map, (size_t)B * H * L.N * L.ld * esize(dt));
     AttnDims d{dt, B, L.N, L.D, H, c.num_channels, L.s, L.ld};
     nb = std::max(nb, stats_blocks(d));
+    npart = std::max(npart, attn_partials_floats(d));
   }
   w.gh = bp.take(hh);
   w.asc.dO = bp.take(act); w.asc.dq = bp.take(act); w.asc.dk = bp.take(act); w.asc.dv = bp.take(act);
   w.asc.dA = bp.take(map);
   w.asc.nblocks = nb;
   for (int j = 0; j < c.depth; ++j) w.dskip[j] = bp.take(act);
-  w.partials = bp.takef((size_t)std::max(nb, B) * 2 * H + 1024);
+  w.partials = bp.takef(std::max((size_t)std::max(nb, B) * 2 * H + 1024, npart));
   w.asc.partials = w.partials;
   w.lnp = bp.takef((size_t)B * vu_ln_nchunks(P) * 3);
   w.lnp2 = bp.takef((size_t)B * vu_ln_nbchunks(P) * 2);
@@ -495,7 +530,7 @@ int block_forward(Ctx& cx, const BlockP& bp, BlockBuf& bb, const void* x, uint64
   const Level& L = cx.pl->lv[bp.level];
   const int dt = c.dtype, B = cx.B;
   const long long P = (long long)L.N * L.D;
-  AttnDims d{dt, B, L.N, L.D, c.num_heads, c.num_channels, L.s, L.ld, 1};
+  AttnDims d{dt, B, L.N, L.D, c.num_heads, c.num_channels, L.s, L.ld, 1, flash_switch()};
   vu_attn_params ap = attn_params(bp.at, c, cx.prm, cx.shadow, cx.bn);
   VU_TRY(attn_forward(d, ap, x, x, bb.z1, bb.at, cx.w->partials, c.attn_drop, c.proj_drop, cx.training,
                       cx.seed, stream_id, cx.salt, cx.st, x));          // z1 = attn(x) + x
@@ -533,11 +568,11 @@ int block_backward(Ctx& cx, const BlockP& bp, BlockBuf& bb, const void* x, void*
   const bool masked = rp.thr != 0;
   VU_TRY(vu_k_ln_bwd(dt, w.gb, bb.z1, cx.prm + bp.ln1w, bb.ln1s, G + bp.ln1w, G + bp.ln1b, w.lnp2, w.ga,
                      masked ? w.gc : nullptr, rp, B, P, cx.st));
-  AttnDims d{dt, B, L.N, L.D, c.num_heads, c.num_channels, L.s, L.ld, 1};
+  AttnDims d{dt, B, L.N, L.D, c.num_heads, c.num_channels, L.s, L.ld, 1, flash_switch()};
   vu_attn_params ap = attn_params(bp.at, c, cx.prm, cx.shadow, cx.bn);
   vu_attn_grads ag = attn_grads(bp.at, G);
   VU_TRY(attn_backward(d, ap, ag, x, x, masked ? w.gc : w.ga, w.ga, nullptr, dx, nullptr, bb.at, w.asc, c.attn_drop,
-                       cx.training, cx.st));
+                       cx.training, cx.seed, stream_id, cx.salt, cx.st));
   return VU_OK;
 }
 
@@ -573,7 +608,7 @@ int model_forward(Ctx& cx, const float* x, float* y) {
       const int lfrom = pl.dec[i].level, lto = lfrom - 1;
       VU_TRY(vu_k_retile(dt, 0, 0, cur, w.up_out[j], nullptr, B, C, im, pl.lv[lfrom].s, pl.lv[lto].s, cx.st));
       const Level& L = pl.lv[lto];
-      AttnDims d{dt, B, L.N, L.D, c.num_heads, C, L.s, L.ld, 1};
+      AttnDims d{dt, B, L.N, L.D, c.num_heads, C, L.s, L.ld, 1, flash_switch()};
       vu_attn_params ap = attn_params(pl.skip[j], c, cx.prm, cx.shadow, cx.bn);
       VU_TRY(attn_forward(d, ap, skips[lto], w.up_out[j], w.skip_out[j], w.skip[j], w.partials, c.attn_drop, c.proj_drop,
                           cx.training, cx.seed, sid++, cx.salt, cx.st));
@@ -623,7 +658,7 @@ int model_backward(Ctx& cx, const float* dy, float* dx, int stage) {
         const uint64_t sid_skip = sid_blk + 1;
         const int lfrom = pl.dec[i].level, lto = lfrom - 1;
         const Level& L = pl.lv[lto];
-        AttnDims d{dt, B, L.N, L.D, c.num_heads, C, L.s, L.ld, 1};
+        AttnDims d{dt, B, L.N, L.D, c.num_heads, C, L.s, L.ld, 1, flash_switch()};
         vu_attn_params ap = attn_params(pl.skip[j], c, cx.prm, cx.shadow, cx.bn);
         vu_attn_grads ag = attn_grads(pl.skip[j], G);
         const void* dz = cur;
@@ -633,7 +668,7 @@ int model_backward(Ctx& cx, const float* dy, float* dx, int stage) {
         // encoder skip tensor at level lto is the output of the last encoder block of that level
         const void* enc_x = w.enc[(lto + 1) * c.depth_te - 1].out;
         VU_TRY(attn_backward(d, ap, ag, enc_x, w.up_out[j], dz, nullptr, nullptr, w.dskip[lto], w.ga, w.skip[j], w.asc,
-                             c.attn_drop, cx.training, cx.st));
+                             c.attn_drop, cx.training, cx.seed, sid_skip, cx.salt, cx.st));
         // gradient of upsampling = retile back to the finer level
         VU_TRY(vu_k_retile(dt, 0, 0, w.ga, cur, nullptr, B, C, im, pl.lv[lto].s, pl.lv[lfrom].s, cx.st));
       }
@@ -767,7 +802,7 @@ static void carve_attn_ws(Bump& bp, const AttnDims& d, AttnBuf& a, AttnScratch& 
   sc.dO = bp.take(act); sc.dq = bp.take(act); sc.dk = bp.take(act); sc.dv = bp.take(act); sc.dA = bp.take(map);
   *dzbuf = bp.take(act);
   sc.nblocks = stats_blocks(d);
-  sc.partials = bp.takef((size_t)std::max(sc.nblocks, d.B) * 2 * d.H);
+  sc.partials = bp.takef(attn_partials_floats(d));
 }
 size_t vu_attn_workspace_bytes(int dtype, int B, int N, int D, int H) {
   AttnDims d{dtype, B, N, D, H, 1, 4, round_up(N, 8)};
@@ -795,6 +830,7 @@ int vu_attn_forward(int dtype, const vu_attn_params* prm, const void* xq, const 
   if (bp.off > ws_bytes) { vu_set_error("attention workspace too small"); return VU_EWORKSPACE; }
   // test switch: the stand-alone op in the model path's centred-map form (only when the map itself is not asked for)
   d.centered = (!map_out && getenv("VU_ATTN_CENTERED")) ? 1 : 0;
+  d.flash = (!map_out && flash_switch()) ? 1 : 0;
   VU_TRY(attn_forward(d, *prm, xq, xkv, y, a, sc.partials, attn_drop, proj_drop, training, seed, stream_id, nullptr,
                       (hipStream_t)stream));
   if (map_out) {  // the attn_next tensor of model.py:160 as (B,H,N,N) without row padding
@@ -815,10 +851,12 @@ int vu_attn_backward(int dtype, const vu_attn_params* prm, const vu_attn_grads* 
   carve_attn_ws(bp, d, a, sc, &dzb);
   if (bp.off > ws_bytes) { vu_set_error("attention workspace too small"); return VU_EWORKSPACE; }
   d.centered = getenv("VU_ATTN_CENTERED") ? 1 : 0;      // must match what the forward call used (test switch)
+  d.flash = flash_switch();
   const void* dz = dy;
   vu_rng rp = vu_make_rng(seed, 2 * stream_id + 1, training ? proj_drop : 0.f);
   if (rp.thr != 0) { VU_TRY(vu_k_dropout(dtype, dy, dzb, (long long)B * N * D, rp, (hipStream_t)stream)); dz = dzb; }
-  return attn_backward(d, *prm, *grd, xq, xkv, dz, nullptr, nullptr, dxq, dxkv, a, sc, attn_drop, training, (hipStream_t)stream);
+  return attn_backward(d, *prm, *grd, xq, xkv, dz, nullptr, nullptr, dxq, dxkv, a, sc, attn_drop, training, seed, stream_id, nullptr,
+                       (hipStream_t)stream);
 }
 
 size_t vu_layernorm_workspace_floats(int B, long long P) {

@@ -80,8 +80,10 @@ class TrainStep:
         self._graph = None
         self._gx = self._gy = self._gout = self._dout = None
         self._buckets = self._make_buckets()
+        model._shadow_clean = False
         model.refresh_shadow()
-        model._shadow_clean = True      # from now on AdamW keeps the bf16 shadow in sync
+        model._shadow_clean = True      # from now on AdamW keeps the bf16 shadow in sync (model.refresh_shadow re-casts
+        #                                 if a torch-side write changed a parameter in between)
 
     def set_lr(self, lr: float):
         self.hyper[0] = lr
@@ -131,9 +133,33 @@ class TrainStep:
         if self._gout is None or self._gout.shape != x.shape:
             self._gout = torch.empty_like(x)
             self._dout = torch.empty_like(x)
+        self.model.refresh_shadow()           # no-op unless a parameter was written outside the fused AdamW
         self._enqueue(x, y, self._gout, self._dout)
         self.model._gen += 1
+        self.model._nbt_pending += 1          # BatchNorm num_batches_tracked, as the autograd path counts it
         return self.loss
+
+    # ---- optimizer state (checkpoint / resume) ----------------------------------------------------
+    def state_dict(self):
+        """AdamW moments over the flat arena, the step counter and the hyper-parameters: what
+        torch.optim.AdamW.state_dict() carries, in arena layout."""
+        return {"exp_avg": self.m.detach().cpu(), "exp_avg_sq": self.v.detach().cpu(), "step": int(self.step_count.item()),
+                "hyper": self.hyper.detach().cpu(), "numel": self.m.numel()}
+
+    def load_state_dict(self, sd):
+        if sd["numel"] != self.m.numel():
+            raise ValueError("optimizer state belongs to a different parameter arena")
+        self.m.copy_(sd["exp_avg"])
+        self.v.copy_(sd["exp_avg_sq"])
+        self.step_count.fill_(int(sd["step"]))
+        self.hyper.copy_(sd["hyper"])
+
+    def set_hyper(self, lr=None, betas=None, eps=None, weight_decay=None):
+        h = self.hyper.tolist()
+        new = [h[0] if lr is None else lr, h[1] if betas is None else betas[0], h[2] if betas is None else betas[1],
+               h[3] if eps is None else eps, h[4] if weight_decay is None else weight_decay]
+        if new != h:
+            self.hyper.copy_(torch.tensor(new, dtype=torch.float32))
 
     # ---- hipGraph capture ----------------------------------------------------------------------
     def capture(self, x: torch.Tensor, y: torch.Tensor):
@@ -159,5 +185,7 @@ class TrainStep:
         if x is not None:
             self._gx.copy_(x)
             self._gy.copy_(y)
+        self.model.refresh_shadow()
         self._graph.replay()
+        self.model._nbt_pending += 1
         return self.loss

@@ -33,6 +33,8 @@ class ImageFitter:
         self._lr = lr
         self._seed = seed
         self._fused = None
+        self._fused_state = None         # optimizer state restored by load(), applied when the fused step is (re)built
+        self._last_hyper = None
 
     # ---- reference surface -----------------------------------------------------------------------
     def unpack(self, data):
@@ -65,12 +67,29 @@ class ImageFitter:
         if self.optimizer is not None:
             g = self.optimizer.param_groups[0]
             kw = dict(lr=g["lr"], betas=tuple(g["betas"]), eps=g["eps"], weight_decay=g["weight_decay"])
-        return TrainStep(self.model, seed=self._seed, loss=self._fused_kind(), **kw)
+        ts = TrainStep(self.model, seed=self._seed, loss=self._fused_kind(), **kw)
+        if self._fused_state is not None:
+            ts.load_state_dict(self._fused_state)
+            self._fused_state = None
+        return ts
+
+    def _sync_hyper(self):
+        """The fused step reads lr / betas / eps / weight_decay from the user's optimizer param group on EVERY batch, so
+        an LR scheduler or a manual param_groups[0]['lr'] edit takes effect as it would with optimizer.step()."""
+        if self.optimizer is None:
+            return
+        g = self.optimizer.param_groups[0]
+        cur = (float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]))
+        if cur != self._last_hyper:
+            self._fused.set_hyper(lr=cur[0], betas=(cur[1], cur[2]), eps=cur[3], weight_decay=cur[4])
+            self._last_hyper = cur
 
     def _train_batch(self, x, y, w) -> float:
         if w is None and self._fused_ok():
             if self._fused is None:
                 self._fused = self._make_fused()
+                self._last_hyper = None
+            self._sync_hyper()
             return float(self._fused.step(x, y).item())
         if self.optimizer is None:
             self.optimizer = torch.optim.AdamW(self.model.parameters(), lr=self._lr)
@@ -78,8 +97,14 @@ class ImageFitter:
         out = self.model(x)
         if w is None:
             loss = self.loss(out, y)
-        else:   # per-sample weights: weighted mean of the per-sample mean squared / criterion error
-            per = ((out - y) ** 2).reshape(out.shape[0], -1).mean(dim=1)
+        else:   # per-sample weights: weighted mean of the per-sample criterion
+            if isinstance(self.loss, torch.nn.MSELoss):
+                per = ((out - y) ** 2).reshape(out.shape[0], -1).mean(dim=1)
+            elif hasattr(self.loss, "reduction"):
+                crit = type(self.loss)(reduction="none")
+                per = crit(out, y).reshape(out.shape[0], -1).mean(dim=1)
+            else:
+                raise NotImplementedError("per-sample weights need a criterion with reduction='none' (e.g. MSELoss, L1Loss)")
             loss = (per * w.reshape(-1)).sum() / w.sum()
         loss.backward()
         self.optimizer.step()
@@ -111,6 +136,7 @@ class ImageFitter:
             if val_loader is not None:
                 log["val"] = self.validate(val_loader)
                 monitored = log["val"]
+            self.epoch += 1               # checkpoints record the number of COMPLETED epochs
             self.save(os.path.join(self.folder, "last-checkpoint.bin"))
             if monitored < self.best_metric:
                 self.best_metric = monitored
@@ -120,20 +146,34 @@ class ImageFitter:
             for cb in callbacks or []:
                 cb(dict(log))
             history.append(log)
-            self.epoch += 1
         return history
 
     # ---- checkpoints (reference key names: state_dict of the nn.Module) ----------------------------
     def save(self, path: str):
+        """model_state_dict (reference key names) + optimizer_state_dict (the fused AdamW's moments / step in arena
+        layout, or the torch optimizer's own state on the autograd path) + epoch / best metric."""
+        opt = None
+        if self._fused is not None:
+            opt = {"kind": "fused_adamw", **self._fused.state_dict()}
+        elif self.optimizer is not None:
+            opt = {"kind": "torch", "state": self.optimizer.state_dict()}
         torch.save({"model_state_dict": {k: v.detach().cpu() for k, v in self.model.state_dict().items()},
-                    "epoch": self.epoch, "best_metric": self.best_metric}, path)
+                    "optimizer_state_dict": opt, "epoch": self.epoch, "best_metric": self.best_metric}, path)
 
-    def load(self, path: str):
-        ck = torch.load(path, map_location="cpu")
-        self.model.load_state_dict(ck["model_state_dict"])
+    def load(self, path: str, weights_only: bool = False):
+        """Restore a checkpoint.  `weights_only=True` is the reference's use (run_denoising.py:100 reloads the best
+        weights for evaluation); otherwise the optimizer state is restored too, so that a resumed run continues the
+        interrupted one (same moments, same bias-correction step)."""
+        ck = torch.load(path, map_location="cpu", weights_only=False)
+        self.model.load_state_dict(ck["model_state_dict"])     # (the model's post-hook invalidates the bf16 shadow)
         self.epoch = ck.get("epoch", 0)
         self.best_metric = ck.get("best_metric", float("inf"))
-        if hasattr(self.model, "_shadow_clean"):
-            self.model._shadow_clean = False  # the bf16 shadow of the weights is re-cast before the next forward
-        self._fused = None                    # optimizer moments restart (the reference reloads weights only)
+        self._fused = None
+        self._fused_state = None
+        opt = ck.get("optimizer_state_dict")
+        if opt is not None and not weights_only:
+            if opt.get("kind") == "fused_adamw":
+                self._fused_state = {k: v for k, v in opt.items() if k != "kind"}
+            elif opt.get("kind") == "torch" and self.optimizer is not None:
+                self.optimizer.load_state_dict(opt["state"])
         return self

@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import List, Optional
 
 import numpy as np
@@ -470,7 +471,30 @@ class HViT_UNet(nn.Module):
         self._table = None
         self._gen = 0
         self._shadow_clean = False
+        self._shadow_version = None      # weight-version stamp the bf16 shadow was cast from / kept in sync at
+        self._nbt_pending = 0            # train-mode forwards not yet added to the num_batches_tracked buffers
         self._step_seed = None
+        if os.path.exists(_lib.LIB_PATH):        # reject what the HIP path cannot run at construction, not at first use
+            check(lib().vu_model_validate(C.byref(self._cfg)), "vu_model_validate")
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._weights_changed())
+        self.register_state_dict_pre_hook(lambda module, prefix, keep_vars: module._flush_bn_counters())
+
+    def _weights_changed(self):
+        """Weights were written from outside the fused AdamW (load_state_dict, a torch optimizer, p.mul_ ...): the
+        bf16 shadow must be re-cast before the next forward."""
+        self._shadow_clean = False
+
+    def _flush_bn_counters(self):
+        if self._nbt_pending:
+            with torch.no_grad():
+                for b in self._bn_modules():
+                    b.num_batches_tracked += self._nbt_pending
+            self._nbt_pending = 0
+
+    def _weight_version(self) -> int:
+        """Sum of the autograd version counters of all parameters: any in-place write through torch (optimizer step,
+        load_state_dict, p.mul_) changes it; the fused AdamW (a C call) does not and re-stamps the shadow itself."""
+        return sum(p._version for p in self._params_list)
 
     # ---- flat arena ------------------------------------------------------------------------
     def _apply(self, fn, *a, **k):
@@ -528,9 +552,12 @@ class HViT_UNet(nn.Module):
         if self._arena is None:
             self._flatten()
             return
-        # load_state_dict(assign=True) or external code may have replaced parameter storage
-        p0 = self._params_list[0]
-        if p0.data_ptr() != self._arena.data_ptr() + 4 * self._table[0][1]:
+        # load_state_dict(assign=True) or external code may have replaced Parameter objects or their storage: every
+        # registered parameter must still be the cached object and still point at its slot of the arena
+        base = self._arena.data_ptr()
+        cur = list(self.parameters())
+        if len(cur) != len(self._params_list) or any(
+                (p is not q) or p.data_ptr() != base + 4 * t[1] for p, q, t in zip(cur, self._params_list, self._table)):
             self._flatten()
 
     def _link_grads(self):
@@ -559,9 +586,16 @@ class HViT_UNet(nn.Module):
         return self._ws
 
     def refresh_shadow(self):
-        if self._shadow is not None and not self._shadow_clean:
-            check(lib().vu_cast_bf16(ptr(self._arena), ptr(self._shadow), self._arena.numel(),
-                                     stream_ptr(self._arena.device)), "vu_cast_bf16")
+        """bf16 copy of the weights for the GEMMs.  A TrainStep keeps it in sync from inside AdamW and vouches for it
+        (`_shadow_clean`); the vouching only holds while no torch-side write touched a parameter since (`_weight_version`)."""
+        if self._shadow is None:
+            return
+        ver = self._weight_version()
+        if self._shadow_clean and ver == self._shadow_version:
+            return
+        check(lib().vu_cast_bf16(ptr(self._arena), ptr(self._shadow), self._arena.numel(),
+                                 stream_ptr(self._arena.device)), "vu_cast_bf16")
+        self._shadow_version = ver
 
     # ---- execution -------------------------------------------------------------------------
     def _run_forward(self, x: torch.Tensor, training: bool, seed: int, salt: Optional[torch.Tensor] = None):
@@ -575,8 +609,7 @@ class HViT_UNet(nn.Module):
                                      ptr(y), ptr(ws), ws.numel(), B, 1 if training else 0, seed, ptr(salt),
                                      stream_ptr(x.device)), "vu_model_forward")
         if training:
-            for b in self._bn_modules():
-                b.num_batches_tracked += 1
+            self._nbt_pending += 1      # added to the num_batches_tracked buffers when state_dict() is taken
         return y
 
     def _run_backward(self, dy: torch.Tensor, training: bool, seed: int, need_dx: bool, stage: int = 0,
