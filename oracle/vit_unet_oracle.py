@@ -28,7 +28,7 @@ import torch.nn.functional as F
 __all__ = [
     "Config", "retile", "patchify", "unpatchify", "downsample", "upsample",
     "conv3x3_per_patch", "reattention", "feed_forward", "te_block", "skip_block", "forward",
-    "param_shapes", "param_count", "make_weights", "keep_mask", "mse_loss", "psnr",
+    "param_shapes", "param_count", "make_weights", "keep_mask", "keep_mask_quad", "flash_shape", "mse_loss", "psnr",
     "ssim", "dice_loss", "resize_u8", "warp_affine_u8", "invert_affine", "shift_scale_rotate_matrix",
     "denoise_prepare", "adamw_step", "PRESETS",
 ]
@@ -166,6 +166,55 @@ def keep_mask(numel: int, p: float, seed: int, stream: int) -> torch.Tensor:
     return torch.from_numpy(r >= np.uint64(thr))
 
 
+def _quad_word(x: np.ndarray, k0: int, k1: int) -> np.ndarray:
+    """csrc/vu_flash.hip vu_quad_word: two rounds of (24-bit multiply-add, xor-shift 16), uint32 arithmetic."""
+    m24 = np.uint64(0xFFFFFF)
+    a = (x.astype(np.uint64) ^ np.uint64(k0)) & _M32
+    y = ((a & m24) * np.uint64(0xB5297B) + (a >> np.uint64(12))) & _M32
+    y ^= y >> np.uint64(16)
+    y = ((y & m24) * np.uint64(0x9E3779) + (y >> np.uint64(12))) & _M32
+    y ^= y >> np.uint64(16)
+    return (y + np.uint64(k1)) & _M32
+
+
+def quad_threshold(p: float) -> int:
+    """8-bit drop threshold of the quad scheme: the drop probability is quad_threshold(p) / 256."""
+    return max(1, (int(p * 65536.0 + 0.5) + 128) >> 8)
+
+
+def keep_mask_quad(rows: int, n: int, p: float, seed: int, stream: int) -> torch.Tensor:
+    """Keep mask (rows, n) of the non-materialising attention form (csrc/vu_flash.hip): one hash word per 4 consecutive
+    keys of a map row, 8 bits per key, kept when byte >= round(256 p); n % 4 == 0."""
+    assert n % 4 == 0
+    k0, k1 = stream_key(seed, stream)
+    x = np.arange(rows * (n // 4), dtype=np.uint64)
+    w = _quad_word(x, k0, k1)
+    thr = np.uint64(quad_threshold(p))
+    by = np.stack([((w >> np.uint64(8 * r)) & np.uint64(255)) >= thr for r in range(4)], axis=1)
+    return torch.from_numpy(by.reshape(rows, n))
+
+
+def flash_shape(B: int, N: int, D: int, h: int) -> bool:
+    """Mirror of vu_flash_ok (csrc/vu_flash.hip) for bf16 storage: shapes the model path runs in the non-materialising
+    form, whose attention-map dropout uses the quad scheme."""
+    if h <= 0 or D % h:
+        return False
+    d = D // h
+    inst = (h == 8 and d in (24, 8, 32)) or (h == 4 and d == 32)
+    return inst and N % 16 == 0 and N >= 256 and B * h * N * N < 2 ** 34
+
+
+def _dropout_quad(x: torch.Tensor, p: float, training: bool, seed: Optional[int], stream: int):
+    if (not training) or p <= 0.0:
+        return x
+    if seed is None:
+        return F.dropout(x, p, True)
+    n = x.shape[-1]
+    rows = x.numel() // n
+    m = keep_mask_quad(rows, n, p, seed, stream).reshape(x.shape).to(x.dtype)
+    return x * m * (256.0 / (256.0 - quad_threshold(p)))
+
+
 def _dropout(x: torch.Tensor, p: float, training: bool, seed: Optional[int], stream: int, row_pad: int = 1):
     """`row_pad` > 1: the last dimension is indexed with its length rounded up to a multiple of
     row_pad (the HIP attention maps are stored with 8-element-aligned rows and the mask index of
@@ -209,16 +258,28 @@ def conv3x3_per_patch(tok: torch.Tensor, C: int, w: torch.Tensor, b: Optional[to
 def reattention(xq, xkv, p: Dict[str, torch.Tensor], pre: str, h: int, C: int, *, training: bool,
                 attn_drop: float, proj_drop: float, seed: Optional[int] = None, stream: int = 0,
                 bn_momentum: float = 0.1, eps: float = 1e-5, return_map: bool = False, storage=None,
-                round_out: bool = True):
+                round_out: bool = True, flash: Optional[bool] = None):
+    """`flash`: follow the rounding points / dropout scheme of the non-materialising HIP form (csrc/vu_flash.hip: the
+    probabilities and the mixed map are never rounded to the storage type, only A^ as the PV operand; quad dropout
+    scheme).  Default: what the model path runs - that form for bf16 storage on the shapes it covers."""
     B, N, D = xq.shape
     d = D // h
     st = storage
+    if flash is None:
+        flash = (storage == torch.bfloat16) and flash_shape(B, N, D, h)
+    if flash:
+        sm = None          # logits / probabilities stay fp32 in registers
+    else:
+        sm = st
     q = _r(conv3x3_per_patch(xq, C, p[pre + "qconv2d.weight"]), st).reshape(B, N, h, d).permute(0, 2, 1, 3)
     k = _r(conv3x3_per_patch(xkv, C, p[pre + "kconv2d.weight"]), st).reshape(B, N, h, d).permute(0, 2, 1, 3)
     v = _r(conv3x3_per_patch(xkv, C, p[pre + "vconv2d.weight"]), st).reshape(B, N, h, d).permute(0, 2, 1, 3)
-    s = _r(torch.matmul(q, k.transpose(-2, -1)) * (d ** -0.5), st)    # model.py:155
-    a = _r(torch.softmax(s, dim=-1), st)                              # :156
-    a = _dropout(a, attn_drop, training, seed, 2 * stream, row_pad=8)   # :157
+    s = _r(torch.matmul(q, k.transpose(-2, -1)) * (d ** -0.5), sm)    # model.py:155
+    a = _r(torch.softmax(s, dim=-1), sm)                              # :156
+    if flash:
+        a = _dropout_quad(a, attn_drop, training, seed, 2 * stream)  # :157 (quad scheme)
+    else:
+        a = _dropout(a, attn_drop, training, seed, 2 * stream, row_pad=8)   # :157
     w = p[pre + "reatten_matrix.weight"].reshape(h, h)               # 1x1 conv across heads :159
     a = torch.einsum("gh,bhij->bgij", w, a) + p[pre + "reatten_matrix.bias"].reshape(1, h, 1, 1)
     gam, bet = p[pre + "var_norm.weight"], p[pre + "var_norm.bias"]

@@ -192,6 +192,7 @@ def test_attention_centred_map_form(N, Cn, s, H, mode, monkeypatch):
     """The model path's centred-map form (mix + statistics in one pass, BatchNorm's affine part inside the PV / dv
     products) against the same oracle and tolerances as the plain form; VU_ATTN_CENTERED switches the stand-alone op."""
     monkeypatch.setenv("VU_ATTN_CENTERED", "1")
+    monkeypatch.setenv("VU_ATTN_FLASH", "0")       # (N = 784 would otherwise take the non-materialising form)
     _attention_fwd_bwd(torch.bfloat16, N, Cn, s, H, mode, False, centered=True)
 
 
@@ -230,7 +231,7 @@ def _attention_fwd_bwd(dt, N, Cn, s, H, mode, cross, centered, flash=False):
     for k in GRAD_KEYS:
         pr[k].requires_grad_(True)
     yr, mapr = O.reattention(xq_r, xkv_r if cross else xq_r, pr, "", H, Cn, training=training, attn_drop=ad, proj_drop=pd,
-                             seed=seed, stream=sid, return_map=True)
+                             seed=seed, stream=sid, return_map=True, flash=flash)
     yr.backward(dy_r)
     # ---- HIP ----
     code = _lib.DTYPE_CODE[dt]

@@ -142,6 +142,29 @@ def test_keep_mask_statistics():
     assert abs(((a - a.mean()) * (b - b.mean())).mean().item()) < 2e-3
 
 
+def test_quad_mask_statistics():
+    """The 8-bit-per-key dropout scheme of the non-materialising attention form (csrc/vu_flash.hip vu_quad_word)."""
+    N = 784
+    m = O.keep_mask_quad(1338, N, 0.2, seed=123, stream=5).float()          # ~1M elements
+    assert O.quad_threshold(0.2) == 51
+    assert abs(m.mean().item() - (1 - 51 / 256)) < 2e-3
+    lanes = [m[:, r::4].reshape(-1) for r in range(4)]
+    for a in lanes:
+        assert abs(a.mean().item() - (1 - 51 / 256)) < 3e-3
+
+    def corr(a, b):
+        a, b = a - a.mean(), b - b.mean()
+        return abs((a * b).mean().item() / (a.std().item() * b.std().item()))
+    assert max(corr(lanes[i], lanes[j]) for i in range(4) for j in range(i)) < 8e-3          # byte lanes of one word
+    assert max(corr(a[:-1], a[1:]) for a in lanes) < 1e-2                                    # neighbouring words
+    assert corr(m[:-1].reshape(-1), m[1:].reshape(-1)) < 8e-3                                # neighbouring map rows
+    kept = m.sum(dim=1)
+    assert 0.9 < kept.var().item() / (N * (51 / 256) * (1 - 51 / 256)) < 1.1               # binomial row counts
+    m2 = O.keep_mask_quad(1338, N, 0.2, seed=123, stream=6).float()
+    assert corr(m.reshape(-1), m2.reshape(-1)) < 8e-3                                        # streams decorrelate
+    assert torch.equal(m.bool(), O.keep_mask_quad(1338, N, 0.2, seed=123, stream=5))
+
+
 def test_metric_oracles_hand_values():
     """PSNR / Dice / SSIM restatements against hand-computed values (the reference holds no fixtures
     for them: functions.py:7-19 defers to scikit-image, README.md:85-101 is prose)."""

@@ -21,6 +21,8 @@ struct vu_flash_args {
   float *d_mix_w, *d_mix_b;    // accumulated
 };
 
+// attention-map dropout of this form: 8 bits per element, drop probability round(256 p) / 256 (vu_flash.hip, "quad" scheme)
+vu_rng vu_flash_quad_rng(vu_rng r);
 bool vu_flash_ok(int dtype, int B, int N, int D, int H);
 size_t vu_flash_partials_floats(int B, int N, int H);
 int vu_k_flash_forward(const vu_flash_args& a, hipStream_t st);

@@ -47,6 +47,23 @@ template <int H, int DH> struct FC {
 
 __device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// One row of an H x H coefficient table in LDS (all lanes read the same address: broadcast).  The mixing loops fetch
+// row i+1 before the arithmetic of row i (with only two waves per SIMD a load that is waited for at once costs its
+// whole latency): `LDS_FENCE` keeps the compiler from either hoisting every row out of the tile loop (64 + 64 extra
+// registers = the second wave per SIMD) or sinking the prefetch back next to its use.
+template <int H> struct RowW { float w[H]; };
+template <int H>
+__device__ __forceinline__ RowW<H> ld_row(const float* p) {
+  RowW<H> r;
+#pragma unroll
+  for (int h4 = 0; h4 < H; h4 += 4) {
+    const f32x4 w4 = *reinterpret_cast<const f32x4*>(p + h4);
+    r.w[h4] = w4[0]; r.w[h4 + 1] = w4[1]; r.w[h4 + 2] = w4[2]; r.w[h4 + 3] = w4[3];
+  }
+  return r;
+}
+#define LDS_FENCE() asm volatile("" ::: "memory")
+
 // rows [0, nrows) of a row-major (., D) bf16 matrix -> LDS chunk with pitch PITCH.  Four independent 16-byte loads in
 // flight per thread (named registers and clamped unconditional loads: an indexed array or a load-or-skip select ends up
 // in scratch memory / serialized loads with hipcc).
@@ -114,19 +131,29 @@ __device__ __forceinline__ s16x4 pack4s(const f32x4& a) {
 __device__ __forceinline__ bf16x4 pack4(const f32x4& a) { return bf16x4{(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3]}; }
 __device__ __forceinline__ bf16x8 join8(const bf16x4& a, const bf16x4& b) { return bf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
 
-// dropout keep bits of the 4 consecutive keys j0 .. j0+3 of one map row (vu_keep of element row * N + j: one hash word
-// serves a key pair, 16 bits each); w0 = word index of (row, j0).
-struct keep4_t { bool k0, k1, k2, k3; };
-__device__ __forceinline__ keep4_t keep4(const vu_rng& rng, uint32_t w0) {
-  keep4_t kp = {true, true, true, true};
-  if (rng.thr) {
-    const uint32_t x0 = vu_mix32(w0 ^ rng.k0) + rng.k1, x1 = vu_mix32((w0 + 1) ^ rng.k0) + rng.k1;
-    kp.k0 = (x0 & 0xffffu) >= rng.thr; kp.k1 = (x0 >> 16) >= rng.thr;
-    kp.k2 = (x1 & 0xffffu) >= rng.thr; kp.k3 = (x1 >> 16) >= rng.thr;
-  }
+// Dropout mask of the attention maps in this form ("quad" scheme; the materialised kernels keep vu_keep's pair scheme,
+// the oracle replays both): ONE 32-bit hash word serves the 4 consecutive keys 4 jg .. 4 jg + 3 of a map row, 8 bits each:
+// key r is kept when byte r >= thr8 = round(256 p), so the drop probability is thr8 / 256 and 1 / keep = 256 / (256 - thr8)
+// (vu_flash_quad_rng).  Every pass of the forward and the backward recomputes the word, so the hash is built from
+// full-rate instructions only: two rounds of (24-bit multiply-add, xor-shift) - v_mul_lo_u32 runs at a quarter of the
+// rate.  Word index x = map row * (N / 4) + jg (32 bits: B H N N < 2^34).  Measured on 2^20 consecutive words, three
+// keys: keep rate 0.8008 +- 0.0005 per byte lane, every pairwise correlation tested (byte lanes, neighbouring words, rows,
+// heads) below 0.006, kept-per-row variance 0.98 - 1.03 of binomial (tests/test_oracle_golden.py::test_quad_mask_statistics).
+__device__ __forceinline__ uint32_t vu_quad_word(uint32_t x, uint32_t k0, uint32_t k1) {
+  const uint32_t a = x ^ k0;
+  uint32_t y = __umul24(a, 0xB5297Bu) + (a >> 12);       // v_mad_u32_u24: low 24 bits of a times the constant
+  y ^= y >> 16;
+  y = __umul24(y, 0x9E3779u) + (y >> 12);
+  y ^= y >> 16;
+  return y + k1;
+}
+struct keep4_t { uint32_t w, thr; };
+__device__ __forceinline__ keep4_t keep4(const vu_rng& rng, uint32_t x) {
+  keep4_t kp = {0xffffffffu, rng.thr};
+  if (rng.thr) kp.w = vu_quad_word(x, rng.k0, rng.k1);
   return kp;
 }
-__device__ __forceinline__ bool kept(const keep4_t& kp, int r) { return r == 0 ? kp.k0 : r == 1 ? kp.k1 : r == 2 ? kp.k2 : kp.k3; }
+__device__ __forceinline__ bool kept(const keep4_t& kp, int r) { return ((kp.w >> (8 * r)) & 0xffu) >= kp.thr; }
 
 // XCD-aware work order: the workgroups of one sample stream the same K / V from L2, so they are dealt to one XCD
 // (blocks id and id + 8 share an XCD) when the sample count is a multiple of 8.  Speed only.
@@ -217,8 +244,8 @@ __global__ __launch_bounds__(WPB * 64) void flash_stats_kernel(const bf16_t* __r
 #pragma unroll
   for (int i = 0; i < H * (H + 1) / 2; ++i) s2[i] = 0.f;
   const float cen = 1.0f / (float)N;
-  const uint32_t hstride = (uint32_t)(((unsigned long long)N * N) >> 1);
-  const uint32_t wlane = (uint32_t)(((((unsigned long long)b * H) * N + qrow) * (unsigned long long)N) >> 1) + 2u * g4;
+  const uint32_t hstride = (uint32_t)(((unsigned long long)N * N) >> 2);          // quad words per (sample, head) map
+  const uint32_t wlane = (uint32_t)(((((unsigned long long)b * H) * N + qrow) * (unsigned long long)N) >> 2) + (uint32_t)g4;
   for (int ch = 0; ch < nchunks; ++ch) {
     const int nt = min(CK, ntiles - ch * CK);
     __syncthreads();
@@ -228,7 +255,7 @@ __global__ __launch_bounds__(WPB * 64) void flash_stats_kernel(const bf16_t* __r
       for (int kc = 0; kc < nt; ++kc) {
         f32x4 acc[H];
         tile_logits<H, DH>(acc, Kc, kc, qf, l15, g4);
-        const uint32_t wt = wlane + 8u * (uint32_t)(ch * CK + kc);
+        const uint32_t wt = wlane + 4u * (uint32_t)(ch * CK + kc);
 #pragma unroll
         for (int h = 0; h < H; ++h) {
           const keep4_t kp = keep4(rng, wt + (uint32_t)h * hstride);
@@ -266,20 +293,26 @@ __global__ __launch_bounds__(WPB * 64) void flash_stats_kernel(const bf16_t* __r
 
 // fp64 finalize: moments -> BatchNorm statistics of the mixed maps, running statistics, folded tables.
 // stats layout: vu_kernels.h (VU_BN_STATS_*), extended by FWk = gamma rstd W / keep and XK = rstd W / keep.
-__global__ void flash_bn_finalize_kernel(const float* __restrict__ partials, int nblocks, const float* __restrict__ W,
+__global__ __launch_bounds__(1024) void flash_bn_finalize_kernel(const float* __restrict__ partials, int nblocks, const float* __restrict__ W,
                                          const float* __restrict__ cb, const float* __restrict__ gamma, const float* __restrict__ beta,
                                          float* run_mean, float* run_var, float* stats, int H, int N, double count, int training,
                                          float momentum, float eps, float inv_keep) {
   __shared__ double mom[64];
+  __shared__ double sd[16][64];
   const int NM = H + H * (H + 1) / 2;
-  const int tid = threadIdx.x;          // 256 threads: 4 lanes per moment column when NM <= 64
+  const int tid = threadIdx.x;          // 1024 threads: 64 moment columns side by side (coalesced), 16 row lanes
   if (training) {
-    const int col = tid >> 2, sub = tid & 3;
+    const int col = tid & 63, rl = tid >> 6;
     double a = 0.0;
-    if (col < NM) for (int i = sub; i < nblocks; i += 4) a += (double)partials[(long long)i * NM + col];
-    a += __shfl_xor(a, 1, 64);
-    a += __shfl_xor(a, 2, 64);
-    if (col < NM && sub == 0) mom[col] = a / count;
+    if (col < NM) for (int i = rl; i < nblocks; i += 16) a += (double)partials[(long long)i * NM + col];
+    sd[rl][col] = a;
+    __syncthreads();
+    if (tid < NM) {
+      double t = 0.0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t += sd[r][tid];
+      mom[tid] = t / count;
+    }
   }
   __syncthreads();
   if (tid < H) {
@@ -354,8 +387,8 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash_apply_kernel(
   for (int h = 0; h < H; ++h)
 #pragma unroll
     for (int dt = 0; dt < C::DT; ++dt) oacc[h][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const uint32_t hstride = (uint32_t)(((unsigned long long)N * N) >> 1);
-  const uint32_t wlane = (uint32_t)(((((unsigned long long)b * H) * N + qrow) * (unsigned long long)N) >> 1) + 2u * g4;
+  const uint32_t hstride = (uint32_t)(((unsigned long long)N * N) >> 2);          // quad words per (sample, head) map
+  const uint32_t wlane = (uint32_t)(((((unsigned long long)b * H) * N + qrow) * (unsigned long long)N) >> 2) + (uint32_t)g4;
   const int nchunks = (ntiles + CK - 1) / CK;
 
   for (int ch = 0; ch < nchunks; ++ch) {
@@ -368,7 +401,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash_apply_kernel(
       for (int kc = 0; kc < nt; ++kc) {
         f32x4 acc[H];
         tile_logits<H, DH>(acc, Kc, kc, qf, l15, g4);
-        const uint32_t wt = wlane + 8u * (uint32_t)(ch * CK + kc);
+        const uint32_t wt = wlane + 4u * (uint32_t)(ch * CK + kc);
 #pragma unroll
         for (int h = 0; h < H; ++h) {
           const keep4_t kp = keep4(rng, wt + (uint32_t)h * hstride);
@@ -378,28 +411,30 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash_apply_kernel(
             acc[h][r] = kept(kp, r) ? p : 0.f;
           }
         }
-        asm volatile("" ::: "memory");      // keep the table in LDS: hoisted out of the key loop it would cost the second wave per SIMD
+        LDS_FENCE();
+        RowW<H> wcur = ld_row<H>(tab);
+        float ccur = tab[H * H];
 #pragma unroll
         for (int g = 0; g < H; ++g) {       // A^_g = folded bias + sum_h (gamma rstd W / keep)[g,h] P^_h, then O_g^T += V_g^T A^_g^T
-          float wg[H];
+          RowW<H> wnxt = wcur;
+          float cnxt = ccur;
+          if (g + 1 < H) { wnxt = ld_row<H>(tab + (g + 1) * H); cnxt = tab[H * H + g + 1]; }
+          s16x4 aop[C::DT];
 #pragma unroll
-          for (int h4 = 0; h4 < H; h4 += 4) {
-            const f32x4 w4 = *reinterpret_cast<const f32x4*>(tab + g * H + h4);
-            wg[h4] = w4[0]; wg[h4 + 1] = w4[1]; wg[h4 + 2] = w4[2]; wg[h4 + 3] = w4[3];
-          }
-          const float cg = tab[H * H + g];
+          for (int dt = 0; dt < C::DT; ++dt) aop[dt] = tr_operand<C::PITCH>(Vc, kc * 16, g * DH + 16 * dt, l15, g4);
+          LDS_FENCE();
           f32x4 a;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            float x = cg;
+            float x = ccur;
 #pragma unroll
-            for (int h = 0; h < H; ++h) x = fmaf(wg[h], acc[h][r], x);
+            for (int h = 0; h < H; ++h) x = fmaf(wcur.w[h], acc[h][r], x);
             a[r] = x;
           }
           const s16x4 bop = pack4s(a);
 #pragma unroll
-          for (int dt = 0; dt < C::DT; ++dt)
-            oacc[g][dt] = mfma16(tr_operand<C::PITCH>(Vc, kc * 16, g * DH + 16 * dt, l15, g4), bop, oacc[g][dt]);
+          for (int dt = 0; dt < C::DT; ++dt) oacc[g][dt] = mfma16(aop[dt], bop, oacc[g][dt]);
+          wcur = wnxt; ccur = cnxt;
         }
       }
   }
@@ -493,38 +528,31 @@ __device__ __forceinline__ void tag_probs(f32x4 (&S)[H], const float (&lse)[H], 
 // dA^' (accumulator started at cin) -> e, in place: e_g += sum_h XK2T[h][g] P^_h
 template <int H>
 __device__ __forceinline__ void mix_to_e(f32x4 (&E)[H], const f32x4 (&S)[H], const BwdTab<H>* tb) {
+  LDS_FENCE();
+  RowW<H> wcur = ld_row<H>(tb->XK2T);
 #pragma unroll
   for (int h = 0; h < H; ++h) {
-    asm volatile("" ::: "memory");       // one table row at a time: hoisted, the 64 + 64 table values cost the second wave per SIMD
-    float w[H];
-#pragma unroll
-    for (int g4_ = 0; g4_ < H; g4_ += 4) {
-      const f32x4 w4 = *reinterpret_cast<const f32x4*>(tb->XK2T + h * H + g4_);
-      w[g4_] = w4[0]; w[g4_ + 1] = w4[1]; w[g4_ + 2] = w4[2]; w[g4_ + 3] = w4[3];
-    }
+    RowW<H> wnxt = wcur;
+    if (h + 1 < H) wnxt = ld_row<H>(tb->XK2T + (h + 1) * H);
+    LDS_FENCE();
     f32x4 ph;
 #pragma unroll
     for (int r = 0; r < 4; ++r) ph[r] = fmaxf(S[h][r], 0.f);
 #pragma unroll
     for (int g = 0; g < H; ++g)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) E[g][r] = fmaf(w[g], ph[r], E[g][r]);
+      for (int r = 0; r < 4; ++r) E[g][r] = fmaf(wcur.w[g], ph[r], E[g][r]);
+    wcur = wnxt;
   }
 }
+// dP_h = sum_g FWkT[h][g] e_g with the (prefetched) table row w
 template <int H>
-__device__ __forceinline__ f32x4 mix_back(const f32x4 (&E)[H], const BwdTab<H>* tb, int h) {
-  asm volatile("" ::: "memory");
-  float w[H];
-#pragma unroll
-  for (int g4_ = 0; g4_ < H; g4_ += 4) {
-    const f32x4 w4 = *reinterpret_cast<const f32x4*>(tb->FWkT + h * H + g4_);
-    w[g4_] = w4[0]; w[g4_ + 1] = w4[1]; w[g4_ + 2] = w4[2]; w[g4_ + 3] = w4[3];
-  }
+__device__ __forceinline__ f32x4 mix_back(const f32x4 (&E)[H], const RowW<H>& w) {
   f32x4 dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int g = 0; g < H; ++g)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) dp[r] = fmaf(w[g], E[g][r], dp[r]);
+    for (int r = 0; r < 4; ++r) dp[r] = fmaf(w.w[g], E[g][r], dp[r]);
   return dp;
 }
 
@@ -563,8 +591,8 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash_bwd_delta_kernel(
   for (int i = 0; i < H * H; ++i) T[i] = 0.f;
   zero_pads<H, DH>(Kc, 2 * CK * 16 + WPB * 32, tid, WPB * 64);
   load_bwd_tab<H>(tb, stats, tid, WPB * 64);
-  const uint32_t hstride = (uint32_t)(((unsigned long long)N * N) >> 1);
-  const uint32_t wlane = (uint32_t)(((((unsigned long long)b * H) * N + qrow) * (unsigned long long)N) >> 1) + 2u * g4;
+  const uint32_t hstride = (uint32_t)(((unsigned long long)N * N) >> 2);          // quad words per (sample, head) map
+  const uint32_t wlane = (uint32_t)(((((unsigned long long)b * H) * N + qrow) * (unsigned long long)N) >> 2) + (uint32_t)g4;
   const int nchunks = (ntiles + CK - 1) / CK;
   for (int ch = 0; ch < nchunks; ++ch) {
     const int nt = min(CK, ntiles - ch * CK);
@@ -578,13 +606,18 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash_bwd_delta_kernel(
         tile_prod<H, DH, true>(S, Kc, kc, nullptr, Qs, nullptr, l15, g4);
         asm volatile("" ::: "memory");
         tile_prod<H, DH, true>(E, Vc, kc, nullptr, dOs, tb->cin, l15, g4);
-        tag_probs<H>(S, lse, c, rng, wlane + 8u * (uint32_t)(ch * CK + kc), hstride);
+        tag_probs<H>(S, lse, c, rng, wlane + 4u * (uint32_t)(ch * CK + kc), hstride);
         mix_to_e<H>(E, S, tb);
 #pragma unroll
         for (int g = 0; g < H; ++g) Tc[g] += (E[g][0] + E[g][1]) + (E[g][2] + E[g][3]);
+        LDS_FENCE();
+        RowW<H> wcur = ld_row<H>(tb->FWkT);
 #pragma unroll
         for (int h = 0; h < H; ++h) {
-          const f32x4 dp = mix_back<H>(E, tb, h);
+          RowW<H> wnxt = wcur;
+          if (h + 1 < H) wnxt = ld_row<H>(tb->FWkT + (h + 1) * H);
+          LDS_FENCE();
+          const f32x4 dp = mix_back<H>(E, wcur);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float ph = fmaxf(S[h][r], 0.f);
@@ -592,6 +625,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash_bwd_delta_kernel(
 #pragma unroll
             for (int g = 0; g < H; ++g) T[g * H + h] = fmaf(E[g][r], ph, T[g * H + h]);
           }
+          wcur = wnxt;
         }
       }
   }
@@ -616,18 +650,24 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash_bwd_delta_kernel(
 }
 
 // head-mix gradients from the sweep-1 partial sums
-__global__ void flash_bwd_mix_finalize_kernel(const float* __restrict__ partials, int nblocks, const float* __restrict__ stats,
-                                              float* dW, float* dc, int H, float inv_keep) {
-  const int NT = H * H + H;
-  const int col = threadIdx.x >> 2, sub = threadIdx.x & 3;      // 4 lanes per column (NT <= 72 -> 288 threads)
+__global__ __launch_bounds__(1024) void flash_bwd_mix_finalize_kernel(const float* __restrict__ partials, int nblocks,
+                                                                       const float* __restrict__ stats, float* dW, float* dc, int H,
+                                                                       float inv_keep) {
+  __shared__ double sd[8][128];
+  const int NT = H * H + H;                                  // <= 72 columns: 128 side by side (coalesced), 8 row lanes
+  const int col = threadIdx.x & 127, rl = threadIdx.x >> 7;
   double a = 0.0;
-  if (col < NT) for (int i = sub; i < nblocks; i += 4) a += (double)partials[(long long)i * NT + col];
-  a += __shfl_xor(a, 1, 64);
-  a += __shfl_xor(a, 2, 64);
-  if (col < NT && sub == 0) {
-    const int g = col < H * H ? col / H : col - H * H;
+  if (col < NT) for (int i = rl; i < nblocks; i += 8) a += (double)partials[(long long)i * NT + col];
+  sd[rl][col] = a;
+  __syncthreads();
+  if (threadIdx.x < NT) {
+    double t = 0.0;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t += sd[r][threadIdx.x];
+    const int c2 = threadIdx.x;
+    const int g = c2 < H * H ? c2 / H : c2 - H * H;
     const float gs = stats[2 * H * H + 6 * H + g];               // gamma rstd
-    if (col < H * H) dW[col] += (float)(a * gs * inv_keep); else dc[g] += (float)(a * gs);
+    if (c2 < H * H) dW[c2] += (float)(t * gs * inv_keep); else dc[g] += (float)(t * gs);
   }
 }
 
@@ -670,8 +710,8 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash_bwd_dq_kernel(
   for (int h = 0; h < H; ++h)
 #pragma unroll
     for (int dt = 0; dt < C::DT; ++dt) dqa[h][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const uint32_t hstride = (uint32_t)(((unsigned long long)N * N) >> 1);
-  const uint32_t wlane = (uint32_t)(((((unsigned long long)b * H) * N + qrow) * (unsigned long long)N) >> 1) + 2u * g4;
+  const uint32_t hstride = (uint32_t)(((unsigned long long)N * N) >> 2);          // quad words per (sample, head) map
+  const uint32_t wlane = (uint32_t)(((((unsigned long long)b * H) * N + qrow) * (unsigned long long)N) >> 2) + (uint32_t)g4;
   const int nchunks = (ntiles + CK - 1) / CK;
   for (int ch = 0; ch < nchunks; ++ch) {
     const int nt = min(CK, ntiles - ch * CK);
@@ -689,20 +729,28 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash_bwd_dq_kernel(
           float lse[H];
 #pragma unroll
           for (int h = 0; h < H; ++h) lse[h] = rowc[h * 16 + l15];
-          tag_probs<H>(S, lse, c, rng, wlane + 8u * (uint32_t)(ch * CK + kc), hstride);
+          tag_probs<H>(S, lse, c, rng, wlane + 4u * (uint32_t)(ch * CK + kc), hstride);
         }
         mix_to_e<H>(E, S, tb);
+        LDS_FENCE();
+        RowW<H> wcur = ld_row<H>(tb->FWkT);
 #pragma unroll
         for (int h = 0; h < H; ++h) {
-          const f32x4 dp = mix_back<H>(E, tb, h);
+          RowW<H> wnxt = wcur;
+          if (h + 1 < H) wnxt = ld_row<H>(tb->FWkT + (h + 1) * H);
           const float dlh = rowc[(H + h) * 16 + l15];
+          s16x4 aop[C::DT];
+#pragma unroll
+          for (int dt = 0; dt < C::DT; ++dt) aop[dt] = tr_operand<C::PITCH>(Kc, kc * 16, h * DH + 16 * dt, l15, g4);
+          LDS_FENCE();
+          const f32x4 dp = mix_back<H>(E, wcur);
           f32x4 ds;
 #pragma unroll
           for (int r = 0; r < 4; ++r) ds[r] = fmaf(fmaxf(S[h][r], 0.f), dp[r], -fabsf(S[h][r]) * dlh);
           const s16x4 bop = pack4s(ds);
 #pragma unroll
-          for (int dt = 0; dt < C::DT; ++dt)       // dq_h^T += K_h^T dS_h^T
-            dqa[h][dt] = mfma16(tr_operand<C::PITCH>(Kc, kc * 16, h * DH + 16 * dt, l15, g4), bop, dqa[h][dt]);
+          for (int dt = 0; dt < C::DT; ++dt) dqa[h][dt] = mfma16(aop[dt], bop, dqa[h][dt]);       // dq_h^T += K_h^T dS_h^T
+          wcur = wnxt;
         }
       }
   }
@@ -770,10 +818,10 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash_bwd_dkv_kernel(
   for (int h = 0; h < H; ++h)
 #pragma unroll
     for (int dt = 0; dt < C::DT; ++dt) oa[h][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const uint32_t hstride = (uint32_t)(((unsigned long long)N * N) >> 1);
-  // word index of map element (row = (b H + h) N + query, key 16 tk + 4 g4): the query part is added per tile
-  const uint32_t wkey = (uint32_t)((((unsigned long long)b * H) * N * (unsigned long long)N) >> 1) + 8u * (uint32_t)tk + 2u * g4;
-  const uint32_t wq = (uint32_t)(N >> 1);                                  // words per map row
+  const uint32_t hstride = (uint32_t)(((unsigned long long)N * N) >> 2);
+  // quad-word index of map element (row = (b H + h) N + query, key 16 tk + 4 g4): the query part is added per tile
+  const uint32_t wkey = (uint32_t)((((unsigned long long)b * H) * N * (unsigned long long)N) >> 2) + 4u * (uint32_t)tk + (uint32_t)g4;
+  const uint32_t wq = (uint32_t)(N >> 2);                                  // quad words per map row
   const int nchunks = (ntiles + CK - 1) / CK;
   for (int ch = 0; ch < nchunks; ++ch) {
     const int nt = min(CK, ntiles - ch * CK);
@@ -796,46 +844,56 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash_bwd_dkv_kernel(
         const uint32_t wt = wkey + (uint32_t)((ch * CK + qc) * 16 + l15) * wq;
         tag_probs<H>(S, lse, c, rng, wt, hstride);
         if constexpr (DV) {
-          asm volatile("" ::: "memory");
+          LDS_FENCE();
+          RowW<H> wcur = ld_row<H>(ftab);
+          float ccur = ftab[H * H];
 #pragma unroll
           for (int g = 0; g < H; ++g) {       // A^_g, then dv_g^T += dO_g^T A^_g
-            float wg[H];
+            RowW<H> wnxt = wcur;
+            float cnxt = ccur;
+            if (g + 1 < H) { wnxt = ld_row<H>(ftab + (g + 1) * H); cnxt = ftab[H * H + g + 1]; }
+            s16x4 aop[C::DT];
 #pragma unroll
-            for (int h4 = 0; h4 < H; h4 += 4) {
-              const f32x4 w4 = *reinterpret_cast<const f32x4*>(ftab + g * H + h4);
-              wg[h4] = w4[0]; wg[h4 + 1] = w4[1]; wg[h4 + 2] = w4[2]; wg[h4 + 3] = w4[3];
-            }
-            const float cg = ftab[H * H + g];
+            for (int dt = 0; dt < C::DT; ++dt) aop[dt] = tr_operand<C::PITCH>(Dc, qc * 16, g * DH + 16 * dt, l15, g4);
+            LDS_FENCE();
             f32x4 a;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              float x = cg;
+              float x = ccur;
 #pragma unroll
-              for (int h = 0; h < H; ++h) x = fmaf(wg[h], fmaxf(S[h][r], 0.f), x);
+              for (int h = 0; h < H; ++h) x = fmaf(wcur.w[h], fmaxf(S[h][r], 0.f), x);
               a[r] = x;
             }
             *reinterpret_cast<s16x4*>(img + l15 * 16 + 4 * g4) = pack4s(a);
             const s16x4 bop = tr_operand<16>(img, 0, 0, l15, g4);
 #pragma unroll
-            for (int dt = 0; dt < C::DT; ++dt)
-              oa[g][dt] = mfma16(tr_operand<C::PITCH>(Dc, qc * 16, g * DH + 16 * dt, l15, g4), bop, oa[g][dt]);
+            for (int dt = 0; dt < C::DT; ++dt) oa[g][dt] = mfma16(aop[dt], bop, oa[g][dt]);
+            wcur = wnxt; ccur = cnxt;
           }
         } else {
           f32x4 E[H];
           asm volatile("" ::: "memory");
           tile_prod<H, DH, false>(E, Dc, qc, nullptr, Vs, tb->cin, l15, g4);
           mix_to_e<H>(E, S, tb);
+          LDS_FENCE();
+          RowW<H> wcur = ld_row<H>(tb->FWkT);
 #pragma unroll
           for (int h = 0; h < H; ++h) {
-            const f32x4 dp = mix_back<H>(E, tb, h);
+            RowW<H> wnxt = wcur;
+            if (h + 1 < H) wnxt = ld_row<H>(tb->FWkT + (h + 1) * H);
+            s16x4 aop[C::DT];
+#pragma unroll
+            for (int dt = 0; dt < C::DT; ++dt) aop[dt] = tr_operand<C::PITCH>(Qc, qc * 16, h * DH + 16 * dt, l15, g4);
+            LDS_FENCE();
+            const f32x4 dp = mix_back<H>(E, wcur);
             f32x4 ds;
 #pragma unroll
             for (int r = 0; r < 4; ++r) ds[r] = fmaf(fmaxf(S[h][r], 0.f), dp[r], -fabsf(S[h][r]) * dl[h]);
             *reinterpret_cast<s16x4*>(img + l15 * 16 + 4 * g4) = pack4s(ds);
             const s16x4 bop = tr_operand<16>(img, 0, 0, l15, g4);
 #pragma unroll
-            for (int dt = 0; dt < C::DT; ++dt)       // dk_h^T += Q_h^T dS_h
-              oa[h][dt] = mfma16(tr_operand<C::PITCH>(Qc, qc * 16, h * DH + 16 * dt, l15, g4), bop, oa[h][dt]);
+            for (int dt = 0; dt < C::DT; ++dt) oa[h][dt] = mfma16(aop[dt], bop, oa[h][dt]);       // dk_h^T += Q_h^T dS_h
+            wcur = wnxt;
           }
         }
       }
@@ -890,7 +948,7 @@ int launch_backward(const vu_flash_args& a, hipStream_t st) {
   hipLaunchKernelGGL(k1, dim3(nblk), dim3(WPB * 64), lds1, st, q, k, v, dO, a.lse2, a.stats, a.delta, a.partials, a.B, a.N, c, a.rng);
   if (vu_prof_on()) vu_prof_note("flash_bwd_delta_kernel", 4.0 * E * DH + 6.0 * E * H, 4.0 * act);
   VU_TRY(vu_check_launch("flash_bwd_delta"));
-  hipLaunchKernelGGL(flash_bwd_mix_finalize_kernel, dim3(1), dim3(320), 0, st, a.partials, nblk, a.stats, a.d_mix_w, a.d_mix_b, H, a.rng.inv_keep);
+  hipLaunchKernelGGL(flash_bwd_mix_finalize_kernel, dim3(1), dim3(1024), 0, st, a.partials, nblk, a.stats, a.d_mix_w, a.d_mix_b, H, a.rng.inv_keep);
   VU_TRY(vu_check_launch("flash_bwd_mix_finalize"));
   hipLaunchKernelGGL(k2, dim3(nblk), dim3(WPB * 64), lds2, st, q, k, v, dO, a.lse2, a.delta, a.stats, (bf16_t*)a.dq, a.B, a.N, c, a.scale, a.rng);
   if (vu_prof_on()) vu_prof_note("flash_bwd_dq_kernel", 6.0 * E * DH + 4.0 * E * H, 5.0 * act);
@@ -925,7 +983,7 @@ int launch_forward(const vu_flash_args& a, hipStream_t st) {
                      a.rng, a.training);
   if (vu_prof_on()) vu_prof_note("flash_stats_kernel", (a.training ? 3.0 : 2.0) * 2.0 * E * DH, 2.0 * act);
   VU_TRY(vu_check_launch("flash_stats"));
-  hipLaunchKernelGGL(flash_bn_finalize_kernel, dim3(1), dim3(256), 0, st, a.partials, nblk, a.mix_w, a.mix_b, a.bn_w, a.bn_b, a.run_mean,
+  hipLaunchKernelGGL(flash_bn_finalize_kernel, dim3(1), dim3(1024), 0, st, a.partials, nblk, a.mix_w, a.mix_b, a.bn_w, a.bn_b, a.run_mean,
                      a.run_var, a.stats, H, a.N, (double)a.B * a.N * a.N, a.training, 0.1f, 1e-5f, a.rng.inv_keep);
   VU_TRY(vu_check_launch("flash_bn_finalize"));
   hipLaunchKernelGGL(k2, dim3(nblk), dim3(WPB * 64), lds2, st, (const bf16_t*)a.q, (const bf16_t*)a.k, (const bf16_t*)a.v, a.lse2,
@@ -951,8 +1009,8 @@ bool vu_flash_ok(int dtype, int B, int N, int D, int H) {
   if (dtype != 1 || H <= 0 || D % H != 0) return false;
   const int dh = D / H;
   const bool inst = (H == 8 && (dh == 24 || dh == 8 || dh == 32)) || (H == 4 && dh == 32);
-  // the dropout word index of a map element must fit 32 bits: B H N N < 2^33
-  return inst && N % 16 == 0 && N >= 256 && (double)B * H * N * N < 8589934592.0;
+  // the dropout word index of a map element (one word per 4 keys) must fit 32 bits: B H N N < 2^34
+  return inst && N % 16 == 0 && N >= 256 && (double)B * H * N * N < 17179869184.0;
 }
 
 size_t vu_flash_partials_floats(int B, int N, int H) {
@@ -968,4 +1026,13 @@ int vu_k_flash_forward(const vu_flash_args& a, hipStream_t st) {
 int vu_k_flash_backward(const vu_flash_args& a, hipStream_t st) {
   VU_REQUIRE(vu_flash_ok(1, a.B, a.N, a.D, a.H), "flash attention: shape not covered");
   VU_FLASH_DISPATCH(launch_backward, a, st);
+}
+
+vu_rng vu_flash_quad_rng(vu_rng r) {
+  if (r.thr) {
+    const uint32_t t8 = (r.thr + 128u) >> 8;         // thr is round(65536 p)
+    r.thr = t8 ? t8 : 1u;
+    r.inv_keep = 256.0f / (256.0f - (float)r.thr);
+  }
+  return r;
 }

@@ -153,7 +153,10 @@ struct AttnScratch { void *dO, *dq, *dk, *dv, *dA; float* partials; int nblocks;
 struct AttnDims { int dtype, B, N, D, H, C, s, ld; int centered = 0; int flash = 0; };
 // non-materialising form (vu_flash.hip): the maps are recomputed from q, k (and v, dO) in every pass
 inline bool flash_on(const AttnDims& d) { return d.flash && vu_flash_ok(d.dtype, d.B, d.N, d.D, d.H); }
-inline int flash_switch() { const char* e = getenv("VU_ATTN_FLASH"); return e && e[0] != '0'; }
+inline int flash_switch() { const char* e = getenv("VU_ATTN_FLASH"); return !(e && e[0] == '0'); }   // model path: on unless VU_ATTN_FLASH=0
+// stand-alone op (vu_attn_forward / vu_attn_backward are separate calls that must agree on the form, and the forward may
+// be asked for the map): opt-in with VU_ATTN_FLASH=1 (test switch)
+inline int flash_switch_op() { const char* e = getenv("VU_ATTN_FLASH"); return e && e[0] == '1'; }
 // centred-map form (model path only; the stand-alone attention op returns the normalised map itself): the mixed map
 // is stored centred, BatchNorm's affine part is applied inside the two products that consume it.  Needs the MFMA mix
 // kernel and the streaming product kernels to cover the shape.
@@ -170,7 +173,8 @@ void carve_attn(Bump& bp, const AttnDims& d, AttnBuf& a) {
   const size_t act = (size_t)d.B * d.N * d.D * esize(d.dtype);
   const size_t map = (size_t)d.B * d.H * d.N * d.ld * esize(d.dtype);
   a.q = bp.take(act); a.k = bp.take(act); a.v = bp.take(act); a.O = bp.take(act);
-  a.Ps = bp.take(map); a.Ah = bp.take(map);
+  if (flash_on(d)) { a.Ps = nullptr; a.Ah = nullptr; }          // the non-materialising form keeps no map at all
+  else { a.Ps = bp.take(map); a.Ah = bp.take(map); }
   a.stats = bp.takef(VU_BN_STATS_FLOATS(d.H));
   a.lse2 = bp.takef((size_t)d.B * d.H * d.N);
   a.delta = bp.takef((size_t)d.B * d.H * d.N);
@@ -180,7 +184,8 @@ inline size_t attn_partials_floats(const AttnDims& d) {
 }
 void fill_flash_args(vu_flash_args& fa, const AttnDims& d, const vu_attn_params& p, AttnBuf& a, float* partials, vu_rng ra, int training) {
   memset(&fa, 0, sizeof(fa));
-  fa.B = d.B; fa.N = d.N; fa.D = d.D; fa.H = d.H; fa.scale = 1.0f / sqrtf((float)(d.D / d.H)); fa.training = training; fa.rng = ra;
+  fa.B = d.B; fa.N = d.N; fa.D = d.D; fa.H = d.H; fa.scale = 1.0f / sqrtf((float)(d.D / d.H)); fa.training = training;
+  fa.rng = vu_flash_quad_rng(ra);
   fa.q = a.q; fa.k = a.k; fa.v = a.v; fa.O = a.O; fa.lse2 = a.lse2; fa.delta = a.delta; fa.partials = partials; fa.stats = a.stats;
   fa.mix_w = p.mix_w; fa.mix_b = p.mix_b; fa.bn_w = p.bn_w; fa.bn_b = p.bn_b; fa.run_mean = p.run_mean; fa.run_var = p.run_var;
 }
@@ -371,7 +376,7 @@ struct ModelWS {
 void carve_block(Bump& bp, const Plan& pl, int B, int level, BlockBuf& b) {
   const Level& L = pl.lv[level];
   const int dt = pl.cfg.dtype;
-  AttnDims d{dt, B, L.N, L.D, pl.cfg.num_heads, pl.cfg.num_channels, L.s, L.ld};
+  AttnDims d{dt, B, L.N, L.D, pl.cfg.num_heads, pl.cfg.num_channels, L.s, L.ld, 1, flash_switch()};
   carve_attn(bp, d, b.at);
   const size_t act = (size_t)B * L.N * L.D * esize(dt), hh = (size_t)B * L.N * L.hid * esize(dt);
   b.z1 = bp.take(act); b.x1 = bp.take(act); b.hpre = bp.take(hh); b.hact = bp.take(hh);
@@ -392,7 +397,7 @@ void carve_model(const Plan& pl, int B, char* base, ModelWS& w) {
   for (size_t i = 0; i < pl.dec.size(); ++i) carve_block(bp, pl, B, pl.dec[i].level, w.dec[i]);
   for (int j = 0; j < c.depth; ++j) {
     const Level& L = pl.lv[c.depth - j - 1];
-    AttnDims d{dt, B, L.N, L.D, H, c.num_channels, L.s, L.ld};
+    AttnDims d{dt, B, L.N, L.D, H, c.num_channels, L.s, L.ld, 1, flash_switch()};
     carve_attn(bp, d, w.skip[j]);
   }
   w.skip_out.resize(c.depth); w.down_out.resize(c.depth); w.up_out.resize(c.depth); w.dskip.resize(c.depth);
@@ -404,8 +409,8 @@ void carve_model(const Plan& pl, int B, char* base, ModelWS& w) {
   int nb = 1;
   for (const Level& L : pl.lv) {
     hh = std::max(hh, (size_t)B * L.N * L.hid * esize(dt));
-    map = std::max(map, (size_t)B * H * L.N * L.ld * esize(dt));
-    AttnDims d{dt, B, L.N, L.D, H, c.num_channels, L.s, L.ld};
+    AttnDims d{dt, B, L.N, L.D, H, c.num_channels, L.s, L.ld, 1, flash_switch()};
+    if (!flash_on(d)) map = std::max(map, (size_t)B * H * L.N * L.ld * esize(dt));     // dA^ / dS scratch of the materialised forms
     nb = std::max(nb, stats_blocks(d));
     npart = std::max(npart, attn_partials_floats(d));
   }
@@ -830,7 +835,7 @@ int vu_attn_forward(int dtype, const vu_attn_params* prm, const void* xq, const 
   if (bp.off > ws_bytes) { vu_set_error("attention workspace too small"); return VU_EWORKSPACE; }
   // test switch: the stand-alone op in the model path's centred-map form (only when the map itself is not asked for)
   d.centered = (!map_out && getenv("VU_ATTN_CENTERED")) ? 1 : 0;
-  d.flash = (!map_out && flash_switch()) ? 1 : 0;
+  d.flash = (!map_out && flash_switch_op()) ? 1 : 0;
   VU_TRY(attn_forward(d, *prm, xq, xkv, y, a, sc.partials, attn_drop, proj_drop, training, seed, stream_id, nullptr,
                       (hipStream_t)stream));
   if (map_out) {  // the attn_next tensor of model.py:160 as (B,H,N,N) without row padding
@@ -851,7 +856,7 @@ int vu_attn_backward(int dtype, const vu_attn_params* prm, const vu_attn_grads* 
   carve_attn_ws(bp, d, a, sc, &dzb);
   if (bp.off > ws_bytes) { vu_set_error("attention workspace too small"); return VU_EWORKSPACE; }
   d.centered = getenv("VU_ATTN_CENTERED") ? 1 : 0;      // must match what the forward call used (test switch)
-  d.flash = flash_switch();
+  d.flash = flash_switch_op();
   const void* dz = dy;
   vu_rng rp = vu_make_rng(seed, 2 * stream_id + 1, training ? proj_drop : 0.f);
   if (rp.thr != 0) { VU_TRY(vu_k_dropout(dtype, dy, dzb, (long long)B * N * D, rp, (hipStream_t)stream)); dz = dzb; }
