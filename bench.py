@@ -35,11 +35,13 @@ HBM_PEAK_GBS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--model", default="base", choices=["lite", "base", "large", "seg512"],
                     help="seg512 = BASELINE config 5 shape: Base ctor at 512x512x1, Dice loss on a sigmoid head")
-    ap.add_argument("--batch", type=int, default=64, help="images per GPU")
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU (weak scaling: the default mode)")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="strong scaling: this many images per step over ALL GPUs (BASELINE config 3: 64 over 2 / 4 GPUs)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-graph", action="store_true", help="N=1: launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -101,6 +103,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.global_batch:
+        if a.global_batch % world:
+            raise SystemExit(f"--global-batch {a.global_batch} is not a multiple of {world} ranks")
+        a.batch = a.global_batch // world
     if a.gpus > 1 and world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} needs torchrun with {a.gpus} ranks (WORLD_SIZE={world})")
     torch.cuda.set_device(local)
@@ -129,10 +135,13 @@ def main():
         x = (y + 0.1 * torch.randn(y.shape, generator=g)).clamp(0, 1)
     x, y = x.to(dev), y.to(dev)
     ts = TrainStep(model, lr=1e-4, seed=1234 + rank, loss="dice" if seg else "mse")
-    use_graph = not dp and not a.no_graph
-    if use_graph:
+    use_graph = not a.no_graph
+    if use_graph and not dp:
         ts.capture(x, y)
         step = lambda: ts.replay()                          # noqa: E731  (inputs stay resident)
+    elif use_graph:
+        ts.capture_dp(x, y)                                 # one hipGraph per gradient bucket, collectives in between
+        step = lambda: ts.replay()                          # noqa: E731
     else:
         step = lambda: ts.step(x, y)                        # noqa: E731
 
@@ -145,11 +154,18 @@ def main():
     for _ in range(a.warmup):
         step()
     fence()
+    # the contract's clock: EXACTLY `steps` steps between two fences (barrier + device synchronize), max over ranks;
+    # besides it, a HIP event after every step on the compute stream: the median per-step time
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    evs[0].record()
+    for i in range(a.steps):
         step()
+        evs[i + 1].record()
     fence()
     dt_s = time.perf_counter() - t0
+    per_step = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(a.steps))
+    med_ms = per_step[len(per_step) // 2]
     if dp:
         t = torch.tensor([dt_s], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -229,7 +245,8 @@ def main():
             traffic, tsrc = None, None
             try:      # HBM bytes per launch from the committed rocprofv3 --pmc passes (not collectable in-process)
                 import glob
-                for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))[::-1]:
+                for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{a.model}_pmc_traffic.json")) or
+                                glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))[::-1]:
                     # several template instances can share the name: the dominant launch is the one with most traffic
                     for sym, rec in json.load(open(f))["kernels"].items():
                         if name.split("<")[0] in sym and rec.get("traffic_bytes") and rec["traffic_bytes"] > (traffic or 0):
@@ -256,7 +273,8 @@ def main():
         mname = "Base@512" if seg else a.model.capitalize()
         out = {"metric": f"images/sec ({shape}) ViT_UNet-{mname} train step",
                "value": value, "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-               "ms_per_step": dt_s / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+               "ms_per_step": dt_s / a.steps * 1e3, "ms_per_step_median_hip_events": med_ms,
+               "higher_is_better": True, "scaling": "strong" if a.global_batch else "weak",
                "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
                "config": {"workload": f"ViT_UNet-{mname} train step: forward + {lossn} + backward + "
                                       f"AdamW on synthetic " + ("CT-style 512x512x1 image/mask pairs" if seg else

@@ -78,6 +78,19 @@ int vu_model_backward(const vu_config* cfg, const float* params, const void* sha
                       size_t ws_bytes, int B, int training, uint64_t seed, const uint32_t* rng_salt,
                       int stage, void* stream);
 
+/* The same backward cut into UNITS in reverse execution order (unit 0 = output conv; then per decoder block, last
+ * first, preceded by the SkipConnection that follows it in the forward; bottleneck blocks; encoder blocks; last unit =
+ * positional embedding + dx), so that a data-parallel caller can start the all-reduce of a gradient bucket as soon
+ * as the units producing it are enqueued.  vu_model_backward_unit_ranges fills lo_hi[2u], lo_hi[2u+1] with
+ * the arena range [lo, hi) of unit u's parameter gradients.  Units must be run in order, each exactly once per step;
+ * any split of [0, n) into calls is equivalent to vu_model_backward(stage = 0). */
+int vu_model_num_backward_units(const vu_config* cfg);
+int vu_model_backward_unit_ranges(const vu_config* cfg, long long* lo_hi, int capacity);
+int vu_model_backward_units(const vu_config* cfg, const float* params, const void* shadow,
+                            const float* bn_state, float* grads, const float* dy, float* dx, void* ws,
+                            size_t ws_bytes, int B, int training, uint64_t seed, const uint32_t* rng_salt,
+                            int first_unit, int last_unit, void* stream);
+
 /* ---- per-op entry points (used by the parity tests and by the stand-alone sub-modules) ---- */
 
 /* patch / unpatch / downsampling / upsampling (model.py:8-53): one latent image re-tiled from

@@ -14,7 +14,7 @@ import torch.multiprocessing as mp
 
 import vit_unet_oracle as O
 from vit_unet.torch import _lib
-from vit_unet.torch.engine import allreduce_bucket, dp_buckets
+from vit_unet.torch.engine import allreduce_bucket, dp_buckets, dp_unit_buckets
 
 KW = dict(depth=1, depth_te=1, size_bottleneck=1, preprocessing="conv", im_size=32, patch_size=8, num_channels=3,
           hidden_dim=16, num_heads=2, attn_drop=0.0, proj_drop=0.0, linear_drop=0.0)
@@ -44,8 +44,10 @@ def _worker(rank, world, port, ret):
     x, y = O.make_batch(cfg, B=4, seed=1234)
     shard = slice(rank * 2, rank * 2 + 2)
     flat = _flat_grads(cfg, table, total, w, x[shard], y[shard])
-    for lo, hi in dp_buckets(table, total):
-        allreduce_bucket(flat, lo, hi)
+    # the engine's schedule: buckets of backward units in reverse execution order, every range all-reduced once
+    for _first, _last, ranges in dp_unit_buckets(_lib.backward_unit_ranges(ccfg), cap_bytes=64 << 10):
+        for lo, hi in ranges:
+            allreduce_bucket(flat, lo, hi)
     flat /= world
     ref = sum(_flat_grads(cfg, table, total, w, x[r * 2:r * 2 + 2], y[r * 2:r * 2 + 2]) for r in range(world)) / world
     ok = torch.allclose(flat, ref, rtol=1e-5, atol=1e-7)
@@ -81,3 +83,30 @@ def test_dp_allreduce_world2_gloo():
     ret = mgr.dict()
     mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
     assert ret[0] == (True, True) and ret[1] == (True, True), dict(ret)
+
+
+def test_unit_buckets_tile_the_arena_in_backward_order():
+    """Buckets built from the C side's backward units cover every gradient exactly once, follow reverse execution
+    order, respect the size cap (one unit may exceed it on its own), and leave only first-encoder + PE for the tail."""
+    for name in ("base", "large", "lite"):
+        ccfg = _lib.make_config(dtype=torch.bfloat16, **O.PRESETS[name])
+        units = _lib.backward_unit_ranges(ccfg)
+        total = _lib.lib().vu_model_param_elems(C.byref(ccfg))
+        table = _lib.param_table(ccfg)
+        assert sum(hi - lo for lo, hi in units) == total
+        names = {off: n for n, off, *_ in table}
+        assert names[units[0][0]].startswith("conv2d.") and units[-1] == (0, table[1][1])      # head first, PE last
+        cap = 48 << 20
+        buckets = dp_unit_buckets(units, cap)
+        covered = sorted(r for _, _, rs in buckets for r in rs)
+        assert covered[0][0] == 0 and covered[-1][1] == total
+        assert all(a[1] == b[0] for a, b in zip(covered, covered[1:]))                        # no gap, no overlap
+        assert [f for f, _, _ in buckets] == [0] + [l + 1 for _, l, _ in buckets[:-1]]        # consecutive unit ranges
+        for f, l, rs in buckets:
+            size = sum(hi - lo for lo, hi in rs) * 4
+            assert size <= cap or f == l
+        f, l, rs = buckets[-1]
+        assert names[min(lo for lo, _ in rs)].startswith("PE.")                               # the exposed tail bucket
+        assert (3 if name != "lite" else 1) <= len(buckets) <= 12, (name, len(buckets))
+        small = dp_unit_buckets(units, 4 << 20)                                               # Lite (20 MB in all) with a 4 MB cap
+        assert len(small) >= 3 and sorted(r for _, _, rs in small for r in rs)[0][0] == 0

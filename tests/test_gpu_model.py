@@ -353,10 +353,15 @@ def test_dp_path_one_rank_rccl_matches_single_gpu_step(golden_dir, monkeypatch):
     dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
                             device_id=torch.device("cuda", torch.cuda.current_device()))
     try:
-        tb = TrainStep(mb, lr=1e-3, seed=5)
-        assert tb.dp and tb.world == 1 and tb.comm_stream is not None
-        for _ in range(3):
+        tb = TrainStep(mb, lr=1e-3, seed=5, bucket_mb=0)      # cap 0: one bucket (and one all-reduce) per backward unit
+        assert tb.dp and tb.world == 1 and tb.comm_stream is not None and len(tb._ubuckets) >= 4
+        for _ in range(2):
             la, lb = ta.step(x, y).item(), tb.step(x, y).item()
+            assert abs(la - lb) < 1e-4 * abs(la)
+        tb.capture_dp(x, y)                                    # per-bucket hipGraphs, collectives between the launches
+        ta.step(x, y)                                          # (capture_dp performs one real warm-up step)
+        for _ in range(2):
+            la, lb = ta.step(x, y).item(), tb.replay(x, y).item()
             assert abs(la - lb) < 1e-4 * abs(la)
         torch.cuda.synchronize()
         for (k, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
@@ -365,3 +370,22 @@ def test_dp_path_one_rank_rccl_matches_single_gpu_step(golden_dir, monkeypatch):
             assert serr(pa, pb) < 1e-4, k
     finally:
         dist.destroy_process_group()
+
+
+def test_two_rank_data_parallel_rehearsal():
+    """Two ranks of the real engine on this one GPU (fresh child processes under torch.distributed.run; gloo moves the
+    CUDA buckets because RCCL cannot put two ranks on one device): every rank ends with bit-identical parameters, equal to
+    a single-process reference that averages both ranks' autograd gradients and steps torch.optim.AdamW."""
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(root, "tools", "dp_rehearsal.py")],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("identical parameters across ranks: True") == 2

@@ -630,8 +630,53 @@ int model_forward(Ctx& cx, const float* x, float* y) {
   return VU_OK;
 }
 
-// number of attention modules executed before decoder block i / skip j etc. follows forward order
-int model_backward(Ctx& cx, const float* dy, float* dx, int stage) {
+// ---------------------------------------------------------------------------------------------
+// backward, as a sequence of UNITS in reverse execution order so that the data-parallel engine can
+// start the all-reduce of a gradient bucket as soon as the units that produce it are enqueued:
+//   unit 0                     output conv (+ re-tiling of dy)                  grads: conv2d.*
+//   per decoder block i = last..0:  [SkipConnections.j when block i closes a level]   Decoders.i
+//   BottleNeck.i = last..0, Encoders.i = last..0 (the level's down-sampling / skip gradient first)
+//   last unit                  positional-embedding gradient (+ dx)             PE.position_embedding.weight
+// The running gradient ping-pongs between gx0 / gx1; a call that starts in the middle replays the
+// pointer swaps of the units it skips (no launches), so any split into calls gives the same result.
+// ---------------------------------------------------------------------------------------------
+struct Unit { int kind; int idx; };   // kind: 0 head, 1 skip j, 2 dec i, 3 bot i, 4 enc i, 5 PE
+std::vector<Unit> backward_units(const Plan& pl) {
+  const vu_config& c = pl.cfg;
+  std::vector<Unit> u;
+  u.push_back({0, 0});
+  for (int i = (int)pl.dec.size() - 1; i >= 0; --i) {
+    if ((i + 1) % c.depth_te == 0) u.push_back({1, (i + 1) / c.depth_te - 1});
+    u.push_back({2, i});
+  }
+  for (int i = (int)pl.bot.size() - 1; i >= 0; --i) u.push_back({3, i});
+  for (int i = (int)pl.enc.size() - 1; i >= 0; --i) u.push_back({4, i});
+  u.push_back({5, 0});
+  return u;
+}
+// arena range [lo, hi) of the parameters whose gradients a unit produces
+void unit_range(const Plan& pl, const Unit& u, long long& lo, long long& hi) {
+  std::string pre;
+  switch (u.kind) {
+    case 0: pre = "conv2d."; break;
+    case 1: pre = "SkipConnections." + std::to_string(u.idx) + "."; break;
+    case 2: pre = "Decoders." + std::to_string(u.idx) + "."; break;
+    case 3: pre = "BottleNeck." + std::to_string(u.idx) + "."; break;
+    case 4: pre = "Encoders." + std::to_string(u.idx) + "."; break;
+    default: pre = "PE."; break;
+  }
+  lo = -1; hi = -1;
+  for (size_t t = 0; t < pl.table.size(); ++t) {
+    const vu_param_entry& e = pl.table[t];
+    if (strncmp(e.name, pre.c_str(), pre.size()) != 0) continue;
+    const long long end = t + 1 < pl.table.size() ? pl.table[t + 1].offset : pl.total;
+    if (lo < 0 || e.offset < lo) lo = e.offset;
+    if (end > hi) hi = end;
+  }
+  if (lo < 0) { lo = 0; hi = 0; }     // (no output conv: unit 0 has no parameters)
+}
+
+int model_backward(Ctx& cx, const float* dy, float* dx, int first, int last) {
   const Plan& pl = *cx.pl;
   const vu_config& c = pl.cfg;
   ModelWS& w = *cx.w;
@@ -640,28 +685,31 @@ int model_backward(Ctx& cx, const float* dy, float* dx, int stage) {
   float* G = cx.grads;
   // forward-order stream ids
   const uint64_t sid_enc0 = 0, sid_bot0 = pl.enc.size(), sid_dec0 = sid_bot0 + pl.bot.size();
-  // which buffer currently holds the running gradient is kept in ws (gx0/gx1 ping-pong); between
-  // stages the running gradient always sits in gx0.
   void* cur = w.gx0;
   void* oth = w.gx1;
   auto swap = [&]() { void* t = cur; cur = oth; oth = t; };
-
-  if (stage == 0 || stage == 1) {
-    if (c.out_conv) {
-      VU_TRY(vu_k_conv3x3_wgrad(dt, 1, dy, w.img, G + pl.outw, G + pl.outb, B, C, im, cx.st));
-      VU_TRY(vu_k_conv3x3_dgrad(dt, 1, dy, cx.prm + pl.outw, nullptr, w.ga, B, C, im, cx.st));
-      VU_TRY(vu_k_retile(dt, 0, 0, w.ga, cur, nullptr, B, C, im, im, pl.lv[0].s, cx.st));
-    } else {
-      VU_TRY(vu_k_retile(dt, 1, 0, dy, cur, nullptr, B, C, im, im, pl.lv[0].s, cx.st));
-    }
-    // decoders in reverse; skip j follows decoder block (j+1)*depth_te-1
-    for (int i = (int)pl.dec.size() - 1; i >= 0; --i) {
-      // stream id of decoder block i in forward order: dec blocks and skips interleave
-      const uint64_t sid_blk = sid_dec0 + i + (uint64_t)(i / c.depth_te);
-      if ((i + 1) % c.depth_te == 0) {
-        const int j = (i + 1) / c.depth_te - 1;
-        const uint64_t sid_skip = sid_blk + 1;
-        const int lfrom = pl.dec[i].level, lto = lfrom - 1;
+  const std::vector<Unit> units = backward_units(pl);
+  for (int ui = 0; ui < (int)units.size() && ui <= last; ++ui) {
+    const Unit& u = units[ui];
+    const bool run = ui >= first;
+    const int i = u.idx;
+    switch (u.kind) {
+      case 0:
+        if (run) {
+          if (c.out_conv) {
+            VU_TRY(vu_k_conv3x3_wgrad(dt, 1, dy, w.img, G + pl.outw, G + pl.outb, B, C, im, cx.st));
+            VU_TRY(vu_k_conv3x3_dgrad(dt, 1, dy, cx.prm + pl.outw, nullptr, w.ga, B, C, im, cx.st));
+            VU_TRY(vu_k_retile(dt, 0, 0, w.ga, cur, nullptr, B, C, im, im, pl.lv[0].s, cx.st));
+          } else {
+            VU_TRY(vu_k_retile(dt, 1, 0, dy, cur, nullptr, B, C, im, im, pl.lv[0].s, cx.st));
+          }
+        }
+        break;
+      case 1: {   // SkipConnections[j] follows decoder block (j+1)*depth_te-1 in the forward
+        if (!run) break;
+        const int j = i, ib = (j + 1) * c.depth_te - 1;
+        const uint64_t sid_skip = sid_dec0 + ib + (uint64_t)(ib / c.depth_te) + 1;
+        const int lfrom = pl.dec[ib].level, lto = lfrom - 1;
         const Level& L = pl.lv[lto];
         AttnDims d{dt, B, L.N, L.D, c.num_heads, C, L.s, L.ld, 1, flash_switch()};
         vu_attn_params ap = attn_params(pl.skip[j], c, cx.prm, cx.shadow, cx.bn);
@@ -676,39 +724,49 @@ int model_backward(Ctx& cx, const float* dy, float* dx, int stage) {
                              c.attn_drop, cx.training, cx.seed, sid_skip, cx.salt, cx.st));
         // gradient of upsampling = retile back to the finer level
         VU_TRY(vu_k_retile(dt, 0, 0, w.ga, cur, nullptr, B, C, im, pl.lv[lto].s, pl.lv[lfrom].s, cx.st));
+        break;
       }
-      const void* xin = (i == 0) ? (pl.bot.empty() ? (c.depth > 0 ? w.down_out[c.depth - 1] : w.tok0) : w.bot.back().out)
-                                 : (((i) % c.depth_te == 0) ? w.skip_out[i / c.depth_te - 1] : w.dec[i - 1].out);
-      VU_TRY(block_backward(cx, pl.dec[i], w.dec[i], xin, cur, oth, sid_blk));
-      swap();
-    }
-    if (cur != w.gx0) { VU_TRY(hipMemcpyAsync(w.gx0, cur, (size_t)B * P * esize(dt), hipMemcpyDeviceToDevice, cx.st) == hipSuccess ? VU_OK : VU_ELAUNCH); cur = w.gx0; oth = w.gx1; }
-  }
-  if (stage == 0 || stage == 2) {
-    cur = w.gx0; oth = w.gx1;
-    for (int i = (int)pl.bot.size() - 1; i >= 0; --i) {
-      const void* xin = (i == 0) ? (c.depth > 0 ? w.down_out[c.depth - 1] : w.tok0) : w.bot[i - 1].out;
-      VU_TRY(block_backward(cx, pl.bot[i], w.bot[i], xin, cur, oth, sid_bot0 + i));
-      swap();
-    }
-    if (cur != w.gx0) { VU_TRY(hipMemcpyAsync(w.gx0, cur, (size_t)B * P * esize(dt), hipMemcpyDeviceToDevice, cx.st) == hipSuccess ? VU_OK : VU_ELAUNCH); cur = w.gx0; oth = w.gx1; }
-  }
-  if (stage == 0 || stage == 3) {
-    cur = w.gx0; oth = w.gx1;
-    for (int i = (int)pl.enc.size() - 1; i >= 0; --i) {
-      if ((i + 1) % c.depth_te == 0) {
-        const int l = pl.enc[i].level;
-        // gradient of downsampling (retile back) + gradient arriving through the skip connection
-        VU_TRY(vu_k_retile(dt, 0, 0, cur, oth, nullptr, B, C, im, pl.lv[l + 1].s, pl.lv[l].s, cx.st));
-        VU_TRY(vu_k_add(dt, oth, w.dskip[l], oth, (long long)B * P, cx.st));
+      case 2: {
+        if (run) {
+          const uint64_t sid_blk = sid_dec0 + i + (uint64_t)(i / c.depth_te);   // dec blocks and skips interleave
+          const void* xin = (i == 0) ? (pl.bot.empty() ? (c.depth > 0 ? w.down_out[c.depth - 1] : w.tok0) : w.bot.back().out)
+                                     : ((i % c.depth_te == 0) ? w.skip_out[i / c.depth_te - 1] : w.dec[i - 1].out);
+          VU_TRY(block_backward(cx, pl.dec[i], w.dec[i], xin, cur, oth, sid_blk));
+        }
         swap();
+        break;
       }
-      const void* xin = (i == 0) ? w.tok0 : ((i % c.depth_te == 0) ? w.down_out[pl.enc[i].level - 1] : w.enc[i - 1].out);
-      VU_TRY(block_backward(cx, pl.enc[i], w.enc[i], xin, cur, oth, sid_enc0 + i));
-      swap();
+      case 3: {
+        if (run) {
+          const void* xin = (i == 0) ? (c.depth > 0 ? w.down_out[c.depth - 1] : w.tok0) : w.bot[i - 1].out;
+          VU_TRY(block_backward(cx, pl.bot[i], w.bot[i], xin, cur, oth, sid_bot0 + i));
+        }
+        swap();
+        break;
+      }
+      case 4: {
+        if ((i + 1) % c.depth_te == 0) {
+          if (run) {   // gradient of downsampling (retile back) + gradient arriving through the skip connection
+            const int l = pl.enc[i].level;
+            VU_TRY(vu_k_retile(dt, 0, 0, cur, oth, nullptr, B, C, im, pl.lv[l + 1].s, pl.lv[l].s, cx.st));
+            VU_TRY(vu_k_add(dt, oth, w.dskip[l], oth, (long long)B * P, cx.st));
+          }
+          swap();
+        }
+        if (run) {
+          const void* xin = (i == 0) ? w.tok0 : ((i % c.depth_te == 0) ? w.down_out[pl.enc[i].level - 1] : w.enc[i - 1].out);
+          VU_TRY(block_backward(cx, pl.enc[i], w.enc[i], xin, cur, oth, sid_enc0 + i));
+        }
+        swap();
+        break;
+      }
+      default:
+        if (run) {
+          VU_TRY(vu_k_batch_sum(dt, cur, G + pl.pos, B, P, cx.st));
+          if (dx) VU_TRY(vu_k_retile(dt, 0, 1, cur, dx, nullptr, B, C, im, c.patch_size, im, cx.st));
+        }
+        break;
     }
-    VU_TRY(vu_k_batch_sum(dt, cur, G + pl.pos, B, P, cx.st));
-    if (dx) VU_TRY(vu_k_retile(dt, 0, 1, cur, dx, nullptr, B, C, im, c.patch_size, im, cx.st));
   }
   return VU_OK;
 }
@@ -769,19 +827,54 @@ int vu_model_forward(const vu_config* cfg, const float* params, const void* shad
   return model_forward(cx, x, y);
 }
 
-int vu_model_backward(const vu_config* cfg, const float* params, const void* shadow, const float* bn_state, float* grads,
-                      const float* dy, float* dx, void* ws, size_t ws_bytes, int B, int training, uint64_t seed,
-                      const uint32_t* rng_salt, int stage, void* stream) {
-  VU_REQUIRE(cfg && params && grads && dy && ws && B > 0, "vu_model_backward: null argument");
-  VU_REQUIRE(stage >= 0 && stage <= 3, "vu_model_backward: stage must be 0..3");
+static int run_backward(const vu_config* cfg, const float* params, const void* shadow, const float* bn_state, float* grads,
+                        const float* dy, float* dx, void* ws, size_t ws_bytes, int B, int training, uint64_t seed,
+                        const uint32_t* rng_salt, int stage, int first, int last, void* stream) {
   Plan pl;
   VU_TRY(build_plan(*cfg, pl));
   VU_REQUIRE(cfg->dtype == 0 || shadow, "vu_model_backward: bf16 mode needs the bf16 shadow arena");
   ModelWS w;
   carve_model(pl, B, (char*)ws, w);
   if (w.bytes > ws_bytes) { vu_set_error("workspace too small: need %zu, have %zu", w.bytes, ws_bytes); return VU_EWORKSPACE; }
+  const int nu = (int)backward_units(pl).size();
+  if (stage >= 0) {   // stage API: 0 = all, 1 = head + decoders + skips, 2 = bottleneck, 3 = encoders + positional embedding
+    const int n1 = 1 + (int)pl.dec.size() + cfg->depth, n2 = n1 + (int)pl.bot.size();
+    first = stage <= 1 ? 0 : (stage == 2 ? n1 : n2);
+    last = stage == 0 ? nu - 1 : (stage == 1 ? n1 - 1 : (stage == 2 ? n2 - 1 : nu - 1));
+  }
+  VU_REQUIRE(first >= 0 && last < nu && first <= last + 1, "vu_model_backward_units: unit range [%d,%d] outside [0,%d)", first, last, nu);
   Ctx cx{&pl, B, params, shadow, (float*)bn_state, grads, training, seed, rng_salt, (hipStream_t)stream, &w};
-  return model_backward(cx, dy, dx, stage);
+  return model_backward(cx, dy, dx, first, last);
+}
+
+int vu_model_backward(const vu_config* cfg, const float* params, const void* shadow, const float* bn_state, float* grads,
+                      const float* dy, float* dx, void* ws, size_t ws_bytes, int B, int training, uint64_t seed,
+                      const uint32_t* rng_salt, int stage, void* stream) {
+  VU_REQUIRE(cfg && params && grads && dy && ws && B > 0, "vu_model_backward: null argument");
+  VU_REQUIRE(stage >= 0 && stage <= 3, "vu_model_backward: stage must be 0..3");
+  return run_backward(cfg, params, shadow, bn_state, grads, dy, dx, ws, ws_bytes, B, training, seed, rng_salt, stage, 0, 0, stream);
+}
+
+int vu_model_num_backward_units(const vu_config* cfg) {
+  Plan pl;
+  if (!cfg || build_plan(*cfg, pl) != VU_OK) return -1;
+  return (int)backward_units(pl).size();
+}
+int vu_model_backward_unit_ranges(const vu_config* cfg, long long* lo_hi, int capacity) {
+  Plan pl;
+  if (!cfg || !lo_hi) return VU_EINVAL;
+  VU_TRY(build_plan(*cfg, pl));
+  const std::vector<Unit> u = backward_units(pl);
+  VU_REQUIRE((int)u.size() <= capacity, "unit ranges: capacity %d < %d", capacity, (int)u.size());
+  for (size_t i = 0; i < u.size(); ++i) unit_range(pl, u[i], lo_hi[2 * i], lo_hi[2 * i + 1]);
+  return (int)u.size();
+}
+int vu_model_backward_units(const vu_config* cfg, const float* params, const void* shadow, const float* bn_state, float* grads,
+                            const float* dy, float* dx, void* ws, size_t ws_bytes, int B, int training, uint64_t seed,
+                            const uint32_t* rng_salt, int first_unit, int last_unit, void* stream) {
+  VU_REQUIRE(cfg && params && grads && dy && ws && B > 0, "vu_model_backward_units: null argument");
+  return run_backward(cfg, params, shadow, bn_state, grads, dy, dx, ws, ws_bytes, B, training, seed, rng_salt, -1, first_unit, last_unit,
+                      stream);
 }
 
 // ---- per-op ----

@@ -60,6 +60,9 @@ SIGNATURES = {
     "vu_model_workspace_bytes": (_sz, [_cfgp, _i]),
     "vu_model_forward": (_i, [_cfgp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _u64, _vp, _vp]),
     "vu_model_backward": (_i, [_cfgp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _u64, _vp, _i, _vp]),
+    "vu_model_num_backward_units": (_i, [_cfgp]),
+    "vu_model_backward_unit_ranges": (_i, [_cfgp, C.POINTER(C.c_longlong), _i]),
+    "vu_model_backward_units": (_i, [_cfgp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _u64, _vp, _i, _i, _vp]),
     "vu_retile": (_i, [_i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "vu_conv3x3_fwd": (_i, [_i, _i, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp]),
     "vu_conv3x3_bwd": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp]),
@@ -148,6 +151,15 @@ def make_config(depth, depth_te, size_bottleneck, preprocessing, im_size, patch_
     return vu_config(int(depth), int(depth_te), int(size_bottleneck), int(im_size), int(patch_size),
                      int(num_channels), int(hidden_dim), int(num_heads), float(attn_drop), float(proj_drop),
                      float(linear_drop), 1 if preprocessing == "conv" else 0, DTYPE_CODE[dtype])
+
+
+def backward_unit_ranges(cfg: vu_config):
+    """[(lo, hi)] arena range of the parameter gradients of every backward unit, in backward order."""
+    L = lib()
+    n = check(L.vu_model_num_backward_units(C.byref(cfg)), "vu_model_num_backward_units")
+    arr = (C.c_longlong * (2 * n))()
+    check(L.vu_model_backward_unit_ranges(C.byref(cfg), arr, n), "vu_model_backward_unit_ranges")
+    return [(int(arr[2 * i]), int(arr[2 * i + 1])) for i in range(n)]
 
 
 def param_table(cfg: vu_config):

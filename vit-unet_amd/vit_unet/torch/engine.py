@@ -40,6 +40,35 @@ def dp_buckets(table, total: int):
     return [(o_dec, total), (o_bot, o_dec), (0, o_bot)]
 
 
+def dp_unit_buckets(unit_ranges, cap_bytes: int = 48 << 20, elem_bytes: int = 4):
+    """Gradient buckets for the overlapped all-reduce, from the backward UNITS of the C side
+    (`vu_model_backward_unit_ranges`: arena range of the gradients each unit produces, in backward = reverse execution
+    order: conv2d, SkipConnections.last, Decoders.last ... Encoders.0, PE).  Consecutive units are merged while the bucket
+    stays under `cap_bytes` (25-50 MB buckets), so that only the LAST bucket - the first encoder block and the
+    positional embedding, whose gradients are complete only when the backward is - cannot overlap with compute.
+    Returns [(first_unit, last_unit, [(lo, hi) arena ranges, adjacent ones merged])]."""
+    buckets, cur, size, first = [], [], 0, 0
+    for u, (lo, hi) in enumerate(unit_ranges):
+        nbytes = (hi - lo) * elem_bytes
+        if cur and size + nbytes > cap_bytes:
+            buckets.append((first, u - 1, cur))
+            cur, size, first = [], 0, u
+        if hi > lo:
+            cur.append((lo, hi))
+        size += nbytes
+    buckets.append((first, len(unit_ranges) - 1, cur))
+    out = []
+    for f, l, rs in buckets:
+        merged = []
+        for lo, hi in sorted(rs):
+            if merged and merged[-1][1] == lo:
+                merged[-1] = (merged[-1][0], hi)
+            else:
+                merged.append((lo, hi))
+        out.append((f, l, merged))
+    return out
+
+
 def allreduce_bucket(flat: torch.Tensor, lo: int, hi: int, group=None):
     """Sum one bucket of the flat gradient arena over the data-parallel group (RCCL on GPU
     tensors, gloo on CPU tensors in the tests).  The 1/world average is applied by AdamW."""
@@ -49,7 +78,7 @@ def allreduce_bucket(flat: torch.Tensor, lo: int, hi: int, group=None):
 
 class TrainStep:
     def __init__(self, model, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
-                 process_group=None, seed: int = 0, overlap: bool = True, loss: str = "mse"):
+                 process_group=None, seed: int = 0, overlap: bool = True, loss: str = "mse", bucket_mb: Optional[int] = None):
         """`loss`: "mse" (run_denoising.py:80) or "dice" (README.md:91-101 on sigmoid(model output),
         the segmentation configuration of BASELINE config 5)."""
         if loss not in ("mse", "dice"):
@@ -78,8 +107,13 @@ class TrainStep:
         self.overlap = overlap and self.dp
         self.comm_stream = torch.cuda.Stream(device=dev) if self.dp else None
         self._graph = None
+        self._seg_graphs = None
         self._gx = self._gy = self._gout = self._dout = None
         self._buckets = self._make_buckets()
+        self._nunits = lib().vu_model_num_backward_units(C.byref(model._cfg))
+        if bucket_mb is None:      # 25-50 MB buckets, at least ~4 of them for the small models
+            bucket_mb = int(min(48, max(4, model._arena.numel() * 4 / 4 / 2 ** 20)))
+        self._ubuckets = dp_unit_buckets(_lib.backward_unit_ranges(model._cfg), bucket_mb << 20)
         model._shadow_clean = False
         model.refresh_shadow()
         model._shadow_clean = True      # from now on AdamW keeps the bf16 shadow in sync (model.refresh_shadow re-casts
@@ -92,16 +126,15 @@ class TrainStep:
         return dp_buckets(self.model._table, self.model._arena.numel())
 
     # ---- the step ----------------------------------------------------------------------------
-    def _enqueue(self, x, y, out, dout):
-        m = self.model
-        L = lib()
+    def _enqueue_head(self, x, y, out, dout):
+        """zero the gradient arena, forward, loss (+ dL/dout)"""
+        m, L = self.model, lib()
         B = x.shape[0]
         st = stream_ptr(self.dev)
-        cfg = C.byref(m._cfg)
         ws = m._workspace(B)
         salt = self.step_count.view(torch.int32)
         m._garena.zero_()
-        check(L.vu_model_forward(cfg, ptr(m._arena), ptr(m._shadow), ptr(m._bn), ptr(x), ptr(out), ptr(ws), ws.numel(),
+        check(L.vu_model_forward(C.byref(m._cfg), ptr(m._arena), ptr(m._shadow), ptr(m._bn), ptr(x), ptr(out), ptr(ws), ws.numel(),
                                  B, 1, self.seed, ptr(salt), st), "vu_model_forward")
         if self.loss_kind == "mse":
             check(L.vu_mse_loss(ptr(out), ptr(y), ptr(dout), ptr(self.loss), ptr(self.partials), out.numel(), 1.0, st),
@@ -109,21 +142,46 @@ class TrainStep:
         else:
             check(L.vu_dice_loss(ptr(out), ptr(y), ptr(dout), ptr(self.loss), ptr(self.partials), out.numel(), 1, 1.0,
                                  st), "vu_dice_loss")
+
+    def _enqueue_units(self, dout, first, last):
+        m, L = self.model, lib()
+        B = dout.shape[0]
+        ws = m._workspace(B)
+        salt = self.step_count.view(torch.int32)
+        check(L.vu_model_backward_units(C.byref(m._cfg), ptr(m._arena), ptr(m._shadow), ptr(m._bn), ptr(m._garena), ptr(dout),
+                                        None, ptr(ws), ws.numel(), B, 1, self.seed, ptr(salt), first, last,
+                                        stream_ptr(self.dev)), "vu_model_backward_units")
+
+    def _enqueue_adamw(self):
+        m = self.model
+        check(lib().vu_adamw(ptr(m._arena), ptr(m._garena), ptr(self.m), ptr(self.v), ptr(m._shadow), m._arena.numel(),
+                             ptr(self.hyper), ptr(self.step_count), 1.0 / self.world, stream_ptr(self.dev)), "vu_adamw")
+
+    def _reduce_bucket(self, ranges):
+        """all-reduce one gradient bucket on the side stream, after everything enqueued so far on the compute stream"""
         cur = torch.cuda.current_stream(self.dev)
-        for stage, (lo, hi) in zip((1, 2, 3), self._buckets):
-            check(L.vu_model_backward(cfg, ptr(m._arena), ptr(m._shadow), ptr(m._bn), ptr(m._garena), ptr(dout), None,
-                                      ptr(ws), ws.numel(), B, 1, self.seed, ptr(salt), stage, st), "vu_model_backward")
-            if self.dp and hi > lo:
-                if self.overlap:
-                    self.comm_stream.wait_stream(cur)
-                    with torch.cuda.stream(self.comm_stream):
-                        allreduce_bucket(m._garena, lo, hi, self.pg)
-                else:
-                    allreduce_bucket(m._garena, lo, hi, self.pg)
-        if self.dp and self.overlap:
-            cur.wait_stream(self.comm_stream)
-        check(L.vu_adamw(ptr(m._arena), ptr(m._garena), ptr(self.m), ptr(self.v), ptr(m._shadow), m._arena.numel(),
-                         ptr(self.hyper), ptr(self.step_count), 1.0 / self.world, st), "vu_adamw")
+        if self.overlap:
+            self.comm_stream.wait_stream(cur)
+            with torch.cuda.stream(self.comm_stream):
+                for lo, hi in ranges:
+                    allreduce_bucket(self.model._garena, lo, hi, self.pg)
+        else:
+            for lo, hi in ranges:
+                allreduce_bucket(self.model._garena, lo, hi, self.pg)
+
+    def _enqueue(self, x, y, out, dout):
+        self._enqueue_head(x, y, out, dout)
+        if not self.dp:
+            self._enqueue_units(dout, 0, self._nunits - 1)
+        else:
+            # backward in gradient buckets (reverse execution order): the all-reduce of bucket k runs on the side stream
+            # under the backward of bucket k+1; only the last bucket (first encoder block + positional embedding) is exposed
+            for first, last, ranges in self._ubuckets:
+                self._enqueue_units(dout, first, last)
+                self._reduce_bucket(ranges)
+            if self.overlap:
+                torch.cuda.current_stream(self.dev).wait_stream(self.comm_stream)
+        self._enqueue_adamw()
 
     def step(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
         """One optimisation step on a float32 (B,C,im,im) batch already resident on the GPU.
@@ -186,6 +244,40 @@ class TrainStep:
             self._gx.copy_(x)
             self._gy.copy_(y)
         self.model.refresh_shadow()
-        self._graph.replay()
+        if self._seg_graphs is not None:
+            # data-parallel: one hipGraph per gradient bucket (forward + loss ride in the first, AdamW is the last); the
+            # collectives are launched between the graph launches, on the side stream
+            graphs = self._seg_graphs
+            for g, (_, _, ranges) in zip(graphs[:-1], self._ubuckets):
+                g.replay()
+                self._reduce_bucket(ranges)
+            if self.overlap:
+                torch.cuda.current_stream(self.dev).wait_stream(self.comm_stream)
+            graphs[-1].replay()
+        else:
+            self._graph.replay()
         self.model._nbt_pending += 1
         return self.loss
+
+    def capture_dp(self, x: torch.Tensor, y: torch.Tensor):
+        """Data-parallel counterpart of `capture`: the compute between two collectives is captured as one hipGraph
+        (launch-bound at the small per-GPU batches of the DP configurations), the RCCL all-reduces stay eager."""
+        assert self.dp
+        self._gx, self._gy = x.float().contiguous().clone(), y.float().contiguous().clone()
+        self._gout, self._dout = torch.empty_like(self._gx), torch.empty_like(self._gx)
+        self.model._workspace(x.shape[0])
+        self.step(self._gx, self._gy)                        # warm-up (a real step, eager)
+        torch.cuda.synchronize(self.dev)
+        graphs = []
+        for k, (first, last, _) in enumerate(self._ubuckets):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                if k == 0:
+                    self._enqueue_head(self._gx, self._gy, self._gout, self._dout)
+                self._enqueue_units(self._dout, first, last)
+            graphs.append(g)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._enqueue_adamw()
+        graphs.append(g)
+        self._seg_graphs = graphs
