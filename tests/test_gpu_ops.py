@@ -271,6 +271,10 @@ def _attention_fwd_bwd(dt, N, Cn, s, H, mode, cross, centered, flash=False):
     assert serr(dxq, xq_r.grad) < bt, "dxq"
     if cross:
         assert serr(dxkv, xkv_r.grad) < bt, "dxkv"
+    if flash and os.environ.get("VU_FLASH_DEBUG"):
+        print(f"flash N={N} H={H} d={D // H} {mode}: y {serr(y, yr):.2e} dxq {serr(dxq, xq_r.grad):.2e} " +
+              " ".join(f"{k.split('.')[0][:6]}.{k.split('.')[1][0]} {serr(g, pr[k].grad):.2e}" for k, g in zip(GRAD_KEYS, grads)
+                       if k != "reatten_matrix.bias"))
     for k, g in zip(GRAD_KEYS, grads):
         if training and k == "reatten_matrix.bias":
             # exactly zero in exact arithmetic (train-mode BN removes the mean); what is left is

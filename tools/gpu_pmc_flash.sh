@@ -19,7 +19,7 @@ for p in "abc":
     for f in glob.glob(f"gpurun_out/pmc_{p}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             import re
-            m = re.search(r"(flash_\w+?)(<[^>]*>)?\(", r["Kernel_Name"] + "(")
+            m = re.search(r"(flash\d?_\w+?)(<[^>]*>)?\(", r["Kernel_Name"] + "(")
             if not m: continue
             k = m.group(1) + (m.group(2) or "")
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[k][r["Counter_Name"]] += 1

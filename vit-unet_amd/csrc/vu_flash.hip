@@ -87,6 +87,45 @@ __device__ __forceinline__ void zero_pads(bf16_t* dst, int rows, int tid, int nt
   for (int r = tid; r < rows; r += nthr) *reinterpret_cast<uint4*>(dst + r * C::PITCH + C::D) = make_uint4(0, 0, 0, 0);
 }
 
+// Register-staged chunk for software prefetch: fetch() issues the global loads of the NEXT chunk before the tile loop of
+// the current one, commit() writes them to LDS after the barrier that ends it - the HBM / L2 latency of a chunk (4 dependent
+// round trips, ~20 % of a sweep with the load-then-compute form: rocprofv3 SQ_WAIT_ANY, profiles/r02b) hides under the
+// arithmetic.  ROWS rows of D elements by NTHR threads: NV 16-byte vectors per thread.
+template <int H, int DH, int ROWS, int NTHR>
+struct ChunkStage {
+  typedef FC<H, DH> C;
+  static constexpr int TOTAL = ROWS * C::VPR;
+  static constexpr int NV = (TOTAL + NTHR - 1) / NTHR;
+  static_assert(NV <= 12, "ChunkStage: more than 12 vectors per thread");
+  uint4 v0, v1, v2, v3, v4, v5, v6, v7, v8, v9, v10, v11;      // named registers (an indexed array ends up in scratch memory)
+  __device__ __forceinline__ static uint4 ld(const bf16_t* __restrict__ src, int total, int x) {
+    const int xx = x < total ? x : total - 1;                   // clamped: an unconditional load (commit() drops it)
+    const int r = xx / C::VPR, c = xx - r * C::VPR;
+    return *reinterpret_cast<const uint4*>(src + (long long)r * C::D + c * 8);
+  }
+  __device__ __forceinline__ static void st(bf16_t* dst, int total, int x, const uint4& val) {
+    if (x < total) { const int r = x / C::VPR, c = x - r * C::VPR; *reinterpret_cast<uint4*>(dst + r * C::PITCH + c * 8) = val; }
+  }
+#define VU_STAGE_EACH(OP) \
+  if constexpr (NV > 0) { OP(0, v0) } if constexpr (NV > 1) { OP(1, v1) } if constexpr (NV > 2) { OP(2, v2) } \
+  if constexpr (NV > 3) { OP(3, v3) } if constexpr (NV > 4) { OP(4, v4) } if constexpr (NV > 5) { OP(5, v5) } \
+  if constexpr (NV > 6) { OP(6, v6) } if constexpr (NV > 7) { OP(7, v7) } if constexpr (NV > 8) { OP(8, v8) } \
+  if constexpr (NV > 9) { OP(9, v9) } if constexpr (NV > 10) { OP(10, v10) } if constexpr (NV > 11) { OP(11, v11) }
+  __device__ __forceinline__ void fetch(const bf16_t* __restrict__ src, int nrows, int tid) {
+    const int total = nrows * C::VPR;
+#define VU_STAGE_LD(i, reg) reg = ld(src, total, tid + (i) * NTHR);
+    VU_STAGE_EACH(VU_STAGE_LD)
+#undef VU_STAGE_LD
+  }
+  __device__ __forceinline__ void commit(bf16_t* dst, int nrows, int tid) const {
+    const int total = nrows * C::VPR;
+#define VU_STAGE_ST(i, reg) st(dst, total, tid + (i) * NTHR, reg);
+    VU_STAGE_EACH(VU_STAGE_ST)
+#undef VU_STAGE_ST
+  }
+#undef VU_STAGE_EACH
+};
+
 // B operand of the logits product for one 16-token tile held in registers: lane (token l15, k-slot g4) has features
 // h DH + 8 g4 .. + 7 of its token, zero where 8 g4 >= DH (so whatever the other operand holds there is multiplied by 0).
 template <int H, int DH>
@@ -123,12 +162,34 @@ __device__ __forceinline__ s16x4 tr_operand(const bf16_t* Xc, int row0, int f0, 
 __device__ __forceinline__ f32x4 mfma16(const s16x4& a, const s16x4& b, const f32x4& c) {
   return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
 }
+// two floats -> one register of two bf16 (round to nearest even): one v_cvt_pk_bf16_f32.  (Packing element by element
+// through bf16 vectors made hipcc emit a convert per element plus v_perm / v_mov shuffles: 2.5x the instructions.)
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+__device__ __forceinline__ unsigned pk2(float a, float b) {
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ float bf_lo(unsigned w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
 __device__ __forceinline__ s16x4 pack4s(const f32x4& a) {
-  const bf16x4 t = {(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3]};
+  const u32x2_t t = {pk2(a[0], a[1]), pk2(a[2], a[3])};
   return __builtin_bit_cast(s16x4, t);
 }
+// a - (float)bf16(a), element-wise, given the packed bf16 of a
+__device__ __forceinline__ f32x4 residual4(const f32x4& a, const s16x4& packed) {
+  const u32x2_t t = __builtin_bit_cast(u32x2_t, packed);
+  return f32x4{a[0] - bf_lo(t[0]), a[1] - bf_hi(t[0]), a[2] - bf_lo(t[1]), a[3] - bf_hi(t[1])};
+}
 
-__device__ __forceinline__ bf16x4 pack4(const f32x4& a) { return bf16x4{(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3]}; }
+__device__ __forceinline__ bf16x4 pack4(const f32x4& a) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 b2;
+  typedef __attribute__((ext_vector_type(2))) unsigned u2;
+  const f32x2 lo = {a[0], a[1]}, hi = {a[2], a[3]};
+  const u2 t = {__builtin_bit_cast(unsigned, __builtin_convertvector(lo, b2)), __builtin_bit_cast(unsigned, __builtin_convertvector(hi, b2))};
+  return __builtin_bit_cast(bf16x4, t);
+}
 __device__ __forceinline__ bf16x8 join8(const bf16x4& a, const bf16x4& b) { return bf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
 
 // Dropout mask of the attention maps in this form ("quad" scheme; the materialised kernels keep vu_keep's pair scheme,
@@ -293,13 +354,15 @@ __global__ __launch_bounds__(WPB * 64) void flash_stats_kernel(const bf16_t* __r
 
 // fp64 finalize: moments -> BatchNorm statistics of the mixed maps, running statistics, folded tables.
 // stats layout: vu_kernels.h (VU_BN_STATS_*), extended by FWk = gamma rstd W / keep and XK = rstd W / keep.
+// `direct`: the partial rows hold the moments of the mixed maps themselves (v2: [sum (A_g - shift_g)] [sum (A_g - shift_g)^2],
+// shift_g = sum_h W[g,h] / N, the bias c_g not included) instead of the first / cross moments of the probabilities.
 __global__ __launch_bounds__(1024) void flash_bn_finalize_kernel(const float* __restrict__ partials, int nblocks, const float* __restrict__ W,
                                          const float* __restrict__ cb, const float* __restrict__ gamma, const float* __restrict__ beta,
                                          float* run_mean, float* run_var, float* stats, int H, int N, double count, int training,
-                                         float momentum, float eps, float inv_keep) {
+                                         float momentum, float eps, float inv_keep, int direct) {
   __shared__ double mom[64];
   __shared__ double sd[16][64];
-  const int NM = H + H * (H + 1) / 2;
+  const int NM = direct ? 2 * H : H + H * (H + 1) / 2;
   const int tid = threadIdx.x;          // 1024 threads: 64 moment columns side by side (coalesced), 16 row lanes
   if (training) {
     const int col = tid & 63, rl = tid >> 6;
@@ -318,7 +381,17 @@ __global__ __launch_bounds__(1024) void flash_bn_finalize_kernel(const float* __
   if (tid < H) {
     const int g = tid;
     double mean, var;
-    if (training) {
+    if (training && direct) {
+      double sw = 0.0;
+      for (int h = 0; h < H; ++h) sw += (double)W[g * H + h];
+      const double d1 = mom[g], d2 = mom[H + g];
+      mean = (double)cb[g] + sw / (double)N + d1;
+      var = d2 - d1 * d1;
+      if (var < 0.0) var = 0.0;
+      const double unb = count > 1.0 ? count / (count - 1.0) : 1.0;
+      run_mean[g] = (1.f - momentum) * run_mean[g] + momentum * (float)mean;
+      run_var[g] = (1.f - momentum) * run_var[g] + momentum * (float)(var * unb);
+    } else if (training) {
       const double cen = 1.0 / (double)N;
       double mu = (double)cb[g], vv = 0.0;
       for (int h = 0; h < H; ++h) mu += (double)W[g * H + h] * (mom[h] + cen);
@@ -917,6 +990,706 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash_bwd_dkv_kernel(
   }
 }
 
+// =============================================================================================
+// v2 tile body (8 heads): the two 8 x 8 head contractions run on the matrix cores.
+//
+// The first version above is bound by VALU issue (rocprofv3: 450 - 770 vector instructions per 16 x 16 x 8 tile, each
+// ~4 cycles of a wave; profiles/r02a_flash_v1_*): of ~24 instructions per map element of the dq sweep, 8 are the
+// fp32 head mixes.  Here the mixes are MFMAs on bf16-packed tiles, with the tables split hi + lo (two MFMAs) so that
+// the coefficients keep 16 significant bits:
+//   OL ("original layout", accumulator of K Q^T):  lane (q, g4): S[h][r] = head h, key 4 g4 + r
+//   for each r: B operand = the lane's 8 heads packed (k = 8 g4 + h); A = block-structured table
+//       A_half[row = (a', g)][k = (kg, h)] = M[g][h] * [kg == 2 half + a']
+//   -> ML ("mixed layout"): lane (q, g4 = 2 a + hh): X[half][r][j] = head 4 hh + j, key 8 half + 4 a + r
+// A lane of ML holds 4 heads at 8 keys instead of 8 heads at 4 keys.  Everything downstream of the first mix lives in
+// ML: the identity table converts any OL tile (exactly, it is already bf16), the transposed mix is a 16x16x16 MFMA that
+// maps ML to ML (k = (a, hh, j), row = (a', h)), and the products that contract over keys take, per (j, half), the
+// lane's 4 keys as the B operand of a 16x16x16 MFMA whose A operand holds 8 features of head j (rows 0..7, from the
+// lanes with hh = 0) and 8 features of head 4 + j (rows 8..15, hh = 1), the other half zero: its accumulator is 8
+// features x 2 heads x 16 queries.  The zero half comes from a zeroed LDS region (an address select per tile, no
+// per-operand masking).
+// =============================================================================================
+struct MixOp { bf16x8 hi[2], lo[2]; };       // [half]
+struct BackOp { s16x4 hi, lo; };
+
+__device__ __forceinline__ void split_hilo(float w, bf16_t& hi, bf16_t& lo) {
+  hi = (bf16_t)w;
+  lo = (bf16_t)(w - (float)hi);
+}
+// M: 8 x 8 row-major fp32 (M[g][h]) anywhere readable; scale[g] optional row factor
+__device__ __forceinline__ void make_mix_op(MixOp& op, const float* M, const float* rowscale, int l15, int g4, float scale = 1.f) {
+  const int ar = l15 >> 3, g = l15 & 7;
+  const float rs = (rowscale ? rowscale[g] : 1.f) * scale;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const bool on = g4 == 2 * half + ar;
+#pragma unroll
+    for (int h = 0; h < 8; ++h) {
+      bf16_t hi, lo;
+      split_hilo(on ? M[g * 8 + h] * rs : 0.f, hi, lo);
+      op.hi[half][h] = hi; op.lo[half][h] = lo;
+    }
+  }
+}
+__device__ __forceinline__ void make_identity_op(bf16x8 (&id)[2], int l15, int g4) {
+  const int ar = l15 >> 3, g = l15 & 7;
+#pragma unroll
+  for (int half = 0; half < 2; ++half)
+#pragma unroll
+    for (int h = 0; h < 8; ++h) id[half][h] = (bf16_t)((g4 == 2 * half + ar && h == g) ? 1.f : 0.f);
+}
+// transposed mix: A[row = (a', h)][k = 4 g4 + jj] = M[g = 4 (g4 & 1) + jj][h] * [(g4 >> 1) == a']
+__device__ __forceinline__ void make_back_op(BackOp& op, const float* M, int l15, int g4) {
+  const int ar = l15 >> 3, h = l15 & 7;
+  bf16x4 hi, lo;
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) {
+    bf16_t a, b;
+    split_hilo(((g4 >> 1) == ar) ? M[(4 * (g4 & 1) + jj) * 8 + h] : 0.f, a, b);
+    hi[jj] = a; lo[jj] = b;
+  }
+  op.hi = __builtin_bit_cast(s16x4, hi); op.lo = __builtin_bit_cast(s16x4, lo);
+}
+
+// the 8 heads of register r, packed: B operand of a mix MFMA
+__device__ __forceinline__ void pack_heads(const f32x4 (&S)[8], bf16x8 (&pk)[4]) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const u32x4_t t = {pk2(S[0][r], S[1][r]), pk2(S[2][r], S[3][r]), pk2(S[4][r], S[5][r]), pk2(S[6][r], S[7][r])};
+    pk[r] = __builtin_bit_cast(bf16x8, t);
+  }
+}
+// negative (= dropped, sign-tagged) entries -> 0: bf16 bit patterns compared as signed 16-bit integers
+__device__ __forceinline__ bf16x8 relu_packed(const bf16x8& x) {
+  const s16x8 v = __builtin_bit_cast(s16x8, x);
+  const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+  return __builtin_bit_cast(bf16x8, __builtin_elementwise_max(v, z));
+}
+__device__ __forceinline__ f32x4 mfma32(const bf16x8& a, const bf16x8& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+// ML tile X[half][r] (f32x4 over j) = cin + (op.hi + op.lo) . pk[r]
+__device__ __forceinline__ void mix_ml(f32x4 (&X)[2][4], const MixOp& op, const bf16x8 (&pk)[4], const f32x4& cin) {
+#pragma unroll
+  for (int half = 0; half < 2; ++half)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) X[half][r] = mfma32(op.lo[half], pk[r], mfma32(op.hi[half], pk[r], cin));
+}
+__device__ __forceinline__ void convert_ml(f32x4 (&X)[2][4], const bf16x8 (&id)[2], const bf16x8 (&pk)[4], bool accumulate) {
+#pragma unroll
+  for (int half = 0; half < 2; ++half)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) X[half][r] = mfma32(id[half], pk[r], accumulate ? X[half][r] : f32x4{0.f, 0.f, 0.f, 0.f});
+}
+
+// Per-lane source of the A operand of a key-contracting product (rows 0..7: 8 features of head j, rows 8..15: 8
+// features of head 4 + j; k-slot 4 g4 + r = key 8 half + 4 (g4 >> 1) + r, live only where (g4 & 1) matches the row's
+// head half).  Returns the lane's element offset into the chunk for tile kc (or into the zero region); the caller adds
+// the compile-time part (8 half PITCH + j DH + fb 8) as an immediate.
+template <int H, int DH>
+struct TrSrc {
+  int lane_off;      // live lanes: (4 (g4 >> 1) + qq) PITCH + 4 (pp >> 1) DH + 4 (pp & 1)
+  bool live;
+  int zero_off;      // dead lanes: start of the zero region (covers the largest immediate), relative to the chunk
+  __device__ __forceinline__ void init(int l15, int g4, int zero_off_) {
+    typedef FC<H, DH> C;
+    const int qq = l15 >> 2, pp = l15 & 3;
+    live = (pp >> 1) == (g4 & 1);
+    lane_off = (4 * (g4 >> 1) + qq) * C::PITCH + 4 * (pp >> 1) * DH + 4 * (pp & 1);
+    zero_off = zero_off_;
+  }
+  __device__ __forceinline__ int base(int kc) const { typedef FC<H, DH> C; return live ? lane_off + kc * 16 * C::PITCH : zero_off; }
+};
+template <int H, int DH>
+__device__ __forceinline__ s16x4 tr_half(const bf16_t* Xc, int base, int half, int j, int fb) {
+  typedef FC<H, DH> C;
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(Xc + base + 8 * half * C::PITCH + j * DH + 8 * fb));
+}
+template <int H, int DH> constexpr int tr_zero_elems() { return 8 * FC<H, DH>::PITCH + 3 * DH + 8 * ((DH + 7) / 8) + 8; }
+
+// ---- stats pass, sweep 3 only (sweeps 1 / 2 are the v1 code): moments of the MIXED map directly -------------------
+// per lane 4 heads x (sum, sum of squares) of A_g - shift_g, shift_g = sum_h W[g,h] / N (the exact mean without dropout)
+template <int DH, int WPB, int CK>
+__global__ __launch_bounds__(WPB * 64, 2) void flash2_moments_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                                      const float* __restrict__ lse2, const float* __restrict__ W,
+                                                                      float* __restrict__ partials, int B, int N, float c, vu_rng rng_in) {
+  constexpr int H = 8;
+  typedef FC<H, DH> C;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* Kc = reinterpret_cast<bf16_t*>(smem_raw);
+  float* red = reinterpret_cast<float*>(Kc + CK * 16 * C::PITCH);        // [WPB][2 H]
+  const vu_rng rng = vu_rng_resolve(rng_in);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
+  const int ntiles = N >> 4, per = (ntiles + WPB - 1) / WPB;
+  int b, grp;
+  work_item(blockIdx.x, B, per, b, grp);
+  const int t = grp * WPB + wave;
+  const bool active = t < ntiles;
+  const int tq = active ? t : ntiles - 1;
+  const int qrow = tq * 16 + l15;
+  const bf16_t* kb = k + (long long)b * N * C::D;
+  bf16x8 qf[H];
+  load_stationary<H, DH>(qf, q + ((long long)b * N + qrow) * C::D, g4);
+  float lse[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) lse[h] = lse2[((long long)b * H + h) * N + qrow];
+  // table: W / keep (the statistics are those of sum_h W[g,h] P~_h); accumulator start: -shift_g
+  MixOp op;
+  make_mix_op(op, W, nullptr, l15, g4, rng.inv_keep);
+  f32x4 cin;
+  {
+    const int hh = g4 & 1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float sw = 0.f;
+#pragma unroll
+      for (int h = 0; h < 8; ++h) sw += W[(4 * hh + j) * 8 + h];
+      cin[j] = -sw / (float)N;
+    }
+  }
+  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+  const uint32_t hstride = (uint32_t)(((unsigned long long)N * N) >> 2);
+  const uint32_t wlane = (uint32_t)(((((unsigned long long)b * H) * N + qrow) * (unsigned long long)N) >> 2) + (uint32_t)g4;
+  const int nchunks = (ntiles + CK - 1) / CK;
+  ChunkStage<H, DH, CK * 16, WPB * 64> st_Kc;
+  st_Kc.fetch(kb, min(CK, ntiles) * 16, tid);
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const int nt = min(CK, ntiles - ch * CK);
+    __syncthreads();                                  // every wave has finished with the previous chunk
+    st_Kc.commit(Kc, nt * 16, tid);
+    __syncthreads();
+    {                                               // next chunk in flight during the tile loop (the last trip re-fetches its own)
+      const int cn = ch + 1 < nchunks ? ch + 1 : ch;
+      st_Kc.fetch(kb + (long long)cn * CK * 16 * C::D, min(CK, ntiles - cn * CK) * 16, tid);
+    }
+    if (active)
+      for (int kc = 0; kc < nt; ++kc) {
+        f32x4 S[H];
+        tile_logits<H, DH>(S, Kc, kc, qf, l15, g4);
+        tag_probs<H>(S, lse, c, rng, wlane + 4u * (uint32_t)(ch * CK + kc), hstride);
+        bf16x8 pk[4];
+        pack_heads(S, pk);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pk[r] = relu_packed(pk[r]);
+        f32x4 A[2][4];
+        mix_ml(A, op, pk, cin);
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s1[j] += A[half][r][j]; s2[j] = fmaf(A[half][r][j], A[half][r][j], s2[j]); }
+      }
+  }
+  // lanes with the same head half (g4 & 1) hold the same 4 heads: reduce over q (16 lanes) and over a (g4 >> 1)
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float a = active ? s1[j] : 0.f, b2 = active ? s2[j] : 0.f;
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1) { a += __shfl_xor(a, m, 64); b2 += __shfl_xor(b2, m, 64); }
+    a += __shfl_xor(a, 32, 64); b2 += __shfl_xor(b2, 32, 64);
+    if (l15 == 0 && g4 < 2) { red[wave * 16 + 4 * g4 + j] = a; red[wave * 16 + 8 + 4 * g4 + j] = b2; }
+  }
+  __syncthreads();
+  if (tid < 16) {
+    float a = 0.f;
+#pragma unroll
+    for (int w = 0; w < WPB; ++w) a += red[w * 16 + tid];
+    partials[(long long)blockIdx.x * 16 + tid] = a;        // [0..7] sums, [8..15] sums of squares (shifted)
+  }
+}
+
+// ---- apply pass --------------------------------------------------------------------------------------------------
+template <int DH, int WPB, int CK>
+__global__ __launch_bounds__(WPB * 64, 2) void flash2_apply_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, const float* __restrict__ lse2,
+    const float* __restrict__ stats, bf16_t* __restrict__ O, int B, int N, float c, vu_rng rng_in) {
+  constexpr int H = 8, FB = DH / 8;
+  typedef FC<H, DH> C;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* Kc = reinterpret_cast<bf16_t*>(smem_raw);
+  bf16_t* Vc = Kc + CK * 16 * C::PITCH;
+  bf16_t* Zr = Vc + CK * 16 * C::PITCH;                                   // zero region for the dead operand halves
+  const vu_rng rng = vu_rng_resolve(rng_in);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
+  const int ntiles = N >> 4, per = (ntiles + WPB - 1) / WPB;
+  int b, grp;
+  work_item(blockIdx.x, B, per, b, grp);
+  const int t = grp * WPB + wave;
+  const bool active = t < ntiles;
+  const int tq = active ? t : ntiles - 1;
+  const int qrow = tq * 16 + l15;
+  const bf16_t* kb = k + (long long)b * N * C::D;
+  const bf16_t* vb = v + (long long)b * N * C::D;
+  bf16x8 qf[H];
+  load_stationary<H, DH>(qf, q + ((long long)b * N + qrow) * C::D, g4);
+  float lse[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) lse[h] = lse2[((long long)b * H + h) * N + qrow];
+  for (int i = tid; i < tr_zero_elems<H, DH>() / 8; i += WPB * 64) *reinterpret_cast<uint4*>(Zr + i * 8) = make_uint4(0, 0, 0, 0);
+  MixOp op;                                                               // gamma rstd W / keep
+  make_mix_op(op, stats + VU_BN_STATS_FWK(H), nullptr, l15, g4);
+  f32x4 cin;                                                              // folded bias of the lane's 4 heads
+#pragma unroll
+  for (int j = 0; j < 4; ++j) cin[j] = stats[H * H + 4 * (g4 & 1) + j];
+  TrSrc<H, DH> src;
+  src.init(l15, g4, (int)(Zr - Vc));
+  f32x4 oacc[4][FB];          // [j][feature block]: rows (head half, 8 features) x 16 queries
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int fb = 0; fb < FB; ++fb) oacc[j][fb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const uint32_t hstride = (uint32_t)(((unsigned long long)N * N) >> 2);
+  const uint32_t wlane = (uint32_t)(((((unsigned long long)b * H) * N + qrow) * (unsigned long long)N) >> 2) + (uint32_t)g4;
+  const int nchunks = (ntiles + CK - 1) / CK;
+  ChunkStage<H, DH, CK * 16, WPB * 64> st_Kc;
+  st_Kc.fetch(kb, min(CK, ntiles) * 16, tid);
+  ChunkStage<H, DH, CK * 16, WPB * 64> st_Vc;
+  st_Vc.fetch(vb, min(CK, ntiles) * 16, tid);
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const int nt = min(CK, ntiles - ch * CK);
+    __syncthreads();                                  // every wave has finished with the previous chunk
+    st_Kc.commit(Kc, nt * 16, tid);
+    st_Vc.commit(Vc, nt * 16, tid);
+    __syncthreads();
+    {                                               // next chunk in flight during the tile loop (the last trip re-fetches its own)
+      const int cn = ch + 1 < nchunks ? ch + 1 : ch;
+      st_Kc.fetch(kb + (long long)cn * CK * 16 * C::D, min(CK, ntiles - cn * CK) * 16, tid);
+      st_Vc.fetch(vb + (long long)cn * CK * 16 * C::D, min(CK, ntiles - cn * CK) * 16, tid);
+    }
+    if (active)
+      for (int kc = 0; kc < nt; ++kc) {
+        f32x4 S[H];
+        tile_logits<H, DH>(S, Kc, kc, qf, l15, g4);
+        tag_probs<H>(S, lse, c, rng, wlane + 4u * (uint32_t)(ch * CK + kc), hstride);
+        bf16x8 pk[4];
+        pack_heads(S, pk);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pk[r] = relu_packed(pk[r]);
+        f32x4 A[2][4];
+        mix_ml(A, op, pk, cin);                       // A^ in ML
+        const int tb = src.base(kc);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+            const f32x4 a4 = {A[half][0][j], A[half][1][j], A[half][2][j], A[half][3][j]};
+            const s16x4 bop = pack4s(a4);
+#pragma unroll
+            for (int fb = 0; fb < FB; ++fb) oacc[j][fb] = mfma16(tr_half<H, DH>(Vc, tb, half, j, fb), bop, oacc[j][fb]);
+          }
+      }
+  }
+  if (active) {   // accumulator row 4 g4 + jj: head 4 (g4 >> 1) + j, feature 8 fb + 4 (g4 & 1) + jj
+    bf16_t* orow = O + ((long long)b * N + qrow) * C::D;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int fb = 0; fb < FB; ++fb)
+        *reinterpret_cast<bf16x4*>(orow + (4 * (g4 >> 1) + j) * DH + 8 * fb + 4 * (g4 & 1)) = pack4(oacc[j][fb]);
+  }
+}
+
+// ---- backward: shared pieces ------------------------------------------------------------------------------------
+struct Bwd2Ops {
+  MixOp xk2;          // -m2_g rstd_g W[g,h] / keep
+  bf16x8 id[2];
+  BackOp back;        // gamma_g rstd_g W[g,h] / keep, transposed use
+  f32x4 cin;          // -m1_g - m2_g Xc_g of the lane's 4 heads
+};
+__device__ __forceinline__ void make_bwd2_ops(Bwd2Ops& o, const float* __restrict__ stats, int l15, int g4) {
+  constexpr int H = 8;
+  make_mix_op(o.xk2, stats + VU_BN_STATS_XK(H), stats + H * H + 4 * H, l15, g4, -1.f);      // rows scaled by -m2_g
+  make_identity_op(o.id, l15, g4);
+  make_back_op(o.back, stats + VU_BN_STATS_FWK(H), l15, g4);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int g = 4 * (g4 & 1) + j;
+    o.cin[j] = -stats[H * H + 3 * H + g] - stats[H * H + 4 * H + g] * stats[2 * H * H + 5 * H + g];
+  }
+}
+// S (logits, OL) -> tagML (sign-tagged probabilities, ML); then dA^ (OL, computed here, late, so that its 32 registers
+// are not live beside the logits) -> e (ML).  STREAM_A as in tile_prod; Dc / dst: streaming chunk and stationary image of
+// the dA^ product (V rows and dO in the q-major sweeps, dO rows and V in the key-major one).
+template <int H, int DH, bool STREAM_A>
+__device__ __forceinline__ void bwd2_chain(f32x4 (&S)[H], const bf16_t* Dc, int kc, const bf16_t* dst, const float (&lse)[H], float c,
+                                           const vu_rng& rng, uint32_t wt, uint32_t hstride, const Bwd2Ops& o, f32x4 (&T)[2][4],
+                                           f32x4 (&E)[2][4], int l15, int g4) {
+  tag_probs<H>(S, lse, c, rng, wt, hstride);
+  bf16x8 pk[4];
+  pack_heads(S, pk);
+  convert_ml(T, o.id, pk, false);                        // tag in ML (exact: already bf16)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) pk[r] = relu_packed(pk[r]);
+  mix_ml(E, o.xk2, pk, o.cin);                           // -m1 - m2 x^
+  LDS_FENCE();
+  f32x4 Dh[H];
+  tile_prod<H, DH, STREAM_A>(Dh, Dc, kc, nullptr, dst, nullptr, l15, g4);
+  pack_heads(Dh, pk);
+  convert_ml(E, o.id, pk, true);                         // + dA^  = e
+}
+// dP (ML) of one (half, r) register group: transposed mix of e
+// (e as a bf16 hi + lo pair: e is what is left of dA^ after the BatchNorm projections, and the q / k gradients downstream
+// are sums of ~1e6 cancelling terms - with a single bf16 rounding of e the conv-weight gradients missed the 5e-2 tolerance)
+__device__ __forceinline__ f32x4 bwd2_dp(const f32x4& e, const BackOp& bk) {
+  const s16x4 b = pack4s(e);
+  const s16x4 bl = pack4s(residual4(e, b));
+  f32x4 dp = mfma16(bk.hi, b, f32x4{0.f, 0.f, 0.f, 0.f});
+  dp = mfma16(bk.lo, b, dp);
+  return mfma16(bk.hi, bl, dp);
+}
+
+// ---- sweep 1: delta and the head-mix gradient sums -------------------------------------------------------------
+template <int DH, int WPB, int CK>
+__global__ __launch_bounds__(WPB * 64, 2) void flash2_bwd_delta_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, const bf16_t* __restrict__ dO,
+    const float* __restrict__ lse2, const float* __restrict__ stats, float* __restrict__ delta, float* __restrict__ partials,
+    int B, int N, float c, vu_rng rng_in) {
+  constexpr int H = 8, NT = H * H + H;
+  typedef FC<H, DH> C;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* Kc = reinterpret_cast<bf16_t*>(smem_raw);
+  bf16_t* Vc = Kc + CK * 16 * C::PITCH;
+  bf16_t* Qs = Vc + CK * 16 * C::PITCH + (threadIdx.x >> 6) * 32 * C::PITCH;
+  bf16_t* dOs = Qs + 16 * C::PITCH;
+  bf16_t* img = Vc + CK * 16 * C::PITCH + WPB * 32 * C::PITCH + (threadIdx.x >> 6) * 640;      // [32 positions][20: 16 + pad]
+  float* red = reinterpret_cast<float*>(Kc);                              // [WPB][NT], after the last tile (aliases the K chunk)
+  const vu_rng rng = vu_rng_resolve(rng_in);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
+  const int ntiles = N >> 4, per = (ntiles + WPB - 1) / WPB;
+  int b, grp;
+  work_item(blockIdx.x, B, per, b, grp);
+  const int t = grp * WPB + wave;
+  const bool active = t < ntiles;
+  const int tq = active ? t : ntiles - 1;
+  const int qrow = tq * 16 + l15;
+  const bf16_t* kb = k + (long long)b * N * C::D;
+  const bf16_t* vb = v + (long long)b * N * C::D;
+  stage_own_rows<H, DH>(Qs, q + ((long long)b * N + tq * 16) * C::D, lane);
+  stage_own_rows<H, DH>(dOs, dO + ((long long)b * N + tq * 16) * C::D, lane);
+  float lse[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) lse[h] = lse2[((long long)b * H + h) * N + qrow];
+  Bwd2Ops ops;
+  make_bwd2_ops(ops, stats, l15, g4);
+  f32x4 dl = {0.f, 0.f, 0.f, 0.f}, tc = {0.f, 0.f, 0.f, 0.f}, Tacc = {0.f, 0.f, 0.f, 0.f};
+  const uint32_t hstride = (uint32_t)(((unsigned long long)N * N) >> 2);
+  const uint32_t wlane = (uint32_t)(((((unsigned long long)b * H) * N + qrow) * (unsigned long long)N) >> 2) + (uint32_t)g4;
+  const int nchunks = (ntiles + CK - 1) / CK;
+  const int hh = g4 & 1, a2 = g4 >> 1;
+  ChunkStage<H, DH, CK * 16, WPB * 64> st_Kc;
+  st_Kc.fetch(kb, min(CK, ntiles) * 16, tid);
+  ChunkStage<H, DH, CK * 16, WPB * 64> st_Vc;
+  st_Vc.fetch(vb, min(CK, ntiles) * 16, tid);
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const int nt = min(CK, ntiles - ch * CK);
+    __syncthreads();                                  // every wave has finished with the previous chunk
+    st_Kc.commit(Kc, nt * 16, tid);
+    st_Vc.commit(Vc, nt * 16, tid);
+    __syncthreads();
+    {                                               // next chunk in flight during the tile loop (the last trip re-fetches its own)
+      const int cn = ch + 1 < nchunks ? ch + 1 : ch;
+      st_Kc.fetch(kb + (long long)cn * CK * 16 * C::D, min(CK, ntiles - cn * CK) * 16, tid);
+      st_Vc.fetch(vb + (long long)cn * CK * 16 * C::D, min(CK, ntiles - cn * CK) * 16, tid);
+    }
+    if (active)
+      for (int kc = 0; kc < nt; ++kc) {
+        f32x4 S[H], T[2][4], E[2][4];
+        tile_prod<H, DH, true>(S, Kc, kc, nullptr, Qs, nullptr, l15, g4);
+        bwd2_chain<H, DH, true>(S, Vc, kc, dOs, lse, c, rng, wlane + 4u * (uint32_t)(ch * CK + kc), hstride, ops, T, E, l15, g4);
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const f32x4 dp = bwd2_dp(E[half][r], ops.back);
+            f32x4 ph;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              ph[j] = fmaxf(T[half][r][j], 0.f);
+              dl[j] = fmaf(ph[j], dp[j], dl[j]);
+              tc[j] += E[half][r][j];
+            }
+            // sum over positions of e_g P^_h as X^T X: image row = position (q, a) of this (half, r), columns
+            // [e_0..7 | P^_0..7]; the lane writes its head half of both.  P^ is exact in bf16 here (it went through the bf16
+            // conversion to ML); e is written as a bf16 hi + lo pair in two rounds (e sums to ~0 over the positions while
+            // P^ is nearly constant, so plain bf16 rounding of e does not cancel: measured 6 - 20 % error on dW).
+            bf16_t* row = img + (a2 * 16 + l15) * 20 + 4 * hh;
+            const s16x4 ehi = pack4s(E[half][r]);
+            const f32x4 elo4 = residual4(E[half][r], ehi);
+            *reinterpret_cast<s16x4*>(row) = ehi;
+            *reinterpret_cast<s16x4*>(row + 8) = pack4s(ph);
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) {       // 32 positions = 2 k-blocks of 16
+              const s16x4 x = tr_operand<20>(img, 16 * pb, 0, l15, g4);
+              Tacc = mfma16(x, x, Tacc);
+            }
+            *reinterpret_cast<s16x4*>(row) = pack4s(elo4);
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) {
+              const s16x4 x = tr_operand<20>(img, 16 * pb, 0, l15, g4);
+              Tacc = mfma16(x, x, Tacc);
+            }
+          }
+      }
+  }
+  // delta: the lanes (q, hh) and (q, hh + 2) hold the two key groups of the same 4 heads
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float d = dl[j];
+    d += __shfl_xor(d, 32, 64);
+    if (active && g4 < 2) delta[((long long)b * H + 4 * hh + j) * N + qrow] = d;
+  }
+  // T: accumulator rows c = 4 g4 + jj, column c' = l15: wanted rows 0..7 (e_g), columns 8..15 (P^_h)
+  __syncthreads();
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) {
+    const int g = 4 * g4 + jj;
+    if (g < 8 && l15 >= 8) red[wave * NT + g * H + (l15 - 8)] = active ? Tacc[jj] : 0.f;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float x = active ? tc[j] : 0.f;
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1) x += __shfl_xor(x, m, 64);
+    x += __shfl_xor(x, 32, 64);
+    if (l15 == 0 && g4 < 2) red[wave * NT + H * H + 4 * g4 + j] = x;
+  }
+  __syncthreads();
+  for (int i = tid; i < NT; i += WPB * 64) {
+    float a = 0.f;
+#pragma unroll
+    for (int w = 0; w < WPB; ++w) a += red[w * NT + i];
+    partials[(long long)blockIdx.x * NT + i] = a;
+  }
+}
+
+// ---- sweep 2: dq ---------------------------------------------------------------------------------------------------
+template <int DH, int WPB, int CK>
+__global__ __launch_bounds__(WPB * 64, 2) void flash2_bwd_dq_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, const bf16_t* __restrict__ dO,
+    const float* __restrict__ lse2, const float* __restrict__ delta, const float* __restrict__ stats, bf16_t* __restrict__ dq,
+    int B, int N, float c, float scale, vu_rng rng_in) {
+  constexpr int H = 8, FB = DH / 8;
+  typedef FC<H, DH> C;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* Kc = reinterpret_cast<bf16_t*>(smem_raw);
+  bf16_t* Vc = Kc + CK * 16 * C::PITCH;
+  bf16_t* Qs = Vc + CK * 16 * C::PITCH + (threadIdx.x >> 6) * 32 * C::PITCH;
+  bf16_t* dOs = Qs + 16 * C::PITCH;
+  bf16_t* Zr = Vc + CK * 16 * C::PITCH + WPB * 32 * C::PITCH;
+  const vu_rng rng = vu_rng_resolve(rng_in);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
+  const int ntiles = N >> 4, per = (ntiles + WPB - 1) / WPB;
+  int b, grp;
+  work_item(blockIdx.x, B, per, b, grp);
+  const int t = grp * WPB + wave;
+  const bool active = t < ntiles;
+  const int tq = active ? t : ntiles - 1;
+  const int qrow = tq * 16 + l15;
+  const bf16_t* kb = k + (long long)b * N * C::D;
+  const bf16_t* vb = v + (long long)b * N * C::D;
+  stage_own_rows<H, DH>(Qs, q + ((long long)b * N + tq * 16) * C::D, lane);
+  stage_own_rows<H, DH>(dOs, dO + ((long long)b * N + tq * 16) * C::D, lane);
+  for (int i = tid; i < tr_zero_elems<H, DH>() / 8; i += WPB * 64) *reinterpret_cast<uint4*>(Zr + i * 8) = make_uint4(0, 0, 0, 0);
+  float lse[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) lse[h] = lse2[((long long)b * H + h) * N + qrow];
+  f32x4 dlt;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) dlt[j] = delta[((long long)b * H + 4 * (g4 & 1) + j) * N + qrow];
+  Bwd2Ops ops;
+  make_bwd2_ops(ops, stats, l15, g4);
+  TrSrc<H, DH> src;
+  src.init(l15, g4, (int)(Zr - Kc));
+  f32x4 acc[4][FB];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int fb = 0; fb < FB; ++fb) acc[j][fb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const uint32_t hstride = (uint32_t)(((unsigned long long)N * N) >> 2);
+  const uint32_t wlane = (uint32_t)(((((unsigned long long)b * H) * N + qrow) * (unsigned long long)N) >> 2) + (uint32_t)g4;
+  const int nchunks = (ntiles + CK - 1) / CK;
+  ChunkStage<H, DH, CK * 16, WPB * 64> st_Kc;
+  st_Kc.fetch(kb, min(CK, ntiles) * 16, tid);
+  ChunkStage<H, DH, CK * 16, WPB * 64> st_Vc;
+  st_Vc.fetch(vb, min(CK, ntiles) * 16, tid);
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const int nt = min(CK, ntiles - ch * CK);
+    __syncthreads();                                  // every wave has finished with the previous chunk
+    st_Kc.commit(Kc, nt * 16, tid);
+    st_Vc.commit(Vc, nt * 16, tid);
+    __syncthreads();
+    {                                               // next chunk in flight during the tile loop (the last trip re-fetches its own)
+      const int cn = ch + 1 < nchunks ? ch + 1 : ch;
+      st_Kc.fetch(kb + (long long)cn * CK * 16 * C::D, min(CK, ntiles - cn * CK) * 16, tid);
+      st_Vc.fetch(vb + (long long)cn * CK * 16 * C::D, min(CK, ntiles - cn * CK) * 16, tid);
+    }
+    if (active)
+      for (int kc = 0; kc < nt; ++kc) {
+        f32x4 S[H], T[2][4], E[2][4];
+        tile_prod<H, DH, true>(S, Kc, kc, nullptr, Qs, nullptr, l15, g4);
+        bwd2_chain<H, DH, true>(S, Vc, kc, dOs, lse, c, rng, wlane + 4u * (uint32_t)(ch * CK + kc), hstride, ops, T, E, l15, g4);
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const f32x4 dp = bwd2_dp(E[half][r], ops.back);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) T[half][r][j] = fmaf(fmaxf(T[half][r][j], 0.f), dp[j], -fabsf(T[half][r][j]) * dlt[j]);   // dS
+          }
+        const int tb = src.base(kc);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+            const f32x4 d4 = {T[half][0][j], T[half][1][j], T[half][2][j], T[half][3][j]};
+            const s16x4 bop = pack4s(d4);
+#pragma unroll
+            for (int fb = 0; fb < FB; ++fb) acc[j][fb] = mfma16(tr_half<H, DH>(Kc, tb, half, j, fb), bop, acc[j][fb]);
+          }
+      }
+  }
+  if (active) {
+    bf16_t* orow = dq + ((long long)b * N + qrow) * C::D;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int fb = 0; fb < FB; ++fb) {
+        f32x4 o = acc[j][fb];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] *= scale;
+        *reinterpret_cast<bf16x4*>(orow + (4 * (g4 >> 1) + j) * DH + 8 * fb + 4 * (g4 & 1)) = pack4(o);
+      }
+  }
+}
+
+// ---- sweeps 3 / 4: dk (DV = false) and dv (DV = true), key-major loop ------------------------------------------------
+template <int DH, int WPB, int CK, bool DV>
+__global__ __launch_bounds__(WPB * 64, 2) void flash2_bwd_dkv_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, const bf16_t* __restrict__ dO,
+    const float* __restrict__ lse2, const float* __restrict__ delta, const float* __restrict__ stats, bf16_t* __restrict__ out,
+    int B, int N, float c, float scale, vu_rng rng_in) {
+  constexpr int H = 8;
+  constexpr int IMP = 20, IMS = 16 * IMP;         // image row pitch 40 B: the 16 rows of a store cover the 32 banks once
+  typedef FC<H, DH> C;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* Qc = reinterpret_cast<bf16_t*>(smem_raw);
+  bf16_t* Dc = Qc + CK * 16 * C::PITCH;
+  bf16_t* Ks = Dc + CK * 16 * C::PITCH + (threadIdx.x >> 6) * 32 * C::PITCH;
+  bf16_t* Vs = Ks + 16 * C::PITCH;
+  bf16_t* img = Dc + CK * 16 * C::PITCH + WPB * 32 * C::PITCH + (threadIdx.x >> 6) * 640;     // 2 x [16 q][IMP]
+  const vu_rng rng = vu_rng_resolve(rng_in);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
+  const int ntiles = N >> 4, per = (ntiles + WPB - 1) / WPB;
+  int b, grp;
+  work_item(blockIdx.x, B, per, b, grp);
+  const int t = grp * WPB + wave;
+  const bool active = t < ntiles;
+  const int tk = active ? t : ntiles - 1;
+  const bf16_t* qb = q + (long long)b * N * C::D;
+  const bf16_t* dob = dO + (long long)b * N * C::D;
+  stage_own_rows<H, DH>(Ks, k + ((long long)b * N + tk * 16) * C::D, lane);
+  if (!DV) stage_own_rows<H, DH>(Vs, v + ((long long)b * N + tk * 16) * C::D, lane);
+  zero_pads<H, DH>(Qc, 2 * CK * 16 + WPB * 32, tid, WPB * 64);
+  Bwd2Ops ops;
+  MixOp fw;
+  f32x4 fcin = {0.f, 0.f, 0.f, 0.f};
+  if (DV) {
+    make_mix_op(fw, stats + VU_BN_STATS_FWK(H), nullptr, l15, g4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fcin[j] = stats[H * H + 4 * (g4 & 1) + j];
+  } else make_bwd2_ops(ops, stats, l15, g4);
+  f32x4 oa[H][C::DT];
+#pragma unroll
+  for (int h = 0; h < H; ++h)
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt) oa[h][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const uint32_t hstride = (uint32_t)(((unsigned long long)N * N) >> 2);
+  const uint32_t wkey = (uint32_t)((((unsigned long long)b * H) * N * (unsigned long long)N) >> 2) + 4u * (uint32_t)tk + (uint32_t)g4;
+  const uint32_t wq = (uint32_t)(N >> 2);
+  const int hh = g4 & 1, a2 = g4 >> 1;
+  const int nchunks = (ntiles + CK - 1) / CK;
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const int nt = min(CK, ntiles - ch * CK);
+    __syncthreads();
+    load_chunk<H, DH>(Qc, qb + (long long)ch * CK * 16 * C::D, nt * 16, tid, WPB * 64);
+    load_chunk<H, DH>(Dc, dob + (long long)ch * CK * 16 * C::D, nt * 16, tid, WPB * 64);
+    __syncthreads();
+    if (active)
+      for (int qc = 0; qc < nt; ++qc) {
+        // row constants of the tile's queries (log-sum-exp of all heads, delta of the lane's 4 heads): L2-resident
+        const long long qg = (long long)(ch * CK + qc) * 16 + l15;
+        float lse[H];
+#pragma unroll
+        for (int h = 0; h < H; ++h) lse[h] = lse2[((long long)b * H + h) * N + qg];
+        f32x4 dlt = {0.f, 0.f, 0.f, 0.f};
+        if (!DV) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) dlt[j] = delta[((long long)b * H + 4 * hh + j) * N + qg];
+        }
+        f32x4 S[H], T[2][4];
+        tile_prod<H, DH, false>(S, Qc, qc, nullptr, Ks, nullptr, l15, g4);
+        const uint32_t wt = wkey + (uint32_t)((ch * CK + qc) * 16 + l15) * wq;
+        if constexpr (DV) {
+          tag_probs<H>(S, lse, c, rng, wt, hstride);
+          bf16x8 pk[4];
+          pack_heads(S, pk);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pk[r] = relu_packed(pk[r]);
+          mix_ml(T, fw, pk, fcin);                     // A^ (ML)
+        } else {
+          f32x4 E[2][4];
+          bwd2_chain<H, DH, false>(S, Dc, qc, Vs, lse, c, rng, wt, hstride, ops, T, E, l15, g4);
+#pragma unroll
+          for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const f32x4 dp = bwd2_dp(E[half][r], ops.back);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) T[half][r][j] = fmaf(fmaxf(T[half][r][j], 0.f), dp[j], -fabsf(T[half][r][j]) * dlt[j]);   // dS
+            }
+        }
+        // contraction over the query (lane) index: per j the two heads j (lanes hh = 0) and 4 + j (hh = 1) go through
+        // wave-private [query][key] images and come back transposed
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          bf16_t* im = img + hh * IMS;
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+            const f32x4 x4 = {T[half][0][j], T[half][1][j], T[half][2][j], T[half][3][j]};
+            *reinterpret_cast<s16x4*>(im + l15 * IMP + 8 * half + 4 * a2) = pack4s(x4);
+          }
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2) {
+            const int h = 4 * h2 + j;
+            const s16x4 bop = tr_operand<IMP>(img + h2 * IMS, 0, 0, l15, g4);
+#pragma unroll
+            for (int dt = 0; dt < C::DT; ++dt)
+              oa[h][dt] = mfma16(tr_operand<C::PITCH>(DV ? Dc : Qc, qc * 16, h * DH + 16 * dt, l15, g4), bop, oa[h][dt]);
+          }
+        }
+      }
+  }
+  if (active) {
+    bf16_t* orow = out + ((long long)b * N + tk * 16 + l15) * C::D;
+#pragma unroll
+    for (int h = 0; h < H; ++h)
+#pragma unroll
+      for (int dt = 0; dt < C::DT; ++dt) {
+        const int f = 16 * dt + 4 * g4;
+        if (f < DH) {
+          f32x4 o = oa[h][dt];
+          if (!DV) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] *= scale;
+          }
+          *reinterpret_cast<bf16x4*>(orow + h * DH + f) = pack4(o);
+        }
+      }
+  }
+}
+
 template <typename K>
 int reserve_lds(K kern, size_t lds) {
   if (lds > 48 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
@@ -984,12 +1757,120 @@ int launch_forward(const vu_flash_args& a, hipStream_t st) {
   if (vu_prof_on()) vu_prof_note("flash_stats_kernel", (a.training ? 3.0 : 2.0) * 2.0 * E * DH, 2.0 * act);
   VU_TRY(vu_check_launch("flash_stats"));
   hipLaunchKernelGGL(flash_bn_finalize_kernel, dim3(1), dim3(1024), 0, st, a.partials, nblk, a.mix_w, a.mix_b, a.bn_w, a.bn_b, a.run_mean,
-                     a.run_var, a.stats, H, a.N, (double)a.B * a.N * a.N, a.training, 0.1f, 1e-5f, a.rng.inv_keep);
+                     a.run_var, a.stats, H, a.N, (double)a.B * a.N * a.N, a.training, 0.1f, 1e-5f, a.rng.inv_keep, 0);
   VU_TRY(vu_check_launch("flash_bn_finalize"));
   hipLaunchKernelGGL(k2, dim3(nblk), dim3(WPB * 64), lds2, st, (const bf16_t*)a.q, (const bf16_t*)a.k, (const bf16_t*)a.v, a.lse2,
                      a.stats, (bf16_t*)a.O, a.B, a.N, c, a.rng);
   if (vu_prof_on()) vu_prof_note("flash_apply_kernel", 4.0 * E * DH + 2.0 * E * H, 4.0 * act);
   return vu_check_launch("flash_apply");
+}
+
+inline bool flash_v2_on() { const char* e = getenv("VU_FLASH_V2"); return !(e && e[0] == '0'); }
+
+// The dq, dk and dv sweeps only depend on the delta sweep and write disjoint tensors: they are enqueued on two forked
+// streams and joined back with events (capturable: a stream capture of `st` follows the fork / join), so that the tail
+// of one launch - 832 workgroups over 512 slots leave the second round 62 % full - is filled by the next one.  The
+// streams and events are per-thread library state created on first use.  OFF by default (VU_FLASH_FORK=1 enables it): on
+// the Base step the forked form measured slower than the serial one.
+struct ForkPool { hipStream_t s[2]; hipEvent_t e[3]; bool ok; };
+inline ForkPool* fork_pool() {
+  static thread_local ForkPool fp = {{nullptr, nullptr}, {nullptr, nullptr, nullptr}, false};
+  static thread_local bool tried = false;
+  if (!tried) {
+    tried = true;
+    const char* ev = getenv("VU_FLASH_FORK");       // opt-in: measured 2 % SLOWER on the Base step (17.96 vs 17.61 ms), kept for experiments
+    bool ok = ev && ev[0] == '1';
+    for (int i = 0; ok && i < 2; ++i) ok = hipStreamCreateWithFlags(&fp.s[i], hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; ok && i < 3; ++i) ok = hipEventCreateWithFlags(&fp.e[i], hipEventDisableTiming) == hipSuccess;
+    fp.ok = ok;
+  }
+  return fp.ok ? &fp : nullptr;
+}
+
+template <int DH>
+int launch_forward_v2(const vu_flash_args& a, hipStream_t st) {
+  constexpr int H = 8, WPB = 4, CK = 4;
+  typedef FC<H, DH> C;
+  const int ntiles = a.N >> 4, per = (ntiles + WPB - 1) / WPB;
+  const int nblk = a.B * per;
+  const float c = a.scale * 1.44269504088896340736f;
+  const size_t rowb = (size_t)16 * C::PITCH * 2;
+  const size_t lds1 = CK * rowb + (size_t)WPB * C::NMOM * 4;
+  const size_t ldsm = CK * rowb + (size_t)WPB * 16 * 4;
+  const size_t lds2 = 2 * CK * rowb + (size_t)tr_zero_elems<H, DH>() * 2;
+  auto k1 = flash_stats_kernel<H, DH, WPB, CK>;
+  auto km = flash2_moments_kernel<DH, WPB, CK>;
+  auto k2 = flash2_apply_kernel<DH, WPB, CK>;
+  VU_TRY(reserve_lds(k1, lds1)); VU_TRY(reserve_lds(km, ldsm)); VU_TRY(reserve_lds(k2, lds2));
+  const double E = (double)a.B * H * a.N * a.N, act = (double)a.B * a.N * C::D * 2.0;
+  const bf16_t *q = (const bf16_t*)a.q, *k = (const bf16_t*)a.k, *v = (const bf16_t*)a.v;
+  hipLaunchKernelGGL(k1, dim3(nblk), dim3(WPB * 64), lds1, st, q, k, a.lse2, a.partials, a.B, a.N, c, a.rng, 0);     // row statistics only
+  if (vu_prof_on()) vu_prof_note("flash_rowstats_kernel", 4.0 * E * DH, 2.0 * act);
+  VU_TRY(vu_check_launch("flash_rowstats"));
+  if (a.training) {
+    hipLaunchKernelGGL(km, dim3(nblk), dim3(WPB * 64), ldsm, st, q, k, a.lse2, a.mix_w, a.partials, a.B, a.N, c, a.rng);
+    if (vu_prof_on()) vu_prof_note("flash2_moments_kernel", 2.0 * E * DH + 2.0 * E * H, 2.0 * act);
+    VU_TRY(vu_check_launch("flash2_moments"));
+  }
+  hipLaunchKernelGGL(flash_bn_finalize_kernel, dim3(1), dim3(1024), 0, st, a.partials, nblk, a.mix_w, a.mix_b, a.bn_w, a.bn_b, a.run_mean,
+                     a.run_var, a.stats, H, a.N, (double)a.B * a.N * a.N, a.training, 0.1f, 1e-5f, a.rng.inv_keep, 1);
+  VU_TRY(vu_check_launch("flash_bn_finalize"));
+  hipLaunchKernelGGL(k2, dim3(nblk), dim3(WPB * 64), lds2, st, q, k, v, a.lse2, a.stats, (bf16_t*)a.O, a.B, a.N, c, a.rng);
+  if (vu_prof_on()) vu_prof_note("flash2_apply_kernel", 4.0 * E * DH + 2.0 * E * H, 4.0 * act);
+  return vu_check_launch("flash2_apply");
+}
+
+template <int DH>
+int launch_backward_v2(const vu_flash_args& a, hipStream_t st) {
+  constexpr int H = 8, WPB = 4, CK = 4, CK2 = 2, NT = H * H + H;
+  typedef FC<H, DH> C;
+  const int ntiles = a.N >> 4, per = (ntiles + WPB - 1) / WPB;
+  const int nblk = a.B * per;
+  const float c = a.scale * 1.44269504088896340736f;
+  const size_t rowb = (size_t)16 * C::PITCH * 2;
+  const size_t zr = (size_t)tr_zero_elems<H, DH>() * 2;
+  // two workgroups per CU: every one of these must stay <= 80 KB (81920 B)
+  const size_t lds1 = (2 * CK2 + 2 * WPB) * rowb + (size_t)WPB * 1280;          // (the final [WPB][NT] reduction aliases the K chunk)
+  const size_t lds2 = (2 * CK2 + 2 * WPB) * rowb + zr;
+  const size_t lds3 = (2 * CK2 + 2 * WPB) * rowb + (size_t)WPB * 1280;
+  static_assert((size_t)WPB * NT * 4 <= (size_t)CK2 * 16 * C::PITCH * 2, "reduction scratch must fit the K chunk");
+  const size_t lds4 = (2 * CK + 2 * WPB) * rowb + (size_t)2 * H * CK * 16 * 4 + (size_t)WPB * 1024;
+  auto k1 = flash2_bwd_delta_kernel<DH, WPB, CK2>;
+  auto k2 = flash2_bwd_dq_kernel<DH, WPB, CK2>;
+  auto k3 = flash2_bwd_dkv_kernel<DH, WPB, CK2, false>;
+  auto k4 = flash2_bwd_dkv_kernel<DH, WPB, CK2, true>;
+  VU_TRY(reserve_lds(k1, lds1)); VU_TRY(reserve_lds(k2, lds2)); VU_TRY(reserve_lds(k3, lds3)); VU_TRY(reserve_lds(k4, lds3));
+  (void)lds4;
+  const double E = (double)a.B * H * a.N * a.N, act = (double)a.B * a.N * C::D * 2.0;
+  const bf16_t *q = (const bf16_t*)a.q, *k = (const bf16_t*)a.k, *v = (const bf16_t*)a.v, *dO = (const bf16_t*)a.dO;
+  hipLaunchKernelGGL(k1, dim3(nblk), dim3(WPB * 64), lds1, st, q, k, v, dO, a.lse2, a.stats, a.delta, a.partials, a.B, a.N, c, a.rng);
+  if (vu_prof_on()) vu_prof_note("flash2_bwd_delta_kernel", 4.0 * E * DH + 6.0 * E * H, 4.0 * act);
+  VU_TRY(vu_check_launch("flash2_bwd_delta"));
+  hipLaunchKernelGGL(flash_bwd_mix_finalize_kernel, dim3(1), dim3(1024), 0, st, a.partials, nblk, a.stats, a.d_mix_w, a.d_mix_b, H, a.rng.inv_keep);
+  VU_TRY(vu_check_launch("flash_bwd_mix_finalize"));
+  ForkPool* fp = vu_prof_on() ? nullptr : fork_pool();
+  hipStream_t s_dk = st, s_dv = st;
+  if (fp) {
+    bool ok = hipEventRecord(fp->e[0], st) == hipSuccess;
+    ok = ok && hipStreamWaitEvent(fp->s[0], fp->e[0], 0) == hipSuccess && hipStreamWaitEvent(fp->s[1], fp->e[0], 0) == hipSuccess;
+    if (!ok) { vu_set_error("flash attention: stream fork failed"); return VU_ELAUNCH; }
+    s_dk = fp->s[0]; s_dv = fp->s[1];
+  }
+  hipLaunchKernelGGL(k2, dim3(nblk), dim3(WPB * 64), lds2, st, q, k, v, dO, a.lse2, a.delta, a.stats, (bf16_t*)a.dq, a.B, a.N, c, a.scale, a.rng);
+  if (vu_prof_on()) vu_prof_note("flash2_bwd_dq_kernel", 6.0 * E * DH + 4.0 * E * H, 5.0 * act);
+  VU_TRY(vu_check_launch("flash2_bwd_dq"));
+  hipLaunchKernelGGL(k3, dim3(nblk), dim3(WPB * 64), lds3, s_dk, q, k, v, dO, a.lse2, a.delta, a.stats, (bf16_t*)a.dk, a.B, a.N, c, a.scale, a.rng);
+  if (vu_prof_on()) vu_prof_note("flash2_bwd_dk_kernel", 6.0 * E * DH + 4.0 * E * H, 5.0 * act);
+  VU_TRY(vu_check_launch("flash2_bwd_dk"));
+  hipLaunchKernelGGL(k4, dim3(nblk), dim3(WPB * 64), lds3, s_dv, q, k, v, dO, a.lse2, (const float*)nullptr, a.stats, (bf16_t*)a.dv, a.B, a.N, c, a.scale, a.rng);
+  if (vu_prof_on()) vu_prof_note("flash2_bwd_dv_kernel", 4.0 * E * DH + 2.0 * E * H, 4.0 * act);
+  VU_TRY(vu_check_launch("flash2_bwd_dv"));
+  if (fp) {
+    bool ok = hipEventRecord(fp->e[1], fp->s[0]) == hipSuccess && hipEventRecord(fp->e[2], fp->s[1]) == hipSuccess;
+    ok = ok && hipStreamWaitEvent(st, fp->e[1], 0) == hipSuccess && hipStreamWaitEvent(st, fp->e[2], 0) == hipSuccess;
+    if (!ok) { vu_set_error("flash attention: stream join failed"); return VU_ELAUNCH; }
+  }
+  return VU_OK;
 }
 
 }  // namespace
@@ -1020,11 +1901,23 @@ size_t vu_flash_partials_floats(int B, int N, int H) {
 
 int vu_k_flash_forward(const vu_flash_args& a, hipStream_t st) {
   VU_REQUIRE(vu_flash_ok(1, a.B, a.N, a.D, a.H), "flash attention: shape not covered");
+  if (a.H == 8 && flash_v2_on()) {       // head mixes on the matrix cores
+    const int dh = a.D / a.H;
+    if (dh == 24) return launch_forward_v2<24>(a, st);
+    if (dh == 8) return launch_forward_v2<8>(a, st);
+    if (dh == 32) return launch_forward_v2<32>(a, st);
+  }
   VU_FLASH_DISPATCH(launch_forward, a, st);
 }
 
 int vu_k_flash_backward(const vu_flash_args& a, hipStream_t st) {
   VU_REQUIRE(vu_flash_ok(1, a.B, a.N, a.D, a.H), "flash attention: shape not covered");
+  if (a.H == 8 && flash_v2_on()) {
+    const int dh = a.D / a.H;
+    if (dh == 24) return launch_backward_v2<24>(a, st);
+    if (dh == 8) return launch_backward_v2<8>(a, st);
+    if (dh == 32) return launch_backward_v2<32>(a, st);
+  }
   VU_FLASH_DISPATCH(launch_backward, a, st);
 }
 
