@@ -202,6 +202,20 @@ int vu_denoise_prepare(const uint8_t* noisy, const uint8_t* clean, float* x, flo
                        uint8_t* scratch, size_t scratch_bytes, const double* inv_affine, int B,
                        int Hs, int Ws, int channels, int im, float mean, float std, void* stream);
 
+/* Device-side input pipeline for SegmentationDataset items (vit_unet/torch/dataset.py:18-38): the
+ * reference reads a DICOM slice (pixel_array, 16-bit) and one NIfTI mask plane on the host and
+ * leaves scaling/augmentation to the caller's `augments`.  Here, for a whole batch: image
+ * (B,Hs,Ws) int16 and mask (B,Hs,Ws) uint8 labels -> cv2.resize to oh x ow (bilinear, float
+ * coefficients, for the slice; nearest for the mask; skipped when sizes match) -> optional
+ * warpAffine with per-image INVERSE 2x3 matrices (B x 6 doubles, device; NULL = no warp;
+ * bilinear / nearest, border 0) -> x = clip((v - lo) / (hi - lo), 0, 1), y = label * (1 - ls) +
+ * ls / 2 (the dataset's `ls` argument); x / y: (B,1,oh,ow) float32.  Either pair may be omitted
+ * (is_test).  scratch: >= vu_seg_prepare_scratch_bytes, 2-byte aligned. */
+size_t vu_seg_prepare_scratch_bytes(int B, int oh, int ow);
+int vu_seg_prepare(const int16_t* image, const uint8_t* mask, float* x, float* y, uint8_t* scratch,
+                   size_t scratch_bytes, const double* inv_affine, int B, int Hs, int Ws, int oh,
+                   int ow, float lo, float hi, float ls, void* stream);
+
 /* In-process launch profiler (bench.py's roofline leg): after vu_prof_enable(stream) an event is
  * recorded behind every launch; vu_prof_report() stops, waits, and returns a JSON object
  * {"<kernel tag>": {"count","ms","flops","bytes"}} with ALGORITHMIC flops / bytes per tag. */

@@ -667,6 +667,106 @@ def denoise_prepare(noisy: np.ndarray, clean: np.ndarray, im: int, fwd: Optional
     return torch.from_numpy(np.stack(xs)), torch.from_numpy(np.stack(ys))
 
 
+def _lin_coef_f(dsize: int, ssize: int):
+    """cv2 resize INTER_LINEAR for non-8-bit types: float tap weights (no fixed point)."""
+    scale = 1.0 / (float(dsize) / float(ssize))
+    d = np.arange(dsize, dtype=np.float64)
+    f = ((d + 0.5) * scale - 0.5).astype(np.float32)
+    s = np.floor(f).astype(np.int64)
+    f = f - s.astype(np.float32)
+    lo, hi = s < 0, s >= ssize - 1
+    f[lo | hi] = 0.0
+    s[lo] = 0
+    s[hi] = ssize - 1
+    return s, np.minimum(s + 1, ssize - 1), np.float32(1.0) - f, f, scale
+
+
+def _sat_s16(v: np.ndarray) -> np.ndarray:
+    return np.clip(np.rint(v).astype(np.int64), -32768, 32767)
+
+
+def seg_resize(img: Optional[np.ndarray], mask: Optional[np.ndarray], oh: int, ow: int):
+    """cv2.resize of one SegmentationDataset item to (oh, ow): the int16 slice with INTER_LINEAR
+    (float coefficients, float accumulation, round-half-even, saturate; exact 2x reduction = 2x2 box
+    mean), the label mask with INTER_NEAREST (floor(x * scale) clamped)."""
+    ref = img if img is not None else mask
+    H, W = ref.shape
+    if H == oh and W == ow:
+        return (None if img is None else img.astype(np.int64)), (None if mask is None else mask.copy())
+    x0, x1, a0, a1, sx = _lin_coef_f(ow, W)
+    y0, y1, b0, b1, sy = _lin_coef_f(oh, H)
+    ri = rm = None
+    if img is not None:
+        v = img.astype(np.int64)
+        if H == 2 * oh and W == 2 * ow:
+            ri = (v[0::2, 0::2] + v[0::2, 1::2] + v[1::2, 0::2] + v[1::2, 1::2] + 2) >> 2
+        else:
+            vf = img.astype(np.float32)
+            S = vf[:, x0] * a0[None, :] + vf[:, x1] * a1[None, :]
+            ri = _sat_s16(S[y0] * b0[:, None] + S[y1] * b1[:, None])
+    if mask is not None:
+        my = np.minimum(np.floor(np.arange(oh, dtype=np.float64) * sy).astype(np.int64), H - 1)
+        mx = np.minimum(np.floor(np.arange(ow, dtype=np.float64) * sx).astype(np.int64), W - 1)
+        rm = mask[my][:, mx]
+    return ri, rm
+
+
+def seg_warp(img: Optional[np.ndarray], mask: Optional[np.ndarray], Minv: np.ndarray):
+    """cv2.warpAffine of an (oh, ow) int16 slice (INTER_LINEAR: 10-bit fixed-point coordinates, 1/32
+    sub-pixel, FLOAT weights (1-fy)(1-fx).., sum left to right, round-half-even) and its mask
+    (INTER_NEAREST), constant border 0, given the INVERSE matrix."""
+    ref = img if img is not None else mask
+    oh, ow = ref.shape
+    xs, ys = np.arange(ow, dtype=np.float64), np.arange(oh, dtype=np.float64)
+    adx = np.rint(Minv[0, 0] * xs * 1024.0).astype(np.int64)[None, :]
+    ady = np.rint(Minv[1, 0] * xs * 1024.0).astype(np.int64)[None, :]
+    X0 = np.rint((Minv[0, 1] * ys + Minv[0, 2]) * 1024.0).astype(np.int64)[:, None]
+    Y0 = np.rint((Minv[1, 1] * ys + Minv[1, 2]) * 1024.0).astype(np.int64)[:, None]
+
+    def tap(a, yy, xx):
+        ok = (yy >= 0) & (yy < oh) & (xx >= 0) & (xx < ow)
+        return np.where(ok, a[np.clip(yy, 0, oh - 1), np.clip(xx, 0, ow - 1)], 0)
+    ri = rm = None
+    if img is not None:
+        X, Y = (X0 + 16 + adx) >> 5, (Y0 + 16 + ady) >> 5
+        sx, sy = X >> 5, Y >> 5
+        fx, fy = (X & 31).astype(np.float32) * np.float32(0.03125), (Y & 31).astype(np.float32) * np.float32(0.03125)
+        gx, gy = np.float32(1.0) - fx, np.float32(1.0) - fy
+        f = lambda a: a.astype(np.float32)
+        acc = f(tap(img, sy, sx)) * (gy * gx)
+        acc = acc + f(tap(img, sy, sx + 1)) * (gy * fx)
+        acc = acc + f(tap(img, sy + 1, sx)) * (fy * gx)
+        acc = acc + f(tap(img, sy + 1, sx + 1)) * (fy * fx)
+        ri = _sat_s16(acc)
+    if mask is not None:
+        rm = tap(mask, (Y0 + 512 + ady) >> 10, (X0 + 512 + adx) >> 10)
+    return ri, rm
+
+
+def seg_prepare(image: Optional[np.ndarray], mask: Optional[np.ndarray], im_size, fwd: Optional[np.ndarray] = None,
+                lo: float = -1024.0, hi: float = 1024.0, ls: float = 0.0):
+    """One batch of SegmentationDataset items (dataset.py:18-38: DICOM slice `x`, NIfTI plane `mask`)
+    through the scaling / augmentation the reference leaves to `augments`: resize to `im_size` ->
+    optional ShiftScaleRotate (`fwd`: (B,2,3) forward matrices) -> x = clip((v-lo)/(hi-lo), 0, 1);
+    y = label (1-ls) + ls/2.  image (B,H,W) int16, mask (B,H,W) uint8 -> (B,1,oh,ow) float32."""
+    oh, ow = (im_size, im_size) if isinstance(im_size, int) else im_size
+    B = (image if image is not None else mask).shape[0]
+    xs, ys = [], []
+    rng_ = np.float32(hi) - np.float32(lo)
+    keep, floor_ = np.float32(1.0) - np.float32(ls), np.float32(0.5) * np.float32(ls)
+    for b in range(B):
+        ri, rm = seg_resize(None if image is None else image[b], None if mask is None else mask[b], oh, ow)
+        if fwd is not None:
+            ri, rm = seg_warp(ri, rm, invert_affine(fwd[b]))
+        if ri is not None:
+            xs.append(np.clip((ri.astype(np.float32) - np.float32(lo)) / rng_, np.float32(0), np.float32(1))[None])
+        if rm is not None:
+            ys.append((rm.astype(np.float32) * keep + floor_)[None])
+    x = torch.from_numpy(np.stack(xs)) if xs else None
+    y = torch.from_numpy(np.stack(ys)) if ys else None
+    return x, y
+
+
 def adamw_step(p, g, m, v, step: int, lr=1e-4, b1=0.9, b2=0.999, eps=1e-8, wd=1e-2):
     """torch.optim.AdamW defaults (run_denoising.py:81), one tensor, in place.  `step` >= 1."""
     p.mul_(1 - lr * wd)

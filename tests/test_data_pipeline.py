@@ -187,3 +187,134 @@ def test_image_fitter_fused_dice(tmp_path):
     assert hist[-1]["train"] < hist[0]["train"] and np.isfinite(hist[-1]["val"])
     g2 = ImageFitter(m, loss=Fn.DiceLoss(apply_sigmoid=False), device=DEV, folder=str(tmp_path))
     assert g2._fused_kind() is None        # plain Dice on raw outputs: autograd path
+
+
+# ---------------------------------------------------------------- SegmentationDataset pipeline (dataset.py:9-41)
+def _seg_batch(B, H, W, seed=0):
+    rng = np.random.default_rng(seed)
+    base = rng.integers(-1200, 2500, (B, 1, H // 8 + 2, W // 8 + 2)).astype(np.float32)
+    up = F.interpolate(torch.from_numpy(base), size=(H, W), mode="bilinear")[:, 0].numpy()
+    img = np.clip(up + rng.normal(0, 40, up.shape), -32768, 32767).astype(np.int16)
+    mask = (up > 600).astype(np.uint8) + (up > 1800).astype(np.uint8)         # labels 0 / 1 / 2
+    return img, mask
+
+
+def test_seg_oracle_properties():
+    img, mask = _seg_batch(1, 96, 80, seed=1)
+    i0, m0 = img[0], mask[0]
+    ri, rm = O.seg_resize(i0, m0, 96, 80)
+    assert np.array_equal(ri, i0) and np.array_equal(rm, m0)                     # same size: copy
+    ri, rm = O.seg_resize(np.full((57, 91), -700, np.int16), np.full((57, 91), 2, np.uint8), 128, 128)
+    assert (ri == -700).all() and (rm == 2).all()                                # weights sum to one
+    ri, rm = O.seg_resize(i0, m0, 48, 40)                                         # exact 2x: box mean / top-left label
+    assert np.array_equal(ri, (i0.astype(int).reshape(48, 2, 40, 2).sum(axis=(1, 3)) + 2) >> 2)
+    assert np.array_equal(rm, m0[::2, ::2])
+    ref = F.interpolate(torch.from_numpy(i0.astype(np.float32))[None, None], size=(128, 128), mode="bilinear")[0, 0].numpy()
+    assert np.abs(O.seg_resize(i0, None, 128, 128)[0] - ref).max() <= 0.5 + 1e-3  # float bilinear, rounded
+    # warp: identity, integer shift, half-pixel mean (round half even on a float sum)
+    I = np.array([[1.0, 0, 0], [0, 1.0, 0]])
+    wi, wm = O.seg_warp(i0.astype(np.int64), m0, I)
+    assert np.array_equal(wi, i0) and np.array_equal(wm, m0)
+    wi, wm = O.seg_warp(i0.astype(np.int64), m0, O.invert_affine(np.array([[1.0, 0, 5], [0, 1.0, -3]])))
+    assert np.array_equal(wi[:93, 5:], i0[3:, :75]) and not wi[:, :5].any() and not wm[93:].any()
+    wi, _ = O.seg_warp(i0.astype(np.int64), None, O.invert_affine(np.array([[1.0, 0, 0.5], [0, 1.0, 0]])))
+    assert np.array_equal(wi[:, 1:], np.rint((i0[:, :-1].astype(np.float64) + i0[:, 1:]) / 2).astype(np.int64))
+    # window + label smoothing hand values
+    v = np.array([[[-2000, -1024, 0, 1024, 3000]]], np.int16)
+    x, y = O.seg_prepare(v, np.array([[[0, 1, 1, 0, 1]]], np.uint8), (1, 5), None, lo=-1024, hi=1024, ls=0.1)
+    assert x.shape == (1, 1, 1, 5) and x.reshape(-1).tolist() == [0.0, 0.0, 0.5, 1.0, 1.0]
+    assert np.allclose(y.reshape(-1).numpy(), [0.05, 0.95, 0.95, 0.05, 0.95], atol=1e-7)
+    x, y = O.seg_prepare(v, None, (1, 5))
+    assert y is None and x is not None
+
+
+def test_dataset_classes_host_side(tmp_path):
+    """Same names and constructor arguments as dataset.py:9-17 / :44-51; items are the decoded pairs."""
+    from PIL import Image
+    from vit_unet.torch import dataset as D
+    rng = np.random.default_rng(0)
+    (tmp_path / "c").mkdir(), (tmp_path / "n").mkdir()
+    rgb = rng.integers(0, 256, (20, 24, 3), dtype=np.uint8)
+    for sub in "cn":
+        Image.fromarray(rgb).save(tmp_path / sub / "a.png")
+    ds = D.DenoisingDataset(["a"], augments=None, clean_folder=str(tmp_path / "c"), noisy_folder=str(tmp_path / "n"), im_size=16)
+    assert len(ds) == 1
+    it = ds[0]
+    assert set(it) == {"x", "y"} and it["x"].dtype == np.uint8 and np.array_equal(it["x"], rgb[:, :, ::-1])    # BGR like cv2.imread
+    with pytest.raises(TypeError):
+        D.DenoisingDataset(["a"], augments=lambda **k: k)
+    import pandas as pd
+    df = pd.DataFrame({"image": ["i0", "i1"], "mask": ["m0", "m1"], "mask_index": [0, 1]})
+    vol = {"m0": rng.integers(0, 2, (12, 10, 2)), "m1": rng.integers(0, 2, (12, 10, 2))}
+    sl = {"i0": rng.integers(-1000, 1000, (12, 10)), "i1": rng.integers(-1000, 1000, (12, 10))}
+    sd = D.SegmentationDataset(df, augments=None, is_test=False, data_folder="output", im_size=(8, 8), ls=0.1,
+                               read_image=lambda p: sl[p].astype(np.int16), read_mask=lambda p, k: vol[p][:, :, k].astype(np.uint8))
+    assert len(sd) == 2 and np.array_equal(sd[1]["y"], vol["m1"][:, :, 1]) and sd[1]["x"].dtype == np.int16
+    assert "y" not in D.SegmentationDataset(df, is_test=True, read_image=lambda p: sl[p].astype(np.int16))[0]
+    fwd = D.shift_scale_rotate_matrices(1, (8, 12), rng=random.Random(3))[0]     # non-square: centre (w/2-.5, h/2-.5)
+    r = random.Random(3)
+    a, s, dx, dy = r.uniform(-20, 20), r.uniform(0.8, 1.2), r.uniform(-0.2, 0.2), r.uniform(-0.2, 0.2)
+    ca, sa = s * np.cos(np.radians(a)), s * np.sin(np.radians(a))
+    assert np.allclose(fwd, [[ca, sa, (1 - ca) * 5.5 - sa * 3.5 + dx * 12], [-sa, ca, sa * 5.5 + (1 - ca) * 3.5 + dy * 8]])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,oh,ow", [(3, 300, 280, 128, 128), (2, 128, 128, 128, 128), (2, 512, 512, 256, 256),
+                                         (2, 100, 131, 64, 96), (1, 512, 512, 512, 512), (5, 37, 53, 32, 48)])
+@pytest.mark.parametrize("train", [False, True])
+def test_seg_prepare_bit_exact(B, H, W, oh, ow, train):
+    from vit_unet.torch import dataset as D
+    img, mask = _seg_batch(B, H, W, seed=B + H)
+    fwd = D.shift_scale_rotate_matrices(B, (oh, ow), rng=random.Random(H + W)) if train else None
+    t = D.SegmentationBatchTransform((oh, ow), train=train, window=(-1000.0, 2000.0), ls=0.1)
+    got = t(img, mask, matrices=fwd)
+    rx, ry = O.seg_prepare(img, mask, (oh, ow), fwd, lo=-1000.0, hi=2000.0, ls=0.1)
+    assert got["x"].shape == (B, 1, oh, ow) and got["x"].dtype == torch.float32 and got["x"].is_cuda
+    assert torch.equal(got["x"].cpu(), rx), (got["x"].cpu() - rx).abs().max()
+    assert torch.equal(got["y"].cpu(), ry), (got["y"].cpu() - ry).abs().max()
+
+
+@pytest.mark.gpu
+def test_seg_dataset_to_device_batches_and_errors():
+    from vit_unet.torch import _lib, dataset as D
+    import pandas as pd
+    img, mask = _seg_batch(5, 72, 64, seed=4)
+    big_i, big_m = _seg_batch(1, 90, 100, seed=5)            # one item of another size: grouped, order kept
+    imgs, masks = list(img) + [big_i[0]], list(mask) + [big_m[0]]
+    df = pd.DataFrame({"image": range(6), "mask": range(6), "mask_index": [0] * 6})
+    ds = D.SegmentationDataset(df, im_size=(32, 32), ls=0.0, read_image=lambda p: imgs[p], read_mask=lambda p, k: masks[p])
+    batches = list(D.DeviceBatches(ds, batch_size=4))
+    assert [b["x"].shape[0] for b in batches] == [4, 2] and batches[0]["x"].shape[1:] == (1, 32, 32)
+    rx, ry = O.seg_prepare(img[4:5], mask[4:5], (32, 32))
+    assert torch.equal(batches[1]["x"][0:1].cpu(), rx) and torch.equal(batches[1]["y"][0:1].cpu(), ry)
+    rx, ry = O.seg_prepare(big_i, big_m, (32, 32))
+    assert torch.equal(batches[1]["x"][1:2].cpu(), rx) and torch.equal(batches[1]["y"][1:2].cpu(), ry)
+    test_only = D.SegmentationDataset(df, is_test=True, im_size=(32, 32), read_image=lambda p: imgs[p])
+    out = test_only.transform([test_only[0], test_only[1]])
+    assert set(out) == {"x"} and out["x"].shape == (2, 1, 32, 32)
+    L = _lib.lib()
+    z16 = torch.zeros(16, dtype=torch.int16, device=DEV)
+    z8 = torch.zeros(16, dtype=torch.uint8, device=DEV)
+    f = torch.zeros(16, device=DEV)
+    st = _lib.stream_ptr()
+    args = lambda **k: (_lib.ptr(z16), _lib.ptr(z8), _lib.ptr(f), _lib.ptr(f), None, 0, None, k.get("B", 1), 4, 4, k.get("oh", 4), 4,
+                        k.get("lo", 0.0), k.get("hi", 1.0), k.get("ls", 0.0), st)
+    assert L.vu_seg_prepare(*args()) == 0
+    assert L.vu_seg_prepare(*args(hi=0.0)) < 0 and L.vu_seg_prepare(*args(ls=1.0)) < 0
+    assert L.vu_seg_prepare(*args(oh=2)) < 0 and L.vu_seg_prepare(*args(B=0)) < 0      # scratch missing / empty
+
+
+@pytest.mark.gpu
+def test_denoising_dataset_device_batches(tmp_path):
+    from PIL import Image
+    from vit_unet.torch import dataset as D
+    noisy, clean = _batch(3, 40, 48, 3, seed=2)
+    (tmp_path / "c").mkdir(), (tmp_path / "n").mkdir()
+    for i in range(3):
+        Image.fromarray(noisy[i][:, :, ::-1]).save(tmp_path / "n" / f"{i}.png")
+        Image.fromarray(clean[i][:, :, ::-1]).save(tmp_path / "c" / f"{i}.png")
+    ds = D.DenoisingDataset(["0", "1", "2"], augments=D.DenoisingBatchTransform(32, train=False), clean_folder=str(tmp_path / "c"),
+                            noisy_folder=str(tmp_path / "n"), im_size=32)
+    (b,) = list(D.DeviceBatches(ds, batch_size=3))
+    rx, ry = O.denoise_prepare(noisy, clean, 32, None)
+    assert torch.equal(b["x"].cpu(), rx) and torch.equal(b["y"].cpu(), ry)

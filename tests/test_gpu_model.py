@@ -377,6 +377,7 @@ def test_dp_path_one_rank_rccl_matches_single_gpu_step(golden_dir, monkeypatch):
             if not k.endswith("reatten_matrix.bias"):
                 assert serr(pc, pd_) < 2e-4, k
     finally:
+        torch.cuda.synchronize()
         dist.destroy_process_group()
 
 

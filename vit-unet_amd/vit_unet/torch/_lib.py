@@ -91,6 +91,8 @@ SIGNATURES = {
     "vu_ssim": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "vu_denoise_prepare_scratch_bytes": (_sz, [_i, _i, _i]),
     "vu_denoise_prepare": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _vp, _i, _i, _i, _i, _i, _f, _f, _vp]),
+    "vu_seg_prepare_scratch_bytes": (_sz, [_i, _i, _i]),
+    "vu_seg_prepare": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _vp, _i, _i, _i, _i, _i, _f, _f, _f, _vp]),
     "vu_prof_enable": (_i, [_vp]),
     "vu_prof_report": (C.c_char_p, []),
 }
