@@ -194,14 +194,18 @@ def keep_mask_quad(rows: int, n: int, p: float, seed: int, stream: int) -> torch
     return torch.from_numpy(by.reshape(rows, n))
 
 
+FLASH_FILL_RULE = True      # False: mirror VU_ATTN_FLASH=1 (the recompute form wherever the shape is covered)
+
+
 def flash_shape(B: int, N: int, D: int, h: int) -> bool:
-    """Mirror of vu_flash_ok (csrc/vu_flash.hip) for bf16 storage: shapes the model path runs in the non-materialising
-    form, whose attention-map dropout uses the quad scheme."""
+    """Mirror of vu_flash_ok and vu_flash_pays (csrc/vu_flash.hip) for bf16 storage: the shapes the model path runs in
+    the non-materialising form by default, whose attention-map dropout uses the quad scheme."""
     if h <= 0 or D % h:
         return False
     d = D // h
     inst = (h == 8 and d in (24, 8, 32)) or (h == 4 and d == 32)
-    return inst and N % 16 == 0 and N >= 256 and B * h * N * N < 2 ** 34
+    fills = (not FLASH_FILL_RULE) or B * ((N // 16 + 3) // 4) >= 320
+    return inst and fills and N % 16 == 0 and N >= 256 and B * h * N * N < 2 ** 34
 
 
 def _dropout_quad(x: torch.Tensor, p: float, training: bool, seed: Optional[int], stream: int):

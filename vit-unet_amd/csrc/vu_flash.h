@@ -24,6 +24,9 @@ struct vu_flash_args {
 // attention-map dropout of this form: 8 bits per element, drop probability round(256 p) / 256 (vu_flash.hip, "quad" scheme)
 vu_rng vu_flash_quad_rng(vu_rng r);
 bool vu_flash_ok(int dtype, int B, int N, int D, int H);
+// the recompute form only pays when its grid (B x ceil(N/64) work groups of 4 waves) gives every CU more than one group;
+// below that the materialising kernels (which parallelise over heads too) are faster (measured, Base: B=16 -5 %, B=32 +3.5 %)
+bool vu_flash_pays(int B, int N);
 size_t vu_flash_partials_floats(int B, int N, int H);
 int vu_k_flash_forward(const vu_flash_args& a, hipStream_t st);
 int vu_k_flash_backward(const vu_flash_args& a, hipStream_t st);

@@ -152,8 +152,12 @@ struct AttnScratch { void *dO, *dq, *dk, *dv, *dA; float* partials; int nblocks;
 
 struct AttnDims { int dtype, B, N, D, H, C, s, ld; int centered = 0; int flash = 0; };
 // non-materialising form (vu_flash.hip): the maps are recomputed from q, k (and v, dO) in every pass
-inline bool flash_on(const AttnDims& d) { return d.flash && vu_flash_ok(d.dtype, d.B, d.N, d.D, d.H); }
-inline int flash_switch() { const char* e = getenv("VU_ATTN_FLASH"); return !(e && e[0] == '0'); }   // model path: on unless VU_ATTN_FLASH=0
+// flash: 0 = never, 1 = wherever the shape is covered, 2 = covered AND the launch fills the chip (vu_flash_pays)
+inline bool flash_on(const AttnDims& d) {
+  return d.flash && vu_flash_ok(d.dtype, d.B, d.N, d.D, d.H) && (d.flash == 1 || vu_flash_pays(d.B, d.N));
+}
+// model path: VU_ATTN_FLASH=0 never, =1 wherever covered, unset: per level by the fill rule
+inline int flash_switch() { const char* e = getenv("VU_ATTN_FLASH"); return !e ? 2 : (e[0] == '0' ? 0 : 1); }
 // stand-alone op (vu_attn_forward / vu_attn_backward are separate calls that must agree on the form, and the forward may
 // be asked for the map): opt-in with VU_ATTN_FLASH=1 (test switch)
 inline int flash_switch_op() { const char* e = getenv("VU_ATTN_FLASH"); return e && e[0] == '1'; }
