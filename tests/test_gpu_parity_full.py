@@ -326,7 +326,10 @@ def test_bf16_vs_fp32_loss_trajectory_base():
     assert rel[0] < 0.1, rel[0]                        # the first step sees identical weights (full depth: chaotic forward)
     assert l32[-1] < 0.35 * l32[0] and l16[-1] < 0.35 * l16[0]   # both train
     w32, w16 = l32.reshape(5, 10).mean(axis=1), l16.reshape(5, 10).mean(axis=1)
-    assert np.abs(np.log(w16 / w32)).max() < 0.3, (w32, w16)     # and along the same curve, window by window
+    # and along the same curve, window by window: the fast drop around steps 10-17 starts a few steps apart in two fp32 /
+    # bf16 runs (and between two runs of one precision: float atomics), which moves that window's mean by up to 35 %
+    assert np.abs(np.log(w16 / w32)).max() < 0.5, (w32, w16)
+    assert abs(np.log(w16[-1] / w32[-1])) < 0.25, (w32, w16)
 
 
 # ------------------------------------------------------------------------------------------------

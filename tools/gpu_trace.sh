@@ -1,0 +1,36 @@
+# rocprofv3 kernel trace of one bench.py run (eager launches), reduced to two summaries under gpurun_out/:
+#   <tag>_kernel_stats.csv   rocprofv3's own --stats table
+#   <tag>_by_grid.csv        per (kernel, grid size): launches per step, average and total us per step
+# usage: bash tools/gpu_trace.sh <tag> [bench.py args...]
+set -x
+TAG=${1:-r02}; shift
+cd $GRAFT_REPO_ROOT
+OUT=$GRAFT_REPO_ROOT/gpurun_out/rocprof_$TAG
+rm -rf $OUT; cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-host-input --no-graph --no-roofline "$@" > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_trace_bench.log 2>&1
+tail -c 300 $GRAFT_REPO_ROOT/gpurun_out/${TAG}_trace_bench.log
+cd $GRAFT_REPO_ROOT
+python - "$TAG" <<'PY'
+import csv, glob, collections, shutil, sys
+tag = sys.argv[1]
+root = f"gpurun_out/rocprof_{tag}"
+for f in glob.glob(root + "/**/*kernel_stats.csv", recursive=True):
+    shutil.copy(f, f"gpurun_out/{tag}_kernel_stats.csv")
+agg = collections.defaultdict(lambda: [0, 0.0])
+steps = 6
+for f in glob.glob(root + "/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = (r["Kernel_Name"][:110], r.get("Grid_Size_X", r.get("Grid_Size", "")), r.get("Grid_Size_Y", ""), r.get("Grid_Size_Z", ""))
+        a = agg[k]
+        a[0] += 1
+        a[1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
+tot = sum(v[1] for _, v in rows)
+with open(f"gpurun_out/{tag}_by_grid.csv", "w") as o:
+    o.write("kernel,grid_x,grid_y,grid_z,launches_per_step,avg_us,us_per_step,share\n")
+    for (k, gx, gy, gz), (n, us) in rows[:120]:
+        o.write('"%s",%s,%s,%s,%.1f,%.1f,%.1f,%.4f\n' % (k, gx, gy, gz, n / steps, us / n, us / steps, us / tot))
+print("total us per step (all launches / %d steps): %.1f" % (steps, tot / steps))
+shutil.rmtree(root, ignore_errors=True)
+PY
+head -45 gpurun_out/${TAG}_by_grid.csv

@@ -31,6 +31,48 @@ __device__ __forceinline__ void load_win(const T* __restrict__ plane, int s, int
   }
 }
 
+// Neighbour-lane forms of the window (consecutive lanes hold consecutive pixel quads of a patch, row-major, and a patch
+// row of s/4 quads never straddles a 16-lane DPP row when s/4 divides 16):
+//   SH = 1: the two halo pixels of every row come from lanes -1 / +1 (row_shr:1 / row_shl:1) instead of two scalar loads;
+//   SH = 2: (s == 8, a DPP row is one whole 8x8 plane) rows y-1 / y+1 come from lanes -2 / +2 as well: one load per plane.
+// The stencil is issue-bound on its many narrow loads (27 per thread for C = 3), not on bytes.
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+template <typename T, int SH>
+__device__ __forceinline__ void load_win_sh(const T* __restrict__ plane, int s, int y, int x0, float (&w)[3][6]) {
+  if constexpr (SH == 0) { load_win(plane, s, y, x0, w); return; }
+  if constexpr (SH == 2) {
+    const vu_f4 c = vu_ld4(plane + y * s + x0);
+    const bool up = y > 0, dn = y < s - 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float u = dpp_mov<0x112>(c.v[i]), d = dpp_mov<0x102>(c.v[i]);   // row_shr:2 / row_shl:2
+      w[0][1 + i] = up ? u : 0.f;
+      w[1][1 + i] = c.v[i];
+      w[2][1 + i] = dn ? d : 0.f;
+    }
+  } else {
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int yy = y + dy - 1;
+      const bool rv = (yy >= 0) && (yy < s);
+      const int yc = yy < 0 ? 0 : (yy >= s ? s - 1 : yy);
+      const vu_f4 c = vu_ld4(plane + yc * s + x0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) w[dy][1 + i] = rv ? c.v[i] : 0.f;
+    }
+  }
+  const bool lv = x0 > 0, rr = x0 + 4 < s;
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy) {
+    const float l = dpp_mov<0x111>(w[dy][4]), r = dpp_mov<0x101>(w[dy][1]);   // row_shr:1 / row_shl:1
+    w[dy][0] = lv ? l : 0.f;
+    w[dy][5] = rr ? r : 0.f;
+  }
+}
+inline int conv_shuffle_form(int s) { return s == 8 ? 2 : ((s >= 8 && s <= 64 && 64 % s == 0) ? 1 : 0); }
+
 __device__ __forceinline__ void quad_coords(long long qid, int s, long long& patch, int& y, int& x0) {
   // 32-bit unsigned arithmetic (the launchers guarantee nquads < 2^32): a 64-bit division by a
   // run-time value costs >100 instructions per quad
@@ -46,7 +88,7 @@ __device__ __forceinline__ void quad_coords(long long qid, int s, long long& pat
 
 // ---- forward ---------------------------------------------------------------------------------
 // NOUT = 1: out0 = conv(in0, w0) (+bias)      NOUT = 3: q = conv(in0,w0), k = conv(in1,w1), v = conv(in1,w2)
-template <typename TI, typename TO, int C, int NOUT>
+template <typename TI, typename TO, int C, int NOUT, int SH = 0>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(const TI* __restrict__ in0, const TI* __restrict__ in1,
                                                        const float* __restrict__ w0, const float* __restrict__ w1,
                                                        const float* __restrict__ w2, const float* __restrict__ bias,
@@ -64,12 +106,12 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const TI* __restrict__ in
     const long long obase = pbase + y * s + x0;
     float win[C][3][6];
 #pragma unroll
-    for (int ci = 0; ci < C; ++ci) load_win(in0 + pbase + ci * ss, s, y, x0, win[ci]);
+    for (int ci = 0; ci < C; ++ci) load_win_sh<TI, SH>(in0 + pbase + ci * ss, s, y, x0, win[ci]);
 #pragma unroll 1
     for (int o = 0; o < NOUT; ++o) {
       if (NOUT == 3 && o == 1 && !same) {
 #pragma unroll
-        for (int ci = 0; ci < C; ++ci) load_win(in1 + pbase + ci * ss, s, y, x0, win[ci]);
+        for (int ci = 0; ci < C; ++ci) load_win_sh<TI, SH>(in1 + pbase + ci * ss, s, y, x0, win[ci]);
       }
       TO* op = o == 0 ? o0 : (o == 1 ? o1 : o2);
       const float* __restrict__ wp = o == 0 ? w0 : (o == 1 ? w1 : w2);
@@ -100,7 +142,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const TI* __restrict__ in
 // NIN = 1: din0 = convT(d0,w0) + add0
 // NIN = 3: same input:  din0 = convT(d0,w0)+convT(d1,w1)+convT(d2,w2) + add0
 //          cross:       din0 = convT(d0,w0) + add0 ; din1 = convT(d1,w1)+convT(d2,w2) + add1
-template <typename TDO, typename T, int C, int NIN>
+template <typename TDO, typename T, int C, int NIN, int SH = 0>
 __global__ __launch_bounds__(256) void conv_dgrad_kernel(const TDO* __restrict__ d0, const TDO* __restrict__ d1,
                                                          const TDO* __restrict__ d2, const float* __restrict__ w0,
                                                          const float* __restrict__ w1, const float* __restrict__ w2,
@@ -129,7 +171,7 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(const TDO* __restrict__
       const float* __restrict__ wp = t == 0 ? w0 : (t == 1 ? w1 : w2);
       float win[C][3][6];
 #pragma unroll
-      for (int co = 0; co < C; ++co) load_win(dp + pbase + co * ss, s, y, x0, win[co]);
+      for (int co = 0; co < C; ++co) load_win_sh<TDO, SH>(dp + pbase + co * ss, s, y, x0, win[co]);
       const bool to1 = cross && t > 0;
       float tmp[C][4];
 #pragma unroll
@@ -328,6 +370,9 @@ __global__ __launch_bounds__(WAVES * 64) void conv_wgrad_mm_kernel(const bf16_t*
   }
 }
 
+// A/B switch for measurements: VU_CONV_SHUFFLE=0 keeps the all-loads window
+inline bool shuffle_off() { static const bool v = [] { const char* e = getenv("VU_CONV_SHUFFLE"); return e && e[0] == '0'; }(); return v; }
+
 inline int grid_for(long long items, int cap) {
   long long g = (items + 255) / 256;
   if (g > cap) g = cap;
@@ -365,9 +410,13 @@ int vu_k_conv3x3_qkv_fwd(int dtype, const void* xq, const void* xkv, const float
   const long long nq = npatch * s * s / 4;
   if (nq == 0) return VU_OK;
   const int grid = grid_for(nq, 256 * 16);
+  const int sh = shuffle_off() ? 0 : conv_shuffle_form(s);
+#define VU_QKV_FWD(SHV) \
+    if (dtype == 0) hipLaunchKernelGGL((conv_fwd_kernel<float, float, CC, 3, SHV>), dim3(grid), dim3(256), 0, st, (const float*)xq, (const float*)xkv, wq, wk, wv, (const float*)nullptr, (float*)q, (float*)k, (float*)v, nq, s); \
+    else hipLaunchKernelGGL((conv_fwd_kernel<bf16_t, bf16_t, CC, 3, SHV>), dim3(grid), dim3(256), 0, st, (const bf16_t*)xq, (const bf16_t*)xkv, wq, wk, wv, (const float*)nullptr, (bf16_t*)q, (bf16_t*)k, (bf16_t*)v, nq, s);
   VU_CONV_C(C,
-    if (dtype == 0) hipLaunchKernelGGL((conv_fwd_kernel<float, float, CC, 3>), dim3(grid), dim3(256), 0, st, (const float*)xq, (const float*)xkv, wq, wk, wv, (const float*)nullptr, (float*)q, (float*)k, (float*)v, nq, s);
-    else hipLaunchKernelGGL((conv_fwd_kernel<bf16_t, bf16_t, CC, 3>), dim3(grid), dim3(256), 0, st, (const bf16_t*)xq, (const bf16_t*)xkv, wq, wk, wv, (const float*)nullptr, (bf16_t*)q, (bf16_t*)k, (bf16_t*)v, nq, s);)
+    if (sh == 2) { VU_QKV_FWD(2) } else if (sh == 1) { VU_QKV_FWD(1) } else { VU_QKV_FWD(0) })
+#undef VU_QKV_FWD
   if (vu_prof_on()) vu_prof_note("conv_fwd_kernel<3>", 0.0, (double)nq * 4 * C * (dtype == 0 ? 4.0 : 2.0) * (xq == xkv ? 4 : 5));
   return vu_check_launch("vu_conv3x3_qkv_fwd");
 }
@@ -396,9 +445,13 @@ int vu_k_conv3x3_qkv_dgrad(int dtype, const void* dq, const void* dk, const void
   const long long nq = npatch * s * s / 4;
   if (nq == 0) return VU_OK;
   const int grid = grid_for(nq, 256 * 16);
+  const int sh = shuffle_off() ? 0 : conv_shuffle_form(s);
+#define VU_QKV_DGRAD(SHV) \
+    if (dtype == 0) hipLaunchKernelGGL((conv_dgrad_kernel<float, float, CC, 3, SHV>), dim3(grid), dim3(256), 0, st, (const float*)dq, (const float*)dk, (const float*)dv, wq, wk, wv, (const float*)add_q, (const float*)add_kv, (float*)dxq, (float*)dxkv, nq, s); \
+    else hipLaunchKernelGGL((conv_dgrad_kernel<bf16_t, bf16_t, CC, 3, SHV>), dim3(grid), dim3(256), 0, st, (const bf16_t*)dq, (const bf16_t*)dk, (const bf16_t*)dv, wq, wk, wv, (const bf16_t*)add_q, (const bf16_t*)add_kv, (bf16_t*)dxq, (bf16_t*)dxkv, nq, s);
   VU_CONV_C(C,
-    if (dtype == 0) hipLaunchKernelGGL((conv_dgrad_kernel<float, float, CC, 3>), dim3(grid), dim3(256), 0, st, (const float*)dq, (const float*)dk, (const float*)dv, wq, wk, wv, (const float*)add_q, (const float*)add_kv, (float*)dxq, (float*)dxkv, nq, s);
-    else hipLaunchKernelGGL((conv_dgrad_kernel<bf16_t, bf16_t, CC, 3>), dim3(grid), dim3(256), 0, st, (const bf16_t*)dq, (const bf16_t*)dk, (const bf16_t*)dv, wq, wk, wv, (const bf16_t*)add_q, (const bf16_t*)add_kv, (bf16_t*)dxq, (bf16_t*)dxkv, nq, s);)
+    if (sh == 2) { VU_QKV_DGRAD(2) } else if (sh == 1) { VU_QKV_DGRAD(1) } else { VU_QKV_DGRAD(0) })
+#undef VU_QKV_DGRAD
   if (vu_prof_on()) vu_prof_note("conv_dgrad_kernel<3>", 0.0, (double)nq * 4 * C * (dtype == 0 ? 4.0 : 2.0) * (dxkv ? 5 + (add_q ? 1 : 0) + (add_kv ? 1 : 0) : 4 + (add_q ? 1 : 0)));
   return vu_check_launch("vu_conv3x3_qkv_dgrad");
 }

@@ -1106,13 +1106,37 @@ __device__ __forceinline__ s16x4 tr_half(const bf16_t* Xc, int base, int half, i
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(Xc + base + 8 * half * C::PITCH + j * DH + 8 * fb));
 }
 template <int H, int DH> constexpr int tr_zero_elems() { return 8 * FC<H, DH>::PITCH + 3 * DH + 8 * ((DH + 7) / 8) + 8; }
+// The same source with one base per key half: the immediates left (j DH + fb 8) stay inside a zero strip of
+// tr_strip_elems() elements instead of a region that spans 8 rows (LDS is the scarce resource of the fused dq sweep).
+template <int H, int DH>
+struct TrSrc2 {
+  int lane_off, zero_off;
+  bool live;
+  __device__ __forceinline__ void init(int l15, int g4, int zero_off_) {
+    typedef FC<H, DH> C;
+    const int qq = l15 >> 2, pp = l15 & 3;
+    live = (pp >> 1) == (g4 & 1);
+    lane_off = (4 * (g4 >> 1) + qq) * C::PITCH + 4 * (pp >> 1) * DH + 4 * (pp & 1);
+    zero_off = zero_off_;
+  }
+  __device__ __forceinline__ int base(int kc, int half) const {
+    typedef FC<H, DH> C;
+    return live ? lane_off + (kc * 16 + 8 * half) * C::PITCH : zero_off;
+  }
+};
+template <int DH>
+__device__ __forceinline__ s16x4 tr_rel(const bf16_t* Xc, int base, int j, int fb) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(Xc + base + j * DH + 8 * fb));
+}
+template <int DH> constexpr int tr_strip_elems() { return ((3 * DH + 8 * ((DH + 7) / 8) + 8 + 7) / 8) * 8; }
 
 // ---- stats pass, sweep 3 only (sweeps 1 / 2 are the v1 code): moments of the MIXED map directly -------------------
 // per lane 4 heads x (sum, sum of squares) of A_g - shift_g, shift_g = sum_h W[g,h] / N (the exact mean without dropout)
 template <int DH, int WPB, int CK>
 __global__ __launch_bounds__(WPB * 64, 2) void flash2_moments_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                                       const float* __restrict__ lse2, const float* __restrict__ W,
-                                                                      float* __restrict__ partials, int B, int N, float c, vu_rng rng_in) {
+                                                                      float* __restrict__ partials, float* __restrict__ pk_out,
+                                                                      int B, int N, float c, vu_rng rng_in) {
   constexpr int H = 8;
   typedef FC<H, DH> C;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1148,6 +1172,14 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_moments_kernel(const bf16_
     }
   }
   f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+  // P k (the UN-dropped probabilities times the keys, per head): the backward's dq sweep needs sum_k P k to take delta out
+  // of its element chain (dq = scale (sum_k P~ dP~ k - delta sum_k P k)), and this sweep has the probabilities and the
+  // key chunk at hand with registers to spare
+  f32x4 pacc[H][C::DT];                       // rows = features 16 dt + 4 g4 + r of head h, column = query l15
+#pragma unroll
+  for (int h = 0; h < H; ++h)
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt) pacc[h][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   const uint32_t hstride = (uint32_t)(((unsigned long long)N * N) >> 2);
   const uint32_t wlane = (uint32_t)(((((unsigned long long)b * H) * N + qrow) * (unsigned long long)N) >> 2) + (uint32_t)g4;
   const int nchunks = (ntiles + CK - 1) / CK;
@@ -1170,6 +1202,14 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_moments_kernel(const bf16_
         bf16x8 pk[4];
         pack_heads(S, pk);
 #pragma unroll
+        for (int h = 0; h < H; ++h) {                  // a logits-shaped tile is the B operand of a key-contracting product as it stands
+          const f32x4 p4 = {fabsf(S[h][0]), fabsf(S[h][1]), fabsf(S[h][2]), fabsf(S[h][3])};
+          const s16x4 bop = pack4s(p4);
+#pragma unroll
+          for (int dt = 0; dt < C::DT; ++dt)
+            pacc[h][dt] = mfma16(tr_operand<C::PITCH>(Kc, kc * 16, h * DH + 16 * dt, l15, g4), bop, pacc[h][dt]);
+        }
+#pragma unroll
         for (int r = 0; r < 4; ++r) pk[r] = relu_packed(pk[r]);
         f32x4 A[2][4];
         mix_ml(A, op, pk, cin);
@@ -1179,6 +1219,16 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_moments_kernel(const bf16_
           for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int j = 0; j < 4; ++j) { s1[j] += A[half][r][j]; s2[j] = fmaf(A[half][r][j], A[half][r][j], s2[j]); }
+      }
+  }
+  if (active) {
+    float* prow = pk_out + ((long long)b * N + qrow) * C::D;
+#pragma unroll
+    for (int h = 0; h < H; ++h)
+#pragma unroll
+      for (int dt = 0; dt < C::DT; ++dt) {
+        const int f = 16 * dt + 4 * g4;
+        if (f < DH) *reinterpret_cast<f32x4*>(prow + h * DH + f) = pacc[h][dt];
       }
   }
   // lanes with the same head half (g4 & 1) hold the same 4 heads: reduce over q (16 lanes) and over a (g4 >> 1)
@@ -1564,6 +1614,180 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_bwd_dq_kernel(
   }
 }
 
+// ---- sweeps 1 + 2 in one: delta, the head-mix gradient sums and dq ------------------------------------------------
+// dS = P~ dP~ - P delta with delta = sum_k P~ dP~ known only after the whole row: instead of a sweep for delta and a
+// second one for dq (each recomputing the chain), accumulate U = sum_k (P~ dP~) k here and take V = sum_k P k from the
+// forward (flash2_moments_kernel): dq = scale (U - delta V).  The u = P~ dP~ terms go to the matrix cores as single bf16
+// values like dS did; U - delta V is the covariance form of the same sum.
+template <int DH, int WPB, int CK>
+__global__ __launch_bounds__(WPB * 64, 2) void flash2_bwd_dqx_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, const bf16_t* __restrict__ dO,
+    const float* __restrict__ lse2, const float* __restrict__ pkv, const float* __restrict__ stats, bf16_t* __restrict__ dq,
+    float* __restrict__ delta, float* __restrict__ partials, int B, int N, float c, float scale, vu_rng rng_in) {
+  constexpr int H = 8, FB = DH / 8, NT = H * H + H, IMP = 16;
+  typedef FC<H, DH> C;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* Kc = reinterpret_cast<bf16_t*>(smem_raw);
+  bf16_t* Vc = Kc + CK * 16 * C::PITCH;
+  bf16_t* Qs = Vc + CK * 16 * C::PITCH + (threadIdx.x >> 6) * 32 * C::PITCH;
+  bf16_t* dOs = Qs + 16 * C::PITCH;
+  // [32 positions][16: e_0..7 | P^_0..7], 8-byte column blocks XOR-swizzled with (row >> 2) & 3 (pitch 32 B: unswizzled,
+  // rows 4 apart would meet on the same banks in the stores)
+  bf16_t* img = Vc + CK * 16 * C::PITCH + WPB * 32 * C::PITCH + (threadIdx.x >> 6) * (32 * IMP);
+  bf16_t* Zr = Vc + CK * 16 * C::PITCH + WPB * 32 * C::PITCH + WPB * (32 * IMP);
+  float* red = reinterpret_cast<float*>(Kc);                              // [WPB][NT], after the last tile (aliases the K chunk)
+  const vu_rng rng = vu_rng_resolve(rng_in);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
+  const int ntiles = N >> 4, per = (ntiles + WPB - 1) / WPB;
+  int b, grp;
+  work_item(blockIdx.x, B, per, b, grp);
+  const int t = grp * WPB + wave;
+  const bool active = t < ntiles;
+  const int tq = active ? t : ntiles - 1;
+  const int qrow = tq * 16 + l15;
+  const bf16_t* kb = k + (long long)b * N * C::D;
+  const bf16_t* vb = v + (long long)b * N * C::D;
+  stage_own_rows<H, DH>(Qs, q + ((long long)b * N + tq * 16) * C::D, lane);
+  stage_own_rows<H, DH>(dOs, dO + ((long long)b * N + tq * 16) * C::D, lane);
+  for (int i = tid; i < tr_strip_elems<DH>() / 8; i += WPB * 64) *reinterpret_cast<uint4*>(Zr + i * 8) = make_uint4(0, 0, 0, 0);
+  float lse[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) lse[h] = lse2[((long long)b * H + h) * N + qrow];
+  Bwd2Ops ops;
+  make_bwd2_ops(ops, stats, l15, g4);
+  TrSrc2<H, DH> src;
+  src.init(l15, g4, (int)(Zr - Kc));
+  f32x4 acc[4][FB];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int fb = 0; fb < FB; ++fb) acc[j][fb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 dl = {0.f, 0.f, 0.f, 0.f}, tc = {0.f, 0.f, 0.f, 0.f}, Tacc = {0.f, 0.f, 0.f, 0.f};
+  const uint32_t hstride = (uint32_t)(((unsigned long long)N * N) >> 2);
+  const uint32_t wlane = (uint32_t)(((((unsigned long long)b * H) * N + qrow) * (unsigned long long)N) >> 2) + (uint32_t)g4;
+  const int nchunks = (ntiles + CK - 1) / CK;
+  const int hh = g4 & 1, a2 = g4 >> 1;
+  // image addresses: the lane's row (a2 16 + l15) and its two swizzled column blocks; the transposed reads of k-block pb
+  const int sw = (l15 >> 2) & 3;
+  bf16_t* im_e = img + (a2 * 16 + l15) * IMP + 4 * (hh ^ sw);
+  bf16_t* im_p = img + (a2 * 16 + l15) * IMP + 4 * ((2 + hh) ^ sw);
+  const bf16_t* im_r = img + (4 * g4 + (l15 >> 2)) * IMP + 4 * ((l15 & 3) ^ g4);
+  ChunkStage<H, DH, CK * 16, WPB * 64> st_Kc;
+  st_Kc.fetch(kb, min(CK, ntiles) * 16, tid);
+  ChunkStage<H, DH, CK * 16, WPB * 64> st_Vc;
+  st_Vc.fetch(vb, min(CK, ntiles) * 16, tid);
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const int nt = min(CK, ntiles - ch * CK);
+    __syncthreads();                                  // every wave has finished with the previous chunk
+    st_Kc.commit(Kc, nt * 16, tid);
+    st_Vc.commit(Vc, nt * 16, tid);
+    __syncthreads();
+    {                                               // next chunk in flight during the tile loop (the last trip re-fetches its own)
+      const int cn = ch + 1 < nchunks ? ch + 1 : ch;
+      st_Kc.fetch(kb + (long long)cn * CK * 16 * C::D, min(CK, ntiles - cn * CK) * 16, tid);
+      st_Vc.fetch(vb + (long long)cn * CK * 16 * C::D, min(CK, ntiles - cn * CK) * 16, tid);
+    }
+    if (active)
+      for (int kc = 0; kc < nt; ++kc) {
+        f32x4 S[H], T[2][4], E[2][4];
+        tile_prod<H, DH, true>(S, Kc, kc, nullptr, Qs, nullptr, l15, g4);
+        bwd2_chain<H, DH, true>(S, Vc, kc, dOs, lse, c, rng, wlane + 4u * (uint32_t)(ch * CK + kc), hstride, ops, T, E, l15, g4);
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const f32x4 dp = bwd2_dp(E[half][r], ops.back);
+            f32x4 ph;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              ph[j] = fmaxf(T[half][r][j], 0.f);
+              tc[j] += E[half][r][j];
+            }
+            // sum over positions of e_g P^_h as X^T X (see flash2_bwd_delta_kernel): e as a bf16 hi + lo pair in two rounds
+            const s16x4 ehi = pack4s(E[half][r]);
+            const f32x4 elo4 = residual4(E[half][r], ehi);
+            *reinterpret_cast<s16x4*>(im_e) = ehi;
+            *reinterpret_cast<s16x4*>(im_p) = pack4s(ph);
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) {       // 32 positions = 2 k-blocks of 16
+              const s16x4 x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(im_r + 16 * pb * IMP));
+              Tacc = mfma16(x, x, Tacc);
+            }
+            *reinterpret_cast<s16x4*>(im_e) = pack4s(elo4);
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) {
+              const s16x4 x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(im_r + 16 * pb * IMP));
+              Tacc = mfma16(x, x, Tacc);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float u = ph[j] * dp[j];         // P~ dP~
+              dl[j] += u;
+              T[half][r][j] = u;
+            }
+          }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const int tb = src.base(kc, half);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const f32x4 d4 = {T[half][0][j], T[half][1][j], T[half][2][j], T[half][3][j]};
+            const s16x4 bop = pack4s(d4);
+#pragma unroll
+            for (int fb = 0; fb < FB; ++fb) acc[j][fb] = mfma16(tr_rel<DH>(Kc, tb, j, fb), bop, acc[j][fb]);
+          }
+        }
+      }
+  }
+  // delta: the lanes (q, hh) and (q, hh + 2) hold the two key groups of the same 4 heads; the accumulators of this lane
+  // belong to heads 4 (g4 >> 1) + j, whose delta sits in the lanes with hh = g4 >> 1
+  f32x4 dsel;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float d = dl[j];
+    d += __shfl_xor(d, 32, 64);
+    if (active && g4 < 2) delta[((long long)b * H + 4 * hh + j) * N + qrow] = d;
+    dsel[j] = __shfl(d, l15 + 16 * (g4 >> 1), 64);
+  }
+  if (active) {
+    bf16_t* orow = dq + ((long long)b * N + qrow) * C::D;
+    const float* vrow = pkv + ((long long)b * N + qrow) * C::D;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int fb = 0; fb < FB; ++fb) {
+        const int off = (4 * (g4 >> 1) + j) * DH + 8 * fb + 4 * (g4 & 1);
+        const f32x4 pv = *reinterpret_cast<const f32x4*>(vrow + off);
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = scale * fmaf(-dsel[j], pv[r], acc[j][fb][r]);
+        *reinterpret_cast<bf16x4*>(orow + off) = pack4(o);
+      }
+  }
+  // T: accumulator rows c = 4 g4 + jj, column c' = l15: wanted rows 0..7 (e_g), columns 8..15 (P^_h)
+  __syncthreads();
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) {
+    const int g = 4 * g4 + jj;
+    if (g < 8 && l15 >= 8) red[wave * NT + g * H + (l15 - 8)] = active ? Tacc[jj] : 0.f;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float x = active ? tc[j] : 0.f;
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1) x += __shfl_xor(x, m, 64);
+    x += __shfl_xor(x, 32, 64);
+    if (l15 == 0 && g4 < 2) red[wave * NT + H * H + 4 * g4 + j] = x;
+  }
+  __syncthreads();
+  for (int i = tid; i < NT; i += WPB * 64) {
+    float a = 0.f;
+#pragma unroll
+    for (int w = 0; w < WPB; ++w) a += red[w * NT + i];
+    partials[(long long)blockIdx.x * NT + i] = a;
+  }
+}
+
 // ---- sweeps 3 / 4: dk (DV = false) and dv (DV = true), key-major loop ------------------------------------------------
 template <int DH, int WPB, int CK, bool DV>
 __global__ __launch_bounds__(WPB * 64, 2) void flash2_bwd_dkv_kernel(
@@ -1808,8 +2032,9 @@ int launch_forward_v2(const vu_flash_args& a, hipStream_t st) {
   if (vu_prof_on()) vu_prof_note("flash_rowstats_kernel", 4.0 * E * DH, 2.0 * act);
   VU_TRY(vu_check_launch("flash_rowstats"));
   if (a.training) {
-    hipLaunchKernelGGL(km, dim3(nblk), dim3(WPB * 64), ldsm, st, q, k, a.lse2, a.mix_w, a.partials, a.B, a.N, c, a.rng);
-    if (vu_prof_on()) vu_prof_note("flash2_moments_kernel", 2.0 * E * DH + 2.0 * E * H, 2.0 * act);
+    VU_REQUIRE(a.pk != nullptr, "flash attention: the training forward needs the P k buffer");
+    hipLaunchKernelGGL(km, dim3(nblk), dim3(WPB * 64), ldsm, st, q, k, a.lse2, a.mix_w, a.partials, a.pk, a.B, a.N, c, a.rng);
+    if (vu_prof_on()) vu_prof_note("flash2_moments_kernel", 4.0 * E * DH + 2.0 * E * H, 4.0 * act);
     VU_TRY(vu_check_launch("flash2_moments"));
   }
   hipLaunchKernelGGL(flash_bn_finalize_kernel, dim3(1), dim3(1024), 0, st, a.partials, nblk, a.mix_w, a.mix_b, a.bn_w, a.bn_b, a.run_mean,
@@ -1835,17 +2060,29 @@ int launch_backward_v2(const vu_flash_args& a, hipStream_t st) {
   const size_t lds3 = (2 * CK2 + 2 * WPB) * rowb + (size_t)WPB * 1280;
   static_assert((size_t)WPB * NT * 4 <= (size_t)CK2 * 16 * C::PITCH * 2, "reduction scratch must fit the K chunk");
   const size_t lds4 = (2 * CK + 2 * WPB) * rowb + (size_t)2 * H * CK * 16 * 4 + (size_t)WPB * 1024;
+  const size_t lds2x = (2 * CK2 + 2 * WPB) * rowb + (size_t)WPB * 1024 + (size_t)tr_strip_elems<DH>() * 2;
   auto k1 = flash2_bwd_delta_kernel<DH, WPB, CK2>;
   auto k2 = flash2_bwd_dq_kernel<DH, WPB, CK2>;
+  auto k2x = flash2_bwd_dqx_kernel<DH, WPB, CK2>;
+  // VU_FLASH_DQX=0: the separate delta and dq sweeps (A/B switch)
+  const bool fused = a.pk != nullptr && !([] { const char* e = getenv("VU_FLASH_DQX"); return e && e[0] == '0'; }());
+  VU_TRY(reserve_lds(k2x, lds2x));
   auto k3 = flash2_bwd_dkv_kernel<DH, WPB, CK2, false>;
   auto k4 = flash2_bwd_dkv_kernel<DH, WPB, CK2, true>;
   VU_TRY(reserve_lds(k1, lds1)); VU_TRY(reserve_lds(k2, lds2)); VU_TRY(reserve_lds(k3, lds3)); VU_TRY(reserve_lds(k4, lds3));
   (void)lds4;
   const double E = (double)a.B * H * a.N * a.N, act = (double)a.B * a.N * C::D * 2.0;
   const bf16_t *q = (const bf16_t*)a.q, *k = (const bf16_t*)a.k, *v = (const bf16_t*)a.v, *dO = (const bf16_t*)a.dO;
-  hipLaunchKernelGGL(k1, dim3(nblk), dim3(WPB * 64), lds1, st, q, k, v, dO, a.lse2, a.stats, a.delta, a.partials, a.B, a.N, c, a.rng);
-  if (vu_prof_on()) vu_prof_note("flash2_bwd_delta_kernel", 4.0 * E * DH + 6.0 * E * H, 4.0 * act);
-  VU_TRY(vu_check_launch("flash2_bwd_delta"));
+  if (fused) {
+    hipLaunchKernelGGL(k2x, dim3(nblk), dim3(WPB * 64), lds2x, st, q, k, v, dO, a.lse2, a.pk, a.stats, (bf16_t*)a.dq, a.delta, a.partials, a.B,
+                       a.N, c, a.scale, a.rng);
+    if (vu_prof_on()) vu_prof_note("flash2_bwd_dqx_kernel", 6.0 * E * DH + 8.0 * E * H, 7.0 * act);
+    VU_TRY(vu_check_launch("flash2_bwd_dqx"));
+  } else {
+    hipLaunchKernelGGL(k1, dim3(nblk), dim3(WPB * 64), lds1, st, q, k, v, dO, a.lse2, a.stats, a.delta, a.partials, a.B, a.N, c, a.rng);
+    if (vu_prof_on()) vu_prof_note("flash2_bwd_delta_kernel", 4.0 * E * DH + 6.0 * E * H, 4.0 * act);
+    VU_TRY(vu_check_launch("flash2_bwd_delta"));
+  }
   hipLaunchKernelGGL(flash_bwd_mix_finalize_kernel, dim3(1), dim3(1024), 0, st, a.partials, nblk, a.stats, a.d_mix_w, a.d_mix_b, H, a.rng.inv_keep);
   VU_TRY(vu_check_launch("flash_bwd_mix_finalize"));
   ForkPool* fp = vu_prof_on() ? nullptr : fork_pool();
@@ -1856,9 +2093,11 @@ int launch_backward_v2(const vu_flash_args& a, hipStream_t st) {
     if (!ok) { vu_set_error("flash attention: stream fork failed"); return VU_ELAUNCH; }
     s_dk = fp->s[0]; s_dv = fp->s[1];
   }
-  hipLaunchKernelGGL(k2, dim3(nblk), dim3(WPB * 64), lds2, st, q, k, v, dO, a.lse2, a.delta, a.stats, (bf16_t*)a.dq, a.B, a.N, c, a.scale, a.rng);
-  if (vu_prof_on()) vu_prof_note("flash2_bwd_dq_kernel", 6.0 * E * DH + 4.0 * E * H, 5.0 * act);
-  VU_TRY(vu_check_launch("flash2_bwd_dq"));
+  if (!fused) {
+    hipLaunchKernelGGL(k2, dim3(nblk), dim3(WPB * 64), lds2, st, q, k, v, dO, a.lse2, a.delta, a.stats, (bf16_t*)a.dq, a.B, a.N, c, a.scale, a.rng);
+    if (vu_prof_on()) vu_prof_note("flash2_bwd_dq_kernel", 6.0 * E * DH + 4.0 * E * H, 5.0 * act);
+    VU_TRY(vu_check_launch("flash2_bwd_dq"));
+  }
   hipLaunchKernelGGL(k3, dim3(nblk), dim3(WPB * 64), lds3, s_dk, q, k, v, dO, a.lse2, a.delta, a.stats, (bf16_t*)a.dk, a.B, a.N, c, a.scale, a.rng);
   if (vu_prof_on()) vu_prof_note("flash2_bwd_dk_kernel", 6.0 * E * DH + 4.0 * E * H, 5.0 * act);
   VU_TRY(vu_check_launch("flash2_bwd_dk"));

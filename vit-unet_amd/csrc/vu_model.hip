@@ -147,7 +147,7 @@ int build_plan(const vu_config& c, Plan& pl) {
 // ---------------------------------------------------------------------------------------------
 // ReAttention / SkipConnection
 // ---------------------------------------------------------------------------------------------
-struct AttnBuf { void *q, *k, *v, *Ps, *Ah, *O; float* stats; float *lse2, *delta; };
+struct AttnBuf { void *q, *k, *v, *Ps, *Ah, *O; float* stats; float *lse2, *delta, *pk; };
 struct AttnScratch { void *dO, *dq, *dk, *dv, *dA; float* partials; int nblocks; };
 
 struct AttnDims { int dtype, B, N, D, H, C, s, ld; int centered = 0; int flash = 0; };
@@ -182,6 +182,7 @@ void carve_attn(Bump& bp, const AttnDims& d, AttnBuf& a) {
   a.stats = bp.takef(VU_BN_STATS_FLOATS(d.H));
   a.lse2 = bp.takef((size_t)d.B * d.H * d.N);
   a.delta = bp.takef((size_t)d.B * d.H * d.N);
+  a.pk = (flash_on(d) && d.H == 8) ? bp.takef((size_t)d.B * d.N * d.D) : nullptr;     // sum_k P k of the recompute form (vu_flash.h)
 }
 inline size_t attn_partials_floats(const AttnDims& d) {
   return std::max((size_t)std::max(stats_blocks(d), d.B) * 2 * d.H + 1024, vu_flash_partials_floats(d.B, d.N, d.H));
@@ -190,7 +191,7 @@ void fill_flash_args(vu_flash_args& fa, const AttnDims& d, const vu_attn_params&
   memset(&fa, 0, sizeof(fa));
   fa.B = d.B; fa.N = d.N; fa.D = d.D; fa.H = d.H; fa.scale = 1.0f / sqrtf((float)(d.D / d.H)); fa.training = training;
   fa.rng = vu_flash_quad_rng(ra);
-  fa.q = a.q; fa.k = a.k; fa.v = a.v; fa.O = a.O; fa.lse2 = a.lse2; fa.delta = a.delta; fa.partials = partials; fa.stats = a.stats;
+  fa.q = a.q; fa.k = a.k; fa.v = a.v; fa.O = a.O; fa.lse2 = a.lse2; fa.pk = a.pk; fa.delta = a.delta; fa.partials = partials; fa.stats = a.stats;
   fa.mix_w = p.mix_w; fa.mix_b = p.mix_b; fa.bn_w = p.bn_w; fa.bn_b = p.bn_b; fa.run_mean = p.run_mean; fa.run_var = p.run_var;
 }
 
@@ -899,6 +900,7 @@ int vu_conv3x3_bwd(int dtype, int dout_f32, const void* dout, const void* in, co
 
 static void carve_attn_ws(Bump& bp, const AttnDims& d, AttnBuf& a, AttnScratch& sc, void** dzbuf) {
   carve_attn(bp, d, a);
+  if (!a.pk) a.pk = bp.takef((size_t)d.B * d.N * d.D);      // the op's form is chosen after the carve (test switch)
   const size_t act = (size_t)d.B * d.N * d.D * esize(d.dtype);
   const size_t map = (size_t)d.B * d.H * d.N * d.ld * esize(d.dtype);
   sc.dO = bp.take(act); sc.dq = bp.take(act); sc.dk = bp.take(act); sc.dv = bp.take(act); sc.dA = bp.take(map);
