@@ -352,6 +352,86 @@ __global__ __launch_bounds__(WPB * 64) void flash_stats_kernel(const bf16_t* __r
   }
 }
 
+// Row statistics alone, ONE sweep (the v2 forward's first pass): every lane carries a running (max, sum) pair per head
+// over its own keys (4 per tile) in the log2 domain and rescales the sum when its maximum moves; the four lane groups of a
+// query are merged at the end.  The next K chunk is fetched into registers while the current one is consumed.
+template <int H, int DH, int WPB, int CK>
+__global__ __launch_bounds__(WPB * 64, 2) void flash_rowstats_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                                      float* __restrict__ lse2, int B, int N, float c) {
+  typedef FC<H, DH> C;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* Kc = reinterpret_cast<bf16_t*>(smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
+  const int ntiles = N >> 4, per = (ntiles + WPB - 1) / WPB;
+  int b, grp;
+  work_item(blockIdx.x, B, per, b, grp);
+  const int t = grp * WPB + wave;
+  const bool active = t < ntiles;
+  const int tq = active ? t : ntiles - 1;
+  const int qrow = tq * 16 + l15;
+  const bf16_t* kb = k + (long long)b * N * C::D;
+  bf16x8 qf[H];
+  load_stationary<H, DH>(qf, q + ((long long)b * N + qrow) * C::D, g4);
+  zero_pads<H, DH>(Kc, CK * 16, tid, WPB * 64);
+  const int nchunks = (ntiles + CK - 1) / CK;
+  float mx[H], sm[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) { mx[h] = -3.0e38f; sm[h] = 0.f; }
+  ChunkStage<H, DH, CK * 16, WPB * 64> st_Kc;
+  st_Kc.fetch(kb, min(CK, ntiles) * 16, tid);
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const int nt = min(CK, ntiles - ch * CK);
+    __syncthreads();
+    st_Kc.commit(Kc, nt * 16, tid);
+    __syncthreads();
+    {
+      const int cn = ch + 1 < nchunks ? ch + 1 : ch;
+      st_Kc.fetch(kb + (long long)cn * CK * 16 * C::D, min(CK, ntiles - cn * CK) * 16, tid);
+    }
+    if (active)
+      for (int kc = 0; kc < nt; ++kc) {
+        f32x4 acc[H];
+        tile_logits<H, DH>(acc, Kc, kc, qf, l15, g4);
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+          const float tm = fmaxf(fmaxf(acc[h][0], acc[h][1]), fmaxf(acc[h][2], acc[h][3])) * c;      // c > 0
+          const float mn = fmaxf(mx[h], tm);
+          float a = sm[h] * fexp2(mx[h] - mn);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) a += fexp2(fmaf(acc[h][r], c, -mn));
+          sm[h] = a;
+          mx[h] = mn;
+        }
+      }
+  }
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    float m = mx[h], s_ = sm[h];
+#pragma unroll
+    for (int o = 16; o <= 32; o <<= 1) {
+      const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s_, o, 64);
+      const float mn = fmaxf(m, m2);
+      s_ = s_ * fexp2(m - mn) + s2 * fexp2(m2 - mn);
+      m = mn;
+    }
+    if (active && g4 == 0) lse2[((long long)b * H + h) * N + qrow] = m + log2f(s_);
+  }
+}
+
+// column sum of a [nblocks][ncol] partial array over the rows rl, rl + step, ...: four independent accumulators over
+// loads issued together (a single dependent chain pays one L2 round trip per row: 30 us for 832 rows)
+__device__ __forceinline__ double strided_colsum(const float* __restrict__ p, int nblocks, int ncol, int col, int rl, int step) {
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  int i = rl;
+  for (; i + 3 * step < nblocks; i += 4 * step) {
+    const float x0 = p[(long long)i * ncol + col], x1 = p[(long long)(i + step) * ncol + col];
+    const float x2 = p[(long long)(i + 2 * step) * ncol + col], x3 = p[(long long)(i + 3 * step) * ncol + col];
+    a0 += (double)x0; a1 += (double)x1; a2 += (double)x2; a3 += (double)x3;
+  }
+  for (; i < nblocks; i += step) a0 += (double)p[(long long)i * ncol + col];
+  return (a0 + a1) + (a2 + a3);
+}
+
 // fp64 finalize: moments -> BatchNorm statistics of the mixed maps, running statistics, folded tables.
 // stats layout: vu_kernels.h (VU_BN_STATS_*), extended by FWk = gamma rstd W / keep and XK = rstd W / keep.
 // `direct`: the partial rows hold the moments of the mixed maps themselves (v2: [sum (A_g - shift_g)] [sum (A_g - shift_g)^2],
@@ -367,7 +447,7 @@ __global__ __launch_bounds__(1024) void flash_bn_finalize_kernel(const float* __
   if (training) {
     const int col = tid & 63, rl = tid >> 6;
     double a = 0.0;
-    if (col < NM) for (int i = rl; i < nblocks; i += 16) a += (double)partials[(long long)i * NM + col];
+    if (col < NM) a = strided_colsum(partials, nblocks, NM, col, rl, 16);
     sd[rl][col] = a;
     __syncthreads();
     if (tid < NM) {
@@ -730,7 +810,7 @@ __global__ __launch_bounds__(1024) void flash_bwd_mix_finalize_kernel(const floa
   const int NT = H * H + H;                                  // <= 72 columns: 128 side by side (coalesced), 8 row lanes
   const int col = threadIdx.x & 127, rl = threadIdx.x >> 7;
   double a = 0.0;
-  if (col < NT) for (int i = rl; i < nblocks; i += 8) a += (double)partials[(long long)i * NT + col];
+  if (col < NT) a = strided_colsum(partials, nblocks, NT, col, rl, 8);
   sd[rl][col] = a;
   __syncthreads();
   if (threadIdx.x < NT) {
@@ -1834,12 +1914,28 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_bwd_dkv_kernel(
   const uint32_t wq = (uint32_t)(N >> 2);
   const int hh = g4 & 1, a2 = g4 >> 1;
   const int nchunks = (ntiles + CK - 1) / CK;
+  // register-staged prefetch of the next chunk: only the dv sweep has the registers for it (dk sits at the 256 cap)
+  ChunkStage<H, DH, CK * 16, WPB * 64> st_Qc, st_Dc;
+  if constexpr (DV) {
+    st_Qc.fetch(qb, min(CK, ntiles) * 16, tid);
+    st_Dc.fetch(dob, min(CK, ntiles) * 16, tid);
+  }
   for (int ch = 0; ch < nchunks; ++ch) {
     const int nt = min(CK, ntiles - ch * CK);
     __syncthreads();
-    load_chunk<H, DH>(Qc, qb + (long long)ch * CK * 16 * C::D, nt * 16, tid, WPB * 64);
-    load_chunk<H, DH>(Dc, dob + (long long)ch * CK * 16 * C::D, nt * 16, tid, WPB * 64);
+    if constexpr (DV) {
+      st_Qc.commit(Qc, nt * 16, tid);
+      st_Dc.commit(Dc, nt * 16, tid);
+    } else {
+      load_chunk<H, DH>(Qc, qb + (long long)ch * CK * 16 * C::D, nt * 16, tid, WPB * 64);
+      load_chunk<H, DH>(Dc, dob + (long long)ch * CK * 16 * C::D, nt * 16, tid, WPB * 64);
+    }
     __syncthreads();
+    if constexpr (DV) {
+      const int cn = ch + 1 < nchunks ? ch + 1 : ch;
+      st_Qc.fetch(qb + (long long)cn * CK * 16 * C::D, min(CK, ntiles - cn * CK) * 16, tid);
+      st_Dc.fetch(dob + (long long)cn * CK * 16 * C::D, min(CK, ntiles - cn * CK) * 16, tid);
+    }
     if (active)
       for (int qc = 0; qc < nt; ++qc) {
         // row constants of the tile's queries (log-sum-exp of all heads, delta of the lane's 4 heads): L2-resident
@@ -2022,13 +2118,13 @@ int launch_forward_v2(const vu_flash_args& a, hipStream_t st) {
   const size_t lds1 = CK * rowb + (size_t)WPB * C::NMOM * 4;
   const size_t ldsm = CK * rowb + (size_t)WPB * 16 * 4;
   const size_t lds2 = 2 * CK * rowb + (size_t)tr_zero_elems<H, DH>() * 2;
-  auto k1 = flash_stats_kernel<H, DH, WPB, CK>;
+  auto k1 = flash_rowstats_kernel<H, DH, WPB, CK>;
   auto km = flash2_moments_kernel<DH, WPB, CK>;
   auto k2 = flash2_apply_kernel<DH, WPB, CK>;
   VU_TRY(reserve_lds(k1, lds1)); VU_TRY(reserve_lds(km, ldsm)); VU_TRY(reserve_lds(k2, lds2));
   const double E = (double)a.B * H * a.N * a.N, act = (double)a.B * a.N * C::D * 2.0;
   const bf16_t *q = (const bf16_t*)a.q, *k = (const bf16_t*)a.k, *v = (const bf16_t*)a.v;
-  hipLaunchKernelGGL(k1, dim3(nblk), dim3(WPB * 64), lds1, st, q, k, a.lse2, a.partials, a.B, a.N, c, a.rng, 0);     // row statistics only
+  hipLaunchKernelGGL(k1, dim3(nblk), dim3(WPB * 64), lds1, st, q, k, a.lse2, a.B, a.N, c);
   if (vu_prof_on()) vu_prof_note("flash_rowstats_kernel", 4.0 * E * DH, 2.0 * act);
   VU_TRY(vu_check_launch("flash_rowstats"));
   if (a.training) {
