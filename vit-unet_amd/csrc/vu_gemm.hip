@@ -105,10 +105,17 @@ static int launch_layout(vu_gemm_args& g0, int c_float, hipStream_t st) {
   return launch_tiles<T, T, true, true>(g, st);
 }
 
+int vu_tsgemm_try(const vu_gemm_args& g, hipStream_t st);      // vu_tsgemm.hip: long-K, small-output weight gradients
+
 // dtype: 0 = fp32 storage, 1 = bf16 storage.
 int vu_gemm_launch(int dtype, int c_float, vu_gemm_args g, hipStream_t st) {
   if (g.M <= 0 || g.N <= 0 || g.Z1 * g.Z2 <= 0) return VU_OK;
   if (g.K <= 0) { vu_set_error("vu_gemm: K must be positive"); return VU_EINVAL; }
+  if (dtype == 1 && c_float) {
+    const int rc = vu_tsgemm_try(g, st);
+    if (rc < 0) return rc;
+    if (rc > 0) return VU_OK;
+  }
   if (dtype == 0) {
     // for fp32 storage every C is float; c_float only selects accumulate-capable paths
     return launch_layout<float>(g, 0, st);
