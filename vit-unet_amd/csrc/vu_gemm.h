@@ -17,6 +17,12 @@
 
 enum { VU_ACT_NONE = 0, VU_ACT_GELU = 1, VU_ACT_DGELU = 2 };
 
+// Scratch for deterministic split-K (vu_tsgemm.hip): a caller that owns a workspace (the model executor) lends a slab for the
+// duration of its call; launches made in between write their K-slice partials there with plain stores and add them up in a
+// fixed order with one small kernel, instead of float atomics on the output.  Per-thread, scoped: set before, cleared after.
+void vu_gemm_set_scratch(void* p, size_t bytes);
+void vu_gemm_get_scratch(void** p, size_t* bytes);
+
 struct vu_gemm_args {
   const void* A; const void* B; void* C;
   int M, N, K;

@@ -105,6 +105,10 @@ static int launch_layout(vu_gemm_args& g0, int c_float, hipStream_t st) {
   return launch_tiles<T, T, true, true>(g, st);
 }
 
+namespace { thread_local void* g_scratch = nullptr; thread_local size_t g_scratch_bytes = 0; }
+void vu_gemm_set_scratch(void* p, size_t bytes) { g_scratch = p; g_scratch_bytes = p ? bytes : 0; }
+void vu_gemm_get_scratch(void** p, size_t* bytes) { *p = g_scratch; *bytes = g_scratch_bytes; }
+
 int vu_tsgemm_try(const vu_gemm_args& g, hipStream_t st);      // vu_tsgemm.hip: long-K, small-output weight gradients
 
 // dtype: 0 = fp32 storage, 1 = bf16 storage.

@@ -375,6 +375,7 @@ struct ModelWS {
   AttnScratch asc;
   std::vector<void*> dskip;
   float *partials, *lnp, *lnp2;
+  void* wgs; size_t wgs_bytes;      // split-K slab of the tall-skinny weight gradients (bf16 storage; vu_gemm_set_scratch)
   size_t bytes;
 };
 
@@ -428,6 +429,8 @@ void carve_model(const Plan& pl, int B, char* base, ModelWS& w) {
   w.asc.partials = w.partials;
   w.lnp = bp.takef((size_t)B * vu_ln_nchunks(P) * 3);
   w.lnp2 = bp.takef((size_t)B * vu_ln_nbchunks(P) * 2);
+  w.wgs_bytes = dt == 1 ? (size_t)24 << 20 : 0;
+  w.wgs = w.wgs_bytes ? bp.take(w.wgs_bytes) : nullptr;
   w.bytes = vu_align_up(bp.off, 256);
 }
 
@@ -849,7 +852,10 @@ static int run_backward(const vu_config* cfg, const float* params, const void* s
   }
   VU_REQUIRE(first >= 0 && last < nu && first <= last + 1, "vu_model_backward_units: unit range [%d,%d] outside [0,%d)", first, last, nu);
   Ctx cx{&pl, B, params, shadow, (float*)bn_state, grads, training, seed, rng_salt, (hipStream_t)stream, &w};
-  return model_backward(cx, dy, dx, first, last);
+  vu_gemm_set_scratch(w.wgs, w.wgs_bytes);          // lent for this call: deterministic split-K of the skinny weight gradients
+  const int rc = model_backward(cx, dy, dx, first, last);
+  vu_gemm_set_scratch(nullptr, 0);
+  return rc;
 }
 
 int vu_model_backward(const vu_config* cfg, const float* params, const void* shadow, const float* bn_state, float* grads,

@@ -17,56 +17,53 @@ namespace {
 
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_p;
 
-template <int TM, int TN>
-__global__ __launch_bounds__(256) void vu_tsgemm_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bm,
-                                                        float* __restrict__ C, float* __restrict__ colsum, int M, int N, int K,
-                                                        int lda, int ldb, int ldc, int rows_per_split, int nsplit) {
-  constexpr int MT = 32 * TM, NT = 32 * TN, BK = 32, PAD = 16;
+// TM x TN: 16 x 16 MFMA tiles per wave; WM x WN waves; PD: k-steps of global loads kept in flight per thread (register ring).
+// Bytes in flight are what sets the rate of a stream that only a few workgroups read (Little: ~2 us of loaded-chip latency
+// x 45 GB/s per CU = 90 KB per CU): many waves with a short register ring each, rather than few waves with long ones.
+template <int TM, int TN, int WM, int WN, int PD>
+__global__ __launch_bounds__(64 * WM * WN) void vu_tsgemm_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bm,
+                                                                float* __restrict__ C, float* __restrict__ colsum, int M, int N, int K,
+                                                                int lda, int ldb, int ldc, int rows_per_split, int nsplit,
+                                                                float* __restrict__ slab, float* __restrict__ slab_cs, long long slab_tile) {
+  constexpr int NTHR = 64 * WM * WN;
+  constexpr int MT = 16 * TM * WM, NT = 16 * TN * WN, BK = 32, PAD = 16;
   constexpr int LDA = MT + PAD, LDB = NT + PAD;
   constexpr int VA = BK * MT / 8, VB = BK * NT / 8;                     // 16-byte vectors per k-step
-  constexpr int NVA = (VA + 255) / 256, NVB = (VB + 255) / 256;
-  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * BK * (LDA + LDB)];
+  constexpr int NV = (VA + VB + NTHR - 1) / NTHR;
+  constexpr int OPND = 2 * BK * (LDA + LDB), CST = WM * 16 * (NT + 4) * 2;       // operand buffers / fp32 C staging tile, in bf16 elements
+  __shared__ __attribute__((aligned(16))) bf16_t smem[OPND > CST ? OPND : CST];
   bf16_t* As = smem;
   bf16_t* Bs = smem + 2 * BK * LDA;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int m_base = blockIdx.y * MT, n_base = blockIdx.z * NT;
   const int k_begin = blockIdx.x * rows_per_split;
   const int k_end = min(K, k_begin + rows_per_split);
   const int nsteps = (k_end - k_begin + BK - 1) / BK;
-  uint4 ra[NVA], rb[NVB];
-  auto fetch = [&](int step) {
+  uint4 ring[PD][NV];
+  // vector v of a k-step: v < VA: A row kk, columns c..c+7; else the same of B
+  auto fetch = [&](int step, uint4 (&r)[NV]) {
     const int k0 = k_begin + step * BK;
 #pragma unroll
-    for (int i = 0; i < NVA; ++i) {
-      const int v = tid + i * 256;
-      const int kk = v / (MT / 8), c = (v - kk * (MT / 8)) * 8;
-      const bool ok = (VA % 256 == 0 || v < VA) && k0 + kk < k_end && m_base + c + 8 <= M;
+    for (int i = 0; i < NV; ++i) {
+      const int v = tid + i * NTHR;
+      const bool isA = v < VA;
+      const int u = isA ? v : v - VA;
+      const int per = (isA ? MT : NT) / 8;
+      const int kk = u / per, c = (u - kk * per) * 8;
+      const bool ok = v < VA + VB && k0 + kk < k_end && (isA ? m_base + c + 8 <= M : n_base + c + 8 <= N);
       // clamped address, zeroed value: the load is unconditional (no branch around it)
-      const long long off = ok ? (long long)(k0 + kk) * lda + m_base + c : 0;
-      const uint4 x = *reinterpret_cast<const uint4*>(A + off);
-      ra[i] = ok ? x : make_uint4(0, 0, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < NVB; ++i) {
-      const int v = tid + i * 256;
-      const int kk = v / (NT / 8), c = (v - kk * (NT / 8)) * 8;
-      const bool ok = (VB % 256 == 0 || v < VB) && k0 + kk < k_end && n_base + c + 8 <= N;
-      const long long off = ok ? (long long)(k0 + kk) * ldb + n_base + c : 0;
-      const uint4 x = *reinterpret_cast<const uint4*>(Bm + off);
-      rb[i] = ok ? x : make_uint4(0, 0, 0, 0);
+      const bf16_t* src = isA ? A + (ok ? (long long)(k0 + kk) * lda + m_base + c : 0) : Bm + (ok ? (long long)(k0 + kk) * ldb + n_base + c : 0);
+      const uint4 x = *reinterpret_cast<const uint4*>(src);
+      r[i] = ok ? x : make_uint4(0, 0, 0, 0);
     }
   };
-  auto commit = [&](int buf) {
+  auto commit = [&](int buf, const uint4 (&r)[NV]) {
 #pragma unroll
-    for (int i = 0; i < NVA; ++i) {
-      const int v = tid + i * 256;
-      if (VA % 256 == 0 || v < VA) { const int kk = v / (MT / 8), c = (v - kk * (MT / 8)) * 8; *reinterpret_cast<uint4*>(&As[(buf * BK + kk) * LDA + c]) = ra[i]; }
-    }
-#pragma unroll
-    for (int i = 0; i < NVB; ++i) {
-      const int v = tid + i * 256;
-      if (VB % 256 == 0 || v < VB) { const int kk = v / (NT / 8), c = (v - kk * (NT / 8)) * 8; *reinterpret_cast<uint4*>(&Bs[(buf * BK + kk) * LDB + c]) = rb[i]; }
+    for (int i = 0; i < NV; ++i) {
+      const int v = tid + i * NTHR;
+      if (v < VA) { const int kk = v / (MT / 8), c = (v - kk * (MT / 8)) * 8; *reinterpret_cast<uint4*>(&As[(buf * BK + kk) * LDA + c]) = r[i]; }
+      else if (v < VA + VB) { const int u = v - VA, kk = u / (NT / 8), c = (u - kk * (NT / 8)) * 8; *reinterpret_cast<uint4*>(&Bs[(buf * BK + kk) * LDB + c]) = r[i]; }
     }
   };
   f32x4 acc[TM][TN], cs[TM];
@@ -80,60 +77,87 @@ __global__ __launch_bounds__(256) void vu_tsgemm_kernel(const bf16_t* __restrict
   bf16x8 ones;
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
-  if (nsteps > 0) {
-    fetch(0);
-    commit(0);
-  }
-  __syncthreads();
+#pragma unroll
+  for (int s_ = 0; s_ < PD; ++s_) fetch(s_ < nsteps ? s_ : 0, ring[s_]);
   const int q = l15 >> 2, p = l15 & 3;
-  for (int t = 0; t < nsteps; ++t) {
-    const int buf = t & 1;
-    if (t + 1 < nsteps) fetch(t + 1);
-    bf16x8 af[TM], bfr[TN];
-    typedef __attribute__((ext_vector_type(8))) short s16x8;
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  for (int t0 = 0; t0 < nsteps; t0 += PD) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const bf16_t* a0 = &As[(buf * BK + 8 * lg + q) * LDA + wm * 16 * TM + 16 * i + 4 * p];
-      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)a0);
-      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(a0 + 4 * LDA));
-      const s16x8 x = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      af[i] = __builtin_bit_cast(bf16x8, x);
+    for (int s_ = 0; s_ < PD; ++s_) {
+      const int t = t0 + s_;
+      if (t < nsteps) {                                      // workgroup-uniform
+        const int buf = t & 1;
+        commit(buf, ring[s_]);                               // (buffer buf was last read in step t - 2: every wave has passed the barrier of step t - 1 since)
+        fetch(t + PD < nsteps ? t + PD : t, ring[s_]);       // PD - 1 further steps stay in flight during the products
+        __syncthreads();
+        bf16x8 af[TM], bfr[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const bf16_t* a0 = &As[(buf * BK + 8 * lg + q) * LDA + wm * 16 * TM + 16 * i + 4 * p];
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)a0);
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(a0 + 4 * LDA));
+          const s16x8 x = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          af[i] = __builtin_bit_cast(bf16x8, x);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const bf16_t* b0 = &Bs[(buf * BK + 8 * lg + q) * LDB + wn * 16 * TN + 16 * j + 4 * p];
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)b0);
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(b0 + 4 * LDB));
+          const s16x8 x = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          bfr[j] = __builtin_bit_cast(bf16x8, x);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+          if (do_cs) cs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, cs[i], 0, 0, 0);
+        }
+      }
     }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const bf16_t* b0 = &Bs[(buf * BK + 8 * lg + q) * LDB + wn * 16 * TN + 16 * j + 4 * p];
-      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)b0);
-      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(b0 + 4 * LDB));
-      const s16x8 x = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      bfr[j] = __builtin_bit_cast(bf16x8, x);
-    }
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-      if (do_cs) cs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, cs[i], 0, 0, 0);
-    }
-    if (t + 1 < nsteps) commit(buf ^ 1);
-    __syncthreads();
   }
-  // epilogue: accumulator rows 4 lg + r = m, column l15 = n
+  // epilogue.  A 16x16 accumulator as it stands is 4 x 64-byte segments per atomic wave-instruction, which the memory-side
+  // adders take at a quarter of their rate (measured: the atomics cost 12 - 22 us per launch, more than the k-loop).  So the
+  // tile goes through LDS (the operand buffers, 16 rows per wave at a time) and leaves as whole rows: 64 consecutive
+  // floats (or two rows of 32) per wave-instruction.
   const bool atomic = nsplit > 1;
+  if (nsplit < 0) return;      // (timing experiment: VU_TSGEMM_NOEPI=1 passes a negative split count)
+  constexpr int LDC = NT + 4;
+  float* Ct = reinterpret_cast<float*>(smem);
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
-    const int m0 = m_base + wm * 16 * TM + 16 * i + 4 * lg;
+    __syncthreads();                                        // the k-loop (or the previous pass) is done with the buffer
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = n_base + wn * 16 * TN + 16 * j + l15;
-      if (n < N) {
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (m0 + r < M) {
-            float* cp = C + (long long)(m0 + r) * ldc + n;
-            if (atomic) atomicAdd(cp, acc[i][j][r]); else *cp += acc[i][j][r];
-          }
+      for (int r = 0; r < 4; ++r) Ct[(wm * 16 + 4 * lg + r) * LDC + wn * 16 * TN + 16 * j + l15] = acc[i][j][r];
+    __syncthreads();
+    if (slab) {     // this K slice's partial tile, plain stores: slab[split][mt MT][nt NT], summed in split order by tsgemm_reduce_kernel
+      const int Np = gridDim.z * NT;
+      float* sp = slab + (long long)blockIdx.x * slab_tile;
+      for (int e = tid; e < WM * 16 * NT; e += NTHR) {
+        const int lr = e / NT, c = e - lr * NT;
+        const int m = m_base + (lr >> 4) * 16 * TM + 16 * i + (lr & 15);
+        sp[(long long)m * Np + n_base + c] = Ct[lr * LDC + c];
+      }
+      if (do_cs && l15 == 0) {
+        const int m0 = m_base + wm * 16 * TM + 16 * i + 4 * lg;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) slab_cs[(long long)blockIdx.x * (gridDim.y * MT) + m0 + r] = cs[i][r];
+      }
+      continue;
+    }
+    for (int e = tid; e < WM * 16 * NT; e += NTHR) {
+      const int lr = e / NT, c = e - lr * NT;
+      const int m = m_base + (lr >> 4) * 16 * TM + 16 * i + (lr & 15), n = n_base + c;
+      if (m < M && n < N) {
+        float* cp = C + (long long)m * ldc + n;
+        const float v = Ct[lr * LDC + c];
+        if (atomic) atomicAdd(cp, v); else *cp += v;
       }
     }
     if (do_cs && l15 == 0) {
+      const int m0 = m_base + wm * 16 * TM + 16 * i + 4 * lg;
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         if (m0 + r < M) { if (atomic) atomicAdd(colsum + m0 + r, cs[i][r]); else colsum[m0 + r] += cs[i][r]; }
@@ -141,31 +165,105 @@ __global__ __launch_bounds__(256) void vu_tsgemm_kernel(const bf16_t* __restrict
   }
 }
 
-template <int TM, int TN>
-int launch_ts(const vu_gemm_args& g, int mt, int nt, hipStream_t st) {
+// C[m][n] += sum over the K slices of slab[s][m][n], and the same for the column sums, in a fixed order (deterministic):
+// a workgroup takes 16 float4 items x 16 slice lanes (lane sl adds slices sl, sl + 16, ...), then one thread per item adds
+// the 16 lane sums in order.  `tile`: floats between two slices' tiles (padded so that the slices do not all start on the
+// same memory channels).
+__global__ __launch_bounds__(256) void tsgemm_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ slab_cs,
+                                                            float* __restrict__ C, float* __restrict__ colsum, int M, int N, int Mp,
+                                                            int Np, int ldc, int nsplit, long long tile, int nitems) {
+  __shared__ float4 part[16][16];
+  const int it = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int id = blockIdx.x * 16 + it;
+  const int nq = N >> 2;                                    // N % 8 == 0 (checked by the launcher)
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool is_c = id < nitems;
+  const int ncs = (M + 3) >> 2;                             // column-sum items (float4 of 4 rows' sums; Mp % 4 == 0)
+  const bool is_cs = !is_c && colsum && id - nitems < ncs;
+  int m = 0, n = 0;
+  if (is_c) {
+    m = id / nq; n = (id - m * nq) * 4;
+    const float* p = slab + (long long)m * Np + n;
+    for (int s_ = sl; s_ < nsplit; s_ += 16) {
+      const float4 x = *reinterpret_cast<const float4*>(p + (long long)s_ * tile);
+      a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
+    }
+  } else if (is_cs) {
+    m = (id - nitems) * 4;
+    for (int s_ = sl; s_ < nsplit; s_ += 16) {
+      const float4 x = *reinterpret_cast<const float4*>(slab_cs + (long long)s_ * Mp + m);
+      a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
+    }
+  }
+  part[sl][it] = a;
+  __syncthreads();
+  if (sl == 0 && (is_c || is_cs)) {
+    float4 t = part[0][it];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) { const float4 x = part[k][it]; t.x += x.x; t.y += x.y; t.z += x.z; t.w += x.w; }
+    if (is_c) {
+      float4* cp = reinterpret_cast<float4*>(C + (long long)m * ldc + n);
+      float4 c4 = *cp;
+      c4.x += t.x; c4.y += t.y; c4.z += t.z; c4.w += t.w;
+      *cp = c4;
+    } else {
+      const float tv[4] = {t.x, t.y, t.z, t.w};
+      for (int r = 0; r < 4; ++r) if (m + r < M) colsum[m + r] += tv[r];
+    }
+  }
+}
+
+inline bool ldc_ok(const vu_gemm_args& g) { return g.ldc % 4 == 0 && ((uintptr_t)g.C & 15) == 0; }
+
+template <int TM, int TN, int WM, int WN, int PD>
+int launch_ts(const vu_gemm_args& g, hipStream_t st) {
+  constexpr int MT = 16 * TM * WM, NT = 16 * TN * WN;
+  const int mt = (g.M + MT - 1) / MT, nt = (g.N + NT - 1) / NT;
   const double in_bytes = (double)g.K * (g.M + g.N) * 2.0, out_bytes = (double)g.M * g.N * 4.0;
-  // K slices: enough blocks to keep the loads of ~200 CUs in flight, but no more float-atomic bytes than a third of the
-  // operand bytes, and at least 8 k-steps (256 rows) per slice
+  void* scr = nullptr; size_t scr_bytes = 0;
+  vu_gemm_get_scratch(&scr, &scr_bytes);
+  static const bool slab_off = [] { const char* e = getenv("VU_TSGEMM_SLAB"); return e && e[0] == '0'; }();      // A/B switch
+  const long long slab_tile = (long long)mt * MT * ((long long)nt * NT) + 1088;        // + 4352 B: spreads the slices over the memory channels
+  const size_t per_split = ((size_t)slab_tile + (size_t)mt * MT) * 4;
+  const bool use_slab = scr && !slab_off && scr_bytes >= 2 * per_split && ldc_ok(g);
+  // K slices: enough workgroups to put a stream on every CU and at least 8 k-steps (256 rows) per slice.  With a slab the
+  // partial tiles cost a plain write and a read (bounded by half the operand bytes and by the slab); without one they are
+  // float atomics on a small, contended output (measured 0.3 TB/s): no more of those than a third of the operand bytes
   int want = (256 + mt * nt - 1) / (mt * nt);
-  const int by_atomics = (int)(in_bytes / (3.0 * out_bytes));
-  if (want > by_atomics) want = by_atomics;
+  const int by_out = (int)(in_bytes / ((use_slab ? 2.0 : 3.0) * out_bytes));
+  if (want > by_out) want = by_out;
   const int by_rows = g.K / 256;
   if (want > by_rows) want = by_rows;
+  if (use_slab && (size_t)want * per_split > scr_bytes) want = (int)(scr_bytes / per_split);
+  { static const int force = getenv("VU_TSGEMM_SPLITS") ? atoi(getenv("VU_TSGEMM_SPLITS")) : 0; if (force > 0 && force < want) want = force; }   // measurement switch
   if (want < 1) want = 1;
   int rows = (g.K + want - 1) / want;
   rows = (rows + 31) / 32 * 32;
   const int nsplit = (g.K + rows - 1) / rows;
-  hipLaunchKernelGGL((vu_tsgemm_kernel<TM, TN>), dim3(nsplit, mt, nt), dim3(256), 0, st, (const bf16_t*)g.A, (const bf16_t*)g.B, (float*)g.C,
-                     g.colsum, g.M, g.N, g.K, (int)g.sAk, (int)g.sBk, (int)g.ldc, rows, nsplit);
+  const bool slab = use_slab && nsplit > 1;
+  float* sl = slab ? (float*)scr : nullptr;
+  float* slcs = slab ? sl + (size_t)nsplit * slab_tile : nullptr;
+  hipLaunchKernelGGL((vu_tsgemm_kernel<TM, TN, WM, WN, PD>), dim3(nsplit, mt, nt), dim3(64 * WM * WN), 0, st, (const bf16_t*)g.A,
+                     (const bf16_t*)g.B, (float*)g.C, g.colsum, g.M, g.N, g.K, (int)g.sAk, (int)g.sBk, (int)g.ldc, rows,
+                     getenv("VU_TSGEMM_NOEPI") ? -nsplit : nsplit, sl, slcs, slab_tile);
   if (vu_prof_on()) {
     char tag[64];
-    snprintf(tag, sizeof(tag), "vu_tsgemm_kernel<%d,%d>", TM, TN);
+    snprintf(tag, sizeof(tag), "vu_tsgemm_kernel<%dx%d>", MT, NT);
     vu_prof_note(tag, 2.0 * g.M * (double)g.N * g.K, in_bytes + out_bytes);
   }
-  return vu_check_launch("vu_tsgemm");
+  { const int rc_ = vu_check_launch("vu_tsgemm"); if (rc_) return rc_; }
+  if (slab) {
+    const int nitems = g.M * (g.N / 4);
+    const long long items = (long long)nitems + (g.colsum ? (g.M + 3) / 4 : 0);
+    hipLaunchKernelGGL(tsgemm_reduce_kernel, dim3((unsigned)((items + 15) / 16)), dim3(256), 0, st, sl, slcs, (float*)g.C, g.colsum, g.M,
+                       g.N, mt * MT, nt * NT, (int)g.ldc, nsplit, slab_tile, nitems);
+    if (vu_prof_on()) vu_prof_note("tsgemm_reduce_kernel", 0.0, (double)nsplit * out_bytes + 2.0 * out_bytes);
+    return vu_check_launch("vu_tsgemm_reduce");
+  }
+  return VU_OK;
 }
 
-inline int tile_units(int n) { return n <= 32 ? 1 : (n <= 64 ? 2 : (n <= 128 ? 4 : 6)); }   // wave-tile size in 16s, workgroup tile = 32 x that
+inline int side_class(int n) { return n <= 32 ? 32 : (n <= 64 ? 64 : (n <= 128 ? 128 : 192)); }   // workgroup tile side
 
 }  // namespace
 
@@ -177,12 +275,20 @@ int vu_tsgemm_try(const vu_gemm_args& g, hipStream_t st) {
   if (g.sAm != 1 || g.sBn != 1 || g.colsum_side == 2) return 0;
   if (g.M % 8 || g.N % 8 || g.sAk % 8 || g.sBk % 8 || ((uintptr_t)g.A & 15) || ((uintptr_t)g.B & 15)) return 0;
   if (g.K < 2048 || (g.M > 192 && g.N > 192)) return 0;             // long K, at least one small side
-  const int tm = tile_units(g.M), tn = tile_units(g.N);
-  const int mt = (g.M + 32 * tm - 1) / (32 * tm), nt = (g.N + 32 * tn - 1) / (32 * tn);
-  if (mt * nt > 16 || mt > 65535 || nt > 65535) return 0;
-#define VU_TS(TMv, TNv) if (tm == TMv && tn == TNv) { int rc = launch_ts<TMv, TNv>(g, mt, nt, st); return rc ? rc : 1; }
-  VU_TS(6, 6) VU_TS(6, 1) VU_TS(1, 6) VU_TS(6, 2) VU_TS(2, 6) VU_TS(6, 4) VU_TS(4, 6)
-  VU_TS(4, 4) VU_TS(4, 2) VU_TS(2, 4) VU_TS(4, 1) VU_TS(1, 4) VU_TS(2, 2) VU_TS(2, 1) VU_TS(1, 2)
+  const int cm = side_class(g.M), cn = side_class(g.N);
+  const long long tiles = (long long)((g.M + cm - 1) / cm) * ((g.N + cn - 1) / cn);
+  if (tiles > 16) return 0;
+#define VU_TS(CM, CN, TMv, TNv, WMv, WNv, PDv) \
+  if (cm == CM && cn == CN) { int rc = launch_ts<TMv, TNv, WMv, WNv, PDv>(g, st); return rc ? rc : 1; }
+  //    tile       per-wave tiles  waves   ring
+  VU_TS(192, 192, 3, 6, 4, 2, 4)                                   // (16 waves of 3 x 3 tiles spill at their 128-register cap)
+  VU_TS(192, 128, 3, 4, 4, 2, 4) VU_TS(128, 192, 4, 3, 2, 4, 4)
+  VU_TS(192, 64, 3, 2, 4, 2, 4)  VU_TS(64, 192, 2, 3, 2, 4, 4)
+  VU_TS(192, 32, 3, 1, 4, 2, 4)  VU_TS(32, 192, 1, 3, 2, 4, 4)
+  VU_TS(128, 128, 2, 4, 4, 2, 4)
+  VU_TS(128, 64, 2, 2, 4, 2, 4)  VU_TS(64, 128, 2, 2, 2, 4, 4)
+  VU_TS(128, 32, 2, 1, 4, 2, 4)  VU_TS(32, 128, 1, 2, 2, 4, 4)
+  VU_TS(64, 64, 2, 2, 2, 2, 4)   VU_TS(64, 32, 2, 1, 2, 2, 4)  VU_TS(32, 64, 1, 2, 2, 2, 4)
 #undef VU_TS
   return 0;
 }
