@@ -104,6 +104,9 @@ def test_tiny_train_dropout_vs_oracle(golden_dir, name):
         assert serr(sd[k].grad, wr[k].grad) < 5e-3, k
 
 
+CORR_MIN, LOSS_TOL = 0.9, 0.1        # measured: correlation 0.964 .. 0.997, loss within 4.5 % (rel. RMS 0.08 .. 0.27)
+
+
 @pytest.mark.parametrize("name", ["tiny_a", "tiny_b", "tiny_c"])
 @pytest.mark.parametrize("drop", [0.0, 0.2])
 def test_tiny_bf16_train(golden_dir, name, drop):
@@ -132,8 +135,15 @@ def test_tiny_bf16_train(golden_dir, name, drop):
     d = (out.detach().cpu().double() - ref.detach().double())
     rel_rms = (d.pow(2).mean().sqrt() / ref.detach().double().pow(2).mean().sqrt()).item()
     assert torch.isfinite(out).all()
-    if name != "tiny_a":      # deeper tiny models: chaotic amplification (see the Base-sized test below)
-        assert rel_rms < 1.0, rel_rms
+    if name != "tiny_a":
+        # deeper tiny models (5 / 7 attention modules): rounding flips are amplified block after block, so the element-wise
+        # statement is made per block elsewhere (test_gpu_parity_full.py, teacher-forced); here the whole output must still
+        # be the same field (correlation) and give the same loss
+        a, b = out.detach().cpu().double().reshape(-1), ref.detach().double().reshape(-1)
+        corr = ((a - a.mean()) @ (b - b.mean()) / ((a - a.mean()).norm() * (b - b.mean()).norm())).item()
+        l_got, l_ref = torch.nn.MSELoss()(out, y).item(), O.mse_loss(ref, y.cpu()).item()
+        print(f"{name} drop {drop}: rel_rms {rel_rms:.3f} corr {corr:.4f} loss {l_got:.4f} vs {l_ref:.4f}")
+        assert corr > CORR_MIN and abs(l_got - l_ref) < LOSS_TOL * abs(l_ref), (rel_rms, corr, l_got, l_ref)
         return
     assert rel_rms < 5e-2, rel_rms
     assert serr(out, ref) < 0.15
