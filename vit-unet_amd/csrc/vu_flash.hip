@@ -1870,7 +1870,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_bwd_dqx_kernel(
 
 // ---- sweeps 3 / 4: dk (DV = false) and dv (DV = true), key-major loop ------------------------------------------------
 template <int DH, int WPB, int CK, bool DV>
-__global__ __launch_bounds__(WPB * 64, 2) void flash2_bwd_dkv_kernel(
+__global__ __launch_bounds__(WPB * 64, DV ? 3 : 2) void flash2_bwd_dkv_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, const bf16_t* __restrict__ dO,
     const float* __restrict__ lse2, const float* __restrict__ delta, const float* __restrict__ stats, bf16_t* __restrict__ out,
     int B, int N, float c, float scale, vu_rng rng_in) {
@@ -1880,9 +1880,10 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_bwd_dkv_kernel(
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* Qc = reinterpret_cast<bf16_t*>(smem_raw);
   bf16_t* Dc = Qc + CK * 16 * C::PITCH;
-  bf16_t* Ks = Dc + CK * 16 * C::PITCH + (threadIdx.x >> 6) * 32 * C::PITCH;
+  constexpr int SROWS = DV ? 16 : 32;            // stationary rows per wave: the keys, and (dk only) their v rows
+  bf16_t* Ks = Dc + CK * 16 * C::PITCH + (threadIdx.x >> 6) * SROWS * C::PITCH;
   bf16_t* Vs = Ks + 16 * C::PITCH;
-  bf16_t* img = Dc + CK * 16 * C::PITCH + WPB * 32 * C::PITCH + (threadIdx.x >> 6) * 640;     // 2 x [16 q][IMP]
+  bf16_t* img = Dc + CK * 16 * C::PITCH + WPB * SROWS * C::PITCH + (threadIdx.x >> 6) * 640;     // 2 x [16 q][IMP]
   const vu_rng rng = vu_rng_resolve(rng_in);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
   const int ntiles = N >> 4, per = (ntiles + WPB - 1) / WPB;
@@ -1895,7 +1896,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_bwd_dkv_kernel(
   const bf16_t* dob = dO + (long long)b * N * C::D;
   stage_own_rows<H, DH>(Ks, k + ((long long)b * N + tk * 16) * C::D, lane);
   if (!DV) stage_own_rows<H, DH>(Vs, v + ((long long)b * N + tk * 16) * C::D, lane);
-  zero_pads<H, DH>(Qc, 2 * CK * 16 + WPB * 32, tid, WPB * 64);
+  zero_pads<H, DH>(Qc, 2 * CK * 16 + WPB * SROWS, tid, WPB * 64);
   Bwd2Ops ops;
   MixOp fw;
   f32x4 fcin = {0.f, 0.f, 0.f, 0.f};
@@ -1915,15 +1916,16 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_bwd_dkv_kernel(
   const int hh = g4 & 1, a2 = g4 >> 1;
   const int nchunks = (ntiles + CK - 1) / CK;
   // register-staged prefetch of the next chunk: only the dv sweep has the registers for it (dk sits at the 256 cap)
+  constexpr bool PRE = DV && CK > 1;
   ChunkStage<H, DH, CK * 16, WPB * 64> st_Qc, st_Dc;
-  if constexpr (DV) {
+  if constexpr (PRE) {
     st_Qc.fetch(qb, min(CK, ntiles) * 16, tid);
     st_Dc.fetch(dob, min(CK, ntiles) * 16, tid);
   }
   for (int ch = 0; ch < nchunks; ++ch) {
     const int nt = min(CK, ntiles - ch * CK);
     __syncthreads();
-    if constexpr (DV) {
+    if constexpr (PRE) {
       st_Qc.commit(Qc, nt * 16, tid);
       st_Dc.commit(Dc, nt * 16, tid);
     } else {
@@ -1931,7 +1933,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_bwd_dkv_kernel(
       load_chunk<H, DH>(Dc, dob + (long long)ch * CK * 16 * C::D, nt * 16, tid, WPB * 64);
     }
     __syncthreads();
-    if constexpr (DV) {
+    if constexpr (PRE) {
       const int cn = ch + 1 < nchunks ? ch + 1 : ch;
       st_Qc.fetch(qb + (long long)cn * CK * 16 * C::D, min(CK, ntiles - cn * CK) * 16, tid);
       st_Dc.fetch(dob + (long long)cn * CK * 16 * C::D, min(CK, ntiles - cn * CK) * 16, tid);
@@ -2164,8 +2166,10 @@ int launch_backward_v2(const vu_flash_args& a, hipStream_t st) {
   const bool fused = a.pk != nullptr && !([] { const char* e = getenv("VU_FLASH_DQX"); return e && e[0] == '0'; }());
   VU_TRY(reserve_lds(k2x, lds2x));
   auto k3 = flash2_bwd_dkv_kernel<DH, WPB, CK2, false>;
-  auto k4 = flash2_bwd_dkv_kernel<DH, WPB, CK2, true>;
-  VU_TRY(reserve_lds(k1, lds1)); VU_TRY(reserve_lds(k2, lds2)); VU_TRY(reserve_lds(k3, lds3)); VU_TRY(reserve_lds(k4, lds3));
+  constexpr int CKV = 1;                 // dv: one tile per chunk, 16 stationary rows per wave: 43.5 KB, three workgroups per CU
+  auto k4 = flash2_bwd_dkv_kernel<DH, WPB, CKV, true>;
+  const size_t lds3v = (2 * CKV + WPB) * rowb + (size_t)WPB * 1280;
+  VU_TRY(reserve_lds(k1, lds1)); VU_TRY(reserve_lds(k2, lds2)); VU_TRY(reserve_lds(k3, lds3)); VU_TRY(reserve_lds(k4, lds3v));
   (void)lds4;
   const double E = (double)a.B * H * a.N * a.N, act = (double)a.B * a.N * C::D * 2.0;
   const bf16_t *q = (const bf16_t*)a.q, *k = (const bf16_t*)a.k, *v = (const bf16_t*)a.v, *dO = (const bf16_t*)a.dO;
@@ -2197,7 +2201,7 @@ int launch_backward_v2(const vu_flash_args& a, hipStream_t st) {
   hipLaunchKernelGGL(k3, dim3(nblk), dim3(WPB * 64), lds3, s_dk, q, k, v, dO, a.lse2, a.delta, a.stats, (bf16_t*)a.dk, a.B, a.N, c, a.scale, a.rng);
   if (vu_prof_on()) vu_prof_note("flash2_bwd_dk_kernel", 6.0 * E * DH + 4.0 * E * H, 5.0 * act);
   VU_TRY(vu_check_launch("flash2_bwd_dk"));
-  hipLaunchKernelGGL(k4, dim3(nblk), dim3(WPB * 64), lds3, s_dv, q, k, v, dO, a.lse2, (const float*)nullptr, a.stats, (bf16_t*)a.dv, a.B, a.N, c, a.scale, a.rng);
+  hipLaunchKernelGGL(k4, dim3(nblk), dim3(WPB * 64), lds3v, s_dv, q, k, v, dO, a.lse2, (const float*)nullptr, a.stats, (bf16_t*)a.dv, a.B, a.N, c, a.scale, a.rng);
   if (vu_prof_on()) vu_prof_note("flash2_bwd_dv_kernel", 4.0 * E * DH + 2.0 * E * H, 4.0 * act);
   VU_TRY(vu_check_launch("flash2_bwd_dv"));
   if (fp) {
