@@ -318,36 +318,54 @@ __global__ __launch_bounds__(WAVES * 64) void conv_wgrad_mm_kernel(const bf16_t*
 #pragma unroll
   for (int tt = 0; tt < 2; ++tt) { accq[tt] = f32x4{0.f, 0.f, 0.f, 0.f}; acckv[tt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   const uint4 z4 = make_uint4(0, 0, 0, 0);
-  for (long long uid = (long long)blockIdx.x * WAVES + wave; uid < nunits; uid += (long long)gridDim.x * WAVES) {
-    const long long patch = uid / upp;
-    const int u = (int)(uid - patch * upp);
-    const int px = (4 * u + lg) * 8;                 // first pixel of this lane group's segment
+  // one unit = 32 pixels of one patch; two units per trip so that twice the loads are in flight per wave (the loop is
+  // bound by the latency of its dependent address -> load -> MFMA chain, not by bytes: 53 -> see DESIGN.md)
+  struct UnitRegs { uint4 a_q, a_kv, bq[2], bkv[2]; unsigned lq[2], rq[2], lkv[2], rkv[2]; };
+  auto load_unit = [&](long long uid, UnitRegs& u) {
+    const bool live = uid < nunits;
+    const long long uc = live ? uid : 0;
+    const long long patch = uc / upp;
+    const int un = (int)(uc - patch * upp);
+    const int px = (4 * un + lg) * 8;                 // first pixel of this lane group's segment
     const int y = px / s, x0 = px - y * s;
     const long long pbase = patch * (long long)(C * ss);
     const int seg = y * s + x0;
-    uint4 a_q = z4, a_kv = z4;
-    if (l15 < 3) a_q = *reinterpret_cast<const uint4*>(aq + pbase + seg);
-    if (l15 < 6) a_kv = *reinterpret_cast<const uint4*>(akv + pbase + seg);
+    u.a_q = z4; u.a_kv = z4;
+    if (live && l15 < 3) u.a_q = *reinterpret_cast<const uint4*>(aq + pbase + seg);
+    if (live && l15 < 6) u.a_kv = *reinterpret_cast<const uint4*>(akv + pbase + seg);
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
       const int r = y + tky[tt] - 1;
-      const bool rv = tv[tt] && r >= 0 && r < s;
+      const bool rv = live && tv[tt] && r >= 0 && r < s;
       const long long off = pbase + tci[tt] * ss + r * s + x0;
-      uint4 bq = z4, bkv = z4;
-      unsigned lq = 0, rq = 0, lkv = 0, rkv = 0;
+      u.bq[tt] = z4; u.bkv[tt] = z4;
+      u.lq[tt] = 0; u.rq[tt] = 0; u.lkv[tt] = 0; u.rkv[tt] = 0;
       if (rv) {
-        bkv = *reinterpret_cast<const uint4*>(xkv + off);
-        if (!same) bq = *reinterpret_cast<const uint4*>(xq + off);
+        u.bkv[tt] = *reinterpret_cast<const uint4*>(xkv + off);
+        if (!same) u.bq[tt] = *reinterpret_cast<const uint4*>(xq + off);
         if (edges) {
-          if (x0 > 0) { lkv = __builtin_bit_cast(unsigned short, xkv[off - 1]); if (!same) lq = __builtin_bit_cast(unsigned short, xq[off - 1]); }
-          if (x0 + 8 < s) { rkv = __builtin_bit_cast(unsigned short, xkv[off + 8]); if (!same) rq = __builtin_bit_cast(unsigned short, xq[off + 8]); }
+          if (x0 > 0) { u.lkv[tt] = __builtin_bit_cast(unsigned short, xkv[off - 1]); if (!same) u.lq[tt] = __builtin_bit_cast(unsigned short, xq[off - 1]); }
+          if (x0 + 8 < s) { u.rkv[tt] = __builtin_bit_cast(unsigned short, xkv[off + 8]); if (!same) u.rq[tt] = __builtin_bit_cast(unsigned short, xq[off + 8]); }
         }
       }
-      const uint4 skv = shift_segment(bkv, lkv, rkv, tkx[tt]);
-      const uint4 sq = same ? skv : shift_segment(bq, lq, rq, tkx[tt]);
-      accq[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a_q), __builtin_bit_cast(bf16x8, sq), accq[tt], 0, 0, 0);
-      acckv[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a_kv), __builtin_bit_cast(bf16x8, skv), acckv[tt], 0, 0, 0);
     }
+  };
+  auto mma_unit = [&](const UnitRegs& u) {
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      const uint4 skv = shift_segment(u.bkv[tt], u.lkv[tt], u.rkv[tt], tkx[tt]);
+      const uint4 sq = same ? skv : shift_segment(u.bq[tt], u.lq[tt], u.rq[tt], tkx[tt]);
+      accq[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, u.a_q), __builtin_bit_cast(bf16x8, sq), accq[tt], 0, 0, 0);
+      acckv[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, u.a_kv), __builtin_bit_cast(bf16x8, skv), acckv[tt], 0, 0, 0);
+    }
+  };
+  const long long stride = (long long)gridDim.x * WAVES;
+  for (long long uid = (long long)blockIdx.x * WAVES + wave; uid < nunits; uid += 2 * stride) {
+    UnitRegs u0, u1;
+    load_unit(uid, u0);
+    load_unit(uid + stride, u1);         // (zero operands past the end)
+    mma_unit(u0);
+    mma_unit(u1);
   }
   // C[row n = 4 lg + r][col = tap l15 (+16)]
 #pragma unroll
