@@ -148,7 +148,10 @@ __device__ __forceinline__ void vu_epilogue_swapped(const vu_gemm_args& g, const
   }
 }
 
-template <typename T, typename TC, bool TA, bool TB, int BM, int BN, int BK>
+// PD: k-tiles of global loads kept in flight per thread (register ring).  1 is the classic one-tile prefetch; the small
+// tiles used for long-K products with few output tiles (64 x 64: 98 - 196 workgroups on 256 CUs) take 4, because a stream
+// that few workgroups read is bound by bytes in flight (one 16 KB k-tile per ~2 us of loaded-chip latency = 8 GB/s per CU).
+template <typename T, typename TC, bool TA, bool TB, int BM, int BN, int BK, int PD = 1>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 2 ? 3 : 1, 8))) void vu_gemm_kernel(const vu_gemm_args g) {
   constexpr int VEC = vu_vec<T>::N;            // elements per 16 B
   constexpr bool IS_BF16 = sizeof(T) == 2;
@@ -179,9 +182,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
   const T* Bb = (const T*)g.B + z1 * g.sB1 + z2 * g.sB2;
 
   // ---- global -> register staging ---------------------------------------------------------
-  uint4 ra[NCA], rb[NCB];
+  uint4 ring_a[PD][NCA], ring_b[PD][NCB];
 
-  auto load_tile = [&](int k0) {
+  auto load_tile = [&](int k0, uint4 (&ra)[NCA], uint4 (&rb)[NCB]) {
 #pragma unroll
     for (int c = 0; c < NCA; ++c) {
       const int ch = tid + c * 256;
@@ -229,7 +232,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
       rb[c] = v;
     }
   };
-  auto store_tile = [&]() {
+  auto store_tile = [&](const uint4 (&ra)[NCA], const uint4 (&rb)[NCB]) {
 #pragma unroll
     for (int c = 0; c < NCA; ++c) {
       const int ch = tid + c * 256;
@@ -264,11 +267,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
   }
   float csum = 0.f;   // bias-gradient column sum carried by the first tile column / row of blocks
   const bool do_cs = g.colsum && ((g.colsum_side == 1 && tile_n == 0 && tid < BM) || (g.colsum_side == 2 && tile_m == 0 && tid < BN));
-  if (kt0 < nk) load_tile(kt0 * BK);
-  for (int kt = kt0; kt < nk; ++kt) {
-    store_tile();
+#pragma unroll
+  for (int s_ = 0; s_ < PD; ++s_)
+    if (kt0 + s_ < nk) load_tile((kt0 + s_) * BK, ring_a[s_], ring_b[s_]);
+  for (int ktb = kt0; ktb < nk; ktb += PD) {
+#pragma unroll
+   for (int s_ = 0; s_ < PD; ++s_) {
+    const int kt = ktb + s_;
+    if (kt >= nk) break;                 // workgroup-uniform
+    store_tile(ring_a[s_], ring_b[s_]);
     __syncthreads();
-    if (kt + 1 < nk) load_tile((kt + 1) * BK);
+    if (kt + PD < nk) load_tile((kt + PD) * BK, ring_a[s_], ring_b[s_]);
     if (do_cs) {
       if (g.colsum_side == 1) {
 #pragma unroll 8
@@ -342,6 +351,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
       }
     }
     __syncthreads();
+   }
   }
 
   if (do_cs) {

@@ -3,7 +3,7 @@
 #include <stdlib.h>
 #include "vu_gemm.h"
 
-template <typename T, typename TC, bool TA, bool TB, int BM, int BN, int BK>
+template <typename T, typename TC, bool TA, bool TB, int BM, int BN, int BK, int PD = 1>
 static int launch_bk(const vu_gemm_args& g, hipStream_t st) {
   vu_gemm_args ga = g;
   const long long blocks = (long long)vu_cdiv(g.M, BM) * vu_cdiv(g.N, BN) * g.Z1 * g.Z2;
@@ -18,7 +18,7 @@ static int launch_bk(const vu_gemm_args& g, hipStream_t st) {
     if (ga.ksplit < 1) ga.ksplit = 1;
   }
   dim3 grid((unsigned)(vu_cdiv(g.M, BM) * vu_cdiv(g.N, BN)), (unsigned)(g.Z1 * g.Z2), (unsigned)ga.ksplit);
-  hipLaunchKernelGGL((vu_gemm_kernel<T, TC, TA, TB, BM, BN, BK>), grid, dim3(256), 0, st, ga);
+  hipLaunchKernelGGL((vu_gemm_kernel<T, TC, TA, TB, BM, BN, BK, PD>), grid, dim3(256), 0, st, ga);
   if (vu_prof_on()) {
     char tag[96];
     static const bool shapes = getenv("VU_PROF_SHAPES") != nullptr;
@@ -42,7 +42,12 @@ static int launch_one(const vu_gemm_args& g, hipStream_t st) {
   // 128x32 tile (map x small-matrix products) takes BK = 128.  fp32 keeps 32 (LDS size).
   // measured (tools/gemm_bench.py, 3072-class GEMMs): BK 64 is +10..12 % over BK 32
   if constexpr (sizeof(T) == 4) return launch_bk<T, TC, TA, TB, BM, BN, 32>(g, st);
-  else return launch_bk<T, TC, TA, TB, BM, BN, 64>(g, st);
+  else if constexpr (BM == 64 && BN == 64) {
+    // long K on a small tile: deep register ring (vu_gemm.h); short K keeps the plain prefetch (fewer registers, no gain)
+    static const bool ring_off = [] { const char* e = getenv("VU_GEMM_RING"); return e && e[0] == '0'; }();      // A/B switch
+    if (g.K >= 512 && !ring_off) return launch_bk<T, TC, TA, TB, BM, BN, 64, 4>(g, st);
+    return launch_bk<T, TC, TA, TB, BM, BN, 64>(g, st);
+  } else return launch_bk<T, TC, TA, TB, BM, BN, 64>(g, st);
 }
 
 template <typename T, typename TC, bool TA, bool TB>
