@@ -295,7 +295,7 @@ template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void conv_wgrad_mm_kernel(const bf16_t* __restrict__ dq, const bf16_t* __restrict__ dk,
                                                             const bf16_t* __restrict__ dv, const bf16_t* __restrict__ xq,
                                                             const bf16_t* __restrict__ xkv, float* dwq, float* dwk, float* dwv,
-                                                            long long nunits, int s) {
+                                                            long long nunits, int s, float* __restrict__ part) {
   constexpr int C = 3, NW = 27;
   __shared__ float red[WAVES][2][2][256];   // [wave][q | kv][tap tile][C-layout element]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, lg = lane >> 4;
@@ -383,9 +383,29 @@ __global__ __launch_bounds__(WAVES * 64) void conv_wgrad_mm_kernel(const bf16_t*
     float v = 0.f;
 #pragma unroll
     for (int w = 0; w < WAVES; ++w) v += red[w][which][tt][e];
+    if (part) { part[(long long)blockIdx.x * 1024 + i] = v; continue; }      // per-block partials, summed in block order below
     float* dst = which == 0 ? dwq + n * NW + t : (n < 3 ? dwk + n * NW + t : dwv + (n - 3) * NW + t);
     atomicAdd(dst, v);
   }
+}
+
+// deterministic tail of conv_wgrad_mm_kernel: element i of every block's partial slab, added in block order
+__global__ __launch_bounds__(1024) void conv_wgrad_mm_reduce_kernel(const float* __restrict__ part, int nblocks, float* dwq, float* dwk,
+                                                                    float* dwv) {
+  constexpr int NW = 27;
+  const int i = threadIdx.x;
+  const int which = i >> 9, tt = (i >> 8) & 1, e = i & 255;
+  const int n = e >> 4, t = tt * 16 + (e & 15);
+  if (t >= NW || n >= (which == 0 ? 3 : 6)) return;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int b = 0;
+  for (; b + 3 < nblocks; b += 4) {
+    a0 += part[(long long)b * 1024 + i]; a1 += part[(long long)(b + 1) * 1024 + i];
+    a2 += part[(long long)(b + 2) * 1024 + i]; a3 += part[(long long)(b + 3) * 1024 + i];
+  }
+  for (; b < nblocks; ++b) a0 += part[(long long)b * 1024 + i];
+  float* dst = which == 0 ? dwq + n * NW + t : (n < 3 ? dwk + n * NW + t : dwv + (n - 3) * NW + t);
+  *dst += (a0 + a1) + (a2 + a3);
 }
 
 // A/B switch for measurements: VU_CONV_SHUFFLE=0 keeps the all-loads window
@@ -489,8 +509,12 @@ static int wgrad_launch(int dtype, int dout_f32, const WgradSet& set, int nconv,
     // 4 waves 131 us, 512 x 4: 93 us, 256 x 4: 141 us per launch)
     constexpr int WV = 16;
     long long g = (nunits + WV - 1) / WV; if (g > 256) g = 256;
+    void* scr = nullptr; size_t scr_bytes = 0;
+    vu_gemm_get_scratch(&scr, &scr_bytes);            // lent by the model executor: deterministic sum instead of float atomics
+    float* part = (scr && scr_bytes >= (size_t)g * 1024 * 4) ? (float*)scr : nullptr;
     hipLaunchKernelGGL(conv_wgrad_mm_kernel<WV>, dim3((unsigned)g), dim3(WV * 64), 0, st, (const bf16_t*)set.dout[0], (const bf16_t*)set.dout[1],
-                       (const bf16_t*)set.dout[2], (const bf16_t*)set.in[0], (const bf16_t*)set.in[1], set.dw[0], set.dw[1], set.dw[2], nunits, s);
+                       (const bf16_t*)set.dout[2], (const bf16_t*)set.in[0], (const bf16_t*)set.in[1], set.dw[0], set.dw[1], set.dw[2], nunits, s, part);
+    if (part) hipLaunchKernelGGL(conv_wgrad_mm_reduce_kernel, dim3(1), dim3(1024), 0, st, part, (int)g, set.dw[0], set.dw[1], set.dw[2]);
     if (vu_prof_on()) vu_prof_note("conv_wgrad_mm_kernel", 0.0, (double)nq * 4 * C * 5 * 2.0);
     return vu_check_launch("vu_conv3x3_wgrad");
   }
