@@ -389,23 +389,23 @@ __global__ __launch_bounds__(WAVES * 64) void conv_wgrad_mm_kernel(const bf16_t*
   }
 }
 
-// deterministic tail of conv_wgrad_mm_kernel: element i of every block's partial slab, added in block order
+// deterministic tail of conv_wgrad_mm_kernel: one wave per output element i, lane l adds the partials of blocks l, l + 64, ...
+// in order, then a fixed shuffle tree (a single thread walking 256 partials pays 64 dependent L2 round trips: 50 us)
 __global__ __launch_bounds__(1024) void conv_wgrad_mm_reduce_kernel(const float* __restrict__ part, int nblocks, float* dwq, float* dwk,
                                                                     float* dwv) {
   constexpr int NW = 27;
-  const int i = threadIdx.x;
+  const int i = blockIdx.x * 16 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int which = i >> 9, tt = (i >> 8) & 1, e = i & 255;
   const int n = e >> 4, t = tt * 16 + (e & 15);
-  if (t >= NW || n >= (which == 0 ? 3 : 6)) return;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  int b = 0;
-  for (; b + 3 < nblocks; b += 4) {
-    a0 += part[(long long)b * 1024 + i]; a1 += part[(long long)(b + 1) * 1024 + i];
-    a2 += part[(long long)(b + 2) * 1024 + i]; a3 += part[(long long)(b + 3) * 1024 + i];
+  if (i >= 1024 || t >= NW || n >= (which == 0 ? 3 : 6)) return;          // wave-uniform
+  float a = 0.f;
+  for (int b = lane; b < nblocks; b += 64) a += part[(long long)b * 1024 + i];
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m, 64);
+  if (lane == 0) {
+    float* dst = which == 0 ? dwq + n * NW + t : (n < 3 ? dwk + n * NW + t : dwv + (n - 3) * NW + t);
+    *dst += a;
   }
-  for (; b < nblocks; ++b) a0 += part[(long long)b * 1024 + i];
-  float* dst = which == 0 ? dwq + n * NW + t : (n < 3 ? dwk + n * NW + t : dwv + (n - 3) * NW + t);
-  *dst += (a0 + a1) + (a2 + a3);
 }
 
 // A/B switch for measurements: VU_CONV_SHUFFLE=0 keeps the all-loads window
@@ -514,7 +514,7 @@ static int wgrad_launch(int dtype, int dout_f32, const WgradSet& set, int nconv,
     float* part = (scr && scr_bytes >= (size_t)g * 1024 * 4) ? (float*)scr : nullptr;
     hipLaunchKernelGGL(conv_wgrad_mm_kernel<WV>, dim3((unsigned)g), dim3(WV * 64), 0, st, (const bf16_t*)set.dout[0], (const bf16_t*)set.dout[1],
                        (const bf16_t*)set.dout[2], (const bf16_t*)set.in[0], (const bf16_t*)set.in[1], set.dw[0], set.dw[1], set.dw[2], nunits, s, part);
-    if (part) hipLaunchKernelGGL(conv_wgrad_mm_reduce_kernel, dim3(1), dim3(1024), 0, st, part, (int)g, set.dw[0], set.dw[1], set.dw[2]);
+    if (part) hipLaunchKernelGGL(conv_wgrad_mm_reduce_kernel, dim3(64), dim3(1024), 0, st, part, (int)g, set.dw[0], set.dw[1], set.dw[2]);
     if (vu_prof_on()) vu_prof_note("conv_wgrad_mm_kernel", 0.0, (double)nq * 4 * C * 5 * 2.0);
     return vu_check_launch("vu_conv3x3_wgrad");
   }
