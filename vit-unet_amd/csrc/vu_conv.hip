@@ -448,7 +448,8 @@ int vu_k_conv3x3_qkv_fwd(int dtype, const void* xq, const void* xkv, const float
   const long long nq = npatch * s * s / 4;
   if (nq == 0) return VU_OK;
   const int grid = grid_for(nq, 256 * 16);
-  const int sh = shuffle_off() ? 0 : conv_shuffle_form(s);
+  int sh = shuffle_off() ? 0 : conv_shuffle_form(s);
+  if (sh == 2) sh = 1;      // forward: VALU-bound (243 MACs per pixel), the extra DPP moves of the one-load form cost more than its loads (37.9 vs 30.9 us)
 #define VU_QKV_FWD(SHV) \
     if (dtype == 0) hipLaunchKernelGGL((conv_fwd_kernel<float, float, CC, 3, SHV>), dim3(grid), dim3(256), 0, st, (const float*)xq, (const float*)xkv, wq, wk, wv, (const float*)nullptr, (float*)q, (float*)k, (float*)v, nq, s); \
     else hipLaunchKernelGGL((conv_fwd_kernel<bf16_t, bf16_t, CC, 3, SHV>), dim3(grid), dim3(256), 0, st, (const bf16_t*)xq, (const bf16_t*)xkv, wq, wk, wv, (const float*)nullptr, (bf16_t*)q, (bf16_t*)k, (bf16_t*)v, nq, s);

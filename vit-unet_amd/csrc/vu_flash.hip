@@ -441,19 +441,19 @@ __global__ __launch_bounds__(1024) void flash_bn_finalize_kernel(const float* __
                                          float* run_mean, float* run_var, float* stats, int H, int N, double count, int training,
                                          float momentum, float eps, float inv_keep, int direct) {
   __shared__ double mom[64];
-  __shared__ double sd[16][64];
+  __shared__ double sd[1024];
   const int NM = direct ? 2 * H : H + H * (H + 1) / 2;
-  const int tid = threadIdx.x;          // 1024 threads: 64 moment columns side by side (coalesced), 16 row lanes
+  const int tid = threadIdx.x;          // 1024 threads: COLS moment columns side by side (coalesced), 1024 / COLS row lanes
   if (training) {
-    const int col = tid & 63, rl = tid >> 6;
+    const int COLS = NM <= 16 ? 16 : 64, RL = 1024 / COLS;      // (the v2 forward has 16 columns: 64 row lanes, 13 rows each)
+    const int col = tid & (COLS - 1), rl = tid / COLS;
     double a = 0.0;
-    if (col < NM) a = strided_colsum(partials, nblocks, NM, col, rl, 16);
-    sd[rl][col] = a;
+    if (col < NM) a = strided_colsum(partials, nblocks, NM, col, rl, RL);
+    sd[rl * COLS + col] = a;
     __syncthreads();
     if (tid < NM) {
       double t = 0.0;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) t += sd[r][tid];
+      for (int r = 0; r < RL; ++r) t += sd[r * COLS + tid];
       mom[tid] = t / count;
     }
   }

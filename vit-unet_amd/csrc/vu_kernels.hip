@@ -46,6 +46,28 @@ __global__ void retile_kernel(const TI* __restrict__ in, TO* __restrict__ out,
   }
 }
 
+// pure permutation of 16-byte pieces (bf16 -> bf16, no positional add, both patch sizes multiples of 8): half the
+// instructions and index divisions per byte of the 4-element form
+__global__ __launch_bounds__(256) void retile_copy16_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, long long total8, int P,
+                                                             int C, int im, int s_in, int s_out) {
+  const int e_in = im / s_in, e_out = im / s_out;
+  const int ss_in = s_in * s_in, ss_out = s_out * s_out;
+  const int D_in = C * ss_in, D_out = C * ss_out;
+  const int P8 = P >> 3;
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total8; t += (long long)gridDim.x * blockDim.x) {
+    const unsigned t32 = (unsigned)t;
+    const unsigned b = t32 / (unsigned)P8;
+    const int r = (int)(t32 - b * (unsigned)P8) << 3;
+    const int n_out = r / D_out, f = r - n_out * D_out;
+    const int ch = f / ss_out, rem = f - ch * ss_out;
+    const int i = rem / s_out, j = rem - i * s_out;
+    const int y = (n_out / e_out) * s_out + i, x = (n_out % e_out) * s_out + j;
+    const int n_in = (y / s_in) * e_in + x / s_in;
+    const int f_in = ch * ss_in + (y % s_in) * s_in + (x % s_in);
+    out[((long long)b * P + r) >> 3] = in[((long long)b * P + (long long)n_in * D_in + f_in) >> 3];
+  }
+}
+
 int vu_k_retile(int dtype, int in_f32, int out_f32, const void* in, void* out, const float* pos,
                 int B, int C, int im, int s_in, int s_out, hipStream_t st) {
   VU_REQUIRE(s_in % 4 == 0 && s_out % 4 == 0 && im % s_in == 0 && im % s_out == 0,
@@ -56,6 +78,11 @@ int vu_k_retile(int dtype, int in_f32, int out_f32, const void* in, void* out, c
   VU_REQUIRE(total4 < 4294967295LL, "vu_retile: more than 2^32 element quads");
   const int grid = grid_for(total4);
   const bool fi = in_f32 || dtype == 0, fo = out_f32 || dtype == 0;
+  if (!fi && !fo && !pos && s_in % 8 == 0 && s_out % 8 == 0 && ((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 15) == 0) {
+    hipLaunchKernelGGL(retile_copy16_kernel, dim3(grid_for(total4 / 2)), dim3(256), 0, st, (const uint4*)in, (uint4*)out, total4 / 2, P, C, im, s_in, s_out);
+    if (vu_prof_on()) vu_prof_note("retile_kernel", 0.0, (double)total4 * 4 * 2 * 2.0);
+    return vu_check_launch("vu_retile");
+  }
   if (fi && fo) hipLaunchKernelGGL((retile_kernel<float, float>), dim3(grid), dim3(256), 0, st, (const float*)in, (float*)out, pos, total4, P, C, im, s_in, s_out);
   else if (fi) hipLaunchKernelGGL((retile_kernel<float, bf16_t>), dim3(grid), dim3(256), 0, st, (const float*)in, (bf16_t*)out, pos, total4, P, C, im, s_in, s_out);
   else if (fo) hipLaunchKernelGGL((retile_kernel<bf16_t, float>), dim3(grid), dim3(256), 0, st, (const bf16_t*)in, (float*)out, pos, total4, P, C, im, s_in, s_out);
