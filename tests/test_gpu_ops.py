@@ -104,7 +104,8 @@ def _gemm(dt, A, Bm, M, N, K, sAm, sAk, sBk, sBn, Z1=1, Z2=1, sA=(0, 0), sB=(0, 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("M,N,K", [(49, 49, 24), (200, 130, 70), (128, 128, 32), (130, 24, 196), (64, 16, 3072),
-                                   (784, 784, 24), (300, 3072 // 8, 392)])
+                                   (784, 784, 24), (300, 3072 // 8, 392),
+                                   (8300, 192, 192), (1100, 32, 192), (2000, 192, 32)])     # persistent small-weight form
 def test_gemm_forms(dt, M, N, K):
     g = torch.Generator().manual_seed(M * 7 + N)
     ft, _ = TOL[dt]

@@ -1,4 +1,4 @@
-"""Copies the bench lines / trace summaries of tools/gpu_round2.sh from gpurun_out/ into profiles/ (tracked) and fills the
+"""Regenerates DESIGN.md section 5 from tools/design_section5.md.in; copies the bench lines / trace summaries of tools/gpu_round2.sh from gpurun_out/ into profiles/ (tracked) and fills the
 R2_* placeholders of DESIGN.md section 5 from them.  usage: python tools/record_round.py [trace_tag]"""
 import json
 import os
@@ -41,8 +41,10 @@ sub = {
 }
 d = os.path.join(R, "DESIGN.md")
 s = open(d).read()
+sec = open(os.path.join(R, "tools", "design_section5.md.in")).read()       # section 5 with R2_* placeholders
 for k in sorted(sub, key=len, reverse=True):
-    s = s.replace(k, sub[k])
-open(d, "w").write(s)
+    sec = sec.replace(k, sub[k])
+a, b = s.index("## 5. Measurement, round 2"), s.index("## 5b. Measurement, round 1")
+open(d, "w").write(s[:a] + sec + s[b:])
 print(json.dumps(sub, indent=1))
 print("dominant kernel:", roof["kernel"], "traffic:", roof.get("traffic"), roof.get("traffic_source"))

@@ -115,6 +115,7 @@ void vu_gemm_set_scratch(void* p, size_t bytes) { g_scratch = p; g_scratch_bytes
 void vu_gemm_get_scratch(void** p, size_t* bytes) { *p = g_scratch; *bytes = g_scratch_bytes; }
 
 int vu_tsgemm_try(const vu_gemm_args& g, hipStream_t st);      // vu_tsgemm.hip: long-K, small-output weight gradients
+int vu_pgemm_try(const vu_gemm_args& g, hipStream_t st);       // vu_pgemm.hip: many rows, small resident weight
 
 // dtype: 0 = fp32 storage, 1 = bf16 storage.
 int vu_gemm_launch(int dtype, int c_float, vu_gemm_args g, hipStream_t st) {
@@ -122,6 +123,11 @@ int vu_gemm_launch(int dtype, int c_float, vu_gemm_args g, hipStream_t st) {
   if (g.K <= 0) { vu_set_error("vu_gemm: K must be positive"); return VU_EINVAL; }
   if (dtype == 1 && c_float) {
     const int rc = vu_tsgemm_try(g, st);
+    if (rc < 0) return rc;
+    if (rc > 0) return VU_OK;
+  }
+  if (dtype == 1 && !c_float) {
+    const int rc = vu_pgemm_try(g, st);
     if (rc < 0) return rc;
     if (rc > 0) return VU_OK;
   }
