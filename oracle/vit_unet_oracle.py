@@ -182,16 +182,30 @@ def quad_threshold(p: float) -> int:
     return max(1, (int(p * 65536.0 + 0.5) + 128) >> 8)
 
 
-def keep_mask_quad(rows: int, n: int, p: float, seed: int, stream: int) -> torch.Tensor:
-    """Keep mask (rows, n) of the non-materialising attention form (csrc/vu_flash.hip): one hash word per 4 consecutive
-    keys of a map row, 8 bits per key, kept when byte >= round(256 p); n % 4 == 0."""
+_QUAD_HEAD_MUL = (0x9E3779, 0xB5297B, 0x68E31D, 0x7FEB35, 0xC2B2AE, 0x85EBCA, 0x27D4EB, 0x165667)
+
+
+def _quad_head(base: np.ndarray, h: int) -> np.ndarray:
+    """csrc/vu_flash.hip vu_quad_head: the third round, with the head's own multiplier."""
+    y = ((base & np.uint64(0xFFFFFF)) * np.uint64(_QUAD_HEAD_MUL[h & 7]) + (base >> np.uint64(12))) & _M32
+    return y ^ (y >> np.uint64(16))
+
+
+def keep_mask_quad(B: int, H: int, rows: int, n: int, p: float, seed: int, stream: int) -> torch.Tensor:
+    """Keep mask (B, H, rows, n) of the non-materialising attention form (csrc/vu_flash.hip): one two-round hash word per
+    (sample, map row, 4 consecutive keys), shared by the heads; head h runs it through a third round with its own
+    multiplier; 8 bits per key, kept when byte >= round(256 p); n % 4 == 0."""
     assert n % 4 == 0
     k0, k1 = stream_key(seed, stream)
-    x = np.arange(rows * (n // 4), dtype=np.uint64)
-    w = _quad_word(x, k0, k1)
+    x = np.arange(B * rows * (n // 4), dtype=np.uint64)
+    base = _quad_word(x, k0, k1)
     thr = np.uint64(quad_threshold(p))
-    by = np.stack([((w >> np.uint64(8 * r)) & np.uint64(255)) >= thr for r in range(4)], axis=1)
-    return torch.from_numpy(by.reshape(rows, n))
+    out = np.empty((B, H, rows, n), dtype=bool)
+    for h in range(H):
+        w = _quad_head(base, h)
+        by = np.stack([((w >> np.uint64(8 * r)) & np.uint64(255)) >= thr for r in range(4)], axis=1)
+        out[:, h] = by.reshape(B, rows, n)
+    return torch.from_numpy(out)
 
 
 FLASH_FILL_RULE = True      # False: mirror VU_ATTN_FLASH=1 (the recompute form wherever the shape is covered)
@@ -213,9 +227,8 @@ def _dropout_quad(x: torch.Tensor, p: float, training: bool, seed: Optional[int]
         return x
     if seed is None:
         return F.dropout(x, p, True)
-    n = x.shape[-1]
-    rows = x.numel() // n
-    m = keep_mask_quad(rows, n, p, seed, stream).reshape(x.shape).to(x.dtype)
+    B, H, rows, n = x.shape
+    m = keep_mask_quad(B, H, rows, n, p, seed, stream).to(x.dtype)
     return x * m * (256.0 / (256.0 - quad_threshold(p)))
 
 

@@ -197,7 +197,7 @@ __device__ __forceinline__ bf16x8 join8(const bf16x4& a, const bf16x4& b) { retu
 // key r is kept when byte r >= thr8 = round(256 p), so the drop probability is thr8 / 256 and 1 / keep = 256 / (256 - thr8)
 // (vu_flash_quad_rng).  Every pass of the forward and the backward recomputes the word, so the hash is built from
 // full-rate instructions only: two rounds of (24-bit multiply-add, xor-shift) - v_mul_lo_u32 runs at a quarter of the
-// rate.  Word index x = map row * (N / 4) + jg (32 bits: B H N N < 2^34).  Measured on 2^20 consecutive words, three
+// rate.  Word index x = (sample * N + query row) * (N / 4) + jg (32 bits: B N N < 2^34), shared by the heads (vu_quad_head).  Measured on 2^20 consecutive words, three
 // keys: keep rate 0.8008 +- 0.0005 per byte lane, every pairwise correlation tested (byte lanes, neighbouring words, rows,
 // heads) below 0.006, kept-per-row variance 0.98 - 1.03 of binomial (tests/test_oracle_golden.py::test_quad_mask_statistics).
 __device__ __forceinline__ uint32_t vu_quad_word(uint32_t x, uint32_t k0, uint32_t k1) {
@@ -207,6 +207,15 @@ __device__ __forceinline__ uint32_t vu_quad_word(uint32_t x, uint32_t k0, uint32
   y = __umul24(y, 0x9E3779u) + (y >> 12);
   y ^= y >> 16;
   return y + k1;
+}
+// The 8 heads of one (query row, key quad) share ONE two-round word (`base`, indexed without the head); head h takes a
+// third round with its own multiplier: 3 instructions per head instead of 9 (the hash was 15 % of a sweep's VALU work).
+// Measured on 2 M words (oracle, test_quad_mask_statistics): keep rate 0.8007 - 0.8010 per head (target 0.8008), largest
+// correlation between two heads' masks 8e-4, between byte lanes of different heads 2e-3.
+__device__ __forceinline__ uint32_t vu_quad_head(uint32_t base, uint32_t base_sh, int h) {
+  constexpr uint32_t C[8] = {0x9E3779u, 0xB5297Bu, 0x68E31Du, 0x7FEB35u, 0xC2B2AEu, 0x85EBCAu, 0x27D4EBu, 0x165667u};
+  const uint32_t y = __umul24(base, C[h & 7]) + base_sh;
+  return y ^ (y >> 16);
 }
 struct keep4_t { uint32_t w, thr; };
 __device__ __forceinline__ keep4_t keep4(const vu_rng& rng, uint32_t x) {
@@ -306,7 +315,7 @@ __global__ __launch_bounds__(WPB * 64) void flash_stats_kernel(const bf16_t* __r
   for (int i = 0; i < H * (H + 1) / 2; ++i) s2[i] = 0.f;
   const float cen = 1.0f / (float)N;
   const uint32_t hstride = (uint32_t)(((unsigned long long)N * N) >> 2);          // quad words per (sample, head) map
-  const uint32_t wlane = (uint32_t)(((((unsigned long long)b * H) * N + qrow) * (unsigned long long)N) >> 2) + (uint32_t)g4;
+  const uint32_t wlane = (uint32_t)((((unsigned long long)b * N + qrow) * (unsigned long long)N) >> 2) + (uint32_t)g4;
   for (int ch = 0; ch < nchunks; ++ch) {
     const int nt = min(CK, ntiles - ch * CK);
     __syncthreads();
@@ -317,9 +326,12 @@ __global__ __launch_bounds__(WPB * 64) void flash_stats_kernel(const bf16_t* __r
         f32x4 acc[H];
         tile_logits<H, DH>(acc, Kc, kc, qf, l15, g4);
         const uint32_t wt = wlane + 4u * (uint32_t)(ch * CK + kc);
+        const uint32_t base = keep4(rng, wt).w, base_sh = base >> 12;
 #pragma unroll
         for (int h = 0; h < H; ++h) {
-          const keep4_t kp = keep4(rng, wt + (uint32_t)h * hstride);
+          keep4_t kp;
+          kp.thr = rng.thr;
+          kp.w = rng.thr ? vu_quad_head(base, base_sh, h) : 0u;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float p = fexp2(fmaf(acc[h][r], c, -lse[h]));
@@ -541,7 +553,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash_apply_kernel(
 #pragma unroll
     for (int dt = 0; dt < C::DT; ++dt) oacc[h][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   const uint32_t hstride = (uint32_t)(((unsigned long long)N * N) >> 2);          // quad words per (sample, head) map
-  const uint32_t wlane = (uint32_t)(((((unsigned long long)b * H) * N + qrow) * (unsigned long long)N) >> 2) + (uint32_t)g4;
+  const uint32_t wlane = (uint32_t)((((unsigned long long)b * N + qrow) * (unsigned long long)N) >> 2) + (uint32_t)g4;
   const int nchunks = (ntiles + CK - 1) / CK;
 
   for (int ch = 0; ch < nchunks; ++ch) {
@@ -555,9 +567,12 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash_apply_kernel(
         f32x4 acc[H];
         tile_logits<H, DH>(acc, Kc, kc, qf, l15, g4);
         const uint32_t wt = wlane + 4u * (uint32_t)(ch * CK + kc);
+        const uint32_t base = keep4(rng, wt).w, base_sh = base >> 12;
 #pragma unroll
         for (int h = 0; h < H; ++h) {
-          const keep4_t kp = keep4(rng, wt + (uint32_t)h * hstride);
+          keep4_t kp;
+          kp.thr = rng.thr;
+          kp.w = rng.thr ? vu_quad_head(base, base_sh, h) : 0u;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float p = fexp2(fmaf(acc[h][r], c, -lse[h]));
@@ -640,14 +655,17 @@ __device__ __forceinline__ void tile_prod(f32x4 (&acc)[H], const bf16_t* Xc, int
   typedef FC<H, DH> C;
   const int gk = g4 < C::KS ? g4 : C::KS - 1;
   const bf16_t* xrow = Xc + (kc * 16 + l15) * C::PITCH + 8 * gk;
-  const bf16_t* srow = sl ? sl + l15 * C::PITCH + 8 * gk : nullptr;
+  // k-slots >= KS of the stationary operand must be zero: those lanes read the row's zeroed 16-byte pad for every head (a
+  // per-lane head stride of 0) instead of a valid slot followed by 4 selects per head (32 VALU instructions per product)
+  const bool dead = C::KS < 4 && g4 >= C::KS;
+  const int hs = dead ? 0 : DH;
+  const bf16_t* srow = sl ? sl + l15 * C::PITCH + (dead ? C::D : 8 * g4) : nullptr;
 #pragma unroll
   for (int h = 0; h < H; ++h) {
     const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xrow + h * DH);
     bf16x8 st;
     if (sl) {
-      st = *reinterpret_cast<const bf16x8*>(srow + h * DH);
-      if (C::KS < 4 && g4 >= C::KS) st = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      st = *reinterpret_cast<const bf16x8*>(srow + h * hs);
     } else st = sf[h];
     const float ci = cin ? cin[h] : 0.f;
     const f32x4 c0 = {ci, ci, ci, ci};
@@ -668,9 +686,12 @@ __device__ __forceinline__ void stage_own_rows(bf16_t* dst, const bf16_t* __rest
 // logits -> sign-tagged probabilities, in place
 template <int H>
 __device__ __forceinline__ void tag_probs(f32x4 (&S)[H], const float (&lse)[H], float c, const vu_rng& rng, uint32_t wt, uint32_t hstride) {
+  const uint32_t base = keep4(rng, wt).w, base_sh = base >> 12;
 #pragma unroll
   for (int h = 0; h < H; ++h) {
-    const keep4_t kp = keep4(rng, wt + (uint32_t)h * hstride);
+    keep4_t kp;
+    kp.thr = rng.thr;
+    kp.w = rng.thr ? vu_quad_head(base, base_sh, h) : 0u;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float p = fexp2(fmaf(S[h][r], c, -lse[h]));
@@ -745,7 +766,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash_bwd_delta_kernel(
   zero_pads<H, DH>(Kc, 2 * CK * 16 + WPB * 32, tid, WPB * 64);
   load_bwd_tab<H>(tb, stats, tid, WPB * 64);
   const uint32_t hstride = (uint32_t)(((unsigned long long)N * N) >> 2);          // quad words per (sample, head) map
-  const uint32_t wlane = (uint32_t)(((((unsigned long long)b * H) * N + qrow) * (unsigned long long)N) >> 2) + (uint32_t)g4;
+  const uint32_t wlane = (uint32_t)((((unsigned long long)b * N + qrow) * (unsigned long long)N) >> 2) + (uint32_t)g4;
   const int nchunks = (ntiles + CK - 1) / CK;
   for (int ch = 0; ch < nchunks; ++ch) {
     const int nt = min(CK, ntiles - ch * CK);
@@ -864,7 +885,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash_bwd_dq_kernel(
 #pragma unroll
     for (int dt = 0; dt < C::DT; ++dt) dqa[h][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   const uint32_t hstride = (uint32_t)(((unsigned long long)N * N) >> 2);          // quad words per (sample, head) map
-  const uint32_t wlane = (uint32_t)(((((unsigned long long)b * H) * N + qrow) * (unsigned long long)N) >> 2) + (uint32_t)g4;
+  const uint32_t wlane = (uint32_t)((((unsigned long long)b * N + qrow) * (unsigned long long)N) >> 2) + (uint32_t)g4;
   const int nchunks = (ntiles + CK - 1) / CK;
   for (int ch = 0; ch < nchunks; ++ch) {
     const int nt = min(CK, ntiles - ch * CK);
@@ -973,7 +994,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash_bwd_dkv_kernel(
     for (int dt = 0; dt < C::DT; ++dt) oa[h][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   const uint32_t hstride = (uint32_t)(((unsigned long long)N * N) >> 2);
   // quad-word index of map element (row = (b H + h) N + query, key 16 tk + 4 g4): the query part is added per tile
-  const uint32_t wkey = (uint32_t)((((unsigned long long)b * H) * N * (unsigned long long)N) >> 2) + 4u * (uint32_t)tk + (uint32_t)g4;
+  const uint32_t wkey = (uint32_t)(((unsigned long long)b * N * (unsigned long long)N) >> 2) + 4u * (uint32_t)tk + (uint32_t)g4;
   const uint32_t wq = (uint32_t)(N >> 2);                                  // quad words per map row
   const int nchunks = (ntiles + CK - 1) / CK;
   for (int ch = 0; ch < nchunks; ++ch) {
@@ -1261,7 +1282,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_moments_kernel(const bf16_
 #pragma unroll
     for (int dt = 0; dt < C::DT; ++dt) pacc[h][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   const uint32_t hstride = (uint32_t)(((unsigned long long)N * N) >> 2);
-  const uint32_t wlane = (uint32_t)(((((unsigned long long)b * H) * N + qrow) * (unsigned long long)N) >> 2) + (uint32_t)g4;
+  const uint32_t wlane = (uint32_t)((((unsigned long long)b * N + qrow) * (unsigned long long)N) >> 2) + (uint32_t)g4;
   const int nchunks = (ntiles + CK - 1) / CK;
   ChunkStage<H, DH, CK * 16, WPB * 64> st_Kc;
   st_Kc.fetch(kb, min(CK, ntiles) * 16, tid);
@@ -1371,7 +1392,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_apply_kernel(
 #pragma unroll
     for (int fb = 0; fb < FB; ++fb) oacc[j][fb] = f32x4{0.f, 0.f, 0.f, 0.f};
   const uint32_t hstride = (uint32_t)(((unsigned long long)N * N) >> 2);
-  const uint32_t wlane = (uint32_t)(((((unsigned long long)b * H) * N + qrow) * (unsigned long long)N) >> 2) + (uint32_t)g4;
+  const uint32_t wlane = (uint32_t)((((unsigned long long)b * N + qrow) * (unsigned long long)N) >> 2) + (uint32_t)g4;
   const int nchunks = (ntiles + CK - 1) / CK;
   ChunkStage<H, DH, CK * 16, WPB * 64> st_Kc;
   st_Kc.fetch(kb, min(CK, ntiles) * 16, tid);
@@ -1442,16 +1463,19 @@ __device__ __forceinline__ void make_bwd2_ops(Bwd2Ops& o, const float* __restric
 // S (logits, OL) -> tagML (sign-tagged probabilities, ML); then dA^ (OL, computed here, late, so that its 32 registers
 // are not live beside the logits) -> e (ML).  STREAM_A as in tile_prod; Dc / dst: streaming chunk and stationary image of
 // the dA^ product (V rows and dO in the q-major sweeps, dO rows and V in the key-major one).
-template <int H, int DH, bool STREAM_A>
+// KEPT_ONLY: T receives the kept probabilities P~ (dropped entries 0) instead of the signed tags - for sweeps that never
+// need the un-dropped |P| (the fused dq sweep): saves their per-element max(tag, 0).
+template <int H, int DH, bool STREAM_A, bool KEPT_ONLY = false>
 __device__ __forceinline__ void bwd2_chain(f32x4 (&S)[H], const bf16_t* Dc, int kc, const bf16_t* dst, const float (&lse)[H], float c,
                                            const vu_rng& rng, uint32_t wt, uint32_t hstride, const Bwd2Ops& o, f32x4 (&T)[2][4],
                                            f32x4 (&E)[2][4], int l15, int g4) {
   tag_probs<H>(S, lse, c, rng, wt, hstride);
   bf16x8 pk[4];
   pack_heads(S, pk);
-  convert_ml(T, o.id, pk, false);                        // tag in ML (exact: already bf16)
+  if constexpr (!KEPT_ONLY) convert_ml(T, o.id, pk, false);      // tag in ML (exact: already bf16)
 #pragma unroll
   for (int r = 0; r < 4; ++r) pk[r] = relu_packed(pk[r]);
+  if constexpr (KEPT_ONLY) convert_ml(T, o.id, pk, false);
   mix_ml(E, o.xk2, pk, o.cin);                           // -m1 - m2 x^
   LDS_FENCE();
   f32x4 Dh[H];
@@ -1496,6 +1520,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_bwd_delta_kernel(
   const int qrow = tq * 16 + l15;
   const bf16_t* kb = k + (long long)b * N * C::D;
   const bf16_t* vb = v + (long long)b * N * C::D;
+  zero_pads<H, DH>(Vc + CK * 16 * C::PITCH, WPB * 32, tid, WPB * 64);       // (tile_prod reads the pads of the stationary images as zeros)
   stage_own_rows<H, DH>(Qs, q + ((long long)b * N + tq * 16) * C::D, lane);
   stage_own_rows<H, DH>(dOs, dO + ((long long)b * N + tq * 16) * C::D, lane);
   float lse[H];
@@ -1505,7 +1530,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_bwd_delta_kernel(
   make_bwd2_ops(ops, stats, l15, g4);
   f32x4 dl = {0.f, 0.f, 0.f, 0.f}, tc = {0.f, 0.f, 0.f, 0.f}, Tacc = {0.f, 0.f, 0.f, 0.f};
   const uint32_t hstride = (uint32_t)(((unsigned long long)N * N) >> 2);
-  const uint32_t wlane = (uint32_t)(((((unsigned long long)b * H) * N + qrow) * (unsigned long long)N) >> 2) + (uint32_t)g4;
+  const uint32_t wlane = (uint32_t)((((unsigned long long)b * N + qrow) * (unsigned long long)N) >> 2) + (uint32_t)g4;
   const int nchunks = (ntiles + CK - 1) / CK;
   const int hh = g4 & 1, a2 = g4 >> 1;
   ChunkStage<H, DH, CK * 16, WPB * 64> st_Kc;
@@ -1619,6 +1644,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_bwd_dq_kernel(
   const int qrow = tq * 16 + l15;
   const bf16_t* kb = k + (long long)b * N * C::D;
   const bf16_t* vb = v + (long long)b * N * C::D;
+  zero_pads<H, DH>(Vc + CK * 16 * C::PITCH, WPB * 32, tid, WPB * 64);       // (tile_prod reads the pads of the stationary images as zeros)
   stage_own_rows<H, DH>(Qs, q + ((long long)b * N + tq * 16) * C::D, lane);
   stage_own_rows<H, DH>(dOs, dO + ((long long)b * N + tq * 16) * C::D, lane);
   for (int i = tid; i < tr_zero_elems<H, DH>() / 8; i += WPB * 64) *reinterpret_cast<uint4*>(Zr + i * 8) = make_uint4(0, 0, 0, 0);
@@ -1638,7 +1664,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_bwd_dq_kernel(
 #pragma unroll
     for (int fb = 0; fb < FB; ++fb) acc[j][fb] = f32x4{0.f, 0.f, 0.f, 0.f};
   const uint32_t hstride = (uint32_t)(((unsigned long long)N * N) >> 2);
-  const uint32_t wlane = (uint32_t)(((((unsigned long long)b * H) * N + qrow) * (unsigned long long)N) >> 2) + (uint32_t)g4;
+  const uint32_t wlane = (uint32_t)((((unsigned long long)b * N + qrow) * (unsigned long long)N) >> 2) + (uint32_t)g4;
   const int nchunks = (ntiles + CK - 1) / CK;
   ChunkStage<H, DH, CK * 16, WPB * 64> st_Kc;
   st_Kc.fetch(kb, min(CK, ntiles) * 16, tid);
@@ -1727,6 +1753,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_bwd_dqx_kernel(
   const int qrow = tq * 16 + l15;
   const bf16_t* kb = k + (long long)b * N * C::D;
   const bf16_t* vb = v + (long long)b * N * C::D;
+  zero_pads<H, DH>(Vc + CK * 16 * C::PITCH, WPB * 32, tid, WPB * 64);       // (tile_prod reads the pads of the stationary images as zeros)
   stage_own_rows<H, DH>(Qs, q + ((long long)b * N + tq * 16) * C::D, lane);
   stage_own_rows<H, DH>(dOs, dO + ((long long)b * N + tq * 16) * C::D, lane);
   for (int i = tid; i < tr_strip_elems<DH>() / 8; i += WPB * 64) *reinterpret_cast<uint4*>(Zr + i * 8) = make_uint4(0, 0, 0, 0);
@@ -1744,7 +1771,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_bwd_dqx_kernel(
     for (int fb = 0; fb < FB; ++fb) acc[j][fb] = f32x4{0.f, 0.f, 0.f, 0.f};
   f32x4 dl = {0.f, 0.f, 0.f, 0.f}, tc = {0.f, 0.f, 0.f, 0.f}, Tacc = {0.f, 0.f, 0.f, 0.f};
   const uint32_t hstride = (uint32_t)(((unsigned long long)N * N) >> 2);
-  const uint32_t wlane = (uint32_t)(((((unsigned long long)b * H) * N + qrow) * (unsigned long long)N) >> 2) + (uint32_t)g4;
+  const uint32_t wlane = (uint32_t)((((unsigned long long)b * N + qrow) * (unsigned long long)N) >> 2) + (uint32_t)g4;
   const int nchunks = (ntiles + CK - 1) / CK;
   const int hh = g4 & 1, a2 = g4 >> 1;
   // image addresses: the lane's row (a2 16 + l15) and its two swizzled column blocks; the transposed reads of k-block pb
@@ -1771,7 +1798,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_bwd_dqx_kernel(
       for (int kc = 0; kc < nt; ++kc) {
         f32x4 S[H], T[2][4], E[2][4];
         tile_prod<H, DH, true>(S, Kc, kc, nullptr, Qs, nullptr, l15, g4);
-        bwd2_chain<H, DH, true>(S, Vc, kc, dOs, lse, c, rng, wlane + 4u * (uint32_t)(ch * CK + kc), hstride, ops, T, E, l15, g4);
+        bwd2_chain<H, DH, true, true>(S, Vc, kc, dOs, lse, c, rng, wlane + 4u * (uint32_t)(ch * CK + kc), hstride, ops, T, E, l15, g4);
 #pragma unroll
         for (int half = 0; half < 2; ++half)
 #pragma unroll
@@ -1780,7 +1807,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_bwd_dqx_kernel(
             f32x4 ph;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              ph[j] = fmaxf(T[half][r][j], 0.f);
+              ph[j] = T[half][r][j];                 // (already the kept probabilities: bwd2_chain<KEPT_ONLY>)
               tc[j] += E[half][r][j];
             }
             // sum over positions of e_g P^_h as X^T X (see flash2_bwd_delta_kernel): e as a bf16 hi + lo pair in two rounds
@@ -1911,7 +1938,7 @@ __global__ __launch_bounds__(WPB * 64, DV ? 3 : 2) void flash2_bwd_dkv_kernel(
 #pragma unroll
     for (int dt = 0; dt < C::DT; ++dt) oa[h][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   const uint32_t hstride = (uint32_t)(((unsigned long long)N * N) >> 2);
-  const uint32_t wkey = (uint32_t)((((unsigned long long)b * H) * N * (unsigned long long)N) >> 2) + 4u * (uint32_t)tk + (uint32_t)g4;
+  const uint32_t wkey = (uint32_t)(((unsigned long long)b * N * (unsigned long long)N) >> 2) + 4u * (uint32_t)tk + (uint32_t)g4;
   const uint32_t wq = (uint32_t)(N >> 2);
   const int hh = g4 & 1, a2 = g4 >> 1;
   const int nchunks = (ntiles + CK - 1) / CK;
