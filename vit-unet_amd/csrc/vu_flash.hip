@@ -1729,7 +1729,7 @@ template <int DH, int WPB, int CK>
 __global__ __launch_bounds__(WPB * 64, 2) void flash2_bwd_dqx_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, const bf16_t* __restrict__ dO,
     const float* __restrict__ lse2, const float* __restrict__ pkv, const float* __restrict__ stats, bf16_t* __restrict__ dq,
-    float* __restrict__ delta, float* __restrict__ partials, int B, int N, float c, float scale, vu_rng rng_in) {
+    float* __restrict__ delta, float* __restrict__ partials, int B, int N, float c, float scale, vu_rng rng_in, int want_dc) {
   constexpr int H = 8, FB = DH / 8, NT = H * H + H, IMP = 16;
   typedef FC<H, DH> C;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1806,9 +1806,12 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_bwd_dqx_kernel(
             const f32x4 dp = bwd2_dp(E[half][r], ops.back);
             f32x4 ph;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              ph[j] = T[half][r][j];                 // (already the kept probabilities: bwd2_chain<KEPT_ONLY>)
-              tc[j] += E[half][r][j];
+            for (int j = 0; j < 4; ++j) ph[j] = T[half][r][j];                 // (already the kept probabilities: bwd2_chain<KEPT_ONLY>)
+            // sum of e_g = the gradient of the mix bias: identically zero under batch statistics (BatchNorm removes any
+            // constant shift of its input), so the training sweep skips it; with running statistics (eval) it is real
+            if (want_dc) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) tc[j] += E[half][r][j];
             }
             // sum over positions of e_g P^_h as X^T X (see flash2_bwd_delta_kernel): e as a bf16 hi + lo pair in two rounds
             const s16x4 ehi = pack4s(E[half][r]);
@@ -2202,7 +2205,7 @@ int launch_backward_v2(const vu_flash_args& a, hipStream_t st) {
   const bf16_t *q = (const bf16_t*)a.q, *k = (const bf16_t*)a.k, *v = (const bf16_t*)a.v, *dO = (const bf16_t*)a.dO;
   if (fused) {
     hipLaunchKernelGGL(k2x, dim3(nblk), dim3(WPB * 64), lds2x, st, q, k, v, dO, a.lse2, a.pk, a.stats, (bf16_t*)a.dq, a.delta, a.partials, a.B,
-                       a.N, c, a.scale, a.rng);
+                       a.N, c, a.scale, a.rng, a.training ? 0 : 1);
     if (vu_prof_on()) vu_prof_note("flash2_bwd_dqx_kernel", 6.0 * E * DH + 8.0 * E * H, 7.0 * act);
     VU_TRY(vu_check_launch("flash2_bwd_dqx"));
   } else {
