@@ -684,7 +684,8 @@ __device__ __forceinline__ void stage_own_rows(bf16_t* dst, const bf16_t* __rest
 }
 
 // logits -> sign-tagged probabilities, in place
-template <int H>
+// ZERO: dropped entries become 0 instead of -p, for sweeps that only need the kept probabilities P~ (no packed ReLU after)
+template <int H, bool ZERO = false>
 __device__ __forceinline__ void tag_probs(f32x4 (&S)[H], const float (&lse)[H], float c, const vu_rng& rng, uint32_t wt, uint32_t hstride) {
   const uint32_t base = keep4(rng, wt).w, base_sh = base >> 12;
 #pragma unroll
@@ -695,7 +696,7 @@ __device__ __forceinline__ void tag_probs(f32x4 (&S)[H], const float (&lse)[H], 
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float p = fexp2(fmaf(S[h][r], c, -lse[h]));
-      S[h][r] = kept(kp, r) ? p : -p;
+      S[h][r] = kept(kp, r) ? p : (ZERO ? 0.f : -p);
     }
   }
 }
@@ -1413,11 +1414,9 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_apply_kernel(
       for (int kc = 0; kc < nt; ++kc) {
         f32x4 S[H];
         tile_logits<H, DH>(S, Kc, kc, qf, l15, g4);
-        tag_probs<H>(S, lse, c, rng, wlane + 4u * (uint32_t)(ch * CK + kc), hstride);
+        tag_probs<H, true>(S, lse, c, rng, wlane + 4u * (uint32_t)(ch * CK + kc), hstride);      // P~ (dropped = 0)
         bf16x8 pk[4];
         pack_heads(S, pk);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) pk[r] = relu_packed(pk[r]);
         f32x4 A[2][4];
         mix_ml(A, op, pk, cin);                       // A^ in ML
         const int tb = src.base(kc);
@@ -1469,13 +1468,14 @@ template <int H, int DH, bool STREAM_A, bool KEPT_ONLY = false>
 __device__ __forceinline__ void bwd2_chain(f32x4 (&S)[H], const bf16_t* Dc, int kc, const bf16_t* dst, const float (&lse)[H], float c,
                                            const vu_rng& rng, uint32_t wt, uint32_t hstride, const Bwd2Ops& o, f32x4 (&T)[2][4],
                                            f32x4 (&E)[2][4], int l15, int g4) {
-  tag_probs<H>(S, lse, c, rng, wt, hstride);
+  tag_probs<H, KEPT_ONLY>(S, lse, c, rng, wt, hstride);
   bf16x8 pk[4];
   pack_heads(S, pk);
-  if constexpr (!KEPT_ONLY) convert_ml(T, o.id, pk, false);      // tag in ML (exact: already bf16)
+  convert_ml(T, o.id, pk, false);                        // tags (or, KEPT_ONLY, P~) in ML: exact, already bf16
+  if constexpr (!KEPT_ONLY) {
 #pragma unroll
-  for (int r = 0; r < 4; ++r) pk[r] = relu_packed(pk[r]);
-  if constexpr (KEPT_ONLY) convert_ml(T, o.id, pk, false);
+    for (int r = 0; r < 4; ++r) pk[r] = relu_packed(pk[r]);
+  }
   mix_ml(E, o.xk2, pk, o.cin);                           // -m1 - m2 x^
   LDS_FENCE();
   f32x4 Dh[H];
@@ -1984,11 +1984,9 @@ __global__ __launch_bounds__(WPB * 64, DV ? 3 : 2) void flash2_bwd_dkv_kernel(
         tile_prod<H, DH, false>(S, Qc, qc, nullptr, Ks, nullptr, l15, g4);
         const uint32_t wt = wkey + (uint32_t)((ch * CK + qc) * 16 + l15) * wq;
         if constexpr (DV) {
-          tag_probs<H>(S, lse, c, rng, wt, hstride);
+          tag_probs<H, true>(S, lse, c, rng, wt, hstride);       // P~ (dropped = 0)
           bf16x8 pk[4];
           pack_heads(S, pk);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) pk[r] = relu_packed(pk[r]);
           mix_ml(T, fw, pk, fcin);                     // A^ (ML)
         } else {
           f32x4 E[2][4];
