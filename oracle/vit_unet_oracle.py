@@ -182,7 +182,7 @@ def quad_threshold(p: float) -> int:
     return max(1, (int(p * 65536.0 + 0.5) + 128) >> 8)
 
 
-_QUAD_HEAD_MUL = (0x9E3779, 0xB5297B, 0x68E31D, 0x7FEB35, 0xC2B2AE, 0x85EBCA, 0x27D4EB, 0x165667)
+_QUAD_HEAD_MUL = (0x1E3779, 0x35297B, 0x68E31D, 0x7FEB35, 0x42B2AF, 0x65EBCB, 0x27D4EB, 0x165667)      # odd, below 2^23 (one v_mad_u32_u24 each)
 
 
 def _quad_head(base: np.ndarray, h: int) -> np.ndarray:

@@ -213,7 +213,8 @@ __device__ __forceinline__ uint32_t vu_quad_word(uint32_t x, uint32_t k0, uint32
 // Measured on 2 M words (oracle, test_quad_mask_statistics): keep rate 0.8007 - 0.8010 per head (target 0.8008), largest
 // correlation between two heads' masks 8e-4, between byte lanes of different heads 2e-3.
 __device__ __forceinline__ uint32_t vu_quad_head(uint32_t base, uint32_t base_sh, int h) {
-  constexpr uint32_t C[8] = {0x9E3779u, 0xB5297Bu, 0x68E31Du, 0x7FEB35u, 0xC2B2AEu, 0x85EBCAu, 0x27D4EBu, 0x165667u};
+  // (odd, below 2^23: with bit 23 set hipcc emits the quarter-rate v_mad_u64_u32 instead of v_mad_u32_u24)
+  constexpr uint32_t C[8] = {0x1E3779u, 0x35297Bu, 0x68E31Du, 0x7FEB35u, 0x42B2AFu, 0x65EBCBu, 0x27D4EBu, 0x165667u};
   const uint32_t y = __umul24(base, C[h & 7]) + base_sh;
   return y ^ (y >> 16);
 }
