@@ -126,6 +126,20 @@ def test_gemm_forms(dt, M, N, K):
     assert serr(out.view(M, N), ref + base.double()) < ft * (4 if dt == torch.bfloat16 else 40)
 
 
+@pytest.mark.parametrize("M,N,K", [(48, 16, 3137), (200, 72, 1500), (192, 192, 4100), (64, 768, 2049), (3072, 128, 1100)])
+def test_gemm_tall_skinny_weight_gradient_form(M, N, K):
+    """C (fp32) += A^T B over a long K with a small output: csrc/vu_tsgemm.hip (ragged K slices, partial tiles, column sums
+    are covered by the model tests; here the stand-alone entry, which has no slab and adds with atomics)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(K, M, generator=g).to(torch.bfloat16)
+    b = torch.randn(K, N, generator=g).to(torch.bfloat16)
+    base = torch.randn(M, N, generator=g)
+    out = dev(base.clone())
+    _gemm(torch.bfloat16, dev(a), dev(b), M, N, K, 1, M, N, 1, c_float=1, accumulate=1, out=out)
+    ref = a.double().t() @ b.double() + base.double()
+    assert serr(out.view(M, N), ref) < 2e-3
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_gemm_batched_heads(dt):
     """the per-head attention products: q k^T and A v on column slices of (B,N,D)."""
