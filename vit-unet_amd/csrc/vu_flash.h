@@ -25,8 +25,9 @@ struct vu_flash_args {
 // attention-map dropout of this form: 8 bits per element, drop probability round(256 p) / 256 (vu_flash.hip, "quad" scheme)
 vu_rng vu_flash_quad_rng(vu_rng r);
 bool vu_flash_ok(int dtype, int B, int N, int D, int H);
-// the recompute form only pays when its grid (B x ceil(N/64) work groups of 4 waves) gives every CU more than one group;
-// below that the materialising kernels (which parallelise over heads too) are faster (measured, Base: B=16 -5 %, B=32 +3.5 %)
+// the recompute form only pays when its grid (B x ceil(N/64) work groups of 4 waves) puts a work group on most CUs; below that
+// the materialising kernels (which parallelise over heads too) are faster.  Measured on Base (N = 784: 13 groups per sample)
+// after the round-2 ISA pass: 8 images -9 %, 16 +3 %, 24 +6 %, 32 +4 %, 64 +12 %; Large at 16: +3 %  ->  threshold 192 groups
 bool vu_flash_pays(int B, int N);
 size_t vu_flash_partials_floats(int B, int N, int H);
 int vu_k_flash_forward(const vu_flash_args& a, hipStream_t st);

@@ -2254,7 +2254,7 @@ int launch_backward_v2(const vu_flash_args& a, hipStream_t st) {
     return VU_EUNSUPPORTED;                                                            \
   } while (0)
 
-bool vu_flash_pays(int B, int N) { return (long long)B * ((N / 16 + 3) / 4) >= 320; }
+bool vu_flash_pays(int B, int N) { return (long long)B * ((N / 16 + 3) / 4) >= 192; }
 
 bool vu_flash_ok(int dtype, int B, int N, int D, int H) {
   if (dtype != 1 || H <= 0 || D % H != 0) return false;

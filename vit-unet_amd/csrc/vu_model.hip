@@ -152,7 +152,7 @@ struct AttnScratch { void *dO, *dq, *dk, *dv, *dA; float* partials; int nblocks;
 
 struct AttnDims { int dtype, B, N, D, H, C, s, ld; int centered = 0; int flash = 0; };
 // non-materialising form (vu_flash.hip): the maps are recomputed from q, k (and v, dO) in every pass
-// flash: 0 = never, 1 = wherever the shape is covered, 2 = covered AND the launch fills the chip (vu_flash_pays)
+// flash: 0 = never, 1 = wherever the shape is covered, 2 = covered AND the launch fills enough of the chip (vu_flash_pays)
 inline bool flash_on(const AttnDims& d) {
   return d.flash && vu_flash_ok(d.dtype, d.B, d.N, d.D, d.H) && (d.flash == 1 || vu_flash_pays(d.B, d.N));
 }
