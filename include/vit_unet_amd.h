@@ -9,7 +9,11 @@
  * Conventions
  *  - plain pointers and sizes only; every pointer is DEVICE memory unless stated otherwise;
  *  - all work is enqueued on the caller's `stream` (a hipStream_t passed as void*); no hidden
- *    synchronisation, no allocation, no global mutable state (thread-local last-error text only);
+ *    synchronisation, no allocation; state between calls: the thread-local last-error text, the
+ *    opt-in launch profiler below (process-global, one instrumented stream at a time), and two
+ *    opt-in experiment switches that keep per-thread streams / events (VU_FLASH_FORK=1,
+ *    VU_SIDE_LANE=1: off by default).  Environment switches (VU_ATTN_FLASH, VU_TSGEMM, ...) are
+ *    A/B measurement aids read at call time;
  *  - return 0 (VU_OK) on success, negative VU_E* otherwise; vu_last_error() gives the text;
  *  - `dtype` selects the STORAGE type of activations / GEMM weights: 0 = fp32, 1 = bf16.
  *    Arithmetic is always fp32 (fp32 MFMA accumulators).  Parameters that are not GEMM operands
@@ -216,7 +220,8 @@ int vu_seg_prepare(const int16_t* image, const uint8_t* mask, float* x, float* y
                    size_t scratch_bytes, const double* inv_affine, int B, int Hs, int Ws, int oh,
                    int ow, float lo, float hi, float ls, void* stream);
 
-/* In-process launch profiler (bench.py's roofline leg): after vu_prof_enable(stream) an event is
+/* In-process launch profiler (bench.py's roofline leg): PROCESS-GLOBAL state, meant for one
+ * instrumented stream at a time.  After vu_prof_enable(stream) an event is
  * recorded behind every launch; vu_prof_report() stops, waits, and returns a JSON object
  * {"<kernel tag>": {"count","ms","flops","bytes"}} with ALGORITHMIC flops / bytes per tag. */
 int vu_prof_enable(void* stream);
