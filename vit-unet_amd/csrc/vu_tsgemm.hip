@@ -288,6 +288,12 @@ int vu_tsgemm_try(const vu_gemm_args& g, hipStream_t st) {
 #define VU_TS(CM, CN, TMv, TNv, WMv, WNv, PDv) \
   if (cm == CM && cn == CN) { int rc = launch_ts<TMv, TNv, WMv, WNv, PDv>(g, st); return rc ? rc : 1; }
   //    tile       per-wave tiles  waves   ring
+  // 192 x 192: two column halves per K slice (192 x 96 tiles): one CU sustains only ~20 GB/s of loads + slab stores, so the
+  // product wants every CU streaming, even at 1.5x the operand traffic (A is read by both halves)
+  {
+    static const bool halves_off = [] { const char* e = getenv("VU_TSGEMM_HALVES"); return e && e[0] == '0'; }();    // A/B switch
+    if (cm == 192 && cn == 192 && tiles == 1 && !halves_off) { int rc = launch_ts<3, 3, 4, 2, 4>(g, st); return rc ? rc : 1; }
+  }
   VU_TS(192, 192, 3, 6, 4, 2, 4)                                   // (16 waves of 3 x 3 tiles spill at their 128-register cap)
   VU_TS(192, 128, 3, 4, 4, 2, 4) VU_TS(128, 192, 4, 3, 2, 4, 4)
   VU_TS(192, 64, 3, 2, 4, 2, 4)  VU_TS(64, 192, 2, 3, 2, 4, 4)
