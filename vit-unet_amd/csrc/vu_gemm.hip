@@ -61,8 +61,15 @@ static int launch_tiles(const vu_gemm_args& g, hipStream_t st) {
   // projections at 16 images per GPU: 168 tiles): quarter tiles
   // put 4x the blocks on the chip (measured 77 -> see tools/gemm_bench.py); split-K is not available for bf16 outputs
   static const int quarter_below = getenv("VU_GEMM_QUARTER_BELOW") ? atoi(getenv("VU_GEMM_QUARTER_BELOW")) : 200;   // measurement switch (64 -> 200: +3 % on the 16-image-per-GPU steps of Base / Large, whose 3072-wide linears have 168 tiles)
-  if (sizeof(TC) == 2 && g.K >= 1024 && (long long)vu_cdiv(g.M, 128) * vu_cdiv(g.N, 128) * g.Z1 * g.Z2 < quarter_below)
+  if (sizeof(TC) == 2 && g.K >= 1024 && (long long)vu_cdiv(g.M, 128) * vu_cdiv(g.N, 128) * g.Z1 * g.Z2 < quarter_below) {
+    // still fewer 64 x 64 tiles than half the CUs (the 3072 -> 128 layers of level 0: 98): one CU sustains ~20 GB/s of
+    // loads, so halve the tile again
+    if constexpr (sizeof(T) == 2) {
+      static const bool eighth_off = [] { const char* e = getenv("VU_GEMM_EIGHTH"); return e && e[0] == '0'; }();     // A/B switch
+      if (!eighth_off && (long long)vu_cdiv(g.M, 64) * vu_cdiv(g.N, 64) * g.Z1 * g.Z2 < 128) return launch_bk<T, TC, TA, TB, 32, 64, 64, 4>(g, st);
+    }
     return launch_one<T, TC, TA, TB, 64, 64>(g, st);
+  }
   return launch_one<T, TC, TA, TB, 128, 128>(g, st);
 }
 
