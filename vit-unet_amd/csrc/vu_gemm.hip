@@ -56,7 +56,7 @@ static int launch_tiles(const vu_gemm_args& g, hipStream_t st) {
   if (force == 12864) return launch_one<T, TC, TA, TB, 128, 64>(g, st);
   if (g.N <= 32) return launch_one<T, TC, TA, TB, 128, 32>(g, st);
   if (g.M <= 64) return launch_one<T, TC, TA, TB, 64, 64>(g, st);
-  if (g.N <= 64) return launch_one<T, TC, TA, TB, 128, 64>(g, st);
+  if (g.N <= 64) return launch_one<T, TC, TA, TB, 128, 64>(g, st);     // (smaller row tiles for the 98-tile 768 -> 64 layers measured no gain)
   // fewer big tiles than CUs and a long K (the 3072 -> 128 feed-forward layers of level 0: 25 tiles of 128x128; the 3072 x 3072
   // projections at 16 images per GPU: 168 tiles): quarter tiles
   // put 4x the blocks on the chip (measured 77 -> see tools/gemm_bench.py); split-K is not available for bf16 outputs

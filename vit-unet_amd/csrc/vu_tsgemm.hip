@@ -230,7 +230,10 @@ int launch_ts(const vu_gemm_args& g, hipStream_t st) {
   // partial tiles cost a plain write and a read (bounded by half the operand bytes and by the slab); without one they are
   // float atomics on a small, contended output (measured 0.3 TB/s): no more of those than a third of the operand bytes
   int want = (256 + mt * nt - 1) / (mt * nt);
-  const int by_out = (int)(in_bytes / ((use_slab ? 2.0 : 3.0) * out_bytes));
+  int by_out = (int)(in_bytes / ((use_slab ? 2.0 : 3.0) * out_bytes));
+  // (few workgroups even so - the 3072 x 128 outputs of level 0: 16 tiles x 6 slices - : let the slab traffic reach the
+  // operand bytes; one CU sustains ~20 GB/s, the stream wants every CU)
+  if (use_slab && (long long)by_out * mt * nt < 160) by_out = (int)(in_bytes / out_bytes);
   if (want > by_out) want = by_out;
   const int by_rows = g.K / 256;
   if (want > by_rows) want = by_rows;
