@@ -469,7 +469,7 @@ void carve_model(const Plan& pl, int B, char* base, ModelWS& w) {
   w.asc.partials = w.partials;
   w.lnp = bp.takef((size_t)B * vu_ln_nchunks(P) * 3);
   w.lnp2 = bp.takef((size_t)B * vu_ln_nbchunks(P) * 2);
-  w.wgs_bytes = dt == 1 ? (size_t)24 << 20 : 0;
+  w.wgs_bytes = dt == 1 ? (size_t)40 << 20 : 0;      // (16 K slices of a 768 x 768 output)
   w.wgs = w.wgs_bytes ? bp.take(w.wgs_bytes) : nullptr;
   w.bytes = vu_align_up(bp.off, 256);
 }
