@@ -55,7 +55,14 @@ static int launch_tiles(const vu_gemm_args& g, hipStream_t st) {
   static const int force = getenv("VU_GEMM_TILE") ? atoi(getenv("VU_GEMM_TILE")) : 0;     // measurement switch
   if (force == 12864) return launch_one<T, TC, TA, TB, 128, 64>(g, st);
   if (g.N <= 32) return launch_one<T, TC, TA, TB, 128, 32>(g, st);
-  if (g.M <= 64) return launch_one<T, TC, TA, TB, 64, 64>(g, st);
+  if (g.M <= 64) {
+    // (the swapped 768 -> 64 layers: 1 x 196 tiles of 64 x 64 over K = 768: halve the row tile so that every CU streams)
+    if constexpr (sizeof(T) == 2 && sizeof(TC) == 2) {
+      static const bool half_off = [] { const char* e = getenv("VU_GEMM_HALFROW"); return e && e[0] == '0'; }();     // A/B switch
+      if (!half_off && g.M > 32 && g.K >= 512 && (long long)vu_cdiv(g.N, 64) * g.Z1 * g.Z2 < 256) return launch_bk<T, TC, TA, TB, 32, 64, 64, 4>(g, st);
+    }
+    return launch_one<T, TC, TA, TB, 64, 64>(g, st);
+  }
   if (g.N <= 64) return launch_one<T, TC, TA, TB, 128, 64>(g, st);     // (smaller row tiles for the 98-tile 768 -> 64 layers measured no gain)
   // fewer big tiles than CUs and a long K (the 3072 -> 128 feed-forward layers of level 0: 25 tiles of 128x128; the 3072 x 3072
   // projections at 16 images per GPU: 168 tiles): quarter tiles

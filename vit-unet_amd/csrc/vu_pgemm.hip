@@ -151,7 +151,8 @@ int launch_p(const vu_gemm_args& g, hipStream_t st) {
   static const int tm_env = getenv("VU_PGEMM_TM") ? atoi(getenv("VU_PGEMM_TM")) : 2;      // measurement switch (64-row slabs measured slower)
   const int TMr = tm_env == 1 ? 1 : 2;
   const int nslab = (g.M + 64 * TMr - 1) / (64 * TMr);
-  int grid = 256;                                               // one persistent workgroup per CU
+  constexpr size_t lds_ = (size_t)(TBF ? (32 * KT32) * (16 * NT16 + 16) : (16 * NT16) * (32 * KT32 + 8)) * 2 + (size_t)4 * 16 * (16 * NT16 + 4) * 4;
+  int grid = lds_ <= 80 * 1024 ? 512 : 256;                     // persistent workgroups: as many as fit the CUs' LDS (two per CU when the weight is small)
   if (grid > nslab) grid = nslab;
   constexpr int N = 16 * NT16, K = 32 * KT32;
   constexpr size_t lds = (size_t)(TBF ? K * (N + 16) : N * (K + 8)) * 2 + (size_t)4 * 16 * (N + 4) * 4;
