@@ -73,7 +73,12 @@ static int launch_tiles(const vu_gemm_args& g, hipStream_t st) {
     // loads, so halve the tile again
     if constexpr (sizeof(T) == 2) {
       static const bool eighth_off = [] { const char* e = getenv("VU_GEMM_EIGHTH"); return e && e[0] == '0'; }();     // A/B switch
-      if (!eighth_off && (long long)vu_cdiv(g.M, 64) * vu_cdiv(g.N, 64) * g.Z1 * g.Z2 < 128) return launch_bk<T, TC, TA, TB, 32, 64, 64, 4>(g, st);
+      if (!eighth_off && (long long)vu_cdiv(g.M, 64) * vu_cdiv(g.N, 64) * g.Z1 * g.Z2 < 128) {
+        static const bool t3232_off = [] { const char* e = getenv("VU_GEMM_3232"); return e && e[0] == '0'; }();      // A/B switch
+        // (98 tiles of 64 x 64: 32 x 32 tiles put 392 workgroups on the chip: 31 -> 26 (32 x 64) -> 23 us)
+        if (!t3232_off && (long long)vu_cdiv(g.M, 32) * vu_cdiv(g.N, 64) * g.Z1 * g.Z2 < 256) return launch_bk<T, TC, TA, TB, 32, 32, 64, 4>(g, st);
+        return launch_bk<T, TC, TA, TB, 32, 64, 64, 4>(g, st);
+      }
     }
     return launch_one<T, TC, TA, TB, 64, 64>(g, st);
   }
