@@ -1041,7 +1041,61 @@ __global__ __launch_bounds__(256) void bn_bwd_small_kernel(const T* __restrict__
   const int b = blockIdx.x, g = blockIdx.y, d = D / H;
   const long long base = (long long)b * N * D + g * d;
   float s1 = 0.f, r = 0.f;
-  if (d % 4 == 0) {
+  if (sizeof(T) == 2 && d % 8 == 0 && d <= 2048) {
+    // bf16, 16-byte loads: a thread owns 8 consecutive features of the rows i = rl, rl + RL, ... with 4 rows (12 loads,
+    // 192 bytes) in flight - the rate of this kernel is bytes in flight per CU over the memory latency
+    const int nv = d >> 3;
+    int TV = 256;                       // feature octets side by side (power of two >= min(nv, 256))
+    while (TV / 2 >= nv) TV /= 2;
+    const int RL = 256 / TV;
+    const int tc = threadIdx.x % TV, rl = threadIdx.x / TV;
+    for (int v0 = 0; v0 < nv; v0 += TV) {
+      const int vq = v0 + tc;
+      float cdo[8], cv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { cdo[e] = 0.f; cv[e] = 0.f; }
+      if (vq < nv) {
+        const long long cb = base + 8 * vq;
+        union U8 { uint4 u; bf16_t h[8]; };
+        for (int i0 = rl; i0 < N; i0 += 4 * RL) {
+          U8 a[4], vv[4], o[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int i = i0 + k * RL;
+            const long long off = cb + (long long)(i < N ? i : rl) * D;
+            a[k].u = *reinterpret_cast<const uint4*>((const bf16_t*)dO + off);
+            vv[k].u = *reinterpret_cast<const uint4*>((const bf16_t*)v + off);
+            o[k].u = *reinterpret_cast<const uint4*>((const bf16_t*)O + off);
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            if (i0 + k * RL < N) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const float av = (float)a[k].h[e];
+                cdo[e] += av; cv[e] += (float)vv[k].h[e]; r = fmaf(av, (float)o[k].h[e], r);
+              }
+            }
+          }
+        }
+      }
+      // column sums over the row lanes, then sum_t cdo[t] * cv[t]
+      for (int e0 = 0; e0 < 8; e0 += 4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { sdo[e * 256 + threadIdx.x] = cdo[e0 + e]; sv[e * 256 + threadIdx.x] = cv[e0 + e]; }
+        __syncthreads();
+        if (rl == 0 && vq < nv) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float a2 = 0.f, c2 = 0.f;
+            for (int q = 0; q < RL; ++q) { a2 += sdo[e * 256 + q * TV + tc]; c2 += sv[e * 256 + q * TV + tc]; }
+            s1 = fmaf(a2, c2, s1);
+          }
+        }
+        __syncthreads();
+      }
+    }
+  } else if (d % 4 == 0) {
     // a thread owns 4 consecutive features (one vector load per tensor and row) of the rows i = rl, rl + RL, ...
     const int nq = d >> 2;
     int TQ = 256;                       // feature quads handled side by side (power of two >= min(nq, 256))
