@@ -56,6 +56,79 @@ __device__ __forceinline__ void stage_slice_T(bf16_t* Xt, const bf16_t* __restri
   }
 }
 
+// Wide head slices (TT > 2) are staged as they lie in memory, Xn[n][mp_pitch] (16-byte LDS stores, no scatter: the
+// transposed image above costs 8 two-byte LDS stores per 16 bytes loaded and was half of the kernel at N = 196,
+// d = 96); the MFMA fragments then come out of transposing LDS reads (ds_read_b64_tr_b16), two per 16x16x32 operand.
+// Pitch 16 TT + 8 elements: the 4 rows x 4 chunks a 16-lane group touches fall in distinct banks.
+constexpr int mp_pitch(int tt) { return 16 * tt + 8; }
+constexpr bool mp_natural(int tt) { return tt > 2; }
+template <int TT>
+__device__ __forceinline__ void stage_slice_N(bf16_t* Xn, const bf16_t* __restrict__ Xg, int N, int D, int d, int ldk, int tid, int nthr) {
+  constexpr int P = mp_pitch(TT);
+  const bool vec = (d % 8 == 0) && (D % 8 == 0);
+  constexpr int CPT = 2 * TT;          // 8-element chunks per token
+  const int cells = ldk * CPT;
+  for (int c0 = tid; c0 < cells; c0 += 4 * nthr) {      // 4 independent 16-byte loads in flight per thread
+    uint4 x[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = c0 + k * nthr;
+      const int n = c / CPT, t0 = (c % CPT) * 8;
+      x[k] = make_uint4(0, 0, 0, 0);
+      if (c < cells && n < N && t0 < d) {
+        if (vec) x[k] = *reinterpret_cast<const uint4*>(Xg + (long long)n * D + t0);
+        else {
+          unsigned w[4] = {0, 0, 0, 0};
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (t0 + e < d) w[e >> 1] |= (unsigned)__builtin_bit_cast(unsigned short, Xg[(long long)n * D + t0 + e]) << (16 * (e & 1));
+          x[k] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = c0 + k * nthr;
+      if (c < cells) *reinterpret_cast<uint4*>(Xn + (c / CPT) * P + (c % CPT) * 8) = x[k];
+    }
+  }
+}
+// column sums of a natural image over its ldk tokens, added to colsum_s[16 TT]; `scratch` holds nparts x 16 TT floats.
+// Fixed summation order (partials per token residue, then residue by residue): the same bits every run.
+template <int TT>
+__device__ __forceinline__ void colsum_N(const bf16_t* Xn, float* scratch, float* colsum_s, int ldk, int nparts, int tid) {
+  constexpr int P = mp_pitch(TT), CPT = 2 * TT;
+  const int chunk = tid % CPT, part = tid / CPT;
+  if (part < nparts) {
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int n = part; n < ldk; n += nparts) {
+      const bf16x8 v8 = *reinterpret_cast<const bf16x8*>(Xn + n * P + 8 * chunk);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] += (float)v8[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) scratch[part * 16 * TT + 8 * chunk + e] = a[e];
+  }
+  __syncthreads();
+  if (tid < 16 * TT) {
+    float s = 0.f;
+    for (int p = 0; p < nparts; ++p) s += scratch[p * 16 * TT + tid];
+    colsum_s[tid] += s;
+  }
+  __syncthreads();
+}
+typedef __attribute__((address_space(3))) s16x4* mp_lds_s16x4_ptr;
+typedef __attribute__((ext_vector_type(8))) short mp_s16x8;
+// 16x16x32 operand (rows = 16 features from f0 [the lane's 4 pp already in p], k-slots = 8 consecutive tokens of the
+// lane group) out of a row-major image: p points at (first token of the group + qq, f0 + 4 pp)
+template <int PITCH>
+__device__ __forceinline__ bf16x8 tr_pair(const bf16_t* p) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((mp_lds_s16x4_ptr)p);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((mp_lds_s16x4_ptr)(p + 4 * PITCH));
+  const mp_s16x8 t8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, t8);
+}
+
 // 4 consecutive t (t0..t0+3) of token row `orow` (points at the head slice): vector store when whole
 __device__ __forceinline__ void store_t4(bf16_t* orow, int t0, int d, bool vec, const f32x4& a) {
   if (t0 >= d) return;
@@ -85,10 +158,13 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4, 8
                                                                  bf16_t* __restrict__ out, const float* __restrict__ sc, const float* __restrict__ kappa,
                                                                  int N, int D, int H, int d, int ld) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr bool NAT = mp_natural(TT);
+  constexpr int P = mp_pitch(TT);
   const int ldk = CHUNKED ? mp_ch(TT) : ((N + 63) & ~63), LDV = ldk + 8;     // tokens per staged image
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
-  bf16_t* Xt = reinterpret_cast<bf16_t*>(smem_raw);                       // [16 TT][LDV] (rows >= d stay zero)
-  bf16_t* T = Xt + 16 * TT * LDV + wave * (16 * MP_LDT);                  // this wave's [16][MP_LDT] tile
+  bf16_t* Xt = reinterpret_cast<bf16_t*>(smem_raw);                       // [16 TT][LDV] (rows >= d stay zero), or [ldk][P]
+  bf16_t* T0 = Xt + (NAT ? ldk * P : 16 * TT * LDV);
+  bf16_t* T = T0 + wave * (16 * MP_LDT);                                  // this wave's [16][MP_LDT] tile
   const int bz = blockIdx.y, b = bz / H, g = bz % H;
   const bf16_t* Xg = X + (long long)b * N * D + g * d;
   // affine form (M is the centred mixed map Ac, the product wanted is with Ahat = sc_g Ac + kappa_g):
@@ -98,6 +174,13 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4, 8
   if (sc) { a_sc = sc[g]; a_kp = kappa[g]; }
   if (tid < 16 * TT) colsum_s[tid] = 0.f;
   auto stage = [&](int n0) {       // tokens [n0, n0 + ldk) of the slice -> Xt, column sums accumulated (affine form)
+    if constexpr (NAT) {
+      stage_slice_N<TT>(Xt, Xg + (long long)n0 * D, min(N - n0, ldk), D, d, ldk, tid, WAVES * 64);
+      __syncthreads();
+      // the wave tiles are idle while the slice is staged: scratch of the column sums
+      if (sc) colsum_N<TT>(Xt, reinterpret_cast<float*>(T0), colsum_s, ldk, min(WAVES * 64 / (2 * TT), WAVES * 16 * MP_LDT / (32 * TT)), tid);
+      return;
+    }
     stage_slice_T<TT>(Xt, Xg + (long long)n0 * D, min(N - n0, ldk), D, d, ldk, LDV, tid, WAVES * 64);
     __syncthreads();
     if (sc) {
@@ -120,7 +203,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4, 8
   const int nrt = (N + 15) >> 4;
   const bool vec = (d % 4 == 0) && (D % 4 == 0);
   const int lrow = lane >> 3, lch = (lane & 7) * 8;                        // load shape: 8 rows x 8 chunks of 16 B
-  const bf16_t* x0 = Xt + l15 * LDV + 16 * lg;
+  const bf16_t* x0 = NAT ? Xt + (16 * lg + (l15 >> 2)) * P + 4 * (l15 & 3) : Xt + l15 * LDV + 16 * lg;
   // one row tile against the staged tokens: map columns cbase + [0, 64 nsteps)
   auto run = [&](int rt, int cbase, int nsteps, f32x4 (&acc)[TT]) {
     // unconditional loads at clamped addresses (rows >= N re-read row N-1, columns >= ld the row's last chunk):
@@ -143,11 +226,20 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4, 8
       // B operand: lane (l15 = map row, lg): columns 16 lg + [0,8) and + [8,16) of the step: k-slots of two MFMAs
       const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(T + l15 * MP_LDT + 16 * lg);
       const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(T + l15 * MP_LDT + 16 * lg + 8);
-      const bf16_t* xa = x0 + sidx * 64;
+      if constexpr (NAT) {
+        const bf16_t* xa = x0 + sidx * 64 * P;
 #pragma unroll
-      for (int tt = 0; tt < TT; ++tt) {
-        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(xa + 16 * tt * LDV), b0, acc[tt], 0, 0, 0);
-        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(xa + 16 * tt * LDV + 8), b1, acc[tt], 0, 0, 0);
+        for (int tt = 0; tt < TT; ++tt) {
+          acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_pair<P>(xa + 16 * tt), b0, acc[tt], 0, 0, 0);
+          acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_pair<P>(xa + 16 * tt + 8 * P), b1, acc[tt], 0, 0, 0);
+        }
+      } else {
+        const bf16_t* xa = x0 + sidx * 64;
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) {
+          acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(xa + 16 * tt * LDV), b0, acc[tt], 0, 0, 0);
+          acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(xa + 16 * tt * LDV + 8), b1, acc[tt], 0, 0, 0);
+        }
       }
     };
     auto step = [&](int sidx, uint4& ma, uint4& mb) {
@@ -215,16 +307,19 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4, 8
 // over map rows, so the B operand (k = row, n = column) comes out of the row-major tile through the
 // transposing LDS read (ds_read_b64_tr_b16).
 template <int WAVES, int TT, bool CHUNKED>
-__global__ __launch_bounds__(WAVES * 64) void attn_map_cols_kernel(const bf16_t* __restrict__ M, const bf16_t* __restrict__ X,
+__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 8))) void attn_map_cols_kernel(const bf16_t* __restrict__ M, const bf16_t* __restrict__ X,
                                                                  bf16_t* __restrict__ out, const float* __restrict__ sc, const float* __restrict__ kappa,
                                                                  int N, int D, int H, int d, int ld) {
   typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
   typedef __attribute__((ext_vector_type(8))) short s16x8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr bool NAT = mp_natural(TT);
+  constexpr int P = mp_pitch(TT);
   const int ldk = CHUNKED ? mp_ch(TT) : ((N + 63) & ~63), LDV = ldk + 8;     // tokens (= map rows here) per staged image
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
-  bf16_t* Xt = reinterpret_cast<bf16_t*>(smem_raw);                       // [16 TT][LDV]
-  bf16_t* T = Xt + 16 * TT * LDV + wave * (32 * MP_LDT);                  // this wave's [32][MP_LDT] tile
+  bf16_t* Xt = reinterpret_cast<bf16_t*>(smem_raw);                       // [16 TT][LDV], or [ldk][P]
+  bf16_t* T0 = Xt + (NAT ? ldk * P : 16 * TT * LDV);
+  bf16_t* T = T0 + wave * (32 * MP_LDT);                                  // this wave's [32][MP_LDT] tile
   const int bz = blockIdx.y, b = bz / H, g = bz % H;
   const bf16_t* Xg = X + (long long)b * N * D + g * d;
   // affine form: see the rows kernel
@@ -233,6 +328,12 @@ __global__ __launch_bounds__(WAVES * 64) void attn_map_cols_kernel(const bf16_t*
   if (sc) { a_sc = sc[g]; a_kp = kappa[g]; }
   if (tid < 16 * TT) colsum_s[tid] = 0.f;
   auto stage = [&](int n0) {
+    if constexpr (NAT) {
+      stage_slice_N<TT>(Xt, Xg + (long long)n0 * D, min(N - n0, ldk), D, d, ldk, tid, WAVES * 64);
+      __syncthreads();
+      if (sc) colsum_N<TT>(Xt, reinterpret_cast<float*>(T0), colsum_s, ldk, min(WAVES * 64 / (2 * TT), WAVES * 32 * MP_LDT / (32 * TT)), tid);
+      return;
+    }
     stage_slice_T<TT>(Xt, Xg + (long long)n0 * D, min(N - n0, ldk), D, d, ldk, LDV, tid, WAVES * 64);
     __syncthreads();
     if (sc) {
@@ -278,7 +379,10 @@ __global__ __launch_bounds__(WAVES * 64) void attn_map_cols_kernel(const bf16_t*
       // A operand: Xt rows t, k-slots = staged rows i0 + 8 lg + e
       bf16x8 xa[TT];
 #pragma unroll
-      for (int tt = 0; tt < TT; ++tt) xa[tt] = *reinterpret_cast<const bf16x8*>(Xt + (16 * tt + l15) * LDV + i0 + 8 * lg);
+      for (int tt = 0; tt < TT; ++tt) {
+        if constexpr (NAT) xa[tt] = tr_pair<P>(Xt + (i0 + 8 * lg + q) * P + 16 * tt + 4 * pq);
+        else xa[tt] = *reinterpret_cast<const bf16x8*>(Xt + (16 * tt + l15) * LDV + i0 + 8 * lg);
+      }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const bf16_t* tb = T + (8 * lg + q) * MP_LDT + 16 * u + 4 * pq;
@@ -354,12 +458,15 @@ __global__ __launch_bounds__(WAVES * 64) void attn_map_cols_kernel(const bf16_t*
   }
 }
 
+constexpr size_t mp_image_bytes(int tt, int ldk) {
+  return mp_natural(tt) ? (size_t)ldk * mp_pitch(tt) * 2 : (size_t)16 * tt * (ldk + 8) * 2;
+}
 template <bool COLS, int WAVES, int TT, bool CHUNKED>
 int launch_map_prod_w(const void* M, const void* X, void* out, const float* sc, const float* kappa, int B, int N, int D, int H, int ld,
                       int nsplit, hipStream_t st) {
   const int d = D / H;
   const int ldk = CHUNKED ? mp_ch(TT) : ((N + 63) & ~63);
-  const size_t lds = (size_t)16 * TT * (ldk + 8) * 2 + (size_t)WAVES * (COLS ? 32 : 16) * MP_LDT * 2;
+  const size_t lds = mp_image_bytes(TT, ldk) + (size_t)WAVES * (COLS ? 32 : 16) * MP_LDT * 2;
   auto kern = COLS ? attn_map_cols_kernel<WAVES, TT, CHUNKED> : attn_map_rows_kernel<WAVES, TT, CHUNKED>;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -376,7 +483,7 @@ template <bool COLS, int TT>
 int launch_map_prod(const void* M, const void* X, void* out, const float* sc, const float* kappa, int B, int N, int D, int H, int ld,
                     hipStream_t st) {
   const int units = COLS ? (N + 63) / 64 : (N + 15) / 16;       // strips / row tiles per (sample, head)
-  if ((size_t)16 * TT * (((N + 63) & ~63) + 8) * 2 + 8 * 32 * MP_LDT * 2 > 150 * 1024) {
+  if (mp_image_bytes(TT, (N + 63) & ~63) + 8 * 32 * MP_LDT * 2 > 150 * 1024) {
     // the head slice does not fit one LDS image: chunked form, one unit per wave, 7 waves per workgroup
     return launch_map_prod_w<COLS, 7, TT, true>(M, X, out, sc, kappa, B, N, D, H, ld, (units + 6) / 7, st);
   }
