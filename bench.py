@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--global-batch", type=int, default=0,
                     help="strong scaling: this many images per step over ALL GPUs (BASELINE config 3: 64 over 2 / 4 GPUs)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--attn-operands", default=None, choices=["storage", "e4m3"],
+                    help="what q, k, v are rounded to before the attention products; default: e4m3 for seg512 "
+                         "(BASELINE config 5: fp8 attention operands), the storage dtype otherwise")
     ap.add_argument("--no-graph", action="store_true", help="N=1: launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -123,13 +126,14 @@ def main():
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     torch.manual_seed(0)                                   # identical initial weights on every rank
     seg = a.model == "seg512"
+    operands = a.attn_operands or ("e4m3" if seg else "storage")
     if seg:
-        model = M.get_vit_unet("base", dtype=dt, im_size=512, num_channels=1).to(dev).train()
+        model = M.get_vit_unet("base", dtype=dt, im_size=512, num_channels=1, attn_operands=operands).to(dev).train()
         g = torch.Generator(device="cpu").manual_seed(4321 + rank)
         x = torch.rand(a.batch, 1, 512, 512, generator=g)
         y = (torch.rand(a.batch, 1, 512, 512, generator=g) < 0.1).float()
     else:
-        model = M.get_vit_unet(a.model, dtype=dt).to(dev).train()
+        model = M.get_vit_unet(a.model, dtype=dt, attn_operands=operands).to(dev).train()
         g = torch.Generator(device="cpu").manual_seed(1234 + rank)
         y = torch.rand(a.batch, 3, 224, 224, generator=g)
         x = (y + 0.1 * torch.randn(y.shape, generator=g)).clamp(0, 1)
@@ -280,7 +284,7 @@ def main():
                                       f"AdamW on synthetic " + ("CT-style 512x512x1 image/mask pairs" if seg else
                                                                 "SIDD-style 224x224x3 noisy/clean pairs") + ", random-init weights",
                           "per_gpu_batch": a.batch, "global_batch": a.batch * world, "parallelism": f"dp{world}", "rccl_path": dp,
-                          "hip_graph": use_graph, "final_loss": loss},
+                          "hip_graph": use_graph, "attn_operands": operands, "final_loss": loss},
                "roofline": roof, "cpu_baseline": cpu, "host_input": host_in}
         print(json.dumps(out), flush=True)
     if dp:

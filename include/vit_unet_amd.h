@@ -45,6 +45,8 @@ typedef struct vu_config {
   float attn_drop, proj_drop, linear_drop;
   int out_conv; /* preprocessing == 'conv' (model.py:369-370, 427-428) */
   int dtype;    /* 0 fp32, 1 bf16 */
+  int attn_operands; /* 0: q, k, v enter the attention products as stored; 1: rounded to OCP e4m3 first
+                      * (BASELINE config 5, "fp8 attention operands"; see vu_round_e4m3) */
 } vu_config;
 
 /* One parameter of the flat arena, in the reference's registration order (model.py:309-370);
@@ -119,6 +121,7 @@ typedef struct vu_attn_params {
   const void* proj_w;  /* storage dtype */
   const float* proj_b;
   float* run_mean; float* run_var;
+  int operands;  /* 0 storage dtype, 1 OCP e4m3 (as vu_config.attn_operands) */
 } vu_attn_params;
 typedef struct vu_attn_grads {
   float* mix_w; float* mix_b; float* bn_w; float* bn_b; float* wq; float* wk; float* wv;
@@ -170,6 +173,12 @@ int vu_mse_loss(const float* out, const float* target, float* dout, float* loss,
 int vu_adamw(float* params, const float* grads, float* m, float* v, void* shadow_bf16, long long n,
              const float* hyper, int* step, float grad_scale, void* stream);
 int vu_cast_bf16(const float* in, void* out, long long n, void* stream);
+/* In place: every element of x (dtype 0 fp32 / 1 bf16, n % 4 == 0) becomes the nearest OCP e4m3fn value (round to
+ * nearest even, 3 mantissa bits, subnormal step 2^-9, saturating at +-448; NaN stays NaN) held in the same container.
+ * An e4m3 value is exactly a bf16 value, so the bf16 MFMA on rounded operands forms the same products an fp8 MFMA
+ * does; at this model's head dims (d <= 96) the non-scaled fp8 MFMA has the bf16 rate, so nothing is lost.
+ * The conversion itself is the hardware's (v_cvt_pk_fp8_f32 / v_cvt_f32_fp8). */
+int vu_round_e4m3(int dtype, void* x, long long n, void* stream);
 
 /* Dice loss with its gradient (README.md:91-101: smooth = 1, flattened,
  * 1 - (2 sum(p t) + 1) / (sum p + sum t + 1)).  apply_sigmoid != 0: p = sigmoid(logits) (the

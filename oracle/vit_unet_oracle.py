@@ -51,6 +51,7 @@ class Config:
     attn_drop: float = 0.0
     proj_drop: float = 0.0
     linear_drop: float = 0.0
+    attn_operands: str = "storage"    # "e4m3": q, k, v rounded to OCP e4m3 before the attention products (BASELINE config 5)
 
     def __post_init__(self):
         # model.py:281-283
@@ -259,6 +260,31 @@ def _r(t: torch.Tensor, st) -> torch.Tensor:
 
 
 # --------------------------------------------------------------------------------------------
+# fp8 attention operands (BASELINE config 5; no counterpart in the reference, which has no reduced-precision path).
+# OCP 8-bit floating point, E4M3 ("e4m3fn"): 1 sign, 4 exponent (bias 7), 3 mantissa bits; no infinities; largest
+# finite value 448 = 1.75 * 2^8; smallest normal 2^-6; subnormals are multiples of 2^-9.  Conversion: round to nearest
+# even, saturating.  Pinned by tests/test_oracle_golden.py against torch.float8_e4m3fn and the format's table values.
+# --------------------------------------------------------------------------------------------
+def round_e4m3(t: torch.Tensor) -> torch.Tensor:
+    x = t.detach().to(torch.float64)
+    a = x.abs().clamp(max=448.0)
+    _, e = torch.frexp(a)                                   # a = m 2^e, m in [0.5, 1): binade exponent e - 1
+    q = torch.pow(2.0, (e - 1).clamp(min=-6).to(torch.float64) - 3)      # spacing of the e4m3 grid around a
+    r = torch.round(a / q) * q                              # torch.round: halves to even
+    r = torch.where(torch.isnan(x), x, torch.copysign(r.clamp(max=448.0), x))
+    return r.to(t.dtype)
+
+
+def _e4(t: torch.Tensor, operands: str) -> torch.Tensor:
+    """operand rounding, straight-through in autograd (the HIP path rounds q, k, v in place where the convolution
+    wrote them and back-propagates as if it had not)"""
+    if operands == "storage":
+        return t
+    assert operands == "e4m3", operands
+    return t + (round_e4m3(t) - t.detach())
+
+
+# --------------------------------------------------------------------------------------------
 # K4: per-patch 3x3 convolution (model.py:137-139,152-154): zero halo at the PATCH border.
 # --------------------------------------------------------------------------------------------
 def conv3x3_per_patch(tok: torch.Tensor, C: int, w: torch.Tensor, b: Optional[torch.Tensor] = None):
@@ -275,7 +301,7 @@ def conv3x3_per_patch(tok: torch.Tensor, C: int, w: torch.Tensor, b: Optional[to
 def reattention(xq, xkv, p: Dict[str, torch.Tensor], pre: str, h: int, C: int, *, training: bool,
                 attn_drop: float, proj_drop: float, seed: Optional[int] = None, stream: int = 0,
                 bn_momentum: float = 0.1, eps: float = 1e-5, return_map: bool = False, storage=None,
-                round_out: bool = True, flash: Optional[bool] = None):
+                round_out: bool = True, flash: Optional[bool] = None, operands: str = "storage"):
     """`flash`: follow the rounding points / dropout scheme of the non-materialising HIP form (csrc/vu_flash.hip: the
     probabilities and the mixed map are never rounded to the storage type, only A^ as the PV operand; quad dropout
     scheme).  Default: what the model path runs - that form for bf16 storage on the shapes it covers."""
@@ -288,9 +314,9 @@ def reattention(xq, xkv, p: Dict[str, torch.Tensor], pre: str, h: int, C: int, *
         sm = None          # logits / probabilities stay fp32 in registers
     else:
         sm = st
-    q = _r(conv3x3_per_patch(xq, C, p[pre + "qconv2d.weight"]), st).reshape(B, N, h, d).permute(0, 2, 1, 3)
-    k = _r(conv3x3_per_patch(xkv, C, p[pre + "kconv2d.weight"]), st).reshape(B, N, h, d).permute(0, 2, 1, 3)
-    v = _r(conv3x3_per_patch(xkv, C, p[pre + "vconv2d.weight"]), st).reshape(B, N, h, d).permute(0, 2, 1, 3)
+    q = _e4(_r(conv3x3_per_patch(xq, C, p[pre + "qconv2d.weight"]), st), operands).reshape(B, N, h, d).permute(0, 2, 1, 3)
+    k = _e4(_r(conv3x3_per_patch(xkv, C, p[pre + "kconv2d.weight"]), st), operands).reshape(B, N, h, d).permute(0, 2, 1, 3)
+    v = _e4(_r(conv3x3_per_patch(xkv, C, p[pre + "vconv2d.weight"]), st), operands).reshape(B, N, h, d).permute(0, 2, 1, 3)
     s = _r(torch.matmul(q, k.transpose(-2, -1)) * (d ** -0.5), sm)    # model.py:155
     a = _r(torch.softmax(s, dim=-1), sm)                              # :156
     if flash:
@@ -330,7 +356,7 @@ def te_block(x, p, pre: str, cfg: Config, *, training: bool, seed=None, stream: 
     st = storage
     a = reattention(x, x, p, pre + "ReAttn.", cfg.num_heads, cfg.num_channels, training=training,
                     attn_drop=cfg.attn_drop, proj_drop=cfg.proj_drop, seed=seed, stream=stream, storage=st,
-                    round_out=False)
+                    round_out=False, operands=cfg.attn_operands)
     x = _r(_layernorm_nd(_r(a + x, st), p[pre + "LN1.weight"], p[pre + "LN1.bias"]), st)
     f = feed_forward(x, p, pre + "FeedForward.", training=training, linear_drop=cfg.linear_drop, seed=seed, stream=stream,
                      storage=st)
@@ -355,7 +381,8 @@ def skip_block(enc, dec, p, pre: str, cfg: Config, *, training: bool, seed=None,
     """SkipConnection.forward(q=enc, k=dec, v=dec) (model.py:244-259): replaces dec, no residual."""
     assert enc.shape == dec.shape
     return reattention(enc, dec, p, pre, cfg.num_heads, cfg.num_channels, training=training,
-                       attn_drop=cfg.attn_drop, proj_drop=cfg.proj_drop, seed=seed, stream=stream, storage=storage)
+                       attn_drop=cfg.attn_drop, proj_drop=cfg.proj_drop, seed=seed, stream=stream, storage=storage,
+                       operands=cfg.attn_operands)
 
 
 # --------------------------------------------------------------------------------------------

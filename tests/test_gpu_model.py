@@ -104,6 +104,36 @@ def test_tiny_train_dropout_vs_oracle(golden_dir, name):
         assert serr(sd[k].grad, wr[k].grad) < 5e-3, k
 
 
+def test_tiny_e4m3_attention_operands_vs_oracle(golden_dir):
+    """attn_operands='e4m3' (BASELINE config 5's fp8 attention operands) through the whole model, fp32 storage so that
+    the e4m3 rounding of q, k, v is the only rounding: output and every gradient against the oracle, which rounds at
+    the same points and back-propagates straight through."""
+    man, g = load_case(golden_dir, "tiny_a")
+    kw = dict(man["cases"]["tiny_a"]["config"], attn_drop=0.2, proj_drop=0.2, linear_drop=0.0)
+    cfg = O.Config(attn_operands="e4m3", **kw)
+    w = O.make_weights(cfg, seed=7)
+    m = build(kw, w, attn_operands="e4m3").train()
+    x, y = torch.from_numpy(g["x"]).to(DEV), torch.from_numpy(g["y"]).to(DEV)
+    m._step_seed = 4242
+    out = m(x)
+    torch.nn.MSELoss()(out, y).backward()
+    wr = {k: v.clone() for k, v in w.items()}
+    for k, _ in O.param_shapes(cfg):
+        wr[k].requires_grad_(True)
+    outr = O.forward(wr, cfg, x.cpu(), training=True, seed=4242)
+    O.mse_loss(outr, y.cpu()).backward()
+    # the same model without the operand rounding is measurably different (the switch reaches the C path)
+    cfg0 = O.Config(**kw)
+    out0 = O.forward({k: v.detach() for k, v in wr.items()}, cfg0, x.cpu(), training=True, seed=4242)
+    assert serr(out0, outr) > 1e-3
+    assert serr(out, outr) < 2e-4
+    sd = dict(m.named_parameters())
+    for k, _ in O.param_shapes(cfg):
+        if k.endswith("reatten_matrix.bias"):
+            continue
+        assert serr(sd[k].grad, wr[k].grad) < 5e-3, k
+
+
 CORR_MIN, LOSS_TOL = 0.9, 0.1        # measured: correlation 0.964 .. 0.997, loss within 4.5 % (rel. RMS 0.08 .. 0.27)
 
 

@@ -224,12 +224,12 @@ def test_attention_flash_form(N, Cn, s, H, mode, cross, monkeypatch):
     _attention_fwd_bwd(torch.bfloat16, N, Cn, s, H, mode, cross, centered=True, flash=True)
 
 
-def _attention_fwd_bwd(dt, N, Cn, s, H, mode, cross, centered, flash=False):
+def _attention_fwd_bwd(dt, N, Cn, s, H, mode, cross, centered, flash=False, operands="storage", B=2):
     if dt == torch.bfloat16 and mode == "eval" and not flash:
         pytest.skip("eval with tiny running_var amplifies bf16 rounding by 100x; covered in fp32")
     if N * Cn * s * s > 50000 and (mode == "eval" or cross):
         pytest.skip("full-size levels: train / train_drop self-attention only (CPU oracle time)")
-    p, xq, xkv, dy, D = _attn_case(N, Cn, s, H)
+    p, xq, xkv, dy, D = _attn_case(N, Cn, s, H, B=B)
     B = xq.shape[0]
     training = mode != "eval"
     ad, pd = (0.2, 0.2) if mode == "train_drop" else (0.0, 0.0)
@@ -246,7 +246,10 @@ def _attention_fwd_bwd(dt, N, Cn, s, H, mode, cross, centered, flash=False):
     for k in GRAD_KEYS:
         pr[k].requires_grad_(True)
     yr, mapr = O.reattention(xq_r, xkv_r if cross else xq_r, pr, "", H, Cn, training=training, attn_drop=ad, proj_drop=pd,
-                             seed=seed, stream=sid, return_map=True, flash=flash)
+                             seed=seed, stream=sid, return_map=True, flash=flash, operands=operands,
+                             # e4m3 of a bf16 value is not e4m3 of the fp32 value it came from (double rounding moves ~3 %
+                             # of the operands by a whole e4m3 step): the oracle must round to the storage type first
+                             storage=(dt if operands != "storage" and dt != torch.float32 else None))
     yr.backward(dy_r)
     # ---- HIP ----
     code = _lib.DTYPE_CODE[dt]
@@ -254,7 +257,8 @@ def _attention_fwd_bwd(dt, N, Cn, s, H, mode, cross, centered, flash=False):
     d = {k: dev(v) for k, v in p.items()}
     pw = dev(p["proj.weight"], dt)
     prm = _lib.vu_attn_params(*[d[k].data_ptr() for k in GRAD_KEYS[:7]], pw.data_ptr(), d["proj.bias"].data_ptr(),
-                              d["var_norm.running_mean"].data_ptr(), d["var_norm.running_var"].data_ptr())
+                              d["var_norm.running_mean"].data_ptr(), d["var_norm.running_var"].data_ptr(),
+                              _lib.operand_code(operands))
     xqd, xkvd, dyd = dev(xq, dt), dev(xkv, dt), dev(dy, dt)
     if not cross:
         xkvd = xqd
@@ -299,6 +303,61 @@ def _attention_fwd_bwd(dt, N, Cn, s, H, mode, cross, centered, flash=False):
                 assert g.abs().max().item() < 1e-2 * grads[0].abs().max().item() + 1e-6
             continue
         assert serr(g, pr[k].grad) < bt, k
+
+
+# ------------------------------------------------------------------------------------------------
+# fp8 (OCP e4m3) attention operands: BASELINE config 5
+def test_round_e4m3_bit_exact():
+    """vu_round_e4m3 (the hardware conversion) against the oracle's arithmetic restatement: every bf16 bit pattern
+    (NaNs stay NaN, everything beyond 448 saturates), and fp32 values around every rounding boundary."""
+    L = lib()
+    bits = torch.arange(65536, dtype=torch.int32).to(torch.int16)
+    x = bits.view(torch.bfloat16)
+    xd = x.to(DEV).clone()
+    check(L.vu_round_e4m3(1, ptr(xd), xd.numel(), st()))
+    ref = O.round_e4m3(x.float())
+    got = xd.float().cpu()
+    nan = torch.isnan(x.float())
+    assert torch.isnan(got[nan]).all()
+    assert torch.equal(got[~nan], ref[~nan])
+    assert got[~nan].abs().max().item() == 448.0
+    # fp32: random values, every e4m3 grid point, every midpoint between neighbours and their fp32 neighbours
+    g = torch.Generator().manual_seed(5)
+    grid = O.round_e4m3(torch.cat([torch.arange(0, 1024) * 2.0 ** -9, torch.arange(1, 449) * 1.0])).unique()
+    mid = (grid[1:] + grid[:-1]) / 2
+    pts = torch.cat([grid, mid, torch.nextafter(mid, torch.tensor(0.0)), torch.nextafter(mid, torch.tensor(1e9)),
+                     torch.randn(1 << 20, generator=g) * 3, torch.randn(4096, generator=g) * 300])
+    pts = torch.cat([pts, -pts])
+    pts = pts[: pts.numel() // 4 * 4].contiguous()
+    pd = pts.to(DEV).clone()
+    check(L.vu_round_e4m3(0, ptr(pd), pd.numel(), st()))
+    assert torch.equal(pd.cpu(), O.round_e4m3(pts))
+
+
+@pytest.mark.parametrize("dt,N,Cn,s,H,B,flash", [(torch.bfloat16, 1024, 1, 8, 8, 2, True),      # 512x512 level 1 geometry, d = 8
+                                                 (torch.bfloat16, 4096, 1, 8, 8, 1, True),      # 512x512 level 2: N = 4096, d = 8
+                                                 (torch.bfloat16, 196, 3, 16, 8, 2, False),     # materialised forms
+                                                 (torch.float32, 49, 3, 8, 4, 2, False)])
+@pytest.mark.parametrize("mode", ["eval", "train", "train_drop"])
+def test_attention_e4m3_operands(dt, N, Cn, s, H, B, flash, mode, monkeypatch):
+    """q, k, v rounded to OCP e4m3 before the attention products (vu_attn_params.operands = 1), gradients passed
+    straight through: same oracle, same tolerances as the storage-dtype operands."""
+    if flash:
+        monkeypatch.setenv("VU_ATTN_FLASH", "1")
+    if N == 4096 and mode == "eval":
+        pytest.skip("N = 4096: train / train_drop only (CPU oracle time)")
+    _attention_fwd_bwd(dt, N, Cn, s, H, mode, False, centered=flash, flash=flash, operands="e4m3", B=B)
+
+
+def test_e4m3_operands_change_the_result():
+    """the switch is live: with e4m3 operands the output moves by about the format's rounding step, not by zero
+    and not by more"""
+    N, Cn, s, H = 196, 3, 16, 8
+    p, xq, _, dy, D = _attn_case(N, Cn, s, H)
+    y0, _, _ = _hip_attention(torch.bfloat16, p, xq, dy, N, D, H, Cn, 0.0, 0.0)
+    y1, _, _ = _hip_attention(torch.bfloat16, p, xq, dy, N, D, H, Cn, 0.0, 0.0, operands="e4m3")
+    e = serr(y1, y0)
+    assert 1e-3 < e < 0.2, e
 
 
 # ------------------------------------------------------------------------------------------------
@@ -366,7 +425,7 @@ def test_mse_and_adamw_and_cast():
     assert torch.equal(c, sh)
 
 
-def _hip_attention(dt, p, xq, dy, N, D, H, Cn, ad, pd, seed=1234, sid=3):
+def _hip_attention(dt, p, xq, dy, N, D, H, Cn, ad, pd, seed=1234, sid=3, operands="storage"):
     """Self-attention forward + backward through the C ABI; returns (y, dxq, grads) as float CPU tensors."""
     code = _lib.DTYPE_CODE[dt]
     L = lib()
@@ -374,7 +433,8 @@ def _hip_attention(dt, p, xq, dy, N, D, H, Cn, ad, pd, seed=1234, sid=3):
     d = {k: dev(v) for k, v in p.items()}
     pw = dev(p["proj.weight"], dt)
     prm = _lib.vu_attn_params(*[d[k].data_ptr() for k in GRAD_KEYS[:7]], pw.data_ptr(), d["proj.bias"].data_ptr(),
-                              d["var_norm.running_mean"].data_ptr(), d["var_norm.running_var"].data_ptr())
+                              d["var_norm.running_mean"].data_ptr(), d["var_norm.running_var"].data_ptr(),
+                              _lib.operand_code(operands))
     xqd, dyd = dev(xq, dt), dev(dy, dt)
     nbytes = L.vu_attn_workspace_bytes(code, B, N, D, H)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)

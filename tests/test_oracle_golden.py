@@ -246,3 +246,27 @@ def test_full_config_train_golden(golden_dir, name, dtype):
     r32 = meta["ref32"]        # the conditioning statement the GPU tests lean on
     if name == "lite":
         assert r32["out_err"] < 1e-4 and r32["grad_cos_all"] > 0.9999
+
+
+def test_round_e4m3_pinned_by_torch_float8_and_table_values():
+    """The oracle's OCP e4m3 rounding (BASELINE config 5's fp8 attention operands) against torch's own
+    float8_e4m3fn conversion on every bf16 bit pattern in range and on a million fp32 values, plus the
+    format's table values: max 448, min normal 2^-6, min subnormal 2^-9, ties to even, saturation."""
+    bits = torch.arange(65536, dtype=torch.int32).to(torch.int16)
+    x = bits.view(torch.bfloat16).float()
+    r = O.round_e4m3(x)
+    ok = (x.abs() <= 448) & ~torch.isnan(x)
+    assert torch.equal(r[ok], x[ok].to(torch.float8_e4m3fn).float())
+    big = (x.abs() > 448) & ~torch.isnan(x)
+    assert torch.equal(r[big].abs().unique(), torch.tensor([448.0]))
+    assert torch.isnan(r[torch.isnan(x)]).all()
+    xf = torch.randn(1 << 20, generator=torch.Generator().manual_seed(3)) * 3
+    assert torch.equal(O.round_e4m3(xf), xf.to(torch.float8_e4m3fn).float())
+    t = torch.tensor([0.0, 2.0 ** -9, 2.0 ** -10, 1.5 * 2.0 ** -10, 2.0 ** -6, 0.3, 17.0, 19.0, 447.0, 464.0, 1e9, -1e9])
+    e = torch.tensor([0.0, 2.0 ** -9, 0.0, 2.0 ** -9, 2.0 ** -6, 0.3125, 16.0, 20.0, 448.0, 448.0, 448.0, -448.0])
+    assert torch.equal(O.round_e4m3(t), e)
+    assert O.round_e4m3(t.to(torch.bfloat16)).dtype == torch.bfloat16
+    # straight-through: identity gradient
+    q = torch.randn(64, requires_grad=True)
+    O._e4(q, "e4m3").sum().backward()
+    assert torch.equal(q.grad, torch.ones(64))

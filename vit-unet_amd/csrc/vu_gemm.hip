@@ -63,6 +63,12 @@ static int launch_tiles(const vu_gemm_args& g, hipStream_t st) {
     }
     return launch_one<T, TC, TA, TB, 64, 64>(g, st);
   }
+  {
+    // many small batched products with one k-step (the per-(sample, head) map x head-slice products of level 0,
+    // 49 x 49 x 384): half-height tiles, twice the workgroups (26 -> 23 us, 24 -> 21 us)
+    static const bool smallk_off = [] { const char* e = getenv("VU_GEMM_SMALLK"); return e && e[0] == '0'; }();     // A/B switch
+    if (!smallk_off && g.N <= 64 && g.K <= 64 && (long long)g.Z1 * g.Z2 >= 64) return launch_one<T, TC, TA, TB, 64, 64>(g, st);
+  }
   if (g.N <= 64) return launch_one<T, TC, TA, TB, 128, 64>(g, st);     // (smaller row tiles for the 98-tile 768 -> 64 layers measured no gain)
   // fewer big tiles than CUs and a long K (the 3072 -> 128 feed-forward layers of level 0: 25 tiles of 128x128; the 3072 x 3072
   // projections at 16 images per GPU: 168 tiles): quarter tiles

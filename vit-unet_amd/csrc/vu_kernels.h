@@ -108,4 +108,5 @@ int vu_k_mse(const float* out, const float* target, float* dout, float* loss, fl
 int vu_k_adamw(float* p, const float* g, float* m, float* v, void* shadow_bf16, long long n,
                const float* hyper, int* step, float gscale, hipStream_t st);
 int vu_k_cast_bf16(const float* in, void* out, long long n, hipStream_t st);
+int vu_k_round_e4m3(int dtype, void* x0, void* x1, void* x2, long long n, hipStream_t st);   // up to three arrays of n elements
 int vu_k_fill(float* p, float v, long long n, hipStream_t st);

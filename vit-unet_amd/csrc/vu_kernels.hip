@@ -1025,6 +1025,33 @@ int vu_k_cast_bf16(const float* in, void* out, long long n, hipStream_t st) {
   hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for(n / 4, 256, 256 * 8)), dim3(256), 0, st, in, (bf16_t*)out, n / 4);
   return vu_check_launch("vu_cast_bf16");
 }
+// OCP e4m3 rounding in place (vit_unet_amd.h: vu_round_e4m3).  The hardware conversion does the rounding; the clamp
+// in front of it makes the saturation explicit (the instruction's own overflow behaviour depends on a mode bit).
+__device__ __forceinline__ float e4m3_round(float a, float b, float& rb) {
+  const float ca = __builtin_fminf(__builtin_fmaxf(a, -448.f), 448.f), cb = __builtin_fminf(__builtin_fmaxf(b, -448.f), 448.f);   // (NaN falls through fmin/fmax)
+  const int w = __builtin_amdgcn_cvt_pk_fp8_f32(a != a ? a : ca, b != b ? b : cb, 0, false);
+  rb = __builtin_amdgcn_cvt_f32_fp8(w, 1);
+  return __builtin_amdgcn_cvt_f32_fp8(w, 0);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void round_e4m3_kernel(T* x0, T* x1, T* x2, long long n4) {
+  T* x = blockIdx.y == 0 ? x0 : (blockIdx.y == 1 ? x1 : x2);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    vu_f4 t = vu_ld4(x + 4 * i);
+    t.v[0] = e4m3_round(t.v[0], t.v[1], t.v[1]);
+    t.v[2] = e4m3_round(t.v[2], t.v[3], t.v[3]);
+    vu_st4(x + 4 * i, t);
+  }
+}
+int vu_k_round_e4m3(int dtype, void* x0, void* x1, void* x2, long long n, hipStream_t st) {
+  VU_REQUIRE(n % 4 == 0, "round_e4m3: n %% 4");
+  if (n == 0) return VU_OK;
+  const int arrays = x2 ? 3 : (x1 ? 2 : 1);
+  VU_DISPATCH_T(dtype,
+    hipLaunchKernelGGL((round_e4m3_kernel<T>), dim3(grid_for(n / 4, 256, 256 * 4), arrays), dim3(256), 0, st, (T*)x0, (T*)x1, (T*)x2, n / 4);)
+  if (vu_prof_on()) vu_prof_note("round_e4m3_kernel", 0.0, (double)arrays * n * 2 * (dtype == 0 ? 4.0 : 2.0));
+  return vu_check_launch("vu_round_e4m3");
+}
 __global__ void fill_kernel(float* p, float v, long long n) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = v;
 }

@@ -69,6 +69,7 @@ int validate(const vu_config& c) {
   VU_REQUIRE(c.attn_drop >= 0.f && c.attn_drop < 1.f && c.proj_drop >= 0.f && c.proj_drop < 1.f && c.linear_drop >= 0.f && c.linear_drop < 1.f,
              "dropout must be in [0,1)");
   VU_REQUIRE(c.dtype == 0 || c.dtype == 1, "dtype must be 0 (fp32) or 1 (bf16)");
+  VU_REQUIRE(c.attn_operands == 0 || c.attn_operands == 1, "attn_operands must be 0 (storage dtype) or 1 (OCP e4m3)");
   return VU_OK;
 }
 
@@ -202,6 +203,9 @@ int attn_forward(const AttnDims& d, const vu_attn_params& p, const void* xq, con
   const int dh = D / H;
   const long long npatch = (long long)B * N;
   VU_TRY(vu_k_conv3x3_qkv_fwd(dt, xq, xkv, p.wq, p.wk, p.wv, a.q, a.k, a.v, npatch, d.C, d.s, st));
+  // e4m3 attention operands: q, k, v are rounded where they are produced, so every product of the forward and of the
+  // backward (which re-reads these buffers) sees the same fp8-valued operands; gradients pass straight through
+  if (p.operands == 1) VU_TRY(vu_k_round_e4m3(dt, a.q, a.k, a.v, npatch * D, st));
   vu_rng ra = vu_make_rng(seed, 2 * stream_id, training ? attn_drop : 0.f);
   ra.salt = salt;
   if (flash_on(d)) {   // O = A^ v without ever forming a map
@@ -482,6 +486,7 @@ vu_attn_params attn_params(const AttnP& a, const vu_config& c, const float* prm,
   p.proj_b = prm + a.projb;
   p.run_mean = bn ? bn + (long long)a.bn * 2 * c.num_heads : nullptr;
   p.run_var = bn ? bn + (long long)a.bn * 2 * c.num_heads + c.num_heads : nullptr;
+  p.operands = c.attn_operands;
   return p;
 }
 vu_attn_grads attn_grads(const AttnP& a, float* g) {
@@ -1076,6 +1081,10 @@ int vu_adamw(float* params, const float* grads, float* m, float* v, void* shadow
 }
 int vu_cast_bf16(const float* in, void* out, long long n, void* stream) {
   return vu_k_cast_bf16(in, out, n, (hipStream_t)stream);
+}
+int vu_round_e4m3(int dtype, void* x, long long n, void* stream) {
+  VU_REQUIRE(dtype == 0 || dtype == 1, "dtype must be 0 (fp32) or 1 (bf16)");
+  return vu_k_round_e4m3(dtype, x, nullptr, nullptr, n, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -27,7 +27,7 @@ class vu_config(C.Structure):
                 ("im_size", C.c_int), ("patch_size", C.c_int), ("num_channels", C.c_int),
                 ("hidden_dim", C.c_int), ("num_heads", C.c_int),
                 ("attn_drop", C.c_float), ("proj_drop", C.c_float), ("linear_drop", C.c_float),
-                ("out_conv", C.c_int), ("dtype", C.c_int)]
+                ("out_conv", C.c_int), ("dtype", C.c_int), ("attn_operands", C.c_int)]
 
 
 class vu_param_entry(C.Structure):
@@ -37,7 +37,7 @@ class vu_param_entry(C.Structure):
 
 class vu_attn_params(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("mix_w", "mix_b", "bn_w", "bn_b", "wq", "wk", "wv",
-                                          "proj_w", "proj_b", "run_mean", "run_var")]
+                                          "proj_w", "proj_b", "run_mean", "run_var")] + [("operands", C.c_int)]
 
 
 class vu_attn_grads(C.Structure):
@@ -82,6 +82,7 @@ SIGNATURES = {
                             _vp]),
     "vu_mse_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _f, _vp]),
     "vu_adamw": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _vp, _vp, _f, _vp]),
+    "vu_round_e4m3": (_i, [_i, _vp, _ll, _vp]),
     "vu_cast_bf16": (_i, [_vp, _vp, _ll, _vp]),
     "vu_dice_partials_floats": (_sz, []),
     "vu_dice_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _i, _f, _vp]),
@@ -146,13 +147,25 @@ def stream_ptr(device=None):
 DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1}
 
 
+# what q, k, v are rounded to before the attention products (vu_config.attn_operands): the storage dtype itself, or
+# OCP e4m3 (BASELINE config 5)
+OPERAND_CODE = {"storage": 0, "e4m3": 1}
+
+
+def operand_code(name) -> int:
+    if name not in OPERAND_CODE:
+        raise ValueError(f"attn_operands must be one of {sorted(OPERAND_CODE)}, got {name!r}")
+    return OPERAND_CODE[name]
+
+
 def make_config(depth, depth_te, size_bottleneck, preprocessing, im_size, patch_size, num_channels,
-                hidden_dim, num_heads, attn_drop, proj_drop, linear_drop, dtype) -> vu_config:
+                hidden_dim, num_heads, attn_drop, proj_drop, linear_drop, dtype, attn_operands="storage") -> vu_config:
     if dtype not in DTYPE_CODE:
         raise ValueError(f"dtype must be torch.float32 or torch.bfloat16, got {dtype}")
     return vu_config(int(depth), int(depth_te), int(size_bottleneck), int(im_size), int(patch_size),
                      int(num_channels), int(hidden_dim), int(num_heads), float(attn_drop), float(proj_drop),
-                     float(linear_drop), 1 if preprocessing == "conv" else 0, DTYPE_CODE[dtype])
+                     float(linear_drop), 1 if preprocessing == "conv" else 0, DTYPE_CODE[dtype],
+                     operand_code(attn_operands))
 
 
 def backward_unit_ranges(cfg: vu_config):

@@ -128,7 +128,7 @@ def _attn_param_struct(m, dtype, need_shadow=True):
     p = _lib.vu_attn_params(f32(m.reatten_matrix.weight), f32(m.reatten_matrix.bias), f32(m.var_norm.weight),
                             f32(m.var_norm.bias), f32(m.qconv2d.weight), f32(m.kconv2d.weight), f32(m.vconv2d.weight),
                             pw.data_ptr(), f32(m.proj.bias), m.var_norm.running_mean.data_ptr(),
-                            m.var_norm.running_var.data_ptr())
+                            m.var_norm.running_var.data_ptr(), _lib.operand_code(getattr(m, "attn_operands", "storage")))
     return p, keep
 
 
@@ -288,6 +288,7 @@ class ReAttention(nn.Module):
         self.attn_drop = nn.Dropout(attn_drop)
         self.proj = nn.Linear(dim, dim)
         self.proj_drop = nn.Dropout(proj_drop)
+        self.attn_operands = "storage"     # or "e4m3": q, k, v rounded to OCP e4m3 before the products (vu_round_e4m3)
 
     def _params(self):
         sd = dict(self.named_parameters())
@@ -343,6 +344,7 @@ class SkipConnection(nn.Module):
         self.attn_drop = nn.Dropout(attn_drop)
         self.proj = nn.Linear(dim, dim)
         self.proj_drop = nn.Dropout(proj_drop)
+        self.attn_operands = "storage"     # or "e4m3": q, k, v rounded to OCP e4m3 before the products (vu_round_e4m3)
 
     def _params(self):
         sd = dict(self.named_parameters())
@@ -422,7 +424,8 @@ class HViT_UNet(nn.Module):
 
     def __init__(self, depth: int, depth_te: int, size_bottleneck: int, preprocessing: str, im_size: int,
                  patch_size: int, num_channels: int, hidden_dim: int, num_heads: int, attn_drop: float,
-                 proj_drop: float, linear_drop: float, verbose: bool = False, dtype=torch.float32):
+                 proj_drop: float, linear_drop: float, verbose: bool = False, dtype=torch.float32,
+                 attn_operands: str = "storage"):
         super().__init__()
         assert patch_size % (2 ** depth) == 0, "Depth must be adjusted, final patch size is incompatible."
         assert patch_size // (2 ** depth) >= 4, "Depth must be adjusted, final patch size is too small (lower than 4)."
@@ -442,7 +445,9 @@ class HViT_UNet(nn.Module):
         self.verbose = verbose
         self.compute_dtype = dtype
         self._cfg = _lib.make_config(depth, depth_te, size_bottleneck, preprocessing, im_size, patch_size,
-                                     num_channels, hidden_dim, num_heads, attn_drop, proj_drop, linear_drop, dtype)
+                                     num_channels, hidden_dim, num_heads, attn_drop, proj_drop, linear_drop, dtype,
+                                     attn_operands)
+        self.attn_operands = attn_operands
         if verbose:                                                       # model.py:301-307
             print("Architecture information:")
             for i in range(depth + 1):
@@ -466,6 +471,9 @@ class HViT_UNet(nn.Module):
             for l in range(depth)])                                                                  # :359-366
         if preprocessing == "conv":
             self.conv2d = nn.Conv2d(num_channels, num_channels, 3, padding="same")                   # :369-370
+        for m in self.modules():
+            if isinstance(m, (ReAttention, SkipConnection)):
+                m.attn_operands = attn_operands
         # flat-arena state (built lazily: needs the HIP library only once tensors reach the GPU)
         self._arena = self._garena = self._shadow = self._bn = self._ws = None
         self._table = None
@@ -645,7 +653,7 @@ class HViT_UNet(nn.Module):
 
 def ViT_UNet(depth, depth_te, size_bottleneck, preprocessing, num_patches, patch_size, num_channels=3,
              hidden_dim=128, num_heads=8, attn_drop=0., proj_drop=0., linear_drop=0., dtype=torch.float32,
-             projection_dim=None, verbose=False):
+             projection_dim=None, verbose=False, attn_operands="storage"):
     """The constructor surface of README.md:18-31 / ViT_UNet.ipynb:974-990 (spec decision D2):
     `num_patches` replaces `im_size` (im_size = sqrt(num_patches) * patch_size)."""
     e = int(round(math.sqrt(num_patches)))
@@ -653,7 +661,8 @@ def ViT_UNet(depth, depth_te, size_bottleneck, preprocessing, num_patches, patch
     if projection_dim is not None:
         assert projection_dim == num_channels * patch_size ** 2, "projection_dim must equal C * patch_size^2"
     return HViT_UNet(depth, depth_te, size_bottleneck, preprocessing, e * patch_size, patch_size, num_channels,
-                     hidden_dim, num_heads, attn_drop, proj_drop, linear_drop, verbose=verbose, dtype=dtype)
+                     hidden_dim, num_heads, attn_drop, proj_drop, linear_drop, verbose=verbose, dtype=dtype,
+                     attn_operands=attn_operands)
 
 
 _PRESETS = {   # model.py:438-485
