@@ -173,6 +173,8 @@ int vu_mse_loss(const float* out, const float* target, float* dout, float* loss,
 int vu_adamw(float* params, const float* grads, float* m, float* v, void* shadow_bf16, long long n,
              const float* hyper, int* step, float grad_scale, void* stream);
 int vu_cast_bf16(const float* in, void* out, long long n, void* stream);
+/* out[n] += sum over rows of in[row * ld + n], n < ncols (bias / embedding gradients: the sum over the batch). */
+int vu_colsum(int dtype, const void* in, float* out, long long rows, int ncols, long long ld, void* stream);
 /* In place: every element of x (dtype 0 fp32 / 1 bf16, n % 4 == 0) becomes the nearest OCP e4m3fn value (round to
  * nearest even, 3 mantissa bits, subnormal step 2^-9, saturating at +-448; NaN stays NaN) held in the same container.
  * An e4m3 value is exactly a bf16 value, so the bf16 MFMA on rounded operands forms the same products an fp8 MFMA

@@ -290,7 +290,7 @@ def _e4(t: torch.Tensor, operands: str) -> torch.Tensor:
 def conv3x3_per_patch(tok: torch.Tensor, C: int, w: torch.Tensor, b: Optional[torch.Tensor] = None):
     B, N, D = tok.shape
     s = int(round(math.sqrt(D // C)))
-    y = F.conv2d(tok.reshape(B * N, C, s, s), w, b, padding=1)
+    y = F.conv2d(tok.reshape(B * N, C, s, s), w, b, padding=w.shape[-1] // 2)   # (1 x 1 kernels: the notebook variant)
     return y.reshape(B, N, D)
 
 
@@ -438,6 +438,84 @@ def forward(p: Dict[str, torch.Tensor], cfg: Config, X: torch.Tensor, *, trainin
         Y = F.conv2d(Y, p["conv2d.weight"], p["conv2d.bias"], padding=1)
     elif cfg.preprocessing == "fourier":
         raise NotImplementedError("D5: the reference 'fourier' branch (model.py:429-430) is a bug")
+    return Y
+
+
+# --------------------------------------------------------------------------------------------
+# f4: the variants sketched in ViT_UNet.ipynb (classes PatchEncoder, FformerEncoder, ReAttention,
+# ReAttentionTransformerEncoder, SkipConnection, ViT_UNet of the notebook).  The notebook does not run as committed
+# (its Unpatch reads a notebook global), so there is no reference output to pin these against: "parity unpinned".
+# They follow the notebook's text, with the re-tiling semantics of model.py:8-53.  `p` uses the module names of
+# vit_unet/torch/variants.py (PE.conv2d, PE.position_embedding, <block>.ReAttn.*, <block>.LN, <block>.FeedForward.net.*).
+# --------------------------------------------------------------------------------------------
+def fft2_real(x: torch.Tensor) -> torch.Tensor:
+    """`torch.fft.fft2(x).real` over the last two axes (FformerEncoder.forward; PatchEncoder 'fourier')."""
+    return torch.fft.fft2(x).real
+
+
+def fformer_block(x, p, pre: str, *, training: bool, linear_drop: float = 0.0, seed=None, stream: int = 0, storage=None):
+    """FformerEncoder.forward: x += Re(fft2 x); x = LN(x); x += FF(x); x = LN(x), the SAME LayerNorm twice."""
+    st = storage
+    w, b = p[pre + "LN.weight"], p[pre + "LN.bias"]
+    x = _r(_layernorm_nd(_r(_r(fft2_real(x), st) + x, st), w, b), st)
+    f = feed_forward(x, p, pre + "FeedForward.", training=training, linear_drop=linear_drop, seed=seed, stream=stream, storage=st)
+    return _r(_layernorm_nd(_r(f + x, st), w, b), st)
+
+
+def notebook_te_block(x, p, pre: str, cfg: Config, *, training: bool, seed=None, stream: int = 0, storage=None):
+    """the notebook's ReAttentionTransformerEncoder.forward: one LayerNorm, 1 x 1 q/k/v kernels (taken from the weights)."""
+    st = storage
+    w, b = p[pre + "LN.weight"], p[pre + "LN.bias"]
+    a = reattention(x, x, p, pre + "ReAttn.", cfg.num_heads, cfg.num_channels, training=training, attn_drop=cfg.attn_drop,
+                    proj_drop=cfg.proj_drop, seed=seed, stream=stream, storage=st, round_out=False, flash=False)
+    x = _r(_layernorm_nd(_r(a + x, st), w, b), st)
+    f = feed_forward(x, p, pre + "FeedForward.", training=training, linear_drop=cfg.linear_drop, seed=seed, stream=stream,
+                     storage=st)
+    return _r(_layernorm_nd(_r(f + x, st), w, b), st)
+
+
+def notebook_forward(p, cfg: Config, X, *, training: bool = False, seed=None, storage=None, block: str = "reattention"):
+    """the notebook's ViT_UNet.forward: PatchEncoder (image conv / Re fft2, positional embedding at the finest patch
+    size, re-tiled to patch_size), the U of blocks, SkipConnections indexed (i - 1) // depth_te, output conv."""
+    C = cfg.num_channels
+    st = storage
+    if cfg.preprocessing == "conv":
+        X = _r(F.conv2d(X, p["PE.conv2d.weight"], p["PE.conv2d.bias"], padding=1), st)
+    elif cfg.preprocessing == "fourier":
+        X = _r(fft2_real(X), st)
+    s_f = cfg.patch_size // 2 ** cfg.depth
+    x = _r(patchify(X, s_f) + p["PE.position_embedding.weight"].unsqueeze(0), st)
+    x = retile(x, C, cfg.patch_size)
+
+    def blk(pre, x, stream):
+        if block == "fformer":
+            return fformer_block(x, p, pre, training=training, linear_drop=cfg.linear_drop, seed=seed, stream=stream, storage=st)
+        return notebook_te_block(x, p, pre, cfg, training=training, seed=seed, stream=stream, storage=st)
+    stream = 0
+    skips: List[torch.Tensor] = []
+    for i in range(cfg.depth * cfg.depth_te):
+        x = blk(f"Encoders.{i}.", x, stream)
+        stream += 1
+        if (i + 1) % cfg.depth_te == 0:
+            skips.append(x)
+            x = downsample(x, C)
+    for i in range(cfg.size_bottleneck):
+        x = blk(f"BottleNeck.{i}.", x, stream)
+        stream += 1
+    for i in range(cfg.depth * cfg.depth_te):
+        x = blk(f"Decoders.{i}.", x, stream)
+        stream += 1
+        if (i + 1) % cfg.depth_te == 0:
+            x = upsample(x, C)
+            enc = skips[cfg.depth - (i + 1) // cfg.depth_te]
+            assert enc.shape == x.shape
+            j = ((i - 1) // cfg.depth_te) % cfg.depth          # python list indexing of the notebook, negative index included
+            x = reattention(enc, x, p, f"SkipConnections.{j}.", cfg.num_heads, C, training=training, attn_drop=cfg.attn_drop,
+                            proj_drop=cfg.proj_drop, seed=seed, stream=stream, storage=st, flash=False)
+            stream += 1
+    Y = unpatchify(x, C)
+    if cfg.preprocessing == "conv":
+        Y = F.conv2d(Y, p["conv2d.weight"], p["conv2d.bias"], padding=1)
     return Y
 
 

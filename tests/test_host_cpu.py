@@ -132,3 +132,19 @@ def test_fitter_surface_and_checkpoint_roundtrip(tmp_path):
     for k, v in m.state_dict().items():
         assert torch.equal(v, ref[k]), k
     assert not f._fused_ok()          # CPU device: never the fused HIP step
+
+
+def test_dft_matrices_give_the_real_part_of_fft2():
+    """variants.fft2_real is C_N X C_D - S_N X S_D with these matrices (two GEMMs on the device): the identity against
+    torch.fft on the host, and the symmetry that makes the operator its own adjoint."""
+    import numpy as np
+    from vit_unet.torch.variants import dft_matrices
+    rng = np.random.default_rng(0)
+    for n, d in ((49, 192), (7, 5), (64, 64)):
+        cn, sn = dft_matrices(n)
+        cd, sd = dft_matrices(d)
+        assert np.array_equal(cn, cn.T) and np.array_equal(sn, sn.T)
+        x = rng.standard_normal((n, d))
+        ref = torch.fft.fft2(torch.from_numpy(x)).real.numpy()
+        got = cn @ x @ cd - sn @ x @ sd
+        assert np.abs(got - ref).max() < 1e-9 * np.abs(ref).max()

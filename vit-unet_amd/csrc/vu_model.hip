@@ -1082,6 +1082,11 @@ int vu_adamw(float* params, const float* grads, float* m, float* v, void* shadow
 int vu_cast_bf16(const float* in, void* out, long long n, void* stream) {
   return vu_k_cast_bf16(in, out, n, (hipStream_t)stream);
 }
+int vu_colsum(int dtype, const void* in, float* out, long long rows, int ncols, long long ld, void* stream) {
+  VU_REQUIRE(dtype == 0 || dtype == 1, "dtype must be 0 (fp32) or 1 (bf16)");
+  VU_REQUIRE(rows >= 0 && ncols >= 0 && ld >= ncols, "colsum: bad shape");
+  return vu_k_colsum(dtype, in, out, rows, ncols, ld, (hipStream_t)stream);
+}
 int vu_round_e4m3(int dtype, void* x, long long n, void* stream) {
   VU_REQUIRE(dtype == 0 || dtype == 1, "dtype must be 0 (fp32) or 1 (bf16)");
   return vu_k_round_e4m3(dtype, x, nullptr, nullptr, n, (hipStream_t)stream);

@@ -83,6 +83,7 @@ SIGNATURES = {
     "vu_mse_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _f, _vp]),
     "vu_adamw": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _vp, _vp, _f, _vp]),
     "vu_round_e4m3": (_i, [_i, _vp, _ll, _vp]),
+    "vu_colsum": (_i, [_i, _vp, _vp, _ll, _i, _ll, _vp]),
     "vu_cast_bf16": (_i, [_vp, _vp, _ll, _vp]),
     "vu_dice_partials_floats": (_sz, []),
     "vu_dice_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _i, _f, _vp]),

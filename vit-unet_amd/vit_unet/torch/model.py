@@ -125,8 +125,10 @@ def _attn_param_struct(m, dtype, need_shadow=True):
     else:
         pw = pw.float().contiguous()
     keep.append(pw)
+    def k3(w):      # a 1 x 1 q/k/v kernel (the notebook variant, ViT_UNet.ipynb ReAttention) is the centre tap of a 3 x 3 one
+        return w if w.shape[-1] == 3 else torch.nn.functional.pad(w.detach(), (1, 1, 1, 1))
     p = _lib.vu_attn_params(f32(m.reatten_matrix.weight), f32(m.reatten_matrix.bias), f32(m.var_norm.weight),
-                            f32(m.var_norm.bias), f32(m.qconv2d.weight), f32(m.kconv2d.weight), f32(m.vconv2d.weight),
+                            f32(m.var_norm.bias), f32(k3(m.qconv2d.weight)), f32(k3(m.kconv2d.weight)), f32(k3(m.vconv2d.weight)),
                             pw.data_ptr(), f32(m.proj.bias), m.var_norm.running_mean.data_ptr(),
                             m.var_norm.running_var.data_ptr(), _lib.operand_code(getattr(m, "attn_operands", "storage")))
     return p, keep
@@ -183,6 +185,9 @@ class _AttnFn(torch.autograd.Function):
             gq, gkv = dxq, None
         else:
             gq, gkv = dxq, dxkv
+        if module.qconv2d.weight.shape[-1] == 1:      # 1 x 1 kernels: the gradient of the centre tap
+            for i in (4, 5, 6):
+                grads[i] = grads[i][:, :, 1:2, 1:2].contiguous()
         return (gq, gkv, None, None, None, None, None, *grads)
 
 
@@ -272,18 +277,19 @@ class ReAttention(nn.Module):
     """model.py:113-164.  apply_transform=False (never used by the model) is not supported."""
 
     def __init__(self, dim, num_channels=3, num_heads=8, qkv_bias=False, qk_scale=None, attn_drop=0.,
-                 proj_drop=0., apply_transform=True, transform_scale=False):
+                 proj_drop=0., apply_transform=True, transform_scale=False, qkv_kernel=3):
         super().__init__()
         assert apply_transform and not qkv_bias and qk_scale is None and not transform_scale, \
             "HIP path implements the configuration the model uses (model.py:187-192)"
+        assert qkv_kernel in (1, 3), "q/k/v kernels: 3 x 3 (model.py:137-139) or 1 x 1 (the notebook variant)"
         self.num_heads, self.num_channels = num_heads, num_channels
         self.apply_transform = True
         self.scale = (dim // num_heads) ** -0.5
         self.reatten_matrix = nn.Conv2d(num_heads, num_heads, 1, 1)
         self.var_norm = nn.BatchNorm2d(num_heads)
-        self.qconv2d = nn.Conv2d(num_channels, num_channels, 3, padding="same", bias=False)
-        self.kconv2d = nn.Conv2d(num_channels, num_channels, 3, padding="same", bias=False)
-        self.vconv2d = nn.Conv2d(num_channels, num_channels, 3, padding="same", bias=False)
+        self.qconv2d = nn.Conv2d(num_channels, num_channels, qkv_kernel, padding="same", bias=False)
+        self.kconv2d = nn.Conv2d(num_channels, num_channels, qkv_kernel, padding="same", bias=False)
+        self.vconv2d = nn.Conv2d(num_channels, num_channels, qkv_kernel, padding="same", bias=False)
         self.reatten_scale = 1.0
         self.attn_drop = nn.Dropout(attn_drop)
         self.proj = nn.Linear(dim, dim)
@@ -330,16 +336,17 @@ class SkipConnection(nn.Module):
     """cross re-attention merge: q <- encoder skip, k,v <- decoder   (model.py:211-259)."""
 
     def __init__(self, dim, num_channels=3, num_heads=8, qkv_bias=False, attn_drop=0., proj_drop=0.,
-                 transform_scale=False):
+                 transform_scale=False, qkv_kernel=3):
         super().__init__()
         assert not qkv_bias and not transform_scale
+        assert qkv_kernel in (1, 3)
         self.num_heads, self.num_channels = num_heads, num_channels
         self.scale = (dim // num_heads) ** -0.5
         self.reatten_matrix = nn.Conv2d(num_heads, num_heads, 1, 1)
         self.var_norm = nn.BatchNorm2d(num_heads)
-        self.qconv2d = nn.Conv2d(num_channels, num_channels, 3, padding="same", bias=False)
-        self.kconv2d = nn.Conv2d(num_channels, num_channels, 3, padding="same", bias=False)
-        self.vconv2d = nn.Conv2d(num_channels, num_channels, 3, padding="same", bias=False)
+        self.qconv2d = nn.Conv2d(num_channels, num_channels, qkv_kernel, padding="same", bias=False)
+        self.kconv2d = nn.Conv2d(num_channels, num_channels, qkv_kernel, padding="same", bias=False)
+        self.vconv2d = nn.Conv2d(num_channels, num_channels, qkv_kernel, padding="same", bias=False)
         self.reatten_scale = 1.0
         self.attn_drop = nn.Dropout(attn_drop)
         self.proj = nn.Linear(dim, dim)
