@@ -12,7 +12,7 @@ int vu_k_attn_scores(int dtype, const void* q, const void* k, void* Ps, int B, i
   const int d = D / H;
   const int dp = (d + 31) / 32 * 32;
   const size_t es = dtype == 0 ? 4 : 2;
-  const size_t lds = (size_t)N * (dp + (es == 2 ? 8 : 4)) * es;
+  const size_t lds = (size_t)((N + 15) & ~15) * (dp + (es == 2 ? 8 : 4)) * es;      // (the kernel zero-pads K to whole key tiles)
   if (lds > 150 * 1024 && !(N > 784 && dp == 32)) return 1;      // (long rows stream K in chunks)
   if ((double)B * H * N * (double)ld >= 4294967295.0) return 1;   // 32-bit mask index in the fused kernel
   if (dtype == 0) return vu_scores_f32_softmax(q, k, Ps, B, N, D, H, ld, scale, rng, st);
@@ -25,7 +25,7 @@ int vu_k_attn_outer(int dtype, const void* a, const void* bmat, void* out, int B
   const int d = D / H;
   const int dp = (d + 31) / 32 * 32;
   const size_t es = dtype == 0 ? 4 : 2;
-  const size_t lds = (size_t)N * (dp + (es == 2 ? 8 : 4)) * es;
+  const size_t lds = (size_t)((N + 15) & ~15) * (dp + (es == 2 ? 8 : 4)) * es;      // (the kernel zero-pads K to whole key tiles)
   if (lds > 150 * 1024 && !(N > 784 && dp == 32)) return 1;
   vu_rng none = vu_make_rng(0, 0, 0.f);
   if (dtype == 0) return vu_scores_f32_plain(a, bmat, out, B, N, D, H, ld, scale, none, st);

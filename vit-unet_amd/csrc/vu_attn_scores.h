@@ -78,11 +78,14 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu((!SO
   {
     constexpr int VE = 16 / sizeof(T);
     const int chunks_per_row = DP / VE;
-    const int total = N * chunks_per_row;
+    const int total = ((N + 15) & ~15) * chunks_per_row;      // rows N .. 16 ceil(N/16) - 1 are zero: the key tiles read them unconditionally
     for (int c = tid; c < total; c += WAVES * 64) {
       const int row = c / chunks_per_row, kc = (c % chunks_per_row) * VE;
       alignas(16) T tmp[VE];
-      if (vec && kc + VE <= d) {
+      if (row >= N) {
+#pragma unroll
+        for (int e = 0; e < VE; ++e) tmp[e] = (T)0.f;
+      } else if (vec && kc + VE <= d) {
         *reinterpret_cast<uint4*>(tmp) = *reinterpret_cast<const uint4*>(kb + (long long)row * D + kc);
       } else {
 #pragma unroll
@@ -144,13 +147,13 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu((!SO
     for (int nt = 0; nt < NTA; ++nt) {
       acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (t0 + nt < ntiles) {
-        const int key = (t0 + nt) * 16 + l15;       // LDS row (the staging pass applied the group permutation)
-        const bool kv = EXACT || key < N;
+        const int key = (t0 + nt) * 16 + l15;       // LDS row (the staging pass applied the group permutation; rows >= N are zero)
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
           Frag kf;
-          if constexpr (MM::FE == 1) kf = kv ? (float)Ks[key * LDK + ks * MM::KS + lg] : 0.f;
-          else kf = kv ? *reinterpret_cast<const Frag*>(&Ks[key * LDK + ks * MM::KS + lg * MM::FE]) : MM::zero();
+          // (a per-lane `key < N` select around the read made every fragment an exec-masked LDS read with its own wait)
+          if constexpr (MM::FE == 1) kf = (float)Ks[key * LDK + ks * MM::KS + lg];
+          else kf = *reinterpret_cast<const Frag*>(&Ks[key * LDK + ks * MM::KS + lg * MM::FE]);
           acc[nt] = MM::mma(kf, qf[ks], acc[nt]);
         }
       }
@@ -294,7 +297,7 @@ int launch_scores_w(const T* q, const T* k, T* Ps, int B, int N, int D, int H, i
   constexpr bool softmax = SOFTMAX;
   const int d = D / H;
   constexpr int LDK = DP + (sizeof(T) == 2 ? 8 : 4);
-  const size_t lds = (size_t)N * LDK * sizeof(T);
+  const size_t lds = (size_t)((N + 15) & ~15) * LDK * sizeof(T);
   const bool full = N == 16 * NT;
   auto kern = full ? attn_scores_kernel<T, NT, DP, WAVES, true, SOFTMAX> : attn_scores_kernel<T, NT, DP, WAVES, false, SOFTMAX>;
   if (lds > 48 * 1024) {
