@@ -17,7 +17,7 @@ def line(name):
 
 lines = {}
 for key, fn in [("base", "r02_bench_base.json"), ("lite", "r02_bench_lite_32.json"), ("large", "r02_bench_large_16.json"),
-                ("seg32", "r02_bench_seg512_32.json"), ("seg8", "r02_bench_seg512_8.json"), ("b16", "r02_bench_base_16.json"),
+                ("seg32", "r02_bench_seg512_32.json"), ("segst", "r02_bench_seg512_32_storage.json"), ("seg8", "r02_bench_seg512_8.json"), ("b16", "r02_bench_base_16.json"),
                 ("b32", "r02_bench_base_32.json"), ("b128", "r02_bench_base_128.json")]:
     lines[key] = line(fn)
     shutil.copy(os.path.join(G, fn), os.path.join(P, fn))
@@ -31,6 +31,7 @@ sub = {
     "R2_LARGE_MS": f"{lines['large']['ms_per_step']:.1f}", "R2_LARGE": f"{lines['large']['value']:.0f}",
     "R2_SEG32_MS": f"{lines['seg32']['ms_per_step']:.1f}", "R2_SEG32": f"{lines['seg32']['value']:.0f}",
     "R2_SEG8_MS": f"{lines['seg8']['ms_per_step']:.1f}", "R2_SEG8": f"{lines['seg8']['value']:.0f}",
+    "R2_SEGST_MS": f"{lines['segst']['ms_per_step']:.1f}", "R2_SEGST": f"{lines['segst']['value']:.0f}",
     "R2_B16_MS": f"{lines['b16']['ms_per_step']:.2f}", "R2_B16": f"{lines['b16']['value']:.0f}",
     "R2_B32_MS": f"{lines['b32']['ms_per_step']:.2f}", "R2_B32": f"{lines['b32']['value']:.0f}",
     "R2_B128_MS": f"{lines['b128']['ms_per_step']:.2f}", "R2_B128": f"{lines['b128']['value']:.0f}",

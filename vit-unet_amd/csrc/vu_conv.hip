@@ -291,7 +291,9 @@ __device__ __forceinline__ uint4 shift_segment(const uint4 v, unsigned left, uns
   return kx == 0 ? a : (kx == 1 ? v : c);
 }
 
-template <int WAVES>
+// SAME: q, k and v come from one input (every transformer block; the skip connections have two): no second set of B
+// operands, and the registers that frees hold a third unit per trip.
+template <int WAVES, bool SAME>
 __global__ __launch_bounds__(WAVES * 64) void conv_wgrad_mm_kernel(const bf16_t* __restrict__ dq, const bf16_t* __restrict__ dk,
                                                             const bf16_t* __restrict__ dv, const bf16_t* __restrict__ xq,
                                                             const bf16_t* __restrict__ xkv, float* dwq, float* dwk, float* dwv,
@@ -300,7 +302,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv_wgrad_mm_kernel(const bf16_t*
   __shared__ float red[WAVES][2][2][256];   // [wave][q | kv][tap tile][C-layout element]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, lg = lane >> 4;
   const int ss = s * s, upp = ss >> 5;      // 32-pixel units per patch
-  const bool same = xq == xkv;
+  constexpr bool same = SAME;
   const bool edges = s > 8;
   // this lane's taps (B operand column l15 of tap tile 0 / 1)
   int tci[2], tky[2], tkx[2]; bool tv[2];
@@ -320,52 +322,91 @@ __global__ __launch_bounds__(WAVES * 64) void conv_wgrad_mm_kernel(const bf16_t*
   const uint4 z4 = make_uint4(0, 0, 0, 0);
   // one unit = 32 pixels of one patch; two units per trip so that twice the loads are in flight per wave (the loop is
   // bound by the latency of its dependent address -> load -> MFMA chain, not by bytes: 53 -> see DESIGN.md)
-  struct UnitRegs { uint4 a_q, a_kv, bq[2], bkv[2]; unsigned lq[2], rq[2], lkv[2], rkv[2]; };
-  auto load_unit = [&](long long uid, UnitRegs& u) {
-    const bool live = uid < nunits;
-    const long long uc = live ? uid : 0;
-    const long long patch = uc / upp;
-    const int un = (int)(uc - patch * upp);
-    const int px = (4 * un + lg) * 8;                 // first pixel of this lane group's segment
-    const int y = px / s, x0 = px - y * s;
-    const long long pbase = patch * (long long)(C * ss);
+  struct UnitRegs { uint4 a_q, a_kv, bq[2], bkv[2]; unsigned lq[2], rq[2], lkv[2], rkv[2]; unsigned lm, rm[2]; };     // raw loads + their masks
+  // unit -> (patch, pixel): shifts when the patch side is a power of two (8, 16, 32: every level of the presets), 32-bit
+  // unsigned divisions otherwise
+  const bool p2 = (s & (s - 1)) == 0;
+  const int ls = 31 - __builtin_clz((unsigned)s), lupp = 2 * ls - 5;
+  const unsigned nun = (unsigned)nunits;              // (launcher: nunits < 2^29)
+  // Branch-free: every lane loads from a clamped, always valid address and the result is masked (AND) where the window
+  // leaves the patch.  (The first version guarded each load with its own condition: ~20 exec-masked regions and 700
+  // instructions per trip.)  Rows / columns of the two products that are not outputs (A rows >= 3 / 6, taps >= 27)
+  // may hold anything finite: an MFMA output element depends on its own A row and B column only.
+  // Edge pixels of a segment (patches wider than 8): for s = 16 / 32 the neighbouring segment of the same image row
+  // is the one the adjacent lane group (lanes +-16) just loaded: two ds_bpermute instead of two 2-byte global loads.
+  const bool edge_shfl = s == 16 || s == 32;
+  const int lane_up = ((lane + 48) & 63) << 2, lane_dn = ((lane + 16) & 63) << 2;      // bpermute addresses: lane - 16, lane + 16
+  auto load_unit = [&](unsigned uid, UnitRegs& u) {
+    const bool live = uid < nun;
+    const unsigned uc = live ? uid : 0u;
+    unsigned patch, un;
+    if (p2) { patch = uc >> lupp; un = uc & ((1u << lupp) - 1u); }
+    else { patch = uc / (unsigned)upp; un = uc - patch * (unsigned)upp; }
+    const int px = (int)(4 * un + lg) * 8;            // first pixel of this lane group's segment
+    int y, x0;
+    if (p2) { y = px >> ls; x0 = px & (s - 1); }
+    else { y = (int)((unsigned)px / (unsigned)s); x0 = px - y * s; }
+    const long long pbase = (long long)patch * (C * ss);
     const int seg = y * s + x0;
-    u.a_q = z4; u.a_kv = z4;
-    if (live && l15 < 3) u.a_q = *reinterpret_cast<const uint4*>(aq + pbase + seg);
-    if (live && l15 < 6) u.a_kv = *reinterpret_cast<const uint4*>(akv + pbase + seg);
+    u.lm = live ? 0xffffffffu : 0u;                   // units past the end contribute zero through a zero A operand
+    u.a_q = *reinterpret_cast<const uint4*>(aq + pbase + seg);
+    u.a_kv = *reinterpret_cast<const uint4*>(akv + pbase + seg);
+    const bool has_l = x0 > 0, has_r = x0 + 8 < s;
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
       const int r = y + tky[tt] - 1;
-      const bool rv = live && tv[tt] && r >= 0 && r < s;
-      const long long off = pbase + tci[tt] * ss + r * s + x0;
-      u.bq[tt] = z4; u.bkv[tt] = z4;
-      u.lq[tt] = 0; u.rq[tt] = 0; u.lkv[tt] = 0; u.rkv[tt] = 0;
-      if (rv) {
-        u.bkv[tt] = *reinterpret_cast<const uint4*>(xkv + off);
-        if (!same) u.bq[tt] = *reinterpret_cast<const uint4*>(xq + off);
-        if (edges) {
-          if (x0 > 0) { u.lkv[tt] = __builtin_bit_cast(unsigned short, xkv[off - 1]); if (!same) u.lq[tt] = __builtin_bit_cast(unsigned short, xq[off - 1]); }
-          if (x0 + 8 < s) { u.rkv[tt] = __builtin_bit_cast(unsigned short, xkv[off + 8]); if (!same) u.rq[tt] = __builtin_bit_cast(unsigned short, xq[off + 8]); }
-        }
+      const unsigned rm = (r >= 0 && r < s) ? 0xffffffffu : 0u;       // zero padding above / below the patch
+      const int rc = min(max(r, 0), s - 1);
+      const long long off = pbase + tci[tt] * ss + rc * s + x0;
+      u.rm[tt] = rm;
+      u.bkv[tt] = *reinterpret_cast<const uint4*>(xkv + off);
+      u.lkv[tt] = 0; u.rkv[tt] = 0; u.lq[tt] = 0; u.rq[tt] = 0;
+      if (!same) u.bq[tt] = *reinterpret_cast<const uint4*>(xq + off);
+      if (edges && !edge_shfl) {      // other widths: edge pixels from memory (clamped inside the row, masked at use)
+        const unsigned short* ekv = reinterpret_cast<const unsigned short*>(xkv) + off;
+        const unsigned short* eq = reinterpret_cast<const unsigned short*>(xq) + off;
+        u.lkv[tt] = ekv[has_l ? -1 : 0]; u.rkv[tt] = ekv[has_r ? 8 : 7];
+        if (!same) { u.lq[tt] = eq[has_l ? -1 : 0]; u.rq[tt] = eq[has_r ? 8 : 7]; }
+        if (!has_l) { u.lkv[tt] = 0; u.lq[tt] = 0; }
+        if (!has_r) { u.rkv[tt] = 0; u.rq[tt] = 0; }
       }
     }
   };
+  // s = 16: a unit is two rows of two segments (lane groups 0,1 | 2,3); s = 32: one row of four
+  const bool sh_l = s == 32 ? lg > 0 : (lg & 1) != 0, sh_r = s == 32 ? lg < 3 : (lg & 1) == 0;
+  auto edge_l = [&](const uint4& v) { const unsigned w = (unsigned)__builtin_amdgcn_ds_bpermute(lane_up, (int)v.w) >> 16; return sh_l ? w : 0u; };
+  auto edge_r = [&](const uint4& v) { const unsigned w = (unsigned)__builtin_amdgcn_ds_bpermute(lane_dn, (int)v.x) & 0xffffu; return sh_r ? w : 0u; };
   auto mma_unit = [&](const UnitRegs& u) {
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
-      const uint4 skv = shift_segment(u.bkv[tt], u.lkv[tt], u.rkv[tt], tkx[tt]);
-      const uint4 sq = same ? skv : shift_segment(u.bq[tt], u.lq[tt], u.rq[tt], tkx[tt]);
-      accq[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, u.a_q), __builtin_bit_cast(bf16x8, sq), accq[tt], 0, 0, 0);
-      acckv[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, u.a_kv), __builtin_bit_cast(bf16x8, skv), acckv[tt], 0, 0, 0);
+      // masks and shuffles here, after every load of the trip has been issued (applied at the load they made hipcc wait
+      // for each load in turn)
+      const unsigned rm = u.rm[tt];
+      uint4 bkv = u.bkv[tt], bq = u.bq[tt];
+      bkv.x &= rm; bkv.y &= rm; bkv.z &= rm; bkv.w &= rm;
+      if (!same) { bq.x &= rm; bq.y &= rm; bq.z &= rm; bq.w &= rm; }
+      unsigned lkv = u.lkv[tt] & rm, rkv = u.rkv[tt] & rm, lq = u.lq[tt] & rm, rq = u.rq[tt] & rm;
+      if (edge_shfl) {
+        lkv = edge_l(bkv); rkv = edge_r(bkv);
+        if (!same) { lq = edge_l(bq); rq = edge_r(bq); }
+      }
+      const uint4 skv = shift_segment(bkv, lkv, rkv, tkx[tt]);
+      const uint4 sq = same ? skv : shift_segment(bq, lq, rq, tkx[tt]);
+      uint4 aq4 = u.a_q, akv4 = u.a_kv;
+      aq4.x &= u.lm; aq4.y &= u.lm; aq4.z &= u.lm; aq4.w &= u.lm;
+      akv4.x &= u.lm; akv4.y &= u.lm; akv4.z &= u.lm; akv4.w &= u.lm;
+      accq[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, aq4), __builtin_bit_cast(bf16x8, sq), accq[tt], 0, 0, 0);
+      acckv[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, akv4), __builtin_bit_cast(bf16x8, skv), acckv[tt], 0, 0, 0);
     }
   };
-  const long long stride = (long long)gridDim.x * WAVES;
-  for (long long uid = (long long)blockIdx.x * WAVES + wave; uid < nunits; uid += 2 * stride) {
-    UnitRegs u0, u1;
-    load_unit(uid, u0);
-    load_unit(uid + stride, u1);         // (zero operands past the end)
-    mma_unit(u0);
-    mma_unit(u1);
+  const unsigned stride = gridDim.x * WAVES;
+  constexpr int UPT = SAME ? 4 : 2;        // units per trip: all their loads are in flight before the first multiply
+  for (unsigned uid = blockIdx.x * WAVES + wave; uid < nun; uid += UPT * stride) {
+    UnitRegs u[UPT];
+#pragma unroll
+    for (int k = 0; k < UPT; ++k) load_unit(uid + k * stride, u[k]);         // (zero operands past the end)
+#pragma unroll
+    for (int k = 0; k < UPT; ++k) mma_unit(u[k]);
   }
   // C[row n = 4 lg + r][col = tap l15 (+16)]
 #pragma unroll
@@ -513,7 +554,8 @@ static int wgrad_launch(int dtype, int dout_f32, const WgradSet& set, int nconv,
     void* scr = nullptr; size_t scr_bytes = 0;
     vu_gemm_get_scratch(&scr, &scr_bytes);            // lent by the model executor: deterministic sum instead of float atomics
     float* part = (scr && scr_bytes >= (size_t)g * 1024 * 4) ? (float*)scr : nullptr;
-    hipLaunchKernelGGL(conv_wgrad_mm_kernel<WV>, dim3((unsigned)g), dim3(WV * 64), 0, st, (const bf16_t*)set.dout[0], (const bf16_t*)set.dout[1],
+    auto kern = set.in[0] == set.in[1] ? conv_wgrad_mm_kernel<WV, true> : conv_wgrad_mm_kernel<WV, false>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(WV * 64), 0, st, (const bf16_t*)set.dout[0], (const bf16_t*)set.dout[1],
                        (const bf16_t*)set.dout[2], (const bf16_t*)set.in[0], (const bf16_t*)set.in[1], set.dw[0], set.dw[1], set.dw[2], nunits, s, part);
     if (part) hipLaunchKernelGGL(conv_wgrad_mm_reduce_kernel, dim3(64), dim3(1024), 0, st, part, (int)g, set.dw[0], set.dw[1], set.dw[2]);
     if (vu_prof_on()) vu_prof_note("conv_wgrad_mm_kernel", 0.0, (double)nq * 4 * C * 5 * 2.0);
