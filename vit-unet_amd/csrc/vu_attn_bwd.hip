@@ -17,7 +17,8 @@ template <typename T, int H, int TPR>
 __global__ __launch_bounds__(256) void map_bwd_row_kernel(const T* __restrict__ Ps, T* dA, const float* __restrict__ W,
                                                           const float* __restrict__ c, const float* __restrict__ gamma,
                                                           const float* __restrict__ stats, float* dW, float* dc,
-                                                          long long rows, int N, int ld, float inv_keep, float scale) {
+                                                          long long rows, int N, int ld, float inv_keep, float scale,
+                                                          float* __restrict__ part) {
   constexpr int RPB = 256 / TPR;
   // W and the backward tables (written by bn_bwd_small_finalize_kernel) come through scalar loads
   const float* __restrict__ tX = stats + H * H + 5 * H;     // X[H*H], Xc[H], Gs[H]
@@ -84,6 +85,14 @@ __global__ __launch_bounds__(256) void map_bwd_row_kernel(const T* __restrict__ 
     if constexpr (TPR == 64) {
 #pragma unroll
       for (int h = 0; h < H; ++h) delta[h] = vu_wave_sum(delta[h]);
+    } else if constexpr (TPR == 16) {       // four rows per wave: sums over aligned 16-lane groups
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        float v = delta[h];
+#pragma unroll
+        for (int m = 1; m <= 8; m <<= 1) v += __shfl_xor(v, m, 64);
+        delta[h] = v;
+      }
     } else {
 #pragma unroll
       for (int h = 0; h < H; ++h) {
@@ -112,8 +121,33 @@ __global__ __launch_bounds__(256) void map_bwd_row_kernel(const T* __restrict__ 
   __syncthreads();
   for (int i = threadIdx.x; i < H * H + H; i += blockDim.x) {
     const float v = red[0][i] + red[1][i] + red[2][i] + red[3][i];
-    if (i < H * H) atomicAdd(dW + i, v); else atomicAdd(dc + (i - H * H), v);
+    if (part) part[(long long)blockIdx.x * (H * H + H) + i] = v;      // summed in block order by map_bwd_partials_reduce_kernel
+    else if (i < H * H) atomicAdd(dW + i, v); else atomicAdd(dc + (i - H * H), v);
   }
+}
+
+// Deterministic tail of the map-backward kernels: every workgroup leaves its h*h + h head-mix gradient sums in a slab of
+// the model workspace (vu_gemm_get_scratch) and one wave per output adds them in block order.  (The float atomics they
+// replace all hit the same 72 addresses at the end of the kernel, ~50 ns each when contended: 512 workgroups spent
+// half of the level-1 kernel's 52 us in that tail.)
+__global__ __launch_bounds__(1024) void map_bwd_partials_reduce_kernel(const float* __restrict__ part, int nblocks, int n, int hh,
+                                                                       float* dW, float* dc) {
+  const int i = blockIdx.x * 16 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= n) return;          // wave-uniform
+  float a = 0.f;
+  for (int b = lane; b < nblocks; b += 64) a += part[(long long)b * n + i];
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m, 64);
+  if (lane == 0) { if (i < hh) dW[i] += a; else dc[i - hh] += a; }
+}
+inline float* map_bwd_slab(long long nblocks, int n) {
+  void* scr = nullptr; size_t bytes = 0;
+  vu_gemm_get_scratch(&scr, &bytes);
+  return (scr && bytes >= (size_t)nblocks * n * sizeof(float)) ? (float*)scr : nullptr;
+}
+inline void map_bwd_reduce(float* part, long long nblocks, int H, float* dW, float* dc, hipStream_t st) {
+  const int n = H * H + H;
+  hipLaunchKernelGGL(map_bwd_partials_reduce_kernel, dim3((unsigned)((n + 15) / 16)), dim3(1024), 0, st, part, (int)nblocks, n, H * H, dW, dc);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -309,7 +343,7 @@ __global__ __launch_bounds__(256, 2) void map_bwd_mm_kernel(const bf16_t* __rest
                                                             const float* __restrict__ W, const float* __restrict__ c,
                                                             const float* __restrict__ gamma, const float* __restrict__ stats,
                                                             float* dW, float* dc, long long rows, int N, int ld,
-                                                            float inv_keep, float scale) {
+                                                            float inv_keep, float scale, float* __restrict__ part) {
   constexpr int H = 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __shared__ float redd[4][H];
@@ -529,7 +563,11 @@ __global__ __launch_bounds__(256, 2) void map_bwd_mm_kernel(const bf16_t* __rest
   {
     const int g = threadIdx.x / 16, hcol = threadIdx.x % 16;
     const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-    if (g < H && hcol < H) atomicAdd(dW + g * H + hcol, v * inv_keep);    // the P image holds kept p, not p/keep
+    if (part) {
+      if (g < H && hcol < H) part[(long long)blockIdx.x * (H * H + H) + g * H + hcol] = v * inv_keep;
+      else if (g < H && hcol == H) part[(long long)blockIdx.x * (H * H + H) + H * H + g] = v;
+    }
+    else if (g < H && hcol < H) atomicAdd(dW + g * H + hcol, v * inv_keep);    // the P image holds kept p, not p/keep
     else if (g < H && hcol == H) atomicAdd(dc + g, v);
   }
 }
@@ -927,9 +965,13 @@ int launch_map_bwd_mm(const void* Ps, void* dA, const float* W, const float* c, 
   }
   long long grid = WPR == 4 ? rows : (rows + 3) / 4;
   const long long cap = WPR == 4 ? 1024 : 512;     // (measured: 512 blocks of 4 one-wave rows beat 1024 at N = 196)
-  if (grid > cap) grid = cap;
+  static const int cap_env = getenv("VU_MAP_BWD_CAP") ? atoi(getenv("VU_MAP_BWD_CAP")) : 0;     // measurement switch
+  if (cap_env > 0 && WPR == 1) { if (grid > cap_env) grid = cap_env; }
+  else if (grid > cap) grid = cap;
+  float* part = map_bwd_slab(grid, 8);
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, (const bf16_t*)Ps, (bf16_t*)dA, W, c, gamma, stats, dW, dc,
-                     rows, N, ld, inv_keep, scale);
+                     rows, N, ld, inv_keep, scale, part);
+  if (part) map_bwd_reduce(part, grid, 8, dW, dc, st);
   if (vu_prof_on()) vu_prof_note(WPR == 4 ? "map_bwd_mm_kernel" : "map_bwd_mm_kernel<1 wave/row>", 0.0, (double)B * 8 * N * N * 3 * 2.0);
   return vu_check_launch("vu_map_bwd");
 }
@@ -956,10 +998,23 @@ int launch_map_bwd_row(const void* Ps, void* dA, const float* W, const float* c,
     if (ld <= 256 && ld >= 64 && !map_bwd_valu_forced())
       return launch_map_bwd_mm<1>(Ps, dA, W, c, gamma, stats, dW, dc, B, N, ld, inv_keep, scale, st);
   }
-  if (ld <= 256) {
+  if (ld <= 64) {
+    // short rows (level 0: N = 49): 16 threads per row, and few workgroups - every workgroup ends in h*h + h float atomics
+    // on the same addresses, ~50 ns each when contended (784 four-row workgroups took 57 us for 2.8 MB of map)
+    long long grid = (rows + 15) / 16;
+    float* part = map_bwd_slab(grid > 512 ? 512 : grid, H);
+    const long long cap = part ? 512 : 96;
+    if (grid > cap) grid = cap;
+    hipLaunchKernelGGL((map_bwd_row_kernel<T, H, 16>), dim3((unsigned)grid), dim3(256), 0, st, (const T*)Ps, (T*)dA, W, c, gamma,
+                       stats, dW, dc, rows, N, ld, inv_keep, scale, part);
+    if (part) map_bwd_reduce(part, grid, H, dW, dc, st);
+    if (vu_prof_on()) vu_prof_note("map_bwd_row_kernel", 0.0, (double)B * H * N * N * 3 * sizeof(T));
+  } else if (ld <= 256) {
     long long grid = (rows + 3) / 4; if (grid > 2048) grid = 2048;
+    float* part = map_bwd_slab(grid, H);
     hipLaunchKernelGGL((map_bwd_row_kernel<T, H, 64>), dim3((unsigned)grid), dim3(256), 0, st, (const T*)Ps, (T*)dA, W, c, gamma,
-                       stats, dW, dc, rows, N, ld, inv_keep, scale);
+                       stats, dW, dc, rows, N, ld, inv_keep, scale, part);
+    if (part) map_bwd_reduce(part, grid, H, dW, dc, st);
     if (vu_prof_on()) vu_prof_note("map_bwd_row_kernel", 0.0, (double)B * H * N * N * 3 * sizeof(T));
   } else if (sizeof(T) == 2 && (ld <= 1024 || (ld <= 4096 && H <= 4))) {
     // one block per row: 256 threads (ld <= 1024) or 1024 threads (ld <= 4096; 128-VGPR budget -> H <= 4)
@@ -983,7 +1038,7 @@ int launch_map_bwd_row(const void* Ps, void* dA, const float* W, const float* c,
   } else {
     long long grid = rows; if (grid > 2048) grid = 2048;
     hipLaunchKernelGGL((map_bwd_row_kernel<T, H, 256>), dim3((unsigned)grid), dim3(256), 0, st, (const T*)Ps, (T*)dA, W, c, gamma,
-                       stats, dW, dc, rows, N, ld, inv_keep, scale);
+                       stats, dW, dc, rows, N, ld, inv_keep, scale, (float*)nullptr);
     if (vu_prof_on()) vu_prof_note("map_bwd_row_kernel", 0.0, (double)B * H * N * N * 3 * sizeof(T));
   }
   return vu_check_launch("vu_map_bwd");
