@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(const TDO* __restrict__
 struct WgradSet { const void* dout[3]; const void* in[3]; float* dw[3]; float* dbias[3]; };
 
 template <typename TDO, typename TI, int C>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradSet set, long long nquads, int s) {
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradSet set, long long nquads, int s, float* __restrict__ part) {
   // blockIdx.y = conv * C + co: one output channel of one convolution per block (27 accumulators
   // for C = 3 instead of 81: twice the waves per SIMD; the input windows come from L1/L2)
   constexpr int NW = C * 9;
@@ -266,8 +266,28 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradSet set, long long
   __syncthreads();
   for (int i = threadIdx.x; i < NW + 1; i += blockDim.x) {
     const float v = red[0][i] + red[1][i] + red[2][i] + red[3][i];
-    if (i < NW) atomicAdd(dw + i, v);
+    if (part) part[((long long)blockIdx.y * gridDim.x + blockIdx.x) * 32 + i] = v;     // summed in block order below
+    else if (i < NW) atomicAdd(dw + i, v);
     else if (dbias) atomicAdd(dbias + co, v);
+  }
+}
+// deterministic tail of conv_wgrad_kernel (C = 3: 27 weights + 1 bias sum per (conv, output channel)): one wave per output
+// element adds the partials of the gridDim.x blocks in order.  (512 blocks per output channel spent ~25 us of the output
+// convolution's 51 us in contended float atomics.)
+template <int C>
+__global__ __launch_bounds__(1024) void conv_wgrad_reduce_kernel(WgradSet set, const float* __restrict__ part, int nblocks, int nconv) {
+  constexpr int NW = C * 9;
+  const int o = blockIdx.x * 16 + (threadIdx.x >> 6), lane = threadIdx.x & 63;       // o = (conv * C + co) * 32 + i
+  const int y = o >> 5, i = o & 31;
+  if (y >= nconv * C || i > NW) return;       // wave-uniform
+  float a = 0.f;
+  for (int b = lane; b < nblocks; b += 64) a += part[((long long)y * nblocks + b) * 32 + i];
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m, 64);
+  if (lane == 0) {
+    const int cv = y / C, co = y % C;
+    if (i < NW) set.dw[cv][co * NW + i] += a;
+    else if (set.dbias[cv]) set.dbias[cv][co] += a;
   }
 }
 
@@ -562,10 +582,17 @@ static int wgrad_launch(int dtype, int dout_f32, const WgradSet& set, int nconv,
     return vu_check_launch("vu_conv3x3_wgrad");
   }
   const int gx = grid_for(nq, nconv == 1 ? 512 : 256);
+  float* part = nullptr;
+  if (C == 3) {        // (the reduce kernel's 32-float rows hold 27 weights + the bias sum)
+    void* scr = nullptr; size_t scr_bytes = 0;
+    vu_gemm_get_scratch(&scr, &scr_bytes);            // lent by the model executor
+    if (scr && scr_bytes >= (size_t)gx * nconv * C * 32 * sizeof(float)) part = (float*)scr;
+  }
   VU_CONV_C(C,
-    if (dtype == 0) hipLaunchKernelGGL((conv_wgrad_kernel<float, float, CC>), dim3(gx, nconv * CC), dim3(256), 0, st, set, nq, s);
-    else if (dout_f32) hipLaunchKernelGGL((conv_wgrad_kernel<float, bf16_t, CC>), dim3(gx, nconv * CC), dim3(256), 0, st, set, nq, s);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, bf16_t, CC>), dim3(gx, nconv * CC), dim3(256), 0, st, set, nq, s);)
+    if (dtype == 0) hipLaunchKernelGGL((conv_wgrad_kernel<float, float, CC>), dim3(gx, nconv * CC), dim3(256), 0, st, set, nq, s, part);
+    else if (dout_f32) hipLaunchKernelGGL((conv_wgrad_kernel<float, bf16_t, CC>), dim3(gx, nconv * CC), dim3(256), 0, st, set, nq, s, part);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, bf16_t, CC>), dim3(gx, nconv * CC), dim3(256), 0, st, set, nq, s, part);)
+  if (part) hipLaunchKernelGGL(conv_wgrad_reduce_kernel<3>, dim3((unsigned)((nconv * 3 * 32 + 15) / 16)), dim3(1024), 0, st, set, part, gx, nconv);
   if (vu_prof_on()) vu_prof_note(nconv == 1 ? "conv_wgrad_kernel<1>" : "conv_wgrad_kernel<3>", 0.0,
                                  (double)nq * 4 * C * nconv * ((dout_f32 || dtype == 0 ? 4.0 : 2.0) + (dtype == 0 ? 4.0 : 2.0)));
   return vu_check_launch("vu_conv3x3_wgrad");
