@@ -60,6 +60,15 @@ __device__ __forceinline__ vu_f4 vu_ld4(const bf16_t* p) {
   r.v[3] = __uint_as_float(t.y & 0xffff0000u);
   return r;
 }
+// 8 consecutive elements (16-byte aligned for bf16): one 16-byte load instead of two 8-byte ones
+__device__ __forceinline__ void vu_ld8(const float* p, vu_f4& lo, vu_f4& hi) { lo = vu_ld4(p); hi = vu_ld4(p + 4); }
+__device__ __forceinline__ void vu_ld8(const bf16_t* p, vu_f4& lo, vu_f4& hi) {
+  const uint4 t = *reinterpret_cast<const uint4*>(p);
+  lo.v[0] = __uint_as_float(t.x << 16); lo.v[1] = __uint_as_float(t.x & 0xffff0000u);
+  lo.v[2] = __uint_as_float(t.y << 16); lo.v[3] = __uint_as_float(t.y & 0xffff0000u);
+  hi.v[0] = __uint_as_float(t.z << 16); hi.v[1] = __uint_as_float(t.z & 0xffff0000u);
+  hi.v[2] = __uint_as_float(t.w << 16); hi.v[3] = __uint_as_float(t.w & 0xffff0000u);
+}
 __device__ __forceinline__ void vu_st4(float* p, const vu_f4& a) {
   *reinterpret_cast<float4*>(p) = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]);
 }

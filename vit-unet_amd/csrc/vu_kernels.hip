@@ -775,8 +775,12 @@ __global__ __launch_bounds__(256) void ln_bwd_stats_kernel(const T* __restrict__
       const int b = bb + 8 * k;
       const long long o = (long long)b * P + e;
       const bool v0 = ok0 && b < B, v1 = ok1 && b < B;
-      d0[k] = v0 ? vu_ld4(dy + o) : zero; z0[k] = v0 ? vu_ld4(z + o) : zero;
-      d1[k] = v1 ? vu_ld4(dy + o + 4) : zero; z1[k] = v1 ? vu_ld4(z + o + 4) : zero;
+      if (v0 && v1 && (P & 7) == 0) {        // whole 8-element chunk, 16-byte aligned rows: one load per operand
+        vu_ld8(dy + o, d0[k], d1[k]); vu_ld8(z + o, z0[k], z1[k]);
+      } else {
+        d0[k] = v0 ? vu_ld4(dy + o) : zero; z0[k] = v0 ? vu_ld4(z + o) : zero;
+        d1[k] = v1 ? vu_ld4(dy + o + 4) : zero; z1[k] = v1 ? vu_ld4(z + o + 4) : zero;
+      }
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
