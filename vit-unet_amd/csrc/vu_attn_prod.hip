@@ -156,7 +156,7 @@ constexpr int mp_ch(int tt) { return tt <= 2 ? 832 : 256; }     // tokens per st
 template <int WAVES, int TT, bool CHUNKED>
 __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4, 8))) void attn_map_rows_kernel(const bf16_t* __restrict__ M, const bf16_t* __restrict__ X,
                                                                  bf16_t* __restrict__ out, const float* __restrict__ sc, const float* __restrict__ kappa,
-                                                                 int N, int D, int H, int d, int ld) {
+                                                                 int N, int D, int H, int d, int ld, int mdiv) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr bool NAT = mp_natural(TT);
   constexpr int P = mp_pitch(TT);
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4, 8
   // out = sc_g (Ac . X) + kappa_g * (column sums of X over the tokens), the sums taken from the staged slice
   __shared__ float colsum_s[16 * TT];
   float a_sc = 1.f, a_kp = 0.f;
-  if (sc) { a_sc = sc[g]; a_kp = kappa[g]; }
+  if (sc) { a_sc = sc[g / mdiv]; a_kp = kappa[g / mdiv]; }
   if (tid < 16 * TT) colsum_s[tid] = 0.f;
   auto stage = [&](int n0) {       // tokens [n0, n0 + ldk) of the slice -> Xt, column sums accumulated (affine form)
     if constexpr (NAT) {
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4, 8
       __syncthreads();
     }
   };
-  const bf16_t* Mb = M + (long long)bz * N * ld;
+  const bf16_t* Mb = M + (long long)(bz / mdiv) * N * ld;      // (wide heads: mdiv slices of 96 features share the head's map)
   const int nrt = (N + 15) >> 4;
   const bool vec = (d % 4 == 0) && (D % 4 == 0);
   const int lrow = lane >> 3, lch = (lane & 7) * 8;                        // load shape: 8 rows x 8 chunks of 16 B
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4, 8
 template <int WAVES, int TT, bool CHUNKED>
 __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 8))) void attn_map_cols_kernel(const bf16_t* __restrict__ M, const bf16_t* __restrict__ X,
                                                                  bf16_t* __restrict__ out, const float* __restrict__ sc, const float* __restrict__ kappa,
-                                                                 int N, int D, int H, int d, int ld) {
+                                                                 int N, int D, int H, int d, int ld, int mdiv) {
   typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
   typedef __attribute__((ext_vector_type(8))) short s16x8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 8
   // affine form: see the rows kernel
   __shared__ float colsum_s[16 * TT];
   float a_sc = 1.f, a_kp = 0.f;
-  if (sc) { a_sc = sc[g]; a_kp = kappa[g]; }
+  if (sc) { a_sc = sc[g / mdiv]; a_kp = kappa[g / mdiv]; }
   if (tid < 16 * TT) colsum_s[tid] = 0.f;
   auto stage = [&](int n0) {
     if constexpr (NAT) {
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 8
       __syncthreads();
     }
   };
-  const bf16_t* Mb = M + (long long)bz * N * ld;
+  const bf16_t* Mb = M + (long long)(bz / mdiv) * N * ld;      // (wide heads: mdiv slices of 96 features share the head's map)
   const bool vec = (d % 4 == 0) && (D % 4 == 0);
   const int lrow = lane >> 3, lch = (lane & 7) * 8;
   const int nstrips = (N + 63) >> 6;
@@ -463,7 +463,7 @@ constexpr size_t mp_image_bytes(int tt, int ldk) {
 }
 template <bool COLS, int WAVES, int TT, bool CHUNKED>
 int launch_map_prod_w(const void* M, const void* X, void* out, const float* sc, const float* kappa, int B, int N, int D, int H, int ld,
-                      int nsplit, hipStream_t st) {
+                      int nsplit, int mdiv, hipStream_t st) {
   const int d = D / H;
   const int ldk = CHUNKED ? mp_ch(TT) : ((N + 63) & ~63);
   const size_t lds = mp_image_bytes(TT, ldk) + (size_t)WAVES * (COLS ? 32 : 16) * MP_LDT * 2;
@@ -473,7 +473,7 @@ int launch_map_prod_w(const void* M, const void* X, void* out, const float* sc, 
     if (e != hipSuccess) { vu_set_error("attn_map_prod: cannot reserve %zu bytes of LDS", lds); return VU_ELAUNCH; }
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)nsplit, (unsigned)(B * H)), dim3(WAVES * 64), lds, st, (const bf16_t*)M,
-                     (const bf16_t*)X, (bf16_t*)out, sc, kappa, N, D, H, d, ld);
+                     (const bf16_t*)X, (bf16_t*)out, sc, kappa, N, D, H, d, ld, mdiv);
   if (vu_prof_on()) vu_prof_note(COLS ? "attn_map_cols_kernel" : "attn_map_rows_kernel", 2.0 * B * H * (double)N * N * d,
                                  ((double)B * H * N * ld + 2.0 * B * N * D) * 2.0);
   return vu_check_launch("vu_attn_map_prod");
@@ -481,11 +481,11 @@ int launch_map_prod_w(const void* M, const void* X, void* out, const float* sc, 
 
 template <bool COLS, int TT>
 int launch_map_prod(const void* M, const void* X, void* out, const float* sc, const float* kappa, int B, int N, int D, int H, int ld,
-                    hipStream_t st) {
+                    int mdiv, hipStream_t st) {
   const int units = COLS ? (N + 63) / 64 : (N + 15) / 16;       // strips / row tiles per (sample, head)
   if (mp_image_bytes(TT, (N + 63) & ~63) + 8 * 32 * MP_LDT * 2 > 150 * 1024) {
     // the head slice does not fit one LDS image: chunked form, one unit per wave, 7 waves per workgroup
-    return launch_map_prod_w<COLS, 7, TT, true>(M, X, out, sc, kappa, B, N, D, H, ld, (units + 6) / 7, st);
+    return launch_map_prod_w<COLS, 7, TT, true>(M, X, out, sc, kappa, B, N, D, H, ld, (units + 6) / 7, mdiv, st);
   }
   // waves per workgroup: as many as there are units, in whole rounds where possible
   const int waves = units <= 4 ? 4 : ((units % 7 == 0 || (units > 8 && units <= 14)) ? 7 : 8);
@@ -493,9 +493,9 @@ int launch_map_prod(const void* M, const void* X, void* out, const float* sc, co
   const int maxsplit = (units + waves - 1) / waves;
   if (nsplit > maxsplit) nsplit = maxsplit;
   if (nsplit < 1) nsplit = 1;
-  if (waves == 4) return launch_map_prod_w<COLS, 4, TT, false>(M, X, out, sc, kappa, B, N, D, H, ld, nsplit, st);
-  if (waves == 7) return launch_map_prod_w<COLS, 7, TT, false>(M, X, out, sc, kappa, B, N, D, H, ld, nsplit, st);
-  return launch_map_prod_w<COLS, 8, TT, false>(M, X, out, sc, kappa, B, N, D, H, ld, nsplit, st);
+  if (waves == 4) return launch_map_prod_w<COLS, 4, TT, false>(M, X, out, sc, kappa, B, N, D, H, ld, nsplit, mdiv, st);
+  if (waves == 7) return launch_map_prod_w<COLS, 7, TT, false>(M, X, out, sc, kappa, B, N, D, H, ld, nsplit, mdiv, st);
+  return launch_map_prod_w<COLS, 8, TT, false>(M, X, out, sc, kappa, B, N, D, H, ld, nsplit, mdiv, st);
 }
 
 }  // namespace
@@ -504,8 +504,16 @@ int launch_map_prod(const void* M, const void* X, void* out, const float* sc, co
 int vu_k_attn_map_prod(int dtype, int cols, const void* M, const void* X, void* out, const float* sc, const float* kappa,
                        int B, int N, int D, int H, int ld, hipStream_t st) {
   const int d = D / H;
-  if (dtype != 1 || d > 96 || N < 64 || ld % 8 != 0) return 1;
-  const int tt = d <= 32 ? 2 : 6;
-  if (tt == 2) return cols ? launch_map_prod<true, 2>(M, X, out, sc, kappa, B, N, D, H, ld, st) : launch_map_prod<false, 2>(M, X, out, sc, kappa, B, N, D, H, ld, st);
-  return cols ? launch_map_prod<true, 6>(M, X, out, sc, kappa, B, N, D, H, ld, st) : launch_map_prod<false, 6>(M, X, out, sc, kappa, B, N, D, H, ld, st);
+  if (dtype != 1 || N < 32 || ld % 8 != 0) return 1;
+  // heads wider than 96 features (level 0: d = 384; Lite level 0: d = 192) run as d / 96 slices of 96 that share the head's
+  // map: to the kernels a slice is a head of its own (H * mdiv heads of 96), only the map index is divided by mdiv
+  int mdiv = 1, Hk = H;
+  if (d > 96) {
+    if (d % 96 != 0 || N > 256) return 1;
+    mdiv = d / 96; Hk = H * mdiv;
+  }
+  const int dk = d / mdiv;
+  const int tt = dk <= 32 ? 2 : 6;
+  if (tt == 2) return cols ? launch_map_prod<true, 2>(M, X, out, sc, kappa, B, N, D, Hk, ld, mdiv, st) : launch_map_prod<false, 2>(M, X, out, sc, kappa, B, N, D, Hk, ld, mdiv, st);
+  return cols ? launch_map_prod<true, 6>(M, X, out, sc, kappa, B, N, D, Hk, ld, mdiv, st) : launch_map_prod<false, 6>(M, X, out, sc, kappa, B, N, D, Hk, ld, mdiv, st);
 }
