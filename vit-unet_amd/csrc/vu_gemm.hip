@@ -88,6 +88,12 @@ static int launch_tiles(const vu_gemm_args& g, hipStream_t st) {
     }
     return launch_one<T, TC, TA, TB, 64, 64>(g, st);
   }
+  // between one and ~1.5 big tiles per CU (the level-0 / level-1 linears at 16 - 32 images per GPU: 150 - 312 tiles): half-width
+  // tiles balance the chip (measured: M1568 N3072 K3072 107 -> 85 us, M3136 N768 K768 26 -> 20 us; tools/gemm_small_batch.py)
+  if constexpr (sizeof(T) == 2) {
+    static const int half_below = getenv("VU_GEMM_HALF_BELOW") ? atoi(getenv("VU_GEMM_HALF_BELOW")) : 400;      // measurement switch
+    if ((long long)vu_cdiv(g.M, 128) * vu_cdiv(g.N, 128) * g.Z1 * g.Z2 < half_below && g.N >= 128) return launch_one<T, TC, TA, TB, 128, 64>(g, st);
+  }
   return launch_one<T, TC, TA, TB, 128, 128>(g, st);
 }
 
