@@ -1,3 +1,5 @@
+"""GEMM shapes of the 16 / 32-images-per-GPU steps (BASELINE configs 3-4) under the tile-selection switches:
+   python tools/gemm_small_batch.py ; VU_GEMM_TILE=12864 ... ; VU_GEMM_QUARTER_BELOW=100 ... ; VU_GEMM_HALF_BELOW=0 ..."""
 import sys, os, torch
 sys.path.insert(0, "/root/repo/vit-unet_amd")
 from vit_unet.torch import _lib
