@@ -89,7 +89,7 @@ __device__ __forceinline__ void quad_coords(long long qid, int s, long long& pat
 // ---- forward ---------------------------------------------------------------------------------
 // NOUT = 1: out0 = conv(in0, w0) (+bias)      NOUT = 3: q = conv(in0,w0), k = conv(in1,w1), v = conv(in1,w2)
 template <typename TI, typename TO, int C, int NOUT, int SH = 0>
-__global__ __launch_bounds__(256) void conv_fwd_kernel(const TI* __restrict__ in0, const TI* __restrict__ in1,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((SH == 1 && NOUT == 3) ? 4 : 1, 8))) void conv_fwd_kernel(const TI* __restrict__ in0, const TI* __restrict__ in1,
                                                        const float* __restrict__ w0, const float* __restrict__ w1,
                                                        const float* __restrict__ w2, const float* __restrict__ bias,
                                                        TO* __restrict__ o0, TO* __restrict__ o1, TO* __restrict__ o2,
