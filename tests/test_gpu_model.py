@@ -374,51 +374,20 @@ def test_image_fitter_fit_checkpoints_and_callbacks(tmp_path):
     assert f2._fused is None and h2[-1]["train"] < h2[0]["train"] * 1.05
 
 
-def test_dp_path_one_rank_rccl_matches_single_gpu_step(golden_dir, monkeypatch):
-    """The data-parallel choreography (NCCL process group, three bucketed all-reduces on the side stream, 1/world
-    folded into AdamW) on ONE rank (VU_DP_FORCE=1) must reproduce the plain single-GPU fused step."""
-    import socket
-    import torch.distributed as dist
-    man, g = load_case(golden_dir, "tiny_c")
-    kw = dict(man["cases"]["tiny_c"]["config"], attn_drop=0.2, proj_drop=0.2, linear_drop=0.0)
-    w = O.make_weights(O.Config(**kw), seed=7)
-    x, y = torch.from_numpy(g["x"]).to(DEV), torch.from_numpy(g["y"]).to(DEV)
-    ma, mb = build(kw, w).train(), build(kw, w).train()
-    ta = TrainStep(ma, lr=1e-3, seed=5)
-    assert not ta.dp
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    monkeypatch.setenv("VU_DP_FORCE", "1")
-    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
-                            device_id=torch.device("cuda", torch.cuda.current_device()))
-    try:
-        tb = TrainStep(mb, lr=1e-3, seed=5, bucket_mb=0)      # cap 0: one bucket (and one all-reduce) per backward unit
-        assert tb.dp and tb.world == 1 and tb.comm_stream is not None and len(tb._ubuckets) >= 4
-        for _ in range(2):
-            la, lb = ta.step(x, y).item(), tb.step(x, y).item()
-            assert abs(la - lb) < 1e-4 * abs(la)
-        torch.cuda.synchronize()
-        for (k, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
-            if k.endswith("reatten_matrix.bias"):
-                continue
-            assert serr(pa, pb) < 1e-4, k
-        # per-bucket hipGraphs with the collectives between the graph launches == the eager single-GPU step (fresh models:
-        # the comparison is made on the first steps, before Adam has amplified float-atomic noise)
-        mc, md = build(kw, w).train(), build(kw, w).train()
-        tc, td = TrainStep(mc, lr=1e-3, seed=5), TrainStep(md, lr=1e-3, seed=5, bucket_mb=0)
-        td.capture_dp(x, y)                                    # performs one real (eager) warm-up step
-        tc.step(x, y)
-        for _ in range(2):
-            lc, ld = tc.step(x, y).item(), td.replay(x, y).item()
-            assert abs(lc - ld) < 2e-4 * abs(lc), (lc, ld)
-        torch.cuda.synchronize()
-        for (k, pc), (_, pd_) in zip(mc.named_parameters(), md.named_parameters()):
-            if not k.endswith("reatten_matrix.bias"):
-                assert serr(pc, pd_) < 2e-4, k
-    finally:
-        torch.cuda.synchronize()
-        dist.destroy_process_group()
+def test_dp_path_one_rank_rccl_matches_single_gpu_step(golden_dir):
+    """The data-parallel choreography (NCCL process group, bucketed all-reduces on the side stream, 1/world folded into
+    AdamW, per-bucket hipGraphs) on ONE rank over RCCL (VU_DP_FORCE=1) must reproduce the plain single-GPU fused step.
+    Runs in a child process (tests/dp_one_rank_worker.py): tearing an RCCL process group down inside a long-lived pytest
+    process aborted intermittently in destroy_process_group (its watchdog thread against captured graphs that still hold
+    the communicator's stream); the worker reports and leaves with os._exit, so no teardown runs at all."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", VU_DP_FORCE="1")
+    r = subprocess.run([sys.executable, os.path.join(here, "dp_one_rank_worker.py"), golden_dir],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert "DP_ONE_RANK_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_two_rank_data_parallel_rehearsal():
