@@ -8,7 +8,8 @@ AdamW) on N MI355X GPUs of one node, the metric BASELINE.json names.
 
 One process per GPU (RANK / LOCAL_RANK / WORLD_SIZE from the environment), data parallel over
 RCCL: every rank holds `--batch` images (weak scaling), gradients of the flat arena are summed in
-three buckets overlapped with the backward.  Inputs are synthetic and resident in HBM before the
+buckets of at most 48 MB cut at backward-unit boundaries in reverse execution order, each all-reduced
+on a side stream while the backward goes on (engine.dp_unit_buckets).  Inputs are synthetic and resident in HBM before the
 timed region.  Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline     - the dominant kernel of the step, timed live with HIP events behind every launch
                  (vu_prof_enable) over extra instrumented steps; achieved = algorithmic flops (or
@@ -101,6 +102,47 @@ def cpu_baseline(model_name: str, threads: int):
             "s_per_step": best}
 
 
+def eval_parity(model_name: str, dtype, B: int = 2, operands: str = "storage"):
+    """error of the GPU forward against the CPU oracle (fp32) on the synthetic batch, and what it
+    does to the metric the reference reports (functions.py:7-19 PSNR; README.md:91-101 Dice for the segmentation shape).
+    Eval mode (running statistics), the oracle's deterministic weights (make_weights: every tensor non-trivial, running
+    variances ~1e-4 as after training), full-size model.  The oracle is the checker here, nothing is timed."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import vit_unet_oracle as O
+    from vit_unet.torch import model as M
+    seg = model_name == "seg512"
+    if seg:
+        kw = dict(O.PRESETS["base"], im_size=512, num_channels=1)
+    else:
+        kw = dict(O.PRESETS[model_name])
+    cfg = O.Config(**kw)
+    w = O.make_weights(cfg, seed=0)
+    if seg:
+        g = torch.Generator().manual_seed(4321)
+        x = torch.rand(B, 1, 512, 512, generator=g)
+        y = (torch.rand(B, 1, 512, 512, generator=g) < 0.1).float()
+    else:
+        x, y = O.make_batch(cfg, B=B, seed=1234)
+    m = M.HViT_UNet(dtype=dtype, attn_operands=operands, **kw)
+    m.load_state_dict({k: v.clone().float() for k, v in w.items()})
+    m = m.to("cuda").eval()
+    with torch.no_grad():
+        got = m(x.to("cuda")).float().cpu()
+        ref = O.forward(w, cfg, x, training=False)
+    err = (got - ref).abs()
+    out = {"model": model_name, "B": B, "dtype": str(dtype).replace("torch.", ""), "mode": "eval forward vs fp32 CPU oracle",
+           "max_abs": err.max().item(), "max_rel": (err.max() / ref.abs().max()).item(),
+           "rms_rel": (err.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()}
+    if seg:
+        dg, dr = O.dice_loss(torch.sigmoid(got), y).item(), O.dice_loss(torch.sigmoid(ref), y).item()
+        out.update({"dice_gpu": dg, "dice_oracle": dr, "ddice": dg - dr})
+    else:
+        pg, pr = O.psnr(y, got), O.psnr(y, ref)
+        out.update({"psnr_gpu": pg.mean().item(), "psnr_oracle": pr.mean().item(), "dpsnr": (pg - pr).abs().max().item()})
+    del m
+    return out
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -177,6 +219,23 @@ def main():
     loss = float(ts.loss.item())
     images = a.batch * world * a.steps
     value = images / dt_s
+    # a short contract run (the driver's --steps 20 is 0.3 s of GPU work) says little about clocks and thermals: when the
+    # timed region was under 2 s, a second, longer region of the same step is timed and reported beside it (`sustained`;
+    # `value` / `steps` stay the contract's K steps)
+    sustained = None
+    if dt_s < 2.0:
+        n2 = int(min(2000, max(a.steps, 2.2 / (dt_s / a.steps))))
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(n2):
+            step()
+        fence()
+        d2 = time.perf_counter() - t1
+        if dp:
+            t = torch.tensor([d2], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            d2 = t.item()
+        sustained = {"steps": n2, "ms_per_step": d2 / n2 * 1e3, "value": a.batch * world * n2 / d2, "wall_s": d2}
 
     # PCIe-inclusive rates (never `value`): the same step fed from pinned host memory, (a) as the float32
     # CHW batch ImageFitter.unpack moves (dataset.py:78-91), (b) as decoded uint8 HWC images that the
@@ -268,9 +327,11 @@ def main():
                                   "TFLOPs": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["flops"] else None,
                                   "GBs": (v["bytes"] / (v["ms"] * 1e-3) / 1e9) if v["bytes"] else None}
                                  for k, v in top[:8]]})
-    cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline and not seg:
-        cpu = cpu_baseline(a.model, host_cores())
+    cpu, parity = None, None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        parity = eval_parity(a.model, dt, B=1 if seg else 2, operands=operands)
+        if not seg:
+            cpu = cpu_baseline(a.model, host_cores())
 
     if rank == 0:
         shape, lossn = ("512x512x1", "Dice(sigmoid)") if seg else ("224x224x3", "MSELoss")
@@ -285,7 +346,7 @@ def main():
                                                                 "SIDD-style 224x224x3 noisy/clean pairs") + ", random-init weights",
                           "per_gpu_batch": a.batch, "global_batch": a.batch * world, "parallelism": f"dp{world}", "rccl_path": dp,
                           "hip_graph": use_graph, "attn_operands": operands, "final_loss": loss},
-               "roofline": roof, "cpu_baseline": cpu, "host_input": host_in}
+               "roofline": roof, "cpu_baseline": cpu, "parity": parity, "host_input": host_in, "sustained": sustained}
         print(json.dumps(out), flush=True)
     if dp:
         # Leave without tearing the RCCL process group down: destroy_process_group() aborted intermittently in the GPU test

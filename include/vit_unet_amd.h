@@ -35,7 +35,8 @@ extern "C" {
 #define VU_EWORKSPACE (-3)
 #define VU_ELAUNCH (-4)
 
-int vu_version(void);
+int vu_version(void);      /* 200 = this header; bumped whenever a struct or a signature changes */
+int vu_config_size(void);  /* sizeof(vu_config) as the library was built: a binding compares it with its own struct before any call */
 const char* vu_last_error(void);
 
 /* HViT_UNet constructor arguments (model.py:264-299). */
@@ -230,6 +231,15 @@ size_t vu_seg_prepare_scratch_bytes(int B, int oh, int ow);
 int vu_seg_prepare(const int16_t* image, const uint8_t* mask, float* x, float* y, uint8_t* scratch,
                    size_t scratch_bytes, const double* inv_affine, int B, int Hs, int Ws, int oh,
                    int ow, float lo, float hi, float ls, void* stream);
+
+/* Which form the re-attention runs in: PROCESS-GLOBAL test / experiment setting (the two forms draw different dropout
+ * masks, so a forward and its backward - and a workspace carved for them - must see the same value: set it between
+ * steps, never between a forward and its backward).
+ *   flash    -1: model path per level by the fill rule (recompute form when the launch fills the chip), stand-alone
+ *                op materialised (default);  0: never the recompute form;  1: the recompute form wherever covered
+ *   centered  1: the stand-alone op uses the model path's centred-map form when the map itself is not asked for
+ * Initial values: the environment variables VU_ATTN_FLASH (0 / 1) and VU_ATTN_CENTERED, read once. */
+int vu_set_attn_form(int flash, int centered);
 
 /* In-process launch profiler (bench.py's roofline leg): PROCESS-GLOBAL state, meant for one
  * instrumented stream at a time.  After vu_prof_enable(stream) an event is

@@ -180,7 +180,7 @@ def _quad_word(x: np.ndarray, k0: int, k1: int) -> np.ndarray:
 
 def quad_threshold(p: float) -> int:
     """8-bit drop threshold of the quad scheme: the drop probability is quad_threshold(p) / 256."""
-    return max(1, (int(p * 65536.0 + 0.5) + 128) >> 8)
+    return min(255, max(1, (int(p * 65536.0 + 0.5) + 128) >> 8))
 
 
 _QUAD_HEAD_MUL = (0x1E3779, 0x35297B, 0x68E31D, 0x7FEB35, 0x42B2AF, 0x65EBCB, 0x27D4EB, 0x165667)      # odd, below 2^23 (one v_mad_u32_u24 each)

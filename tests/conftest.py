@@ -18,3 +18,14 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture
+def attn_form():
+    """Set the process-level re-attention form for one test (vu_set_attn_form) and restore the default afterwards."""
+    from vit_unet.torch import _lib
+
+    def setter(flash=-1, centered=0):
+        _lib.set_attn_form(flash, centered)
+    yield setter
+    _lib.set_attn_form(-1, 0)

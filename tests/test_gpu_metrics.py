@@ -141,18 +141,21 @@ def test_train_step_dice_matches_autograd_path():
         TrainStep(build(), loss="l1")
 
 
-def test_seg512_bf16_dice_train_step_runs_and_learns():
-    """BASELINE config 5 shape on one GPU (Base ctor at 512x512x1, Dice loss, bf16 storage; the fp8
-    attention operands that config names are not implemented - DESIGN.md section 7): a few fused steps
-    run, the loss is finite and decreases on a fixed batch."""
+@pytest.mark.parametrize("operands,drop", [("e4m3", 0.2), ("storage", 0.0)])
+def test_seg512_bf16_dice_train_step_runs_and_learns(operands, drop):
+    """BASELINE config 5 on one GPU: Base ctor at 512x512x1, Dice loss on the sigmoid head, bf16 storage; as written
+    (q, k, v rounded to OCP e4m3 = fp8 attention operands, dropout 0.2 / 0.2 as the Base preset has it) and with storage
+    operands, dropout off.  A few fused steps run, the loss is finite and comes down on a fixed batch.  (Parity of this
+    configuration is stated block by block: test_gpu_parity_full.py::test_teacher_forced_*[seg512].)"""
     m = M.HViT_UNet(depth=2, depth_te=2, size_bottleneck=2, preprocessing="conv", im_size=512, patch_size=32,
-                    num_channels=1, hidden_dim=128, num_heads=8, attn_drop=0.0, proj_drop=0.0, linear_drop=0.0,
-                    dtype=torch.bfloat16).to(DEV).train()
+                    num_channels=1, hidden_dim=128, num_heads=8, attn_drop=drop, proj_drop=drop, linear_drop=0.0,
+                    dtype=torch.bfloat16, attn_operands=operands).to(DEV).train()
     g = torch.Generator().manual_seed(4321)
     B = 4
     x = torch.rand(B, 1, 512, 512, generator=g).to(DEV)
     y = (torch.rand(B, 1, 512, 512, generator=g) < 0.1).float().to(DEV)
-    ts = TrainStep(m, lr=1e-3, loss="dice")
-    losses = [ts.step(x, y).item() for _ in range(8)]
+    ts = TrainStep(m, lr=1e-3, loss="dice", seed=7)
+    losses = [ts.step(x, y).item() for _ in range(10)]
+    print(f"seg512 {operands} drop {drop}: dice losses {np.round(losses, 4).tolist()}")
     assert all(np.isfinite(losses)), losses
-    assert 0.0 < min(losses[-3:]) < losses[0], losses      # (dropout off: the fixed batch's loss must come down)
+    assert 0.0 < min(losses[-4:]) < losses[0], losses      # the fixed batch's loss must come down

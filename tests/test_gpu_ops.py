@@ -203,32 +203,34 @@ def test_attention_fwd_bwd(dt, N, Cn, s, H, mode, cross):
 
 @pytest.mark.parametrize("N,Cn,s,H", [(784, 3, 8, 8), (289, 3, 8, 8)])
 @pytest.mark.parametrize("mode", ["train", "train_drop"])
-def test_attention_centred_map_form(N, Cn, s, H, mode, monkeypatch):
+def test_attention_centred_map_form(N, Cn, s, H, mode, attn_form):
     """The model path's centred-map form (mix + statistics in one pass, BatchNorm's affine part inside the PV / dv
-    products) against the same oracle and tolerances as the plain form; VU_ATTN_CENTERED switches the stand-alone op."""
-    monkeypatch.setenv("VU_ATTN_CENTERED", "1")
-    monkeypatch.setenv("VU_ATTN_FLASH", "0")       # (N = 784 would otherwise take the non-materialising form)
+    products) against the same oracle and tolerances as the plain form; vu_set_attn_form(centered=1) switches the stand-alone op."""
+    attn_form(flash=0, centered=1)       # (N = 784 would otherwise take the non-materialising form)
     _attention_fwd_bwd(torch.bfloat16, N, Cn, s, H, mode, False, centered=True)
 
 
-@pytest.mark.parametrize("N,Cn,s,H", [(784, 3, 8, 8), (1024, 1, 8, 8), (1024, 1, 16, 8), (256, 2, 8, 4), (272, 3, 8, 8)])
+@pytest.mark.parametrize("N,Cn,s,H", [(784, 3, 8, 8), (1024, 1, 8, 8), (1024, 1, 16, 8), (256, 2, 8, 4), (272, 3, 8, 8), (4096, 1, 8, 8)])
 @pytest.mark.parametrize("mode", ["eval", "train", "train_drop"])
 @pytest.mark.parametrize("cross", [False, True])
-def test_attention_flash_form(N, Cn, s, H, mode, cross, monkeypatch):
+def test_attention_flash_form(N, Cn, s, H, mode, cross, attn_form):
     """The non-materialising form (csrc/vu_flash.hip: no (B,h,N,N) map in HBM, everything recomputed per pass from
-    q, k, v) against the same oracle and tolerances as the materialised forms; VU_ATTN_FLASH switches the stand-alone op.
+    q, k, v) against the same oracle and tolerances as the materialised forms; vu_set_attn_form(flash=1) switches the stand-alone op.
     Shapes: Base / Large level 2 (N = 784, d = 24), the 512x512 levels (d = 8, d = 32), 4 heads, an odd tile count."""
-    monkeypatch.setenv("VU_ATTN_FLASH", "1")
+    attn_form(flash=1)
     if cross and N != 784:
         pytest.skip("cross inputs: one shape")
-    _attention_fwd_bwd(torch.bfloat16, N, Cn, s, H, mode, cross, centered=True, flash=True)
+    if N == 4096 and mode != "eval":
+        pytest.skip("N = 4096 train / train_drop: test_attention_e4m3_operands")
+    # eval mode (running statistics: flash_rowstats -> finalize(training = 0) -> apply; the backward takes the separate
+    # delta and dq sweeps because no moments sweep wrote sum_k P k) runs at every shape, forward AND backward
+    _attention_fwd_bwd(torch.bfloat16, N, Cn, s, H, mode, cross, centered=True, flash=True, B=1 if N == 4096 else 2)
 
 
 def _attention_fwd_bwd(dt, N, Cn, s, H, mode, cross, centered, flash=False, operands="storage", B=2):
-    if dt == torch.bfloat16 and mode == "eval" and not flash:
-        pytest.skip("eval with tiny running_var amplifies bf16 rounding by 100x; covered in fp32")
-    if N * Cn * s * s > 50000 and (mode == "eval" or cross):
-        pytest.skip("full-size levels: train / train_drop self-attention only (CPU oracle time)")
+    heavy = B * H * N * N > 2.5e7 and not (flash and mode == "eval")      # (the oracle's autograd keeps ~10 maps: CPU time / memory)
+    if (heavy and mode == "eval") or (N * Cn * s * s > 50000 and cross and not flash):
+        pytest.skip("longest rows: train / train_drop self-attention only (CPU oracle time)")
     p, xq, xkv, dy, D = _attn_case(N, Cn, s, H, B=B)
     B = xq.shape[0]
     training = mode != "eval"
@@ -236,6 +238,17 @@ def _attention_fwd_bwd(dt, N, Cn, s, H, mode, cross, centered, flash=False, oper
     seed, sid = 1234, 3
     if not cross:
         xkv = xq
+    # bf16 eval of the materialised forms: the stored probabilities carry 8 significant bits, so the oracle follows the
+    # same rounding points (storage emulation), and the running statistics are the batch statistics of these very maps
+    # (one train step with momentum 1: the regime a trained model evaluates in) instead of arbitrary numbers
+    emulate = dt == torch.bfloat16 and mode == "eval" and not flash
+    if emulate:
+        pt = {k: v.clone() for k, v in p.items()}
+        pt["proj.weight"] = p["proj.weight"].to(dt).float()
+        with torch.no_grad():
+            O.reattention(xq.to(dt).float(), (xkv if cross else xq).to(dt).float(), pt, "", H, Cn, training=True, attn_drop=0.0,
+                          proj_drop=0.0, bn_momentum=1.0, flash=False, operands=operands, storage=dt)
+        p["var_norm.running_mean"], p["var_norm.running_var"] = pt["var_norm.running_mean"], pt["var_norm.running_var"]
     # bf16 storage: the oracle sees the same rounded inputs / GEMM weights
     xq_r, xkv_r, dy_r = xq.to(dt).float(), xkv.to(dt).float(), dy.to(dt).float()
     pr = {k: v.clone() for k, v in p.items()}
@@ -249,7 +262,7 @@ def _attention_fwd_bwd(dt, N, Cn, s, H, mode, cross, centered, flash=False, oper
                              seed=seed, stream=sid, return_map=True, flash=flash, operands=operands,
                              # e4m3 of a bf16 value is not e4m3 of the fp32 value it came from (double rounding moves ~3 %
                              # of the operands by a whole e4m3 step): the oracle must round to the storage type first
-                             storage=(dt if operands != "storage" and dt != torch.float32 else None))
+                             storage=(dt if (operands != "storage" or emulate) and dt != torch.float32 else None))
     yr.backward(dy_r)
     # ---- HIP ----
     code = _lib.DTYPE_CODE[dt]
@@ -339,11 +352,11 @@ def test_round_e4m3_bit_exact():
                                                  (torch.bfloat16, 196, 3, 16, 8, 2, False),     # materialised forms
                                                  (torch.float32, 49, 3, 8, 4, 2, False)])
 @pytest.mark.parametrize("mode", ["eval", "train", "train_drop"])
-def test_attention_e4m3_operands(dt, N, Cn, s, H, B, flash, mode, monkeypatch):
+def test_attention_e4m3_operands(dt, N, Cn, s, H, B, flash, mode, attn_form):
     """q, k, v rounded to OCP e4m3 before the attention products (vu_attn_params.operands = 1), gradients passed
     straight through: same oracle, same tolerances as the storage-dtype operands."""
     if flash:
-        monkeypatch.setenv("VU_ATTN_FLASH", "1")
+        attn_form(flash=1)
     if N == 4096 and mode == "eval":
         pytest.skip("N = 4096: train / train_drop only (CPU oracle time)")
     _attention_fwd_bwd(dt, N, Cn, s, H, mode, False, centered=flash, flash=flash, operands="e4m3", B=B)

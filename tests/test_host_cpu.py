@@ -25,6 +25,46 @@ def test_header_symbols_exported():
     assert set(_lib.SIGNATURES) == names, set(_lib.SIGNATURES) ^ names
 
 
+def _c_struct_fields(text, name):
+    """[(ctype, field)] of `typedef struct <name> { ... } <name>;` in a C header (comments stripped, `int a, b;` expanded)."""
+    body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), text, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    out = []
+    for decl in body.split(";"):
+        decl = " ".join(decl.replace("*", " * ").split())
+        if not decl:
+            continue
+        first, *rest = decl.split(",")
+        toks = first.split()
+        tname = " ".join(t for t in toks[:-1] if t not in ("const", "*"))       # "int", "float", "long long", "void"
+        for piece in [first] + rest:
+            ptoks = piece.split()
+            out.append(("ptr" if "*" in ptoks else tname, ptoks[-1].split("[")[0]))
+    return out
+
+
+def test_header_structs_match_ctypes_and_integration_stub():
+    """Field count, order and type of every struct the C ABI passes by pointer: header vs vit_unet/torch/_lib.py vs the
+    ctypes stub a maintainer would copy from INTEGRATION.md (a short struct makes the C side read past its end)."""
+    hdr = open(os.path.join(ROOT, "include", "vit_unet_amd.h")).read()
+    cmap = {"int": C.c_int, "float": C.c_float, "long long": C.c_longlong}
+    for sname, cls in (("vu_config", _lib.vu_config), ("vu_attn_params", _lib.vu_attn_params), ("vu_attn_grads", _lib.vu_attn_grads)):
+        want = _c_struct_fields(hdr, sname)
+        got = [(n, t) for n, t in cls._fields_]
+        assert [n for _, n in want] == [n for n, _ in got], (sname, want, got)
+        for (ct, n), (_, t) in zip(want, got):
+            assert t is (C.c_void_p if ct == "ptr" else cmap[ct]), (sname, n, ct, t)
+    L = _lib.lib()
+    assert L.vu_config_size() == C.sizeof(_lib.vu_config) and L.vu_version() == _lib.ABI_VERSION
+    # the INTEGRATION.md stub: same field names in the same order, and a constructor call with as many arguments
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    stub = doc[doc.index("class vu_config(C.Structure)"):doc.index("lib = C.CDLL")]
+    assert re.findall(r'\("([a-z_]+)", C\.c_', stub) == [n for n, _ in _lib.vu_config._fields_]
+    call = re.search(r"cfg = vu_config\(([^)]*)\)", doc).group(1)
+    assert len(call.split(",")) == len(_lib.vu_config._fields_)
+    assert f"vu_version() == {_lib.ABI_VERSION}" in doc
+
+
 @pytest.mark.parametrize("name", ["lite", "base", "large"])
 def test_param_table_matches_reference_layout(name):
     kw = O.PRESETS[name]

@@ -2114,8 +2114,6 @@ int launch_forward(const vu_flash_args& a, hipStream_t st) {
   return vu_check_launch("flash_apply");
 }
 
-inline bool flash_v2_on() { const char* e = getenv("VU_FLASH_V2"); return !(e && e[0] == '0'); }
-
 // The dq, dk and dv sweeps only depend on the delta sweep and write disjoint tensors: they are enqueued on two forked
 // streams and joined back with events (capturable: a stream capture of `st` follows the fork / join), so that the tail
 // of one launch - 832 workgroups over 512 slots leave the second round 62 % full - is filled by the next one.  The
@@ -2189,8 +2187,9 @@ int launch_backward_v2(const vu_flash_args& a, hipStream_t st) {
   auto k1 = flash2_bwd_delta_kernel<DH, WPB, CK2>;
   auto k2 = flash2_bwd_dq_kernel<DH, WPB, CK2>;
   auto k2x = flash2_bwd_dqx_kernel<DH, WPB, CK2>;
-  // VU_FLASH_DQX=0: the separate delta and dq sweeps (A/B switch)
-  const bool fused = a.pk != nullptr && !([] { const char* e = getenv("VU_FLASH_DQX"); return e && e[0] == '0'; }());
+  // The fused sweep takes V = sum_k P k from the TRAINING forward (flash2_moments_kernel); with running statistics (eval
+  // mode + autograd) no moments sweep ran and pk holds nothing, so that case takes the separate delta and dq sweeps.
+  const bool fused = a.pk != nullptr && a.training;
   VU_TRY(reserve_lds(k2x, lds2x));
   auto k3 = flash2_bwd_dkv_kernel<DH, WPB, CK2, false>;
   constexpr int CKV = 1;                 // dv: one tile per chunk, 16 stationary rows per wave: 43.5 KB, three workgroups per CU
@@ -2244,9 +2243,6 @@ int launch_backward_v2(const vu_flash_args& a, hipStream_t st) {
 #define VU_FLASH_DISPATCH(FN, ...)                                                     \
   do {                                                                                 \
     const int dh_ = a.D / a.H;                                                         \
-    if (a.H == 8 && dh_ == 24) return FN<8, 24>(__VA_ARGS__);                         \
-    if (a.H == 8 && dh_ == 8) return FN<8, 8>(__VA_ARGS__);                           \
-    if (a.H == 8 && dh_ == 32) return FN<8, 32>(__VA_ARGS__);                         \
     if (a.H == 4 && dh_ == 32) return FN<4, 32>(__VA_ARGS__);                         \
     vu_set_error("flash attention: shape H=%d d=%d not instantiated", a.H, dh_);      \
     return VU_EUNSUPPORTED;                                                            \
@@ -2269,7 +2265,7 @@ size_t vu_flash_partials_floats(int B, int N, int H) {
 
 int vu_k_flash_forward(const vu_flash_args& a, hipStream_t st) {
   VU_REQUIRE(vu_flash_ok(1, a.B, a.N, a.D, a.H), "flash attention: shape not covered");
-  if (a.H == 8 && flash_v2_on()) {       // head mixes on the matrix cores
+  if (a.H == 8) {       // head mixes on the matrix cores (v2 tile body)
     const int dh = a.D / a.H;
     if (dh == 24) return launch_forward_v2<24>(a, st);
     if (dh == 8) return launch_forward_v2<8>(a, st);
@@ -2280,7 +2276,7 @@ int vu_k_flash_forward(const vu_flash_args& a, hipStream_t st) {
 
 int vu_k_flash_backward(const vu_flash_args& a, hipStream_t st) {
   VU_REQUIRE(vu_flash_ok(1, a.B, a.N, a.D, a.H), "flash attention: shape not covered");
-  if (a.H == 8 && flash_v2_on()) {
+  if (a.H == 8) {
     const int dh = a.D / a.H;
     if (dh == 24) return launch_backward_v2<24>(a, st);
     if (dh == 8) return launch_backward_v2<8>(a, st);
@@ -2292,7 +2288,7 @@ int vu_k_flash_backward(const vu_flash_args& a, hipStream_t st) {
 vu_rng vu_flash_quad_rng(vu_rng r) {
   if (r.thr) {
     const uint32_t t8 = (r.thr + 128u) >> 8;         // thr is round(65536 p)
-    r.thr = t8 ? t8 : 1u;
+    r.thr = t8 ? (t8 > 255u ? 255u : t8) : 1u;       // (p >= 0.998 would give 256: every byte dropped, 1 / keep = inf)
     r.inv_keep = 256.0f / (256.0f - (float)r.thr);
   }
   return r;

@@ -157,11 +157,22 @@ struct AttnDims { int dtype, B, N, D, H, C, s, ld; int centered = 0; int flash =
 inline bool flash_on(const AttnDims& d) {
   return d.flash && vu_flash_ok(d.dtype, d.B, d.N, d.D, d.H) && (d.flash == 1 || vu_flash_pays(d.B, d.N));
 }
-// model path: VU_ATTN_FLASH=0 never, =1 wherever covered, unset: per level by the fill rule
-inline int flash_switch() { const char* e = getenv("VU_ATTN_FLASH"); return !e ? 2 : (e[0] == '0' ? 0 : 1); }
+// Which attention form runs is a PROCESS-LEVEL setting (vu_set_attn_form, include/vit_unet_amd.h): -1 = per level by the
+// fill rule (model path) / materialised (stand-alone op), 0 = never the recompute form, 1 = wherever the shape is covered.
+// The environment (VU_ATTN_FLASH, VU_ATTN_CENTERED) is read ONCE, as the initial value - never inside a launch path, so a
+// forward and its backward cannot disagree on the workspace layout because somebody changed the environment in between.
+struct AttnForm { int flash, centered; };
+inline AttnForm& attn_form() {
+  static AttnForm f = [] {
+    const char* e = getenv("VU_ATTN_FLASH");
+    return AttnForm{!e ? -1 : (e[0] == '0' ? 0 : 1), getenv("VU_ATTN_CENTERED") ? 1 : 0};
+  }();
+  return f;
+}
+inline int flash_switch() { const int f = attn_form().flash; return f < 0 ? 2 : f; }
 // stand-alone op (vu_attn_forward / vu_attn_backward are separate calls that must agree on the form, and the forward may
-// be asked for the map): opt-in with VU_ATTN_FLASH=1 (test switch)
-inline int flash_switch_op() { const char* e = getenv("VU_ATTN_FLASH"); return e && e[0] == '1'; }
+// be asked for the map): the recompute form only when asked for (form 1)
+inline int flash_switch_op() { return attn_form().flash == 1; }
 // centred-map form (model path only; the stand-alone attention op returns the normalised map itself): the mixed map
 // is stored centred, BatchNorm's affine part is applied inside the two products that consume it.  Needs the MFMA mix
 // kernel and the streaming product kernels to cover the shape.
@@ -836,7 +847,14 @@ int model_backward(Ctx& cx, const float* dy, float* dx, int first, int last) {
 // =============================================================================================
 extern "C" {
 
-int vu_version(void) { return 100; }
+// 200: vu_config gained attn_operands, vu_attn_params gained operands (round 2) - callers check the version AND the struct size
+int vu_version(void) { return 200; }
+int vu_config_size(void) { return (int)sizeof(vu_config); }
+int vu_set_attn_form(int flash, int centered) {
+  if (flash < -1 || flash > 1 || centered < 0 || centered > 1) { vu_set_error("vu_set_attn_form: flash in {-1, 0, 1}, centered in {0, 1}"); return VU_EINVAL; }
+  attn_form() = AttnForm{flash, centered};
+  return VU_OK;
+}
 const char* vu_last_error(void) { return vu_get_error(); }
 
 int vu_model_validate(const vu_config* cfg) { return cfg ? validate(*cfg) : VU_EINVAL; }
@@ -989,7 +1007,7 @@ int vu_attn_forward(int dtype, const vu_attn_params* prm, const void* xq, const 
   carve_attn_ws(bp, d, a, sc, &dz);
   if (bp.off > ws_bytes) { vu_set_error("attention workspace too small"); return VU_EWORKSPACE; }
   // test switch: the stand-alone op in the model path's centred-map form (only when the map itself is not asked for)
-  d.centered = (!map_out && getenv("VU_ATTN_CENTERED")) ? 1 : 0;
+  d.centered = (!map_out && attn_form().centered) ? 1 : 0;
   d.flash = (!map_out && flash_switch_op()) ? 1 : 0;
   VU_TRY(attn_forward(d, *prm, xq, xkv, y, a, sc.partials, attn_drop, proj_drop, training, seed, stream_id, nullptr,
                       (hipStream_t)stream));
@@ -1010,7 +1028,7 @@ int vu_attn_backward(int dtype, const vu_attn_params* prm, const vu_attn_grads* 
   AttnBuf a; AttnScratch sc; void* dzb;
   carve_attn_ws(bp, d, a, sc, &dzb);
   if (bp.off > ws_bytes) { vu_set_error("attention workspace too small"); return VU_EWORKSPACE; }
-  d.centered = getenv("VU_ATTN_CENTERED") ? 1 : 0;      // must match what the forward call used (test switch)
+  d.centered = attn_form().centered;      // must match what the forward call used (test switch)
   d.flash = flash_switch_op();
   const void* dz = dy;
   vu_rng rp = vu_make_rng(seed, 2 * stream_id + 1, training ? proj_drop : 0.f);

@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvitunet_amd.so")
 
 VU_OK = 0
+ABI_VERSION = 200        # include/vit_unet_amd.h: vu_version()
 
 
 class VuError(RuntimeError):
@@ -51,6 +52,7 @@ _cfgp = C.POINTER(vu_config)
 # name -> (restype, argtypes); mirrors include/vit_unet_amd.h one to one
 SIGNATURES = {
     "vu_version": (_i, []),
+    "vu_config_size": (_i, []),
     "vu_last_error": (C.c_char_p, []),
     "vu_model_validate": (_i, [_cfgp]),
     "vu_model_param_elems": (_ll, [_cfgp]),
@@ -95,6 +97,7 @@ SIGNATURES = {
     "vu_denoise_prepare": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _vp, _i, _i, _i, _i, _i, _f, _f, _vp]),
     "vu_seg_prepare_scratch_bytes": (_sz, [_i, _i, _i]),
     "vu_seg_prepare": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _vp, _i, _i, _i, _i, _i, _f, _f, _f, _vp]),
+    "vu_set_attn_form": (_i, [_i, _i]),
     "vu_prof_enable": (_i, [_vp]),
     "vu_prof_report": (C.c_char_p, []),
 }
@@ -113,6 +116,10 @@ def lib() -> C.CDLL:
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)     # AttributeError if the symbol is not exported
             fn.restype, fn.argtypes = res, args
+        # ABI guard: a stale binding (or a stale .so) must not pass a short struct - the C side would read past its end
+        if L.vu_version() != ABI_VERSION or L.vu_config_size() != C.sizeof(vu_config):
+            raise VuError(f"{LIB_PATH}: ABI mismatch (library version {L.vu_version()}, vu_config {L.vu_config_size()} bytes; "
+                          f"binding expects version {ABI_VERSION}, {C.sizeof(vu_config)} bytes): rebuild with `make -C vit-unet_amd/csrc`")
         _lib = L
     return _lib
 
@@ -157,6 +164,12 @@ def operand_code(name) -> int:
     if name not in OPERAND_CODE:
         raise ValueError(f"attn_operands must be one of {sorted(OPERAND_CODE)}, got {name!r}")
     return OPERAND_CODE[name]
+
+
+def set_attn_form(flash: int = -1, centered: int = 0) -> None:
+    """Process-level choice of the re-attention form (include/vit_unet_amd.h: vu_set_attn_form): flash -1 auto / 0 never /
+    1 wherever covered; centered 1: the stand-alone op in the centred-map form.  Tests and experiments only."""
+    check(lib().vu_set_attn_form(int(flash), int(centered)), "vu_set_attn_form")
 
 
 def make_config(depth, depth_te, size_bottleneck, preprocessing, im_size, patch_size, num_channels,

@@ -194,7 +194,13 @@ class SegmentationDataset(torch.utils.data.Dataset):
     @staticmethod
     def _dicom(path):
         import pydicom
-        return np.asarray(pydicom.read_file(path).pixel_array).astype(np.int16)
+        a = np.asarray(pydicom.read_file(path).pixel_array)
+        # the device pipeline takes int16 slices (vu_seg_prepare): unsigned 16-bit DICOM (PixelRepresentation = 0) values
+        # >= 32768 would wrap negative in the cast - refuse them instead of silently windowing wrapped intensities
+        if a.dtype != np.int16 and a.size and (int(a.max()) > 32767 or int(a.min()) < -32768):
+            raise ValueError(f"{path}: pixel values outside the int16 range ({a.dtype}, max {int(a.max())}): pass a `read_image` "
+                             "that applies RescaleSlope / RescaleIntercept (or shifts the range) and returns int16")
+        return a.astype(np.int16)
 
     @staticmethod
     def _nifti(path, index):

@@ -5,9 +5,10 @@ This is the counterpart of what `benatools.TorchFitterBase.fit` does per batch f
 run_denoising.py:78-98 (`out = model(x); loss = MSELoss()(out, y); loss.backward();
 AdamW.step()`), minus Python-side autograd: one C call for the forward, one per backward stage,
 one for the loss and one for the optimizer.  Data parallelism: one process per GPU, gradients of
-the flat arena are all-reduced (sum) in three buckets - decoder side, bottleneck, encoder side -
-each launched on a side stream as soon as its backward stage has been enqueued, so the
-collective overlaps the remaining backward; the 1/world average is folded into AdamW.
+the flat arena are all-reduced (sum) in buckets of at most `bucket_mb` (default: a quarter of the
+arena clamped to 4-48 MB) cut at backward-unit boundaries in reverse execution order
+(`dp_unit_buckets`), each launched on a side stream as soon as its units have been enqueued, so
+the collective overlaps the remaining backward; the 1/world average is folded into AdamW.
 """
 from __future__ import annotations
 

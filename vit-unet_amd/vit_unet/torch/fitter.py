@@ -16,6 +16,7 @@ autograd); any other loss / optimizer runs through the module's autograd path.
 from __future__ import annotations
 
 import os
+import warnings
 from typing import Callable, Dict, Iterable, List, Optional
 
 import torch
@@ -34,6 +35,7 @@ class ImageFitter:
         self._seed = seed
         self._fused = None
         self._fused_state = None         # optimizer state restored by load(), applied when the fused step is (re)built
+        self._torch_state = None         # torch optimizer state restored by load() before the autograd path made its optimizer
         self._last_hyper = None
 
     # ---- reference surface -----------------------------------------------------------------------
@@ -71,6 +73,10 @@ class ImageFitter:
         if self._fused_state is not None:
             ts.load_state_dict(self._fused_state)
             self._fused_state = None
+        if self._torch_state is not None:
+            warnings.warn("ImageFitter: the checkpoint holds torch-optimizer state but this run takes the fused HIP step; "
+                          "the optimizer moments start from zero")
+            self._torch_state = None
         return ts
 
     def _sync_hyper(self):
@@ -93,6 +99,13 @@ class ImageFitter:
             return float(self._fused.step(x, y).item())
         if self.optimizer is None:
             self.optimizer = torch.optim.AdamW(self.model.parameters(), lr=self._lr)
+        if self._torch_state is not None:          # a resumed run: the checkpoint's moments, applied now that the optimizer exists
+            self.optimizer.load_state_dict(self._torch_state)
+            self._torch_state = None
+        if self._fused_state is not None:
+            warnings.warn("ImageFitter: the checkpoint holds fused-AdamW state but this run takes the autograd path; "
+                          "the optimizer moments start from zero")
+            self._fused_state = None
         self.optimizer.zero_grad()
         out = self.model(x)
         if w is None:
@@ -164,16 +177,21 @@ class ImageFitter:
         """Restore a checkpoint.  `weights_only=True` is the reference's use (run_denoising.py:100 reloads the best
         weights for evaluation); otherwise the optimizer state is restored too, so that a resumed run continues the
         interrupted one (same moments, same bias-correction step)."""
-        ck = torch.load(path, map_location="cpu", weights_only=False)
+        # weights_only: tensors and plain containers only (nothing is unpickled from an untrusted file)
+        ck = torch.load(path, map_location="cpu", weights_only=bool(weights_only))
         self.model.load_state_dict(ck["model_state_dict"])     # (the model's post-hook invalidates the bf16 shadow)
         self.epoch = ck.get("epoch", 0)
         self.best_metric = ck.get("best_metric", float("inf"))
         self._fused = None
         self._fused_state = None
+        self._torch_state = None
         opt = ck.get("optimizer_state_dict")
         if opt is not None and not weights_only:
             if opt.get("kind") == "fused_adamw":
                 self._fused_state = {k: v for k, v in opt.items() if k != "kind"}
-            elif opt.get("kind") == "torch" and self.optimizer is not None:
-                self.optimizer.load_state_dict(opt["state"])
+            elif opt.get("kind") == "torch":
+                if self.optimizer is not None:
+                    self.optimizer.load_state_dict(opt["state"])
+                else:
+                    self._torch_state = opt["state"]       # applied when the autograd path creates its optimizer
         return self

@@ -491,13 +491,19 @@ class HViT_UNet(nn.Module):
         self._step_seed = None
         if os.path.exists(_lib.LIB_PATH):        # reject what the HIP path cannot run at construction, not at first use
             check(lib().vu_model_validate(C.byref(self._cfg)), "vu_model_validate")
-        self.register_load_state_dict_post_hook(lambda module, incompatible: module._weights_changed())
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._state_loaded())
         self.register_state_dict_pre_hook(lambda module, prefix, keep_vars: module._flush_bn_counters())
 
     def _weights_changed(self):
         """Weights were written from outside the fused AdamW (load_state_dict, a torch optimizer, p.mul_ ...): the
         bf16 shadow must be re-cast before the next forward."""
         self._shadow_clean = False
+
+    def _state_loaded(self):
+        """load_state_dict post-hook: the loaded num_batches_tracked are the truth - train-mode forwards counted before
+        the load must not be added on top of them."""
+        self._nbt_pending = 0
+        self._weights_changed()
 
     def _flush_bn_counters(self):
         if self._nbt_pending:

@@ -79,5 +79,7 @@ def run_denoising(noisy: np.ndarray, clean: np.ndarray, n_epochs: int = 5, folds
         if verbose:
             print(f"FOLD {fold}: Mean PSNR {np.mean(score)}")
         results.append(score)
-    means = [float(np.mean(r)) for r in results]
-    return {"psnr": results, "psnr_mean": float(np.mean(means)), "psnr_std": float(np.std(means)), "history": histories}
+    # run_denoising.py:109-112: np.mean(results) / np.std(results) over the list of per-fold score arrays, i.e. over ALL
+    # per-image scores of all folds (not the spread of the fold means)
+    allv = np.concatenate([np.asarray(r, dtype=np.float64).reshape(-1) for r in results])
+    return {"psnr": results, "psnr_mean": float(allv.mean()), "psnr_std": float(allv.std()), "history": histories}
