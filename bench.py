@@ -128,17 +128,29 @@ def eval_parity(model_name: str, dtype, B: int = 2, operands: str = "storage"):
     m = m.to("cuda").eval()
     with torch.no_grad():
         got = m(x.to("cuda")).float().cpu()
-        ref = O.forward(w, cfg, x, training=False)
-    err = (got - ref).abs()
-    out = {"model": model_name, "B": B, "dtype": str(dtype).replace("torch.", ""), "mode": "eval forward vs fp32 CPU oracle",
-           "max_abs": err.max().item(), "max_rel": (err.max() / ref.abs().max()).item(),
-           "rms_rel": (err.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()}
-    if seg:
-        dg, dr = O.dice_loss(torch.sigmoid(got), y).item(), O.dice_loss(torch.sigmoid(ref), y).item()
-        out.update({"dice_gpu": dg, "dice_oracle": dr, "ddice": dg - dr})
-    else:
-        pg, pr = O.psnr(y, got), O.psnr(y, ref)
-        out.update({"psnr_gpu": pg.mean().item(), "psnr_oracle": pr.mean().item(), "dpsnr": (pg - pr).abs().max().item()})
+        ref = O.forward(w, cfg, x, training=False)           # fp32 everywhere, operands as stored: the reference's arithmetic
+
+    def deltas(r):
+        e = (got - r).abs()
+        d = {"max_abs": e.max().item(), "max_rel": (e.max() / r.abs().max()).item(),
+             "rms_rel": (e.pow(2).mean().sqrt() / r.pow(2).mean().sqrt()).item()}
+        if seg:
+            dg, dr = O.dice_loss(torch.sigmoid(got), y).item(), O.dice_loss(torch.sigmoid(r), y).item()
+            d.update({"dice_gpu": dg, "dice_oracle": dr, "ddice": dg - dr})
+        else:
+            pg, pr = O.psnr(y, got), O.psnr(y, r)
+            d.update({"psnr_gpu": pg.mean().item(), "psnr_oracle": pr.mean().item(), "dpsnr": (pg - pr).abs().max().item()})
+        return d
+    out = {"model": model_name, "B": B, "dtype": str(dtype).replace("torch.", ""), "attn_operands": operands,
+           "mode": "eval forward vs fp32 CPU oracle"}
+    out.update(deltas(ref))
+    if dtype != torch.float32 or operands != "storage":
+        # the same comparison against the oracle that rounds where this path rounds (bf16 where a tensor is stored, e4m3
+        # operands): what is left is kernel error, the rest above is the number format
+        with torch.no_grad():
+            cfg_r = O.Config(**dict(kw, attn_operands=operands))
+            ref_r = O.forward(w, cfg_r, x, training=False, storage=dtype if dtype != torch.float32 else None)
+        out["vs_same_rounding_points"] = deltas(ref_r)
     del m
     return out
 

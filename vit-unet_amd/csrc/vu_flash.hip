@@ -238,7 +238,8 @@ __device__ __forceinline__ void work_item(int id, int B, int per, int& b, int& g
 // =============================================================================================
 template <int H, int DH, int WPB, int CK>
 __global__ __launch_bounds__(WPB * 64) void flash_stats_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
-                                                               float* __restrict__ lse2, float* __restrict__ partials, int B, int N,
+                                                               float* __restrict__ lse2, float* __restrict__ rinv,
+                                                               float* __restrict__ partials, int B, int N,
                                                                float c, vu_rng rng_in, int want_moments) {
   typedef FC<H, DH> C;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -304,7 +305,10 @@ __global__ __launch_bounds__(WPB * 64) void flash_stats_kernel(const bf16_t* __r
     sm[h] += __shfl_xor(sm[h], 16, 64);
     sm[h] += __shfl_xor(sm[h], 32, 64);
     lse[h] = mx[h] + log2f(sm[h]);
-    if (active && g4 == 0) lse2[((long long)b * H + h) * N + qrow] = lse[h];
+    if (active && g4 == 0) {
+      lse2[((long long)b * H + h) * N + qrow] = lse[h];
+      rinv[((long long)b * H + h) * N + qrow] = 1.0f / (sm[h] * fexp2(mx[h] - lse[h]));      // (row_norm_note below)
+    }
   }
   if (!want_moments) return;                                      // (uniform: eval mode needs the row statistics only)
 
@@ -369,8 +373,18 @@ __global__ __launch_bounds__(WPB * 64) void flash_stats_kernel(const bf16_t* __r
 // over its own keys (4 per tile) in the log2 domain and rescales the sum when its maximum moves; the four lane groups of a
 // query are merged at the end.  The next K chunk is fetched into registers while the current one is consumed.
 template <int H, int DH, int WPB, int CK>
+// row_norm_note: every later sweep recomputes P = exp2(c s - lse) from the ONE stored float lse = m + log2(sum).  When the
+// logits are huge (un-normalised skip outputs through saturating e4m3 operands reach c s ~ 1.6e6, where a float resolves
+// 0.125) the rounding of that sum leaves every P of the row off by one common factor g = sum 2^(m - lse) (up to 4.4 % at
+// 2^21; below 0.1 % for |c s| < 2^15): harmless as a factor, but the softmax backward dS = P~ dP~ - P delta relies on
+// sum_k P = 1 to cancel, and with sum_k P = g it leaves a spurious - (g - 1) P delta - for saturated (one-hot) rows, whose
+// true dS is 0, that term IS the gradient (measured: 100 - 400 % error of the q / k convolution weight gradients of the
+// 512 x 512 configuration's first level-1 decoder block).  rinv = 1 / g is stored beside lse; the backward uses delta / g,
+// which restores the cancellation exactly (dS becomes g times the true dS: the common factor again).
+// (measured, round 3: capped at 128 registers for four waves per SIMD - 832 work groups in ONE round - it is slower, 103 vs
+// 96 us: the sweep is bound by its exp2 chain per wave, not by the second, nearly empty round)
 __global__ __launch_bounds__(WPB * 64, 2) void flash_rowstats_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
-                                                                      float* __restrict__ lse2, int B, int N, float c) {
+                                                                      float* __restrict__ lse2, float* __restrict__ rinv, int B, int N, float c) {
   typedef FC<H, DH> C;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* Kc = reinterpret_cast<bf16_t*>(smem_raw);
@@ -427,7 +441,11 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash_rowstats_kernel(const bf16_
       s_ = s_ * fexp2(m - mn) + s2 * fexp2(m2 - mn);
       m = mn;
     }
-    if (active && g4 == 0) lse2[((long long)b * H + h) * N + qrow] = m + log2f(s_);
+    if (active && g4 == 0) {
+      const float l = m + log2f(s_);
+      lse2[((long long)b * H + h) * N + qrow] = l;
+      rinv[((long long)b * H + h) * N + qrow] = 1.0f / (s_ * fexp2(m - l));
+    }
   }
 }
 
@@ -736,8 +754,8 @@ __device__ __forceinline__ f32x4 mix_back(const f32x4 (&E)[H], const RowW<H>& w)
 template <int H, int DH, int WPB, int CK>
 __global__ __launch_bounds__(WPB * 64, 2) void flash_bwd_delta_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, const bf16_t* __restrict__ dO,
-    const float* __restrict__ lse2, const float* __restrict__ stats, float* __restrict__ delta, float* __restrict__ partials,
-    int B, int N, float c, vu_rng rng_in) {
+    const float* __restrict__ lse2, const float* __restrict__ rinv, const float* __restrict__ stats, float* __restrict__ delta,
+    float* __restrict__ partials, int B, int N, float c, vu_rng rng_in) {
   typedef FC<H, DH> C;
   constexpr int NT = H * H + H;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -809,7 +827,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash_bwd_delta_kernel(
   for (int h = 0; h < H; ++h) {
     dl[h] += __shfl_xor(dl[h], 16, 64);
     dl[h] += __shfl_xor(dl[h], 32, 64);
-    if (active && g4 == 0) delta[((long long)b * H + h) * N + qrow] = dl[h];
+    if (active && g4 == 0) delta[((long long)b * H + h) * N + qrow] = dl[h] * rinv[((long long)b * H + h) * N + qrow];      // row_norm_note
   }
   __syncthreads();
 #pragma unroll
@@ -1497,8 +1515,8 @@ __device__ __forceinline__ f32x4 bwd2_dp(const f32x4& e, const BackOp& bk) {
 template <int DH, int WPB, int CK>
 __global__ __launch_bounds__(WPB * 64, 2) void flash2_bwd_delta_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, const bf16_t* __restrict__ dO,
-    const float* __restrict__ lse2, const float* __restrict__ stats, float* __restrict__ delta, float* __restrict__ partials,
-    int B, int N, float c, vu_rng rng_in) {
+    const float* __restrict__ lse2, const float* __restrict__ rinv, const float* __restrict__ stats, float* __restrict__ delta,
+    float* __restrict__ partials, int B, int N, float c, vu_rng rng_in) {
   constexpr int H = 8, NT = H * H + H;
   typedef FC<H, DH> C;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1592,7 +1610,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_bwd_delta_kernel(
   for (int j = 0; j < 4; ++j) {
     float d = dl[j];
     d += __shfl_xor(d, 32, 64);
-    if (active && g4 < 2) delta[((long long)b * H + 4 * hh + j) * N + qrow] = d;
+    if (active && g4 < 2) delta[((long long)b * H + 4 * hh + j) * N + qrow] = d * rinv[((long long)b * H + 4 * hh + j) * N + qrow];   // row_norm_note
   }
   // T: accumulator rows c = 4 g4 + jj, column c' = l15: wanted rows 0..7 (e_g), columns 8..15 (P^_h)
   __syncthreads();
@@ -1727,8 +1745,9 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_bwd_dq_kernel(
 template <int DH, int WPB, int CK>
 __global__ __launch_bounds__(WPB * 64, 2) void flash2_bwd_dqx_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, const bf16_t* __restrict__ dO,
-    const float* __restrict__ lse2, const float* __restrict__ pkv, const float* __restrict__ stats, bf16_t* __restrict__ dq,
-    float* __restrict__ delta, float* __restrict__ partials, int B, int N, float c, float scale, vu_rng rng_in, int want_dc) {
+    const float* __restrict__ lse2, const float* __restrict__ rinv, const float* __restrict__ pkv, const float* __restrict__ stats,
+    bf16_t* __restrict__ dq, float* __restrict__ delta, float* __restrict__ partials, int B, int N, float c, float scale,
+    vu_rng rng_in, int want_dc) {
   constexpr int H = 8, FB = DH / 8, NT = H * H + H, IMP = 16;
   typedef FC<H, DH> C;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1855,6 +1874,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_bwd_dqx_kernel(
   for (int j = 0; j < 4; ++j) {
     float d = dl[j];
     d += __shfl_xor(d, 32, 64);
+    d *= rinv[((long long)b * H + 4 * hh + j) * N + qrow];                // row_norm_note: delta / (row sum of the recomputed P)
     if (active && g4 < 2) delta[((long long)b * H + 4 * hh + j) * N + qrow] = d;
     dsel[j] = __shfl(d, l15 + 16 * (g4 >> 1), 64);
   }
@@ -2067,7 +2087,7 @@ int launch_backward(const vu_flash_args& a, hipStream_t st) {
   VU_TRY(reserve_lds(k1, lds1)); VU_TRY(reserve_lds(k2, lds2)); VU_TRY(reserve_lds(k3, lds3)); VU_TRY(reserve_lds(k4, lds4));
   const double E = (double)a.B * H * a.N * a.N, act = (double)a.B * a.N * C::D * 2.0;
   const bf16_t *q = (const bf16_t*)a.q, *k = (const bf16_t*)a.k, *v = (const bf16_t*)a.v, *dO = (const bf16_t*)a.dO;
-  hipLaunchKernelGGL(k1, dim3(nblk), dim3(WPB * 64), lds1, st, q, k, v, dO, a.lse2, a.stats, a.delta, a.partials, a.B, a.N, c, a.rng);
+  hipLaunchKernelGGL(k1, dim3(nblk), dim3(WPB * 64), lds1, st, q, k, v, dO, a.lse2, a.rinv, a.stats, a.delta, a.partials, a.B, a.N, c, a.rng);
   if (vu_prof_on()) vu_prof_note("flash_bwd_delta_kernel", 4.0 * E * DH + 6.0 * E * H, 4.0 * act);
   VU_TRY(vu_check_launch("flash_bwd_delta"));
   hipLaunchKernelGGL(flash_bwd_mix_finalize_kernel, dim3((unsigned)((H * H + H + 15) / 16)), dim3(1024), 0, st, a.partials, nblk, a.stats, a.d_mix_w, a.d_mix_b, H, a.rng.inv_keep);
@@ -2101,7 +2121,7 @@ int launch_forward(const vu_flash_args& a, hipStream_t st) {
     vu_set_error("flash attention: cannot reserve %zu bytes of LDS", lds2); return VU_ELAUNCH;
   }
   const double E = (double)a.B * H * a.N * a.N, act = (double)a.B * a.N * C::D * 2.0;
-  hipLaunchKernelGGL(k1, dim3(nblk), dim3(WPB * 64), lds1, st, (const bf16_t*)a.q, (const bf16_t*)a.k, a.lse2, a.partials, a.B, a.N, c,
+  hipLaunchKernelGGL(k1, dim3(nblk), dim3(WPB * 64), lds1, st, (const bf16_t*)a.q, (const bf16_t*)a.k, a.lse2, a.rinv, a.partials, a.B, a.N, c,
                      a.rng, a.training);
   if (vu_prof_on()) vu_prof_note("flash_stats_kernel", (a.training ? 3.0 : 2.0) * 2.0 * E * DH, 2.0 * act);
   VU_TRY(vu_check_launch("flash_stats"));
@@ -2151,7 +2171,7 @@ int launch_forward_v2(const vu_flash_args& a, hipStream_t st) {
   VU_TRY(reserve_lds(k1, lds1)); VU_TRY(reserve_lds(km, ldsm)); VU_TRY(reserve_lds(k2, lds2));
   const double E = (double)a.B * H * a.N * a.N, act = (double)a.B * a.N * C::D * 2.0;
   const bf16_t *q = (const bf16_t*)a.q, *k = (const bf16_t*)a.k, *v = (const bf16_t*)a.v;
-  hipLaunchKernelGGL(k1, dim3(nblk), dim3(WPB * 64), lds1, st, q, k, a.lse2, a.B, a.N, c);
+  hipLaunchKernelGGL(k1, dim3(nblk), dim3(WPB * 64), lds1, st, q, k, a.lse2, a.rinv, a.B, a.N, c);
   if (vu_prof_on()) vu_prof_note("flash_rowstats_kernel", 4.0 * E * DH, 2.0 * act);
   VU_TRY(vu_check_launch("flash_rowstats"));
   if (a.training) {
@@ -2189,7 +2209,9 @@ int launch_backward_v2(const vu_flash_args& a, hipStream_t st) {
   auto k2x = flash2_bwd_dqx_kernel<DH, WPB, CK2>;
   // The fused sweep takes V = sum_k P k from the TRAINING forward (flash2_moments_kernel); with running statistics (eval
   // mode + autograd) no moments sweep ran and pk holds nothing, so that case takes the separate delta and dq sweeps.
-  const bool fused = a.pk != nullptr && a.training;
+  // (VU_FLASH_UNFUSED=1, read once: diagnostic switch that takes the separate sweeps in training too)
+  static const bool unfused_dbg = [] { const char* e = getenv("VU_FLASH_UNFUSED"); return e && e[0] == '1'; }();
+  const bool fused = a.pk != nullptr && a.training && !unfused_dbg;
   VU_TRY(reserve_lds(k2x, lds2x));
   auto k3 = flash2_bwd_dkv_kernel<DH, WPB, CK2, false>;
   constexpr int CKV = 1;                 // dv: one tile per chunk, 16 stationary rows per wave: 43.5 KB, three workgroups per CU
@@ -2200,12 +2222,12 @@ int launch_backward_v2(const vu_flash_args& a, hipStream_t st) {
   const double E = (double)a.B * H * a.N * a.N, act = (double)a.B * a.N * C::D * 2.0;
   const bf16_t *q = (const bf16_t*)a.q, *k = (const bf16_t*)a.k, *v = (const bf16_t*)a.v, *dO = (const bf16_t*)a.dO;
   if (fused) {
-    hipLaunchKernelGGL(k2x, dim3(nblk), dim3(WPB * 64), lds2x, st, q, k, v, dO, a.lse2, a.pk, a.stats, (bf16_t*)a.dq, a.delta, a.partials, a.B,
+    hipLaunchKernelGGL(k2x, dim3(nblk), dim3(WPB * 64), lds2x, st, q, k, v, dO, a.lse2, a.rinv, a.pk, a.stats, (bf16_t*)a.dq, a.delta, a.partials, a.B,
                        a.N, c, a.scale, a.rng, a.training ? 0 : 1);
     if (vu_prof_on()) vu_prof_note("flash2_bwd_dqx_kernel", 6.0 * E * DH + 8.0 * E * H, 7.0 * act);
     VU_TRY(vu_check_launch("flash2_bwd_dqx"));
   } else {
-    hipLaunchKernelGGL(k1, dim3(nblk), dim3(WPB * 64), lds1, st, q, k, v, dO, a.lse2, a.stats, a.delta, a.partials, a.B, a.N, c, a.rng);
+    hipLaunchKernelGGL(k1, dim3(nblk), dim3(WPB * 64), lds1, st, q, k, v, dO, a.lse2, a.rinv, a.stats, a.delta, a.partials, a.B, a.N, c, a.rng);
     if (vu_prof_on()) vu_prof_note("flash2_bwd_delta_kernel", 4.0 * E * DH + 6.0 * E * H, 4.0 * act);
     VU_TRY(vu_check_launch("flash2_bwd_delta"));
   }
