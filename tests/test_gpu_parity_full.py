@@ -282,7 +282,7 @@ def test_teacher_forced_blocks_bf16_full_size(name, dt, attn_form, monkeypatch):
             if k.endswith("reatten_matrix.bias"):
                 continue                                    # analytically zero in train mode (rounding noise only)
             e = serr(sd["BottleNeck.0." + k].grad, wr[pre + k].grad)
-            if unnormalised and k in ("ReAttn.qconv2d.weight", "ReAttn.kconv2d.weight"):
+            if e >= tol_b and unnormalised and name == "seg512" and k in ("ReAttn.qconv2d.weight", "ReAttn.kconv2d.weight"):
                 print(f"   {pre}{k}: scaled error {e:.2e} (saturated-rows limit, not asserted)")
                 continue
             if k.endswith("var_norm.weight") and e >= tol_b:
