@@ -270,21 +270,14 @@ def test_teacher_forced_blocks_bf16_full_size(name, dt, attn_form, monkeypatch):
             print("   dgamma", gw.tolist(), "\n   dbeta ", gbb.tolist(), "\n   beta", wr[pre + "ReAttn.var_norm.bias"].tolist(),
                   "\n   hip dgamma", sd["BottleNeck.0.ReAttn.var_norm.weight"].grad.tolist(), flush=True)
             continue
-        # KNOWN LIMIT ("saturated rows"): the first decoder block of a level reads the un-normalised output
-        # of a SkipConnection (model.py:418: no LayerNorm, no residual); at 512 x 512 its input has std ~80, 92 % of the softmax
-        # rows are one-hot and dP~ is dominated by a row-constant part that cancels in exact arithmetic.  The recompute sweeps
-        # round P to bf16 where the tile changes layout, and (bf16(P) - P) x that constant does not cancel: dq / dk come out
-        # with O(1) relative error there (measured with tools/attn_diag.py: dq relative L2 2.0, dk 0.04 with a bias), which
-        # the q / k convolution weight gradients - sums of dq, dk over all pixels - inherit.  Every other gradient of the
-        # block, the input gradient included, is within the usual bound; those two are printed, not asserted, for such a block.
-        unnormalised = dt == torch.bfloat16 and xin.std().item() > 10.0
+        # (Round 3: the first decoder block of a level reads the un-normalised output of a SkipConnection - at 512 x 512 its
+        # input has std ~80 and 92 % of the softmax rows are one-hot.  The recompute backward used to lose the q / k convolution
+        # weight gradients there (errors of 100 - 2000 %): three fixes, DESIGN.md section 2 "saturated rows"; this test now holds
+        # that block to the same bound as every other one.)
         for k in BLOCK_KEYS:
             if k.endswith("reatten_matrix.bias"):
                 continue                                    # analytically zero in train mode (rounding noise only)
             e = serr(sd["BottleNeck.0." + k].grad, wr[pre + k].grad)
-            if e >= tol_b and unnormalised and name == "seg512" and k in ("ReAttn.qconv2d.weight", "ReAttn.kconv2d.weight"):
-                print(f"   {pre}{k}: scaled error {e:.2e} (saturated-rows limit, not asserted)")
-                continue
             if k.endswith("var_norm.weight") and e >= tol_b:
                 # d gamma = (sum dA^ A^ - beta sum dA^) / gamma is formed from dO, O and v (no pass over the maps), with O as
                 # stored (bf16: 2^-8).  Where |beta d beta| is orders above |d gamma| (seen at 512 x 512: 240 against 4) the

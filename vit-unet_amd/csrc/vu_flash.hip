@@ -171,6 +171,11 @@ __device__ __forceinline__ unsigned pk2(float a, float b) {
   const f32x2 v = {a, b};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
+// acc + (the two bf16 halves of w): v_dot2c_f32_bf16 against (1, 1) - the sum of bf16-ROUNDED values exactly as an MFMA sees
+// them, one instruction per packed pair
+__device__ __forceinline__ float sum2_bf16(unsigned w, float acc) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w), __builtin_bit_cast(bf16x2_t, 0x3F803F80u), acc, false);
+}
 __device__ __forceinline__ float bf_lo(unsigned w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
 __device__ __forceinline__ s16x4 pack4s(const f32x4& a) {
@@ -1255,7 +1260,7 @@ template <int DH, int WPB, int CK>
 __global__ __launch_bounds__(WPB * 64, 2) void flash2_moments_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                                       const float* __restrict__ lse2, const float* __restrict__ W,
                                                                       float* __restrict__ partials, float* __restrict__ pk_out,
-                                                                      int B, int N, float c, vu_rng rng_in) {
+                                                                      float* __restrict__ rinv, int B, int N, float c, vu_rng rng_in) {
   constexpr int H = 8;
   typedef FC<H, DH> C;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1295,6 +1300,12 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_moments_kernel(const bf16_
   // of its element chain (dq = scale (sum_k P~ dP~ k - delta sum_k P k)), and this sweep has the probabilities and the
   // key chunk at hand with registers to spare
   f32x4 pacc[H][C::DT];                       // rows = features 16 dt + 4 g4 + r of head h, column = query l15
+  // s_b = sum_k bf16(P): the row sum of the probabilities AS THE PRODUCT ABOVE SEES THEM (row_norm_note: the fused dq sweep
+  // needs sum_k [bf16(u) - bf16(P) delta] = 0 to hold for the rounded operands, or saturated rows - true dS = 0 - keep
+  // 2^-9 |u| |k| of noise each)
+  float sb[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) sb[h] = 0.f;
 #pragma unroll
   for (int h = 0; h < H; ++h)
 #pragma unroll
@@ -1324,6 +1335,10 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_moments_kernel(const bf16_
         for (int h = 0; h < H; ++h) {                  // a logits-shaped tile is the B operand of a key-contracting product as it stands
           const f32x4 p4 = {fabsf(S[h][0]), fabsf(S[h][1]), fabsf(S[h][2]), fabsf(S[h][3])};
           const s16x4 bop = pack4s(p4);
+          {
+            const u32x2_t bw = __builtin_bit_cast(u32x2_t, bop);
+            sb[h] = sum2_bf16(bw[1], sum2_bf16(bw[0], sb[h]));
+          }
 #pragma unroll
           for (int dt = 0; dt < C::DT; ++dt)
             pacc[h][dt] = mfma16(tr_operand<C::PITCH>(Kc, kc * 16, h * DH + 16 * dt, l15, g4), bop, pacc[h][dt]);
@@ -1349,6 +1364,13 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_moments_kernel(const bf16_
         const int f = 16 * dt + 4 * g4;
         if (f < DH) *reinterpret_cast<f32x4*>(prow + h * DH + f) = pacc[h][dt];
       }
+  }
+#pragma unroll
+  for (int h = 0; h < H; ++h) {       // the four lane groups of a query hold its four key quarters
+    float x = sb[h];
+    x += __shfl_xor(x, 16, 64);
+    x += __shfl_xor(x, 32, 64);
+    if (active && g4 == 0) rinv[((long long)b * H + h) * N + qrow] = 1.0f / x;
   }
   // lanes with the same head half (g4 & 1) hold the same 4 heads: reduce over q (16 lanes) and over a (g4 >> 1)
   __syncthreads();
@@ -1545,7 +1567,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_bwd_delta_kernel(
   for (int h = 0; h < H; ++h) lse[h] = lse2[((long long)b * H + h) * N + qrow];
   Bwd2Ops ops;
   make_bwd2_ops(ops, stats, l15, g4);
-  f32x4 dl = {0.f, 0.f, 0.f, 0.f}, tc = {0.f, 0.f, 0.f, 0.f}, Tacc = {0.f, 0.f, 0.f, 0.f};
+  f32x4 dl = {0.f, 0.f, 0.f, 0.f}, sp = {0.f, 0.f, 0.f, 0.f}, tc = {0.f, 0.f, 0.f, 0.f}, Tacc = {0.f, 0.f, 0.f, 0.f};
   const uint32_t hstride = (uint32_t)(((unsigned long long)N * N) >> 2);
   const uint32_t wlane = (uint32_t)((((unsigned long long)b * N + qrow) * (unsigned long long)N) >> 2) + (uint32_t)g4;
   const int nchunks = (ntiles + CK - 1) / CK;
@@ -1580,6 +1602,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_bwd_delta_kernel(
             for (int j = 0; j < 4; ++j) {
               ph[j] = fmaxf(T[half][r][j], 0.f);
               dl[j] = fmaf(ph[j], dp[j], dl[j]);
+              sp[j] += fabsf(T[half][r][j]);        // row sum of the probabilities as this chain holds them (bf16 values)
               tc[j] += E[half][r][j];
             }
             // sum over positions of e_g P^_h as X^T X: image row = position (q, a) of this (half, r), columns
@@ -1608,9 +1631,10 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_bwd_delta_kernel(
   // delta: the lanes (q, hh) and (q, hh + 2) hold the two key groups of the same 4 heads
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    float d = dl[j];
+    float d = dl[j], sx = sp[j];
     d += __shfl_xor(d, 32, 64);
-    if (active && g4 < 2) delta[((long long)b * H + 4 * hh + j) * N + qrow] = d * rinv[((long long)b * H + 4 * hh + j) * N + qrow];   // row_norm_note
+    sx += __shfl_xor(sx, 32, 64);
+    if (active && g4 < 2) delta[((long long)b * H + 4 * hh + j) * N + qrow] = d / sx;   // row_norm_note
   }
   // T: accumulator rows c = 4 g4 + jj, column c' = l15: wanted rows 0..7 (e_g), columns 8..15 (P^_h)
   __syncthreads();
@@ -1787,7 +1811,9 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_bwd_dqx_kernel(
   for (int j = 0; j < 4; ++j)
 #pragma unroll
     for (int fb = 0; fb < FB; ++fb) acc[j][fb] = f32x4{0.f, 0.f, 0.f, 0.f};
-  f32x4 dl = {0.f, 0.f, 0.f, 0.f}, tc = {0.f, 0.f, 0.f, 0.f}, Tacc = {0.f, 0.f, 0.f, 0.f};
+  // dl: sum_k u (fp32 products, what the dk sweep's dS = P~ dP~ - P delta cancels against); dlb: sum_k bf16(u), the operand
+  // values of THIS sweep's dq product (row_norm_note)
+  f32x4 dl = {0.f, 0.f, 0.f, 0.f}, dlb = {0.f, 0.f, 0.f, 0.f}, tc = {0.f, 0.f, 0.f, 0.f}, Tacc = {0.f, 0.f, 0.f, 0.f};
   const uint32_t hstride = (uint32_t)(((unsigned long long)N * N) >> 2);
   const uint32_t wlane = (uint32_t)((((unsigned long long)b * N + qrow) * (unsigned long long)N) >> 2) + (uint32_t)g4;
   const int nchunks = (ntiles + CK - 1) / CK;
@@ -1861,6 +1887,10 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_bwd_dqx_kernel(
           for (int j = 0; j < 4; ++j) {
             const f32x4 d4 = {T[half][0][j], T[half][1][j], T[half][2][j], T[half][3][j]};
             const s16x4 bop = pack4s(d4);
+            {
+              const u32x2_t bw = __builtin_bit_cast(u32x2_t, bop);
+              dlb[j] = sum2_bf16(bw[1], sum2_bf16(bw[0], dlb[j]));
+            }
 #pragma unroll
             for (int fb = 0; fb < FB; ++fb) acc[j][fb] = mfma16(tr_rel<DH>(Kc, tb, j, fb), bop, acc[j][fb]);
           }
@@ -1872,11 +1902,12 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_bwd_dqx_kernel(
   f32x4 dsel;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    float d = dl[j];
+    float d = dl[j], db = dlb[j];
     d += __shfl_xor(d, 32, 64);
-    d *= rinv[((long long)b * H + 4 * hh + j) * N + qrow];                // row_norm_note: delta / (row sum of the recomputed P)
-    if (active && g4 < 2) delta[((long long)b * H + 4 * hh + j) * N + qrow] = d;
-    dsel[j] = __shfl(d, l15 + 16 * (g4 >> 1), 64);
+    db += __shfl_xor(db, 32, 64);
+    const float rs = rinv[((long long)b * H + 4 * hh + j) * N + qrow];    // row_norm_note: 1 / sum_k bf16(P) (moments sweep)
+    if (active && g4 < 2) delta[((long long)b * H + 4 * hh + j) * N + qrow] = d * rs;
+    dsel[j] = __shfl(db * rs, l15 + 16 * (g4 >> 1), 64);
   }
   if (active) {
     bf16_t* orow = dq + ((long long)b * N + qrow) * C::D;
@@ -2059,6 +2090,52 @@ __global__ __launch_bounds__(WPB * 64, DV ? 3 : 2) void flash2_bwd_dkv_kernel(
   }
 }
 
+// dk <- dk - mean over the keys of dk, per (sample, feature).  The softmax is invariant to a common shift of all keys, so
+// the exact gradient satisfies sum_k dk[k,:] = 0; the sweeps' dk violates it by the rounding of the dS operand (row sums
+// of bf16(dS) are not 0), a component that is pure error - and the one the k convolution's weight gradient, a sum of
+// dk x over ALL pixels, picks up coherently when its input has a non-zero mean (un-normalised skip outputs; measured on
+// the 512 x 512 configuration's level-1 decoder block: weight-gradient error 0.6 -> 2e-3 of its range).  One workgroup per
+// (sample, 64-feature slab): column sums in registers -> LDS -> subtract on a second pass (L2-resident).
+__global__ __launch_bounds__(256) void flash_center_dk_kernel(bf16_t* __restrict__ dk, int N, int D) {
+  __shared__ float red[32][65];
+  const int b = blockIdx.x, slab = blockIdx.y, v = threadIdx.x & 7, rl = threadIdx.x >> 3;
+  const int f0 = slab * 64 + v * 8;
+  if (f0 >= D) { /* (D is a multiple of 8; slabs past D do not exist) */ }
+  bf16_t* base = dk + (long long)b * N * D + f0;
+  float a[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i] = 0.f;
+  const bool live = f0 < D;
+  if (live)
+    for (int r = rl; r < N; r += 32) {
+      const bf16x8 x = *reinterpret_cast<const bf16x8*>(base + (long long)r * D);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) a[i] += (float)x[i];
+    }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) red[rl][v * 8 + i] = a[i];
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) t += red[r][threadIdx.x];
+    red[0][threadIdx.x] = t / (float)N;
+  }
+  __syncthreads();
+  if (live)
+    for (int r = rl; r < N; r += 32) {
+      bf16x8 x = *reinterpret_cast<const bf16x8*>(base + (long long)r * D);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) x[i] = (bf16_t)((float)x[i] - red[0][v * 8 + i]);
+      *reinterpret_cast<bf16x8*>(base + (long long)r * D) = x;
+    }
+}
+int launch_center_dk(const vu_flash_args& a, hipStream_t st) {
+  hipLaunchKernelGGL(flash_center_dk_kernel, dim3(a.B, (a.D + 63) / 64), dim3(256), 0, st, (bf16_t*)a.dk, a.N, a.D);
+  if (vu_prof_on()) vu_prof_note("flash_center_dk_kernel", 0.0, 4.0 * (double)a.B * a.N * a.D * 2.0);
+  return vu_check_launch("flash_center_dk");
+}
+
 template <typename K>
 int reserve_lds(K kern, size_t lds) {
   if (lds > 48 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
@@ -2098,6 +2175,7 @@ int launch_backward(const vu_flash_args& a, hipStream_t st) {
   hipLaunchKernelGGL(k3, dim3(nblk), dim3(WPB * 64), lds3, st, q, k, v, dO, a.lse2, a.delta, a.stats, (bf16_t*)a.dk, a.B, a.N, c, a.scale, a.rng);
   if (vu_prof_on()) vu_prof_note("flash_bwd_dk_kernel", 6.0 * E * DH + 4.0 * E * H, 5.0 * act);
   VU_TRY(vu_check_launch("flash_bwd_dk"));
+  VU_TRY(launch_center_dk(a, st));
   hipLaunchKernelGGL(k4, dim3(nblk), dim3(WPB * 64), lds4, st, q, k, v, dO, a.lse2, (const float*)nullptr, a.stats, (bf16_t*)a.dv, a.B, a.N, c, a.scale, a.rng);
   if (vu_prof_on()) vu_prof_note("flash_bwd_dv_kernel", 4.0 * E * DH + 2.0 * E * H, 4.0 * act);
   return vu_check_launch("flash_bwd_dv");
@@ -2176,7 +2254,7 @@ int launch_forward_v2(const vu_flash_args& a, hipStream_t st) {
   VU_TRY(vu_check_launch("flash_rowstats"));
   if (a.training) {
     VU_REQUIRE(a.pk != nullptr, "flash attention: the training forward needs the P k buffer");
-    hipLaunchKernelGGL(km, dim3(nblk), dim3(WPB * 64), ldsm, st, q, k, a.lse2, a.mix_w, a.partials, a.pk, a.B, a.N, c, a.rng);
+    hipLaunchKernelGGL(km, dim3(nblk), dim3(WPB * 64), ldsm, st, q, k, a.lse2, a.mix_w, a.partials, a.pk, a.rinv, a.B, a.N, c, a.rng);
     if (vu_prof_on()) vu_prof_note("flash2_moments_kernel", 4.0 * E * DH + 2.0 * E * H, 4.0 * act);
     VU_TRY(vu_check_launch("flash2_moments"));
   }
@@ -2249,6 +2327,7 @@ int launch_backward_v2(const vu_flash_args& a, hipStream_t st) {
   hipLaunchKernelGGL(k3, dim3(nblk), dim3(WPB * 64), lds3, s_dk, q, k, v, dO, a.lse2, a.delta, a.stats, (bf16_t*)a.dk, a.B, a.N, c, a.scale, a.rng);
   if (vu_prof_on()) vu_prof_note("flash2_bwd_dk_kernel", 6.0 * E * DH + 4.0 * E * H, 5.0 * act);
   VU_TRY(vu_check_launch("flash2_bwd_dk"));
+  VU_TRY(launch_center_dk(a, s_dk));
   hipLaunchKernelGGL(k4, dim3(nblk), dim3(WPB * 64), lds3v, s_dv, q, k, v, dO, a.lse2, (const float*)nullptr, a.stats, (bf16_t*)a.dv, a.B, a.N, c, a.scale, a.rng);
   if (vu_prof_on()) vu_prof_note("flash2_bwd_dv_kernel", 4.0 * E * DH + 2.0 * E * H, 4.0 * act);
   VU_TRY(vu_check_launch("flash2_bwd_dv"));
