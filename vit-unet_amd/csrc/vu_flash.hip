@@ -2234,7 +2234,13 @@ inline ForkPool* fork_pool() {
 
 template <int DH>
 int launch_forward_v2(const vu_flash_args& a, hipStream_t st) {
-  constexpr int H = 8, WPB = 4, CK = 4;
+#ifndef VU_CKF
+#define VU_CKF 4
+#endif
+#ifndef VU_CKK
+#define VU_CKK 2
+#endif
+  constexpr int H = 8, WPB = 4, CK = VU_CKF;
   typedef FC<H, DH> C;
   const int ntiles = a.N >> 4, per = (ntiles + WPB - 1) / WPB;
   const int nblk = a.B * per;
@@ -2278,20 +2284,22 @@ int launch_backward_v2(const vu_flash_args& a, hipStream_t st) {
   // two workgroups per CU: every one of these must stay <= 80 KB (81920 B)
   const size_t lds1 = (2 * CK2 + 2 * WPB) * rowb + (size_t)WPB * 1280;          // (the final [WPB][NT] reduction aliases the K chunk)
   const size_t lds2 = (2 * CK2 + 2 * WPB) * rowb + zr;
-  const size_t lds3 = (2 * CK2 + 2 * WPB) * rowb + (size_t)WPB * 1280;
+  constexpr int CKK = VU_CKK;
+  const size_t lds3 = (2 * CKK + 2 * WPB) * rowb + (size_t)WPB * 1280;
   static_assert((size_t)WPB * NT * 4 <= (size_t)CK2 * 16 * C::PITCH * 2, "reduction scratch must fit the K chunk");
   const size_t lds4 = (2 * CK + 2 * WPB) * rowb + (size_t)2 * H * CK * 16 * 4 + (size_t)WPB * 1024;
-  const size_t lds2x = (2 * CK2 + 2 * WPB) * rowb + (size_t)WPB * 1024 + (size_t)tr_strip_elems<DH>() * 2;
+  constexpr int CKX = 1;
+  const size_t lds2x = (2 * CKX + 2 * WPB) * rowb + (size_t)WPB * 1024 + (size_t)tr_strip_elems<DH>() * 2;
   auto k1 = flash2_bwd_delta_kernel<DH, WPB, CK2>;
   auto k2 = flash2_bwd_dq_kernel<DH, WPB, CK2>;
-  auto k2x = flash2_bwd_dqx_kernel<DH, WPB, CK2>;
+  auto k2x = flash2_bwd_dqx_kernel<DH, WPB, CKX>;
   // The fused sweep takes V = sum_k P k from the TRAINING forward (flash2_moments_kernel); with running statistics (eval
   // mode + autograd) no moments sweep ran and pk holds nothing, so that case takes the separate delta and dq sweeps.
   // (VU_FLASH_UNFUSED=1, read once: diagnostic switch that takes the separate sweeps in training too)
   static const bool unfused_dbg = [] { const char* e = getenv("VU_FLASH_UNFUSED"); return e && e[0] == '1'; }();
   const bool fused = a.pk != nullptr && a.training && !unfused_dbg;
   VU_TRY(reserve_lds(k2x, lds2x));
-  auto k3 = flash2_bwd_dkv_kernel<DH, WPB, CK2, false>;
+  auto k3 = flash2_bwd_dkv_kernel<DH, WPB, CKK, false>;
   constexpr int CKV = 1;                 // dv: one tile per chunk, 16 stationary rows per wave: 43.5 KB, three workgroups per CU
   auto k4 = flash2_bwd_dkv_kernel<DH, WPB, CKV, true>;
   const size_t lds3v = (2 * CKV + WPB) * rowb + (size_t)WPB * 1280;
