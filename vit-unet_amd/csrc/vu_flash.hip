@@ -1266,8 +1266,15 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_moments_kernel(const bf16_
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* Kc = reinterpret_cast<bf16_t*>(smem_raw);
   float* red = reinterpret_cast<float*>(Kc + CK * 16 * C::PITCH);        // [WPB][2 H]
+  // s_b = sum_k bf16(P) (row_norm_note) for free where the head dim leaves spare rows in its last 16-feature block (d = 24:
+  // rows 24..31; d = 8: rows 8..15): the lanes that supply those rows' addresses to the transposing read point at a strip
+  // of ones instead of the next head's features, so the P k product accumulates sum_k bf16(P) * 1 in rows that were unused
+  constexpr bool SPARE = 16 * C::DT > DH;
+  constexpr int ONES = 7 * DH + 16;                                       // covers the per-head immediates of a spare lane
+  bf16_t* ones = reinterpret_cast<bf16_t*>(red + WPB * 16);
   const vu_rng rng = vu_rng_resolve(rng_in);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
+  if (SPARE) for (int i = tid; i < ONES; i += WPB * 64) ones[i] = (bf16_t)1.0f;
   const int ntiles = N >> 4, per = (ntiles + WPB - 1) / WPB;
   int b, grp;
   work_item(blockIdx.x, B, per, b, grp);
@@ -1281,6 +1288,9 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_moments_kernel(const bf16_
   float lse[H];
 #pragma unroll
   for (int h = 0; h < H; ++h) lse[h] = lse2[((long long)b * H + h) * N + qrow];
+  // last feature block of a head: per-lane source of the transposing read (element offsets from Kc; spare lanes: the ones strip)
+  const bool spare_lane = SPARE && (16 * (C::DT - 1) + 4 * (l15 & 3) >= DH);
+  const int last_base = spare_lane ? (int)(ones - Kc) : (4 * g4 + (l15 >> 2)) * C::PITCH + 16 * (C::DT - 1) + 4 * (l15 & 3);
   // table: W / keep (the statistics are those of sum_h W[g,h] P~_h); accumulator start: -shift_g
   MixOp op;
   make_mix_op(op, W, nullptr, l15, g4, rng.inv_keep);
@@ -1331,17 +1341,19 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_moments_kernel(const bf16_
         tag_probs<H>(S, lse, c, rng, wlane + 4u * (uint32_t)(ch * CK + kc), hstride);
         bf16x8 pk[4];
         pack_heads(S, pk);
+        const int last_kc = last_base + (spare_lane ? 0 : kc * 16 * C::PITCH);
 #pragma unroll
         for (int h = 0; h < H; ++h) {                  // a logits-shaped tile is the B operand of a key-contracting product as it stands
           const f32x4 p4 = {fabsf(S[h][0]), fabsf(S[h][1]), fabsf(S[h][2]), fabsf(S[h][3])};
           const s16x4 bop = pack4s(p4);
-          {
+          if constexpr (!SPARE) {
             const u32x2_t bw = __builtin_bit_cast(u32x2_t, bop);
             sb[h] = sum2_bf16(bw[1], sum2_bf16(bw[0], sb[h]));
           }
 #pragma unroll
-          for (int dt = 0; dt < C::DT; ++dt)
+          for (int dt = 0; dt < C::DT - 1; ++dt)
             pacc[h][dt] = mfma16(tr_operand<C::PITCH>(Kc, kc * 16, h * DH + 16 * dt, l15, g4), bop, pacc[h][dt]);
+          pacc[h][C::DT - 1] = mfma16(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(Kc + last_kc + h * DH)), bop, pacc[h][C::DT - 1]);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) pk[r] = relu_packed(pk[r]);
@@ -1365,12 +1377,18 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_moments_kernel(const bf16_
         if (f < DH) *reinterpret_cast<f32x4*>(prow + h * DH + f) = pacc[h][dt];
       }
   }
+  if constexpr (SPARE) {              // the spare rows of the last feature block (lane group 2, register 0) hold sum_k bf16(P)
 #pragma unroll
-  for (int h = 0; h < H; ++h) {       // the four lane groups of a query hold its four key quarters
-    float x = sb[h];
-    x += __shfl_xor(x, 16, 64);
-    x += __shfl_xor(x, 32, 64);
-    if (active && g4 == 0) rinv[((long long)b * H + h) * N + qrow] = 1.0f / x;
+    for (int h = 0; h < H; ++h)
+      if (active && g4 == 2) rinv[((long long)b * H + h) * N + qrow] = 1.0f / pacc[h][C::DT - 1][0];
+  } else {
+#pragma unroll
+    for (int h = 0; h < H; ++h) {     // the four lane groups of a query hold its four key quarters
+      float x = sb[h];
+      x += __shfl_xor(x, 16, 64);
+      x += __shfl_xor(x, 32, 64);
+      if (active && g4 == 0) rinv[((long long)b * H + h) * N + qrow] = 1.0f / x;
+    }
   }
   // lanes with the same head half (g4 & 1) hold the same 4 heads: reduce over q (16 lanes) and over a (g4 >> 1)
   __syncthreads();
@@ -2247,7 +2265,7 @@ int launch_forward_v2(const vu_flash_args& a, hipStream_t st) {
   const float c = a.scale * 1.44269504088896340736f;
   const size_t rowb = (size_t)16 * C::PITCH * 2;
   const size_t lds1 = CK * rowb + (size_t)WPB * C::NMOM * 4;
-  const size_t ldsm = CK * rowb + (size_t)WPB * 16 * 4;
+  const size_t ldsm = CK * rowb + (size_t)WPB * 16 * 4 + (size_t)(7 * DH + 16) * 2 + 16;
   const size_t lds2 = 2 * CK * rowb + (size_t)tr_zero_elems<H, DH>() * 2;
   auto k1 = flash_rowstats_kernel<H, DH, WPB, CK>;
   auto km = flash2_moments_kernel<DH, WPB, CK>;
