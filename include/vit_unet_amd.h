@@ -232,6 +232,30 @@ int vu_seg_prepare(const int16_t* image, const uint8_t* mask, float* x, float* y
                    size_t scratch_bytes, const double* inv_affine, int B, int Hs, int Ws, int oh,
                    int ow, float lo, float hi, float ls, void* stream);
 
+/* ---- ops of the reference's Keras re-implementation (csrc/vu_tfops.hip).  Not on the benchmarked path.
+ * n % 4 == 0 everywhere; dropout masks replay from (seed, stream_id) with element index = linear index (vu_dropout) or
+ * row * ld + j (softmax rows), as every other dropout site of this library. ---- */
+/* out = a + b: the input residual Y = X + unpatch(...) of /root/reference/vit_unet/tf/model.py:208 */
+int vu_add(int dtype, const void* a, const void* b, void* out, long long n, void* stream);
+/* out = dropout_p(in) (tf/functions.py:176,179 FeedForward.Drop1 / Drop2); the backward is the same call on the gradient */
+int vu_dropout(int dtype, const void* in, void* out, long long n, float p, uint64_t seed, uint64_t stream_id, void* stream);
+/* exact (erf) GELU and its backward dx = dy * gelu'(x) (tf.keras.activations.gelu, tf/functions.py:175,178) */
+int vu_gelu_fwd(int dtype, const void* x, void* y, long long n, void* stream);
+int vu_gelu_bwd(int dtype, const void* x, const void* dy, void* dx, long long n, void* stream);
+/* Resampling 'max' (mode 0) / 'avg' (mode 1), tf/functions.py:101-124, pool_size 4: (B,N,P) -> (B,N/4,P),
+ * y[b, w + s N/8, :] = pool of x[b, 8 w + 2 s + {0,1,4,5}, :] (+ pos[m, :] if pos != NULL: the layer's position embedding). */
+int vu_token_pool4_fwd(int dtype, int mode, const void* x, const float* pos, void* y, int B, int N, int P, void* stream);
+int vu_token_pool4_bwd(int dtype, int mode, const void* x, const void* dy, void* dx, int B, int N, int P, void* stream);
+/* Keras MultiHeadAttention probabilities (tf/functions.py:288-293): p = softmax(scale * s) over the n keys of each of `rows`
+ * rows (leading dimension ld), pd = dropout(p).  Backward: ds = scale * p * (g - sum_k p g), g = mask / keep * dpd. */
+int vu_softmax_rows_fwd(int dtype, const void* s, void* p, void* pd, long long rows, int n, int ld, float scale, float p_drop,
+                        uint64_t seed, uint64_t stream_id, void* stream);
+int vu_softmax_rows_bwd(int dtype, const void* p, const void* dpd, void* ds, long long rows, int n, int ld, float scale,
+                        float p_drop, uint64_t seed, uint64_t stream_id, void* stream);
+/* vu_add_layernorm_fwd with the epsilon as an argument (Keras LayerNormalization: 1e-3, per token: B = rows, P = features) */
+int vu_add_layernorm_fwd_eps(int dtype, const void* a, const void* x, void* z, const float* w, const float* b, void* y,
+                             float* ws, float* stats, int B, long long P, float eps, void* stream);
+
 /* Which form the re-attention runs in: PROCESS-GLOBAL test / experiment setting (the two forms draw different dropout
  * masks, so a forward and its backward - and a workspace carved for them - must see the same value: set it between
  * steps, never between a forward and its backward).

@@ -520,6 +520,132 @@ def notebook_forward(p, cfg: Config, X, *, training: bool = False, seed=None, st
 
 
 # --------------------------------------------------------------------------------------------
+# f4, second half: the layers of the reference's Keras re-implementation (/root/reference/vit_unet/tf/functions.py,
+# tf/model.py).  TensorFlow is not in this image and the reference holds no outputs of these layers: "parity unpinned" -
+# these functions restate the reference TEXT with torch CPU ops.  Conventions of vit_unet/torch/variants_tf.py: tokens
+# (B, N, P) in this repository's channel-major feature order, Dense weights torch-style (out, in), parameter names = that
+# module tree's state_dict keys.  Dropout masks: keep_mask with the linear element index (softmax rows: row * ld + j,
+# ld = n rounded up to 8), streams 2 s (attention probabilities) and FF_STREAM + 2 s (+ 1) (FeedForward).
+# --------------------------------------------------------------------------------------------
+def tf_dense(x, p, pre, st=None):
+    return F.linear(x, _r(p[pre + "weight"], st), p[pre + "bias"])
+
+
+def tf_token_layernorm(x, p, pre, eps: float = 1e-3):
+    """keras LayerNormalization(): axis -1, epsilon 1e-3 (tf/functions.py:281-282)."""
+    return F.layer_norm(x, x.shape[-1:], p[pre + "weight"], p[pre + "bias"], eps)
+
+
+def tf_feed_forward(x, p, pre, *, dropout: float, training: bool, seed=None, stream: int = 0, storage=None):
+    """tf/functions.py:163-182: Dense -> gelu -> Dropout -> Dense -> gelu -> Dropout."""
+    st = storage
+    h = _r(F.gelu(_r(tf_dense(x, p, pre + "D1.", st), st)), st)
+    h = _r(_dropout(h, dropout, training, seed, FF_STREAM + 2 * stream), st)
+    f = _r(F.gelu(_r(tf_dense(h, p, pre + "D2.", st), st)), st)
+    return _r(_dropout(f, dropout, training, seed, FF_STREAM + 2 * stream + 1), st)
+
+
+def keras_mha(query, value, p, pre, *, num_heads: int, dropout: float, training: bool, seed=None, stream: int = 0, storage=None):
+    """keras MultiHeadAttention(num_heads, key_dim)(query, value) with key = value (tf/functions.py:288, :389)."""
+    st = storage
+    B, Nq, _ = query.shape
+    Nk = value.shape[1]
+    q = _r(tf_dense(query, p, pre + "query.", st), st)
+    k = _r(tf_dense(value, p, pre + "key.", st), st)
+    v = _r(tf_dense(value, p, pre + "value.", st), st)
+    kd = q.shape[-1] // num_heads
+    qh = q.reshape(B, Nq, num_heads, kd).permute(0, 2, 1, 3)
+    kh = k.reshape(B, Nk, num_heads, kd).permute(0, 2, 1, 3)
+    vh = v.reshape(B, Nk, num_heads, kd).permute(0, 2, 1, 3)
+    s = _r(torch.matmul(qh, kh.transpose(-2, -1)), st)
+    a = _r(torch.softmax(s * (kd ** -0.5), dim=-1), st)
+    a = _r(_dropout(a, dropout, training, seed, 2 * stream, row_pad=8), st)
+    o = _r(torch.matmul(a, vh).permute(0, 2, 1, 3).reshape(B, Nq, num_heads * kd), st)
+    return _r(tf_dense(o, p, pre + "output.", st), st)
+
+
+def tf_attention_te(x, p, pre, *, layers: int, num_heads: int, attn_drop: float, proj_drop: float, training: bool, seed=None,
+                    stream: int = 0, storage=None):
+    """AttentionTransformerEncoder.call (tf/functions.py:302-311)."""
+    st = storage
+    for i in range(layers):
+        a = keras_mha(x, x, p, f"{pre}Attn.{i}.", num_heads=num_heads, dropout=attn_drop, training=training, seed=seed,
+                      stream=stream + i, storage=st)
+        x = _r(tf_token_layernorm(_r(a + x, st), p, f"{pre}LN1.{i}."), st)
+        f = tf_feed_forward(x, p, f"{pre}FF.{i}.", dropout=proj_drop, training=training, seed=seed, stream=stream + i, storage=st)
+        x = _r(tf_token_layernorm(_r(f + x, st), p, f"{pre}LN2.{i}."), st)
+    return x
+
+
+def tf_token_pool4(x, mode: str):
+    """Resampling 'max' / 'avg' before the position embedding (tf/functions.py:101-124), followed step by step:
+    pool pairs of consecutive tokens; reshape (B, N/2, P) -> (B, N/4, 2, P); transpose to (B, 2, N/4, P); inside a map over
+    the batch pool pairs along N/4; transpose back; concatenate the two slices of the middle axis along the tokens."""
+    B, N, P = x.shape
+    pool = (lambda t: torch.maximum(t[:, 0::2], t[:, 1::2])) if mode == "max" else (lambda t: 0.5 * (t[:, 0::2] + t[:, 1::2]))
+    t1 = pool(x)                                            # (B, N/2, P)
+    t3 = t1.reshape(B, N // 4, 2, P).permute(0, 2, 1, 3)    # (B, 2, N/4, P)
+    t4 = pool(t3.reshape(B * 2, N // 4, P)).reshape(B, 2, N // 8, P)
+    t5 = t4.permute(0, 2, 1, 3)                             # (B, N/8, 2, P)
+    return torch.cat([t5[:, :, 0], t5[:, :, 1]], dim=-2)    # (B, N/4, P)
+
+
+def tf_resampling(x, p, pre, *, kind: str, img_size: int, patch_size, C: int, storage=None):
+    """Resampling.call (tf/functions.py:100-132); patch_size = [from, to]."""
+    st = storage
+    pos = p[pre + "position_embedding.weight"]
+    if kind in ("max", "avg"):
+        return _r(tf_token_pool4(x, kind) + pos, st)
+    if kind == "standard":
+        y = retile(x, C, patch_size[1])
+        return _r(_r(tf_dense(y, p, pre + "linear.", st), st) + _r(pos, st), st)
+    assert kind == "conv"
+    B, N0, P0 = x.shape
+    s = int(round(math.sqrt(P0 // C)))
+    t = x.reshape(B, N0, C, s, s).permute(0, 2, 1, 3, 4).reshape(B * C, N0, s, s)         # patches are the channels
+    t = _r(F.conv2d(t, _r(p[pre + "conv.weight"], st), p[pre + "conv.bias"], stride=2), st)  # kernel 2, stride 2: 'same' pads nothing
+    N1 = t.shape[1]
+    t = t.reshape(B, C, N1, s // 2, s // 2).permute(0, 2, 1, 3, 4).reshape(B, N1, P0 // 4)
+    return _r(_r(tf_dense(t, p, pre + "linear.", st), st) + _r(pos, st), st)
+
+
+def tf_patch_encoder(X, p, pre, *, patch: int, storage=None):
+    """PatchEncoder.call (tf/functions.py:155-160)."""
+    st = storage
+    return _r(_r(tf_dense(patchify(X, patch), p, pre + "projection.", st), st) + _r(p[pre + "position_embedding.weight"], st), st)
+
+
+def tf_forward(p, X, *, img_size: int, patch_size, num_channels: int, num_heads: int, transformer_layers, size_bottleneck: int,
+               drop_attn: float, drop_proj: float, resampling_type: str, training: bool = False, seed=None, storage=None):
+    """HViT_UNet.call of the Keras model with original_attn=True (tf/model.py:188-209)."""
+    st = storage
+    L = len(patch_size)
+    rev = list(patch_size)[::-1]
+    enc = tf_patch_encoder(_r(X, st), p, "PE.", patch=patch_size[0], storage=st)
+    stream, skips = 0, []
+    kw = dict(num_heads=num_heads, attn_drop=drop_attn, proj_drop=drop_proj, training=training, seed=seed, storage=st)
+    for i in range(L - 1):
+        enc = tf_attention_te(enc, p, f"Encoder.{i}.", layers=transformer_layers[i], stream=stream, **kw)
+        stream += transformer_layers[i]
+        skips.append(enc)
+        enc = tf_resampling(enc, p, f"Encoder_RS.{i}.", kind=resampling_type, img_size=img_size, patch_size=list(patch_size[i:i + 2]),
+                            C=num_channels, storage=st)
+    enc = tf_attention_te(enc, p, "BottleNeck.", layers=size_bottleneck, stream=stream, **kw)
+    stream += size_bottleneck
+    skips = skips[::-1]
+    for i in range(L - 1):
+        enc = tf_resampling(enc, p, f"Decoder_RS.{i}.", kind=resampling_type, img_size=img_size, patch_size=rev[i:i + 2], C=num_channels,
+                            storage=st)
+        lay = transformer_layers[L - (i + 2)]
+        enc = tf_attention_te(enc, p, f"Decoder.{i}.", layers=lay, stream=stream, **kw)
+        stream += lay
+        enc = keras_mha(skips[i], enc, p, f"SkipConnections.{i}.Attn.", num_heads=num_heads, dropout=drop_attn, training=training,
+                        seed=seed, stream=stream, storage=st)
+        stream += 1
+    return (_r(X, st) + _r(unpatchify(enc, num_channels), st)).float()                   # tf/model.py:208: input residual
+
+
+# --------------------------------------------------------------------------------------------
 # parameters: names / shapes in reference registration order (model.py:309-370) and the
 # builder-owned deterministic weight generator used by the golden fixtures.
 # --------------------------------------------------------------------------------------------

@@ -188,3 +188,19 @@ def test_dft_matrices_give_the_real_part_of_fft2():
         ref = torch.fft.fft2(torch.from_numpy(x)).real.numpy()
         got = cn @ x @ cd - sn @ x @ sd
         assert np.abs(got - ref).max() < 1e-9 * np.abs(ref).max()
+
+
+def test_tf_token_pool_index_formula():
+    """The oracle follows Resampling 'max' / 'avg' (tf/functions.py:101-124) reshape by reshape; the HIP kernel uses the closed
+    form out[b, w + s N/8] = pool(x[b, 8 w + 2 s + {0, 1, 4, 5}]) (csrc/vu_tfops.hip): the two must be the same map."""
+    import vit_unet_oracle as O
+    g = torch.Generator().manual_seed(0)
+    for N in (16, 64, 256):
+        x = torch.randn(2, N, 12, generator=g)
+        for mode, red in (("max", lambda t: t.max(0).values), ("avg", lambda t: t.mean(0))):
+            got = O.tf_token_pool4(x, mode)
+            for m in range(N // 4):
+                s_, w = divmod(m, N // 8)
+                src = 8 * w + 2 * s_
+                ref = red(torch.stack([x[:, src], x[:, src + 1], x[:, src + 4], x[:, src + 5]]))
+                assert torch.allclose(got[:, m], ref, atol=1e-6), (N, mode, m)

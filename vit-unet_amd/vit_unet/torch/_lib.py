@@ -97,6 +97,15 @@ SIGNATURES = {
     "vu_denoise_prepare": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _vp, _i, _i, _i, _i, _i, _f, _f, _vp]),
     "vu_seg_prepare_scratch_bytes": (_sz, [_i, _i, _i]),
     "vu_seg_prepare": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _vp, _i, _i, _i, _i, _i, _f, _f, _f, _vp]),
+    "vu_add": (_i, [_i, _vp, _vp, _vp, _ll, _vp]),
+    "vu_dropout": (_i, [_i, _vp, _vp, _ll, _f, _u64, _u64, _vp]),
+    "vu_gelu_fwd": (_i, [_i, _vp, _vp, _ll, _vp]),
+    "vu_gelu_bwd": (_i, [_i, _vp, _vp, _vp, _ll, _vp]),
+    "vu_token_pool4_fwd": (_i, [_i, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "vu_token_pool4_bwd": (_i, [_i, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "vu_softmax_rows_fwd": (_i, [_i, _vp, _vp, _vp, _ll, _i, _i, _f, _f, _u64, _u64, _vp]),
+    "vu_softmax_rows_bwd": (_i, [_i, _vp, _vp, _vp, _ll, _i, _i, _f, _f, _u64, _u64, _vp]),
+    "vu_add_layernorm_fwd_eps": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _ll, _f, _vp]),
     "vu_set_attn_form": (_i, [_i, _i]),
     "vu_prof_enable": (_i, [_vp]),
     "vu_prof_report": (C.c_char_p, []),
