@@ -15,14 +15,15 @@ for C in ("FETCH_SIZE", "WRITE_SIZE"):
     for f in glob.glob(f"gpurun_out/pmc_{C}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             if r.get("Counter_Name") == C:
-                k = r["Kernel_Name"][:90]
+                k = r["Kernel_Name"][:160]
                 agg[k][0] += 1; agg[k][1] += float(r["Counter_Value"])
-    rows = sorted(agg.items(), key=lambda kv: -kv[1][1])[:24]
+    rows = sorted(agg.items(), key=lambda kv: -kv[1][1])      # every symbol: the two passes are joined on the name (pmc_traffic_json.py)
     with open(f"gpurun_out/pmc_{C}_summary.csv", "w") as o:
         o.write("kernel,launches,sum_%s,avg_per_launch\n" % C)
         for k, (n, v) in rows:
             o.write('"%s",%d,%.1f,%.1f\n' % (k, n, v, v / n))
-            print(C, n, "%.1f" % (v / n), k)
+        for k, (n, v) in rows[:24]:
+            print(C, n, "%.1f" % (v / n), k[:90])
     # drop the bulky raw files
 import shutil
 for C in ("FETCH_SIZE", "WRITE_SIZE"):

@@ -16,9 +16,14 @@ out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/
                "traffic_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: on gfx950 FETCH_SIZE counts half the bytes of wide "
                "coalesced reads (MI355X_MICROARCH.md, HBM)",
        "kernels": {}}
+missing = []
 for name, v in sorted(k.items()):
     f, w = v.get("FETCH_SIZE"), v.get("WRITE_SIZE")
-    out["kernels"][name] = {"FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w,
-                            "traffic_bytes": (2 * f + w) * 1024 if f is not None and w is not None else None}
+    if f is None or w is None:        # (a symbol seen in one pass only: a launch-count difference between the two runs)
+        missing.append(name)
+        continue
+    out["kernels"][name] = {"FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "traffic_bytes": (2 * f + w) * 1024}
+out["symbols_in_one_pass_only"] = missing
 json.dump(out, open(f"profiles/{tag}_pmc_traffic.json", "w"), indent=1)
-print(json.dumps({n: r["traffic_bytes"] for n, r in out["kernels"].items() if "map_bwd_mm" in n}))
+print(len(out["kernels"]), "symbols joined,", len(missing), "in one pass only")
+print(json.dumps({n[:60]: r["traffic_bytes"] for n, r in out["kernels"].items() if "flash2_bwd_dqx" in n}))
