@@ -47,10 +47,13 @@ def parse():
     ap.add_argument("--attn-operands", default=None, choices=["storage", "e4m3"],
                     help="what q, k, v are rounded to before the attention products; default: e4m3 for seg512 "
                          "(BASELINE config 5: fp8 attention operands), the storage dtype otherwise")
-    ap.add_argument("--no-graph", action="store_true", help="N=1: launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--force-graph", action="store_true", help="replay a hipGraph even where TrainStep.prefers_eager() says that "
+                    "eager launches are faster (the low-priority dv sweep of the recompute attention's backward)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-host-input", action="store_true", help="skip the PCIe-inclusive legs (N=1 only)")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the second, longer timed region (profiler runs)")
     ap.add_argument("--profile-steps", type=int, default=2)
     ap.add_argument("--dump-profile", default=None, help="write the full per-kernel table (JSON) here")
     return ap.parse_args()
@@ -193,7 +196,9 @@ def main():
         x = (y + 0.1 * torch.randn(y.shape, generator=g)).clamp(0, 1)
     x, y = x.to(dev), y.to(dev)
     ts = TrainStep(model, lr=1e-4, seed=1234 + rank, loss="dice" if seg else "mse")
-    use_graph = not a.no_graph
+    # eager where the step has tails to fill (TrainStep.prefers_eager: Base at >= 40 images per GPU), a hipGraph elsewhere
+    tail_overlap = ts.prefers_eager(a.batch) and not a.force_graph
+    use_graph = not a.no_graph and not tail_overlap
     if use_graph and not dp:
         ts.capture(x, y)
         step = lambda: ts.replay()                          # noqa: E731  (inputs stay resident)
@@ -235,7 +240,7 @@ def main():
     # timed region was under 2 s, a second, longer region of the same step is timed and reported beside it (`sustained`;
     # `value` / `steps` stay the contract's K steps)
     sustained = None
-    if dt_s < 2.0:
+    if dt_s < 2.0 and not a.no_sustained:
         n2 = int(min(2000, max(a.steps, 2.2 / (dt_s / a.steps))))
         fence()
         t1 = time.perf_counter()
@@ -357,7 +362,7 @@ def main():
                                       f"AdamW on synthetic " + ("CT-style 512x512x1 image/mask pairs" if seg else
                                                                 "SIDD-style 224x224x3 noisy/clean pairs") + ", random-init weights",
                           "per_gpu_batch": a.batch, "global_batch": a.batch * world, "parallelism": f"dp{world}", "rccl_path": dp,
-                          "hip_graph": use_graph, "attn_operands": operands, "final_loss": loss},
+                          "hip_graph": use_graph, "tail_overlap": bool(not use_graph and ts.prefers_eager(a.batch)), "attn_operands": operands, "final_loss": loss},
                "roofline": roof, "cpu_baseline": cpu, "parity": parity, "host_input": host_in, "sustained": sustained}
         print(json.dumps(out), flush=True)
     if dp:

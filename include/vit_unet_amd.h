@@ -66,6 +66,11 @@ int vu_model_num_params(const vu_config* cfg);
 int vu_model_param_table(const vu_config* cfg, vu_param_entry* out, int capacity);
 int vu_model_num_attn(const vu_config* cfg);                    /* BatchNorm modules           */
 size_t vu_model_workspace_bytes(const vu_config* cfg, int B);
+/* 1 when a training step of this configuration at B images per GPU is faster launched eagerly than replayed from a captured
+ * graph: the recompute attention's backward then runs its dv sweep on a low-priority stream in the tails of the dq / dk
+ * sweeps (more workgroups than the chip holds at once), and a captured kernel node carries no stream priority.  Needs a
+ * current device.  (No reference counterpart: launch policy of this library.) */
+int vu_model_prefers_eager(const vu_config* cfg, int B);
 
 /* HViT_UNet.forward (model.py:372-435).
  *  params      fp32 master arena            shadow   bf16 copy of the arena (dtype 1) or NULL

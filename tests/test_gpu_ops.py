@@ -481,3 +481,60 @@ def test_long_rows_4096_bf16_tracks_fp32(drop):
         if k == "reatten_matrix.bias":
             continue
         assert serr(g16[k], g32[k]) < bt, k
+
+
+def test_flash_backward_tail_overlap_is_bit_identical_to_the_serial_order(attn_form):
+    """Where the serial order would start a nearly empty round (44 images x 13 groups = 572 workgroups on 512 slots) an
+    EAGER backward of the recompute form runs its dv sweep on a low-priority stream beside the dq / dk sweeps
+    (csrc/vu_flash.hip "Tail overlap"); inside a stream capture the serial order is kept.  Same kernels, same operands,
+    disjoint outputs: bit-identical dx and parameter gradients (the convolution and projection weight gradients of the STAND-ALONE op end in
+    float atomics, so those are held to 1e-5), and the rule itself (vu_model_prefers_eager) says Base at 64 images, not at 32
+    or 128, never Lite."""
+    attn_form(flash=1)
+    dt, N, Cn, s, H, B = torch.bfloat16, 784, 3, 8, 8, 44
+    p, xq, _, dy, D = _attn_case(N, Cn, s, H, B=B)
+    L = lib()
+    d = {k: dev(v) for k, v in p.items()}
+    pw = dev(p["proj.weight"], dt)
+    prm = _lib.vu_attn_params(*[d[k].data_ptr() for k in GRAD_KEYS[:7]], pw.data_ptr(), d["proj.bias"].data_ptr(),
+                              d["var_norm.running_mean"].data_ptr(), d["var_norm.running_var"].data_ptr(), 0)
+    xd, dyd = dev(xq, dt), dev(dy, dt)
+    nbytes = L.vu_attn_workspace_bytes(1, B, N, D, H)
+    ws = torch.zeros(nbytes, dtype=torch.uint8, device=DEV)
+    y, dx = torch.empty_like(xd), torch.empty_like(xd)
+    grads = [torch.zeros_like(d[k]) for k in GRAD_KEYS]
+    gs = _lib.vu_attn_grads(*[g.data_ptr() for g in grads])
+
+    def run(stream):
+        check(L.vu_attn_forward(1, C.byref(prm), ptr(xd), ptr(xd), ptr(y), None, ptr(ws), nbytes, B, N, D, H, Cn, 0.2, 0.2, 1, 99, 3, stream))
+        check(L.vu_attn_backward(1, C.byref(prm), C.byref(gs), ptr(xd), ptr(xd), ptr(dyd), ptr(dx), None, ptr(ws), nbytes, B, N, D, H,
+                                 Cn, 0.2, 0.2, 1, 99, 3, stream))
+
+    run(st())                                               # eager: overlapped
+    torch.cuda.synchronize()
+    eager = [dx.clone()] + [g.clone() for g in grads]
+    assert all(torch.isfinite(t.float()).all() for t in eager)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=side):
+            run(_lib.stream_ptr())
+    torch.cuda.synchronize()
+    for g in grads:
+        g.zero_()
+    dx.zero_()
+    gr.replay()                                             # captured: serial order
+    torch.cuda.synchronize()
+    for a_, b_, name in zip(eager, [dx] + grads, ["dx"] + GRAD_KEYS):
+        if "conv2d" in name or name.startswith("proj."):
+            assert serr(a_, b_) < 1e-5, name
+        else:
+            assert torch.equal(a_, b_), name
+    from vit_unet.torch import model as M
+    attn_form()                                             # back to the per-level fill rule
+    base, lite = M.get_vit_unet("base", dtype=dt), M.get_vit_unet("lite", dtype=dt)
+    assert L.vu_model_prefers_eager(C.byref(base._cfg), 64) == 1
+    assert L.vu_model_prefers_eager(C.byref(base._cfg), 32) == 0
+    assert L.vu_model_prefers_eager(C.byref(base._cfg), 128) == 0
+    assert L.vu_model_prefers_eager(C.byref(lite._cfg), 64) == 0

@@ -23,6 +23,8 @@ ap.add_argument("--s", type=int, default=8)
 ap.add_argument("--H", type=int, default=8)
 ap.add_argument("--drop", type=float, default=0.2)
 ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--wall", action="store_true", help="event-time forward+backward as a whole, eager and as a hipGraph replay, instead "
+                "of the per-kernel profile (the profiler serialises the optional stream fork of the backward)")
 a = ap.parse_args()
 dev = "cuda"
 D = a.C * a.s * a.s
@@ -56,6 +58,33 @@ def run():
 
 run()
 torch.cuda.synchronize()
+if a.wall:
+    def timed(fn, n):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fn()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n * 1e3
+    n = max(a.reps, 20)
+    eager = timed(run, n)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        st = _lib.stream_ptr()
+        run()
+        side.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=side):
+            st = _lib.stream_ptr()
+            run()
+    torch.cuda.synchronize()
+    graph = timed(gr.replay, n)
+    print(f"wall: eager {eager:.1f} us, hipGraph replay {graph:.1f} us per fwd+bwd  (B={a.B} N={a.N} fork={os.environ.get('VU_FLASH_FORK', 'auto')})")
+    sys.exit(0)
 L.vu_prof_enable(C.c_void_p(torch.cuda.current_stream().cuda_stream))
 for _ in range(a.reps):
     run()

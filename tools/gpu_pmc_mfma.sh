@@ -1,8 +1,14 @@
 # MFMA utilisation per kernel: SQ_VALU_MFMA_BUSY_CYCLES (cycles, summed over SIMDs) against
 # GRBM_GUI_ACTIVE (sum over the 8 XCDs) - one --pmc pass, kernel-trace only.
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_WAVES --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_mfma -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-host-input --no-graph --no-roofline > $GRAFT_REPO_ROOT/gpurun_out/pmc_mfma.log 2>&1
-tail -c 200 $GRAFT_REPO_ROOT/gpurun_out/pmc_mfma.log
+# (one pass per kernel family: see tools/gpu_pmc.sh)
+FAMILIES=('flash' 'gemm' 'ln_|layernorm' 'map_|scores|mix_' 'conv' 'adamw|retile|bn_|colsum|cast|mse|tsgemm')
+i=0
+for RX in "${FAMILIES[@]}"; do
+  i=$((i+1))
+  timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_WAVES --kernel-trace --kernel-include-regex "$RX" --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_mfma/f$i -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-host-input --no-graph --no-roofline --no-sustained > $GRAFT_REPO_ROOT/gpurun_out/pmc_mfma_f$i.log 2>&1
+  echo "mfma / $RX: rc=$?"
+done
 cd $GRAFT_REPO_ROOT
 python - <<'PY'
 import csv, glob, collections

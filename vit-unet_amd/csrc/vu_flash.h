@@ -25,6 +25,9 @@ struct vu_flash_args {
 
 // attention-map dropout of this form: 8 bits per element, drop probability round(256 p) / 256 (vu_flash.hip, "quad" scheme)
 vu_rng vu_flash_quad_rng(vu_rng r);
+// true when the backward of this shape, launched eagerly (outside a stream capture), overlaps its dv sweep with the tails of the
+// dq / dk sweeps on a low-priority stream (vu_flash.hip "Tail overlap")
+bool vu_flash_tail_overlap(int B, int N, int H);
 bool vu_flash_ok(int dtype, int B, int N, int D, int H);
 // the recompute form only pays when its grid (B x ceil(N/64) work groups of 4 waves) puts a work group on most CUs; below that
 // the materialising kernels (which parallelise over heads too) are faster.  Measured on Base (N = 784: 13 groups per sample)

@@ -2230,24 +2230,54 @@ int launch_forward(const vu_flash_args& a, hipStream_t st) {
   return vu_check_launch("flash_apply");
 }
 
-// The dq, dk and dv sweeps only depend on the delta sweep and write disjoint tensors: they are enqueued on two forked
-// streams and joined back with events (capturable: a stream capture of `st` follows the fork / join), so that the tail
-// of one launch - 832 workgroups over 512 slots leave the second round 62 % full - is filled by the next one.  The
-// streams and events are per-thread library state created on first use.  OFF by default (VU_FLASH_FORK=1 enables it): on
-// the Base step the forked form measured slower than the serial one.
-struct ForkPool { hipStream_t s[2]; hipEvent_t e[3]; bool ok; };
+// Tail overlap of the backward (round 3).  The dv sweep needs nothing of the dq / dk sweeps and writes only dv, so it can
+// be enqueued FIRST, on a LOW-PRIORITY stream forked from `st`, and joined back at the end: the dispatcher serves the dq
+// and dk sweeps first and dv's workgroups take the slots their last, partly filled round leaves empty.  Measured on one
+// Base level-2 module (N = 784, 13 workgroups per image; forward + backward, us, serial order replayed from a graph ->
+// overlapped, eager; tools/flash_bench.py --wall): 40 images 1229 -> 1151, 48: 1286 -> 1253, 56: 1310 -> 1341 (worse),
+// 64: 1641 -> 1561, 72: 1672 -> 1678, 80: 1969 -> 1877, 96: 2046 -> 2114 (worse), 128: 2768 -> 2820 (worse); the Base step
+// at 64 images 13.42 -> 13.11 ms.  A partly filled round is not a loss by itself - its workgroups have their CU to
+// themselves and run ~1.3x faster (two waves per SIMD deliver 1.56x the throughput of one) - so the overlap only pays where
+// the serial order starts a nearly EMPTY round: the dq / dk sweeps (two workgroups per CU, 512 slots) with at most 22 % of a
+// round left over, or the dv sweep (three per CU, 768 slots) with at most 10 %.  That is the rule below; it is the fit of
+// those eight points, nothing deeper.  Never inside a stream capture: a captured kernel node carries no priority
+// (hipGraphKernelNodeSetAttribute rejects hipKernelNodeAttributePriority on this runtime), and at EQUAL priority dv's
+// workgroups take LDS and slots from the dq sweep from its first round on (64 images: 1942 - 2165 us against 1641).  A caller
+// that wants the overlap launches eagerly (vu_model_prefers_eager tells; engine.TrainStep / bench.py follow it).
+// VU_FLASH_FORK: unset = that rule; 0 = never; 2 = always when launched eagerly or captured (experiments); 1 = the round-2
+// form (dk and dv forked at equal priority after the dq sweep; 2 % slower on the Base step).  Streams and events are
+// per-thread library state, created on first use.
+struct ForkPool { hipStream_t s[2]; hipEvent_t e[3]; bool ok; int mode; int slots; };
 inline ForkPool* fork_pool() {
-  static thread_local ForkPool fp = {{nullptr, nullptr}, {nullptr, nullptr, nullptr}, false};
+  static thread_local ForkPool fp = {{nullptr, nullptr}, {nullptr, nullptr, nullptr}, false, 3, 512};
   static thread_local bool tried = false;
   if (!tried) {
     tried = true;
-    const char* ev = getenv("VU_FLASH_FORK");       // opt-in: measured 2 % SLOWER on the Base step (17.96 vs 17.61 ms), kept for experiments
-    bool ok = ev && ev[0] == '1';
-    for (int i = 0; ok && i < 2; ++i) ok = hipStreamCreateWithFlags(&fp.s[i], hipStreamNonBlocking) == hipSuccess;
+    const char* ev = getenv("VU_FLASH_FORK");
+    fp.mode = (ev && ev[0] >= '0' && ev[0] <= '2') ? ev[0] - '0' : 3;
+    bool ok = fp.mode != 0;
+    int lo = 0, hi = 0, dev = 0, cus = 0;
+    if (ok) ok = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess;          // lo: the least priority (largest number)
+    if (ok && hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+      fp.slots = 2 * cus;
+    for (int i = 0; ok && i < 2; ++i)
+      ok = (fp.mode == 1 ? hipStreamCreateWithFlags(&fp.s[i], hipStreamNonBlocking) : hipStreamCreateWithPriority(&fp.s[i], hipStreamNonBlocking, lo)) == hipSuccess;
     for (int i = 0; ok && i < 3; ++i) ok = hipEventCreateWithFlags(&fp.e[i], hipEventDisableTiming) == hipSuccess;
     fp.ok = ok;
   }
   return fp.ok ? &fp : nullptr;
+}
+// does the backward of this shape, launched eagerly on `st`, overlap its dv sweep (see above)?
+inline bool tail_overlap(const ForkPool* fp, int nblk, hipStream_t st, bool check_capture) {
+  if (!fp || fp->mode == 1) return false;
+  if (fp->mode == 2) return true;
+  const int r2 = nblk % fp->slots, s3 = fp->slots / 2 * 3, r3 = nblk % s3;
+  if (nblk <= fp->slots || !((r2 > 0 && 100 * r2 <= 22 * fp->slots) || (r3 > 0 && 10 * r3 <= s3))) return false;
+  if (check_capture) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;
+  }
+  return true;
 }
 
 template <int DH>
@@ -2325,6 +2355,20 @@ int launch_backward_v2(const vu_flash_args& a, hipStream_t st) {
   (void)lds4;
   const double E = (double)a.B * H * a.N * a.N, act = (double)a.B * a.N * C::D * 2.0;
   const bf16_t *q = (const bf16_t*)a.q, *k = (const bf16_t*)a.k, *v = (const bf16_t*)a.v, *dO = (const bf16_t*)a.dO;
+  ForkPool* fp = vu_prof_on() ? nullptr : fork_pool();
+  hipStream_t s_dk = st, s_dv = st;
+  const bool early_dv = tail_overlap(fp, nblk, st, true);
+  auto launch_dv = [&]() -> int {
+    hipLaunchKernelGGL(k4, dim3(nblk), dim3(WPB * 64), lds3v, s_dv, q, k, v, dO, a.lse2, (const float*)nullptr, a.stats, (bf16_t*)a.dv, a.B, a.N, c, a.scale, a.rng);
+    if (vu_prof_on()) vu_prof_note("flash2_bwd_dv_kernel", 4.0 * E * DH + 2.0 * E * H, 4.0 * act);
+    return vu_check_launch("flash2_bwd_dv");
+  };
+  if (early_dv) {
+    bool ok = hipEventRecord(fp->e[0], st) == hipSuccess && hipStreamWaitEvent(fp->s[1], fp->e[0], 0) == hipSuccess;
+    if (!ok) { vu_set_error("flash attention: stream fork failed"); return VU_ELAUNCH; }
+    s_dv = fp->s[1];
+    VU_TRY(launch_dv());
+  }
   if (fused) {
     hipLaunchKernelGGL(k2x, dim3(nblk), dim3(WPB * 64), lds2x, st, q, k, v, dO, a.lse2, a.rinv, a.pk, a.stats, (bf16_t*)a.dq, a.delta, a.partials, a.B,
                        a.N, c, a.scale, a.rng, a.training ? 0 : 1);
@@ -2337,9 +2381,8 @@ int launch_backward_v2(const vu_flash_args& a, hipStream_t st) {
   }
   hipLaunchKernelGGL(flash_bwd_mix_finalize_kernel, dim3((unsigned)((H * H + H + 15) / 16)), dim3(1024), 0, st, a.partials, nblk, a.stats, a.d_mix_w, a.d_mix_b, H, a.rng.inv_keep);
   VU_TRY(vu_check_launch("flash_bwd_mix_finalize"));
-  ForkPool* fp = vu_prof_on() ? nullptr : fork_pool();
-  hipStream_t s_dk = st, s_dv = st;
-  if (fp) {
+  const bool late_fork = fp && fp->mode == 1;
+  if (late_fork) {
     bool ok = hipEventRecord(fp->e[0], st) == hipSuccess;
     ok = ok && hipStreamWaitEvent(fp->s[0], fp->e[0], 0) == hipSuccess && hipStreamWaitEvent(fp->s[1], fp->e[0], 0) == hipSuccess;
     if (!ok) { vu_set_error("flash attention: stream fork failed"); return VU_ELAUNCH; }
@@ -2354,12 +2397,10 @@ int launch_backward_v2(const vu_flash_args& a, hipStream_t st) {
   if (vu_prof_on()) vu_prof_note("flash2_bwd_dk_kernel", 6.0 * E * DH + 4.0 * E * H, 5.0 * act);
   VU_TRY(vu_check_launch("flash2_bwd_dk"));
   VU_TRY(launch_center_dk(a, s_dk));
-  hipLaunchKernelGGL(k4, dim3(nblk), dim3(WPB * 64), lds3v, s_dv, q, k, v, dO, a.lse2, (const float*)nullptr, a.stats, (bf16_t*)a.dv, a.B, a.N, c, a.scale, a.rng);
-  if (vu_prof_on()) vu_prof_note("flash2_bwd_dv_kernel", 4.0 * E * DH + 2.0 * E * H, 4.0 * act);
-  VU_TRY(vu_check_launch("flash2_bwd_dv"));
-  if (fp) {
-    bool ok = hipEventRecord(fp->e[1], fp->s[0]) == hipSuccess && hipEventRecord(fp->e[2], fp->s[1]) == hipSuccess;
-    ok = ok && hipStreamWaitEvent(st, fp->e[1], 0) == hipSuccess && hipStreamWaitEvent(st, fp->e[2], 0) == hipSuccess;
+  if (!early_dv) VU_TRY(launch_dv());
+  if (early_dv || late_fork) {
+    bool ok = (!late_fork || hipEventRecord(fp->e[1], fp->s[0]) == hipSuccess) && hipEventRecord(fp->e[2], fp->s[1]) == hipSuccess;
+    ok = ok && (!late_fork || hipStreamWaitEvent(st, fp->e[1], 0) == hipSuccess) && hipStreamWaitEvent(st, fp->e[2], 0) == hipSuccess;
     if (!ok) { vu_set_error("flash attention: stream join failed"); return VU_ELAUNCH; }
   }
   return VU_OK;
@@ -2374,6 +2415,11 @@ int launch_backward_v2(const vu_flash_args& a, hipStream_t st) {
     vu_set_error("flash attention: shape H=%d d=%d not instantiated", a.H, dh_);      \
     return VU_EUNSUPPORTED;                                                            \
   } while (0)
+
+bool vu_flash_tail_overlap(int B, int N, int H) {
+  if (H != 8) return false;                 // (the 4-head form keeps the serial backward)
+  return tail_overlap(fork_pool(), B * (((N >> 4) + 3) / 4), nullptr, false);
+}
 
 bool vu_flash_pays(int B, int N) { return (long long)B * ((N / 16 + 3) / 4) >= 192; }
 

@@ -890,6 +890,17 @@ size_t vu_model_workspace_bytes(const vu_config* cfg, int B) {
   return w.bytes;
 }
 
+int vu_model_prefers_eager(const vu_config* cfg, int B) {
+  Plan pl;
+  if (!cfg || B <= 0 || build_plan(*cfg, pl) != VU_OK) return 0;
+  const int dt = cfg->dtype;
+  for (const Level& L : pl.lv) {
+    AttnDims d{dt, B, L.N, L.D, cfg->num_heads, cfg->num_channels, L.s, L.ld, 1, flash_switch()};
+    if (flash_on(d) && vu_flash_tail_overlap(B, L.N, cfg->num_heads)) return 1;
+  }
+  return 0;
+}
+
 int vu_model_forward(const vu_config* cfg, const float* params, const void* shadow, float* bn_state, const float* x,
                      float* y, void* ws, size_t ws_bytes, int B, int training, uint64_t seed, const uint32_t* rng_salt,
                      void* stream) {

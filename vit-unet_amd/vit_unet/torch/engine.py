@@ -221,6 +221,14 @@ class TrainStep:
             self.hyper.copy_(torch.tensor(new, dtype=torch.float32))
 
     # ---- hipGraph capture ----------------------------------------------------------------------
+    def prefers_eager(self, batch: int) -> bool:
+        """True when `step` (eager launches) beats `capture` + `replay` for this model at `batch` images per GPU: with more
+        workgroups than the chip holds at once, the recompute attention's backward runs its dv sweep on a low-priority
+        stream in the tails of the dq / dk sweeps (csrc/vu_flash.hip "Tail overlap"); a captured graph cannot carry the
+        priority and takes the serial order.  Base at 64 images: 13.1 ms eager against 13.4 ms replayed; the ~420 launches
+        of a step cost the host 2 ms, hidden behind the 13 ms of GPU work."""
+        return bool(lib().vu_model_prefers_eager(C.byref(self.model._cfg), int(batch)))
+
     def capture(self, x: torch.Tensor, y: torch.Tensor):
         """Capture one step into a hipGraph (static input buffers); `replay(x, y)` then copies the
         batch into the static buffers and launches the graph.  Single-GPU only: the collective is
