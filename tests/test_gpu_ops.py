@@ -35,6 +35,45 @@ def dev(t, dt=None):
     return t.to(dt).contiguous() if dt is not None else t.contiguous()
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cross", [False, True])
+@pytest.mark.parametrize("C_,s,npatch", [(3, 8, 98), (3, 8, 1571), (3, 16, 37), (3, 32, 5), (1, 8, 333), (1, 16, 10), (1, 32, 7),
+                                         (3, 4, 100), (2, 8, 20)])
+def test_conv3x3_qkv_forms(dt, cross, C_, s, npatch):
+    """q / k / v convolutions of one module at once and the sum of their data gradients (model.py:137-139,152-154; the
+    SkipConnection takes q and k / v from different tensors): bf16 with C in {1, 3} and s in {8, 16, 32} runs on the matrix
+    cores (csrc/vu_conv_mm.hip; weights as bf16 hi + lo), the rest on the stencil kernels; ragged patch counts included."""
+    g = torch.Generator().manual_seed(5)
+    xq = torch.randn(npatch, C_, s, s, generator=g).to(dt)
+    xkv = torch.randn(npatch, C_, s, s, generator=g).to(dt) if cross else xq
+    ws = [torch.randn(C_, C_, 3, 3, generator=g) * 0.3 for _ in range(3)]
+    dys = [torch.randn(npatch, C_, s, s, generator=g).to(dt) for _ in range(3)]
+    adds = [torch.randn(npatch, C_, s, s, generator=g).to(dt) for _ in range(2)]
+    xqr = xq.float().requires_grad_(True)
+    xkr = xkv.float().requires_grad_(True) if cross else xqr
+    ref = [torch.nn.functional.conv2d(xqr if t == 0 else xkr, ws[t], None, padding=1) for t in range(3)]
+    sum((r * d.float()).sum() for r, d in zip(ref, dys)).backward()
+    code = _lib.DTYPE_CODE[dt]
+    xqd = dev(xq)
+    xkd = dev(xkv) if cross else xqd
+    wd = [dev(w) for w in ws]
+    out = [torch.full_like(xqd, float("nan")) for _ in range(3)]
+    check(lib().vu_conv3x3_qkv_fwd(code, ptr(xqd), ptr(xkd), ptr(wd[0]), ptr(wd[1]), ptr(wd[2]), ptr(out[0]), ptr(out[1]), ptr(out[2]),
+                                   npatch, C_, s, st()))
+    ft, bt = TOL[dt]
+    for t in range(3):
+        assert serr(out[t], ref[t]) < (ft if dt == torch.float32 else 8e-3), t       # bf16: only the output rounding
+    dyd, addd = [dev(d) for d in dys], [dev(a_) for a_ in adds]
+    dxq = torch.full_like(xqd, float("nan"))
+    dxkv = torch.full_like(xqd, float("nan")) if cross else None
+    check(lib().vu_conv3x3_qkv_dgrad(code, ptr(dyd[0]), ptr(dyd[1]), ptr(dyd[2]), ptr(wd[0]), ptr(wd[1]), ptr(wd[2]), ptr(addd[0]),
+                                     ptr(addd[1]) if cross else None, ptr(dxq), ptr(dxkv) if cross else None, npatch, C_, s, st()))
+    tol = bt if dt == torch.float32 else 8e-3
+    assert serr(dxq, xqr.grad + adds[0].float()) < tol
+    if cross:
+        assert serr(dxkv, xkr.grad + adds[1].float()) < tol
+
+
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("C_,im,s_in,s_out", [(3, 32, 32, 8), (3, 32, 8, 4), (3, 32, 4, 16), (1, 64, 16, 64),

@@ -508,6 +508,11 @@ int vu_k_conv3x3_qkv_fwd(int dtype, const void* xq, const void* xkv, const float
   VU_REQUIRE(npatch * s * s / 4 < 4294967295LL, "conv3x3: more than 2^32 pixel quads");
   const long long nq = npatch * s * s / 4;
   if (nq == 0) return VU_OK;
+  if (vu_conv_mm_ok(dtype, C, s, 0) && npatch < 2147483647LL) {
+    if (int e = vu_k_conv_mm_qkv_fwd(xq, xkv, wq, wk, wv, q, k, v, npatch, C, s, st)) return e;
+    if (vu_prof_on()) vu_prof_note("conv_qkv_mm_kernel", 2.0 * 243.0 / 9.0 * C * C * nq * 4, (double)nq * 4 * C * 2.0 * (xq == xkv ? 4 : 5));
+    return vu_check_launch("vu_conv3x3_qkv_fwd (MFMA form)");
+  }
   const int grid = grid_for(nq, 256 * 16);
   int sh = shuffle_off() ? 0 : conv_shuffle_form(s);
   if (sh == 2) sh = 1;      // forward: VALU-bound (243 MACs per pixel), the extra DPP moves of the one-load form cost more than its loads (37.9 vs 30.9 us)
@@ -544,6 +549,11 @@ int vu_k_conv3x3_qkv_dgrad(int dtype, const void* dq, const void* dk, const void
   VU_REQUIRE(npatch * s * s / 4 < 4294967295LL, "conv3x3: more than 2^32 pixel quads");
   const long long nq = npatch * s * s / 4;
   if (nq == 0) return VU_OK;
+  if (vu_conv_mm_ok(dtype, C, s, 1) && npatch < 2147483647LL) {
+    if (int e = vu_k_conv_mm_qkv_dgrad(dq, dk, dv, wq, wk, wv, add_q, add_kv, dxq, dxkv, npatch, C, s, st)) return e;
+    if (vu_prof_on()) vu_prof_note("conv_qkv_dgrad_mm_kernel", 2.0 * 243.0 / 9.0 * C * C * nq * 4, (double)nq * 4 * C * 2.0 * (dxkv ? 5 + (add_q ? 1 : 0) + (add_kv ? 1 : 0) : 4 + (add_q ? 1 : 0)));
+    return vu_check_launch("vu_conv3x3_qkv_dgrad (MFMA form)");
+  }
   const int grid = grid_for(nq, 256 * 16);
   const int sh = shuffle_off() ? 0 : conv_shuffle_form(s);
 #define VU_QKV_DGRAD(SHV) \

@@ -984,6 +984,18 @@ int vu_conv3x3_bwd(int dtype, int dout_f32, const void* dout, const void* in, co
   return VU_OK;
 }
 
+int vu_conv3x3_qkv_fwd(int dtype, const void* xq, const void* xkv, const float* wq, const float* wk, const float* wv, void* q,
+                       void* k, void* v, long long npatch, int C, int s, void* stream) {
+  VU_REQUIRE(xq && xkv && wq && wk && wv && q && k && v, "vu_conv3x3_qkv_fwd: null argument");
+  return vu_k_conv3x3_qkv_fwd(dtype, xq, xkv, wq, wk, wv, q, k, v, npatch, C, s, (hipStream_t)stream);
+}
+int vu_conv3x3_qkv_dgrad(int dtype, const void* dq, const void* dk, const void* dv, const float* wq, const float* wk,
+                         const float* wv, const void* add_q, const void* add_kv, void* dxq, void* dxkv, long long npatch, int C,
+                         int s, void* stream) {
+  VU_REQUIRE(dq && dk && dv && wq && wk && wv && dxq, "vu_conv3x3_qkv_dgrad: null argument");
+  return vu_k_conv3x3_qkv_dgrad(dtype, dq, dk, dv, wq, wk, wv, add_q, add_kv, dxq, dxkv, npatch, C, s, (hipStream_t)stream);
+}
+
 static void carve_attn_ws(Bump& bp, const AttnDims& d, AttnBuf& a, AttnScratch& sc, void** dzbuf) {
   carve_attn(bp, d, a);
   if (!a.pk) a.pk = bp.takef((size_t)d.B * d.N * d.D);      // the op's form is chosen after the carve (test switch)
