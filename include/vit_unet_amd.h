@@ -122,8 +122,8 @@ int vu_conv3x3_bwd(int dtype, int dout_f32, const void* dout, const void* in, co
 /* The three convolutions of a ReAttention / SkipConnection at once (model.py:137-139 qconv2d / kconv2d / vconv2d applied at
  * :152-154; SkipConnection :246-248 takes q from one tensor and k, v from another: xq != xkv): one read of the input(s),
  * no bias; and the sum of their data gradients: dxq = convT(dq) [+ convT(dk) + convT(dv) when dxkv is NULL] + add_q,
- * dxkv = convT(dk) + convT(dv) + add_kv (add_* may be NULL).  bf16 with C in {1, 3} and patch size 8 / 16 / 32 runs on the
- * matrix cores (csrc/vu_conv_mm.hip), everything else on the stencil kernels. */
+ * dxkv = convT(dk) + convT(dv) + add_kv (add_* may be NULL).  Stencil kernels (csrc/vu_conv.hip); a matrix-core form exists
+ * behind VU_CONV_MM=1 (csrc/vu_conv_mm.hip: measured, not faster). */
 int vu_conv3x3_qkv_fwd(int dtype, const void* xq, const void* xkv, const float* wq, const float* wk, const float* wv,
                        void* q, void* k, void* v, long long npatch, int C, int s, void* stream);
 int vu_conv3x3_qkv_dgrad(int dtype, const void* dq, const void* dk, const void* dv, const float* wq, const float* wk,

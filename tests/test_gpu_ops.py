@@ -41,8 +41,8 @@ def dev(t, dt=None):
                                          (3, 4, 100), (2, 8, 20)])
 def test_conv3x3_qkv_forms(dt, cross, C_, s, npatch):
     """q / k / v convolutions of one module at once and the sum of their data gradients (model.py:137-139,152-154; the
-    SkipConnection takes q and k / v from different tensors): bf16 with C in {1, 3} and s in {8, 16, 32} runs on the matrix
-    cores (csrc/vu_conv_mm.hip; weights as bf16 hi + lo), the rest on the stencil kernels; ragged patch counts included."""
+    SkipConnection takes q and k / v from different tensors), ragged patch counts included.  The same test covers the
+    matrix-core form (csrc/vu_conv_mm.hip: bf16, C in {1, 3}, s in {8, 16, 32}) when the suite runs under VU_CONV_MM=1."""
     g = torch.Generator().manual_seed(5)
     xq = torch.randn(npatch, C_, s, s, generator=g).to(dt)
     xkv = torch.randn(npatch, C_, s, s, generator=g).to(dt) if cross else xq
@@ -163,6 +163,36 @@ def test_gemm_forms(dt, M, N, K):
     out = dev(base.clone())
     _gemm(dt, dev(a.t().contiguous()), dev(b), M, N, K, 1, M, N, 1, c_float=1, accumulate=1, out=out)
     assert serr(out.view(M, N), ref + base.double()) < ft * (4 if dt == torch.bfloat16 else 40)
+
+
+def test_gemm_library_route_for_plain_big_products():
+    """Plain big bf16 products (no fused epilogue beyond a bias; both output extents and K >= 512) go to hipBLASLt
+    (csrc/vu_blaslt.hip): the three layouts the Linear layers use - forward x W^T + b, data gradient dy W, fp32-accumulating
+    weight gradient dy^T x - against float64 on the bf16-rounded operands, and the launch profiler shows the route taken."""
+    import json
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(17)
+    M, N, K = 2176, 1536, 1600
+    x = torch.randn(M, K, generator=g).to(dt)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dt)
+    dy = torch.randn(M, N, generator=g).to(dt)
+    bias = torch.randn(N, generator=g)
+    L = lib()
+    L.vu_prof_enable(C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    y = _gemm(dt, dev(x), dev(w), M, N, K, K, 1, 1, K, bias=dev(bias))                      # B stored (N, K)
+    assert serr(y.view(M, N), x.double() @ w.double().t() + bias.double()) < 8e-3
+    dx = _gemm(dt, dev(dy), dev(w), M, K, N, N, 1, K, 1)                                      # B stored (K', N') = (N, K) row-major
+    assert serr(dx.view(M, K), dy.double() @ w.double()) < 8e-3
+    M2, N2, K2 = 2048, 2048, 1111                                                             # weight gradient: A stored (K2, M2)
+    a = torch.randn(K2, M2, generator=g).to(dt)
+    b = torch.randn(K2, N2, generator=g).to(dt)
+    acc0 = torch.randn(M2, N2, generator=g)
+    out = dev(acc0).clone().reshape(-1)
+    _gemm(dt, dev(a), dev(b), M2, N2, K2, 1, M2, N2, 1, c_float=1, accumulate=1, out=out)
+    assert serr(out.view(M2, N2), acc0.double() + a.double().t() @ b.double()) < 2e-5
+    torch.cuda.synchronize()
+    rep = json.loads(L.vu_prof_report().decode())
+    assert rep.get("hipblaslt_gemm<bf16>", {}).get("count") == 2 and rep.get("hipblaslt_gemm<f32 acc>", {}).get("count") == 1, rep.keys()
 
 
 @pytest.mark.parametrize("M,N,K", [(48, 16, 3137), (200, 72, 1500), (192, 192, 4100), (64, 768, 2049), (3072, 128, 1100)])

@@ -1,0 +1,143 @@
+// Plain big GEMMs through hipBLASLt (round 3).  The Linear layers of levels 0 / 1 (3072 x 3072 and 768 x 768 weights over
+// 3136 / 12544 tokens; model.py:102-108,147-148) with NO fused epilogue beyond a bias - the projections' data gradients, the
+// forward when no dropout rides on it - are exactly what the vendor library is tuned for: measured on this box with random
+// operands, M 3136 N 3072 K 3072: vu_gemm 126 us (469 TFLOP/s) against 52.7 us (1122); M 12544 N 768 K 768: 34.8 against
+// 28.0 forward, 32.8 against 20.8 for the data gradient (tools/gemm_lib_compare.py).  Everything with a fused epilogue
+// (GELU, residual addend; dropout and bias-gradient column sums below the 3072 x 3072 class), every batched / per-head
+// product, the skinny shapes and the fp32-accumulating weight gradients below 3072 x 3072 stay on csrc/vu_gemm.hip /
+// vu_tsgemm.hip / vu_pgemm.hip.
+// Row-major C (M x N) = A B is handed over as the column-major product C^T = B^T A^T.
+// Plans (descriptors + the heuristic's first algorithm) are cached per shape; a plan is never CREATED while the stream is
+// being captured (the heuristic query and the workspace allocation are not capturable) - such a call falls back to vu_gemm.
+#include <hipblaslt/hipblaslt.h>
+#include <map>
+#include <mutex>
+#include <stdlib.h>
+#include <tuple>
+#include "vu_kernels.h"
+
+namespace {
+
+typedef std::tuple<int, int, int, int, int, long long, long long, long long, int, int, int> Key;
+struct Plan {
+  hipblasLtMatmulDesc_t desc = nullptr;
+  hipblasLtMatrixLayout_t a = nullptr, b = nullptr, c = nullptr;
+  hipblasLtMatmulAlgo_t algo;
+  size_t ws = 0;
+  bool ok = false;
+};
+struct State {
+  std::mutex mu;
+  hipblasLtHandle_t handle = nullptr;
+  void* ws = nullptr;
+  size_t ws_bytes = 0;
+  std::map<Key, Plan> plans;
+  bool dead = false;
+};
+State& state() { static State s; return s; }
+
+inline int lt_mode() {        // VU_GEMM_LT: 0 = never, unset / 1 = where eligible
+  static const int v = [] { const char* e = getenv("VU_GEMM_LT"); return (e && e[0] == '0') ? 0 : 1; }();
+  return v;
+}
+constexpr size_t WS_BYTES = 32u << 20;
+
+bool make_plan(State& s, Plan& p, int m, int n, int k, hipblasOperation_t opA, hipblasOperation_t opB, long long lda, long long ldb,
+               long long ldc, int c_float, int has_bias) {
+  if (!s.handle && hipblasLtCreate(&s.handle) != HIPBLAS_STATUS_SUCCESS) return false;
+  if (!s.ws) {
+    if (hipMalloc(&s.ws, WS_BYTES) != hipSuccess) { s.ws = nullptr; return false; }
+    s.ws_bytes = WS_BYTES;
+  }
+  if (hipblasLtMatmulDescCreate(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F) != HIPBLAS_STATUS_SUCCESS) return false;
+  int32_t ta = (int32_t)opA, tb = (int32_t)opB;
+  hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &ta, sizeof(ta));
+  hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &tb, sizeof(tb));
+  if (has_bias) {
+    uint32_t epi = HIPBLASLT_EPILOGUE_BIAS;
+    int32_t bt = (int32_t)HIP_R_32F;
+    hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_EPILOGUE, &epi, sizeof(epi));
+    hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_DATA_TYPE, &bt, sizeof(bt));
+  }
+  // column-major operands: A' is (m x k) or, transposed, stored (k x m); B' is (k x n) or stored (n x k)
+  const bool okl =
+      hipblasLtMatrixLayoutCreate(&p.a, HIP_R_16BF, opA == HIPBLAS_OP_N ? m : k, opA == HIPBLAS_OP_N ? k : m, lda) == HIPBLAS_STATUS_SUCCESS &&
+      hipblasLtMatrixLayoutCreate(&p.b, HIP_R_16BF, opB == HIPBLAS_OP_N ? k : n, opB == HIPBLAS_OP_N ? n : k, ldb) == HIPBLAS_STATUS_SUCCESS &&
+      hipblasLtMatrixLayoutCreate(&p.c, c_float ? HIP_R_32F : HIP_R_16BF, m, n, ldc) == HIPBLAS_STATUS_SUCCESS;
+  if (!okl) return false;
+  hipblasLtMatmulPreference_t pref = nullptr;
+  if (hipblasLtMatmulPreferenceCreate(&pref) != HIPBLAS_STATUS_SUCCESS) return false;
+  uint64_t wsb = s.ws_bytes;
+  hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &wsb, sizeof(wsb));
+  hipblasLtMatmulHeuristicResult_t res[1];
+  int got = 0;
+  const hipblasStatus_t hs = hipblasLtMatmulAlgoGetHeuristic(s.handle, p.desc, p.a, p.b, p.c, p.c, pref, 1, res, &got);
+  hipblasLtMatmulPreferenceDestroy(pref);
+  if (hs != HIPBLAS_STATUS_SUCCESS || got < 1 || res[0].state != HIPBLAS_STATUS_SUCCESS || res[0].workspaceSize > s.ws_bytes) return false;
+  p.algo = res[0].algo;
+  p.ws = res[0].workspaceSize;
+  p.ok = true;
+  return true;
+}
+
+}  // namespace
+
+// 1 = done by the library, 0 = not eligible (caller goes on with vu_gemm), < 0 = error
+int vu_lt_try(const vu_gemm_args& g, int c_float, hipStream_t st) {
+  if (!lt_mode()) return 0;
+  if (g.Z1 * g.Z2 != 1 || g.act != VU_ACT_NONE || g.aux || g.addend || g.alpha != 1.f) return 0;
+  if (!c_float && g.accumulate) return 0;
+  if (c_float && (g.bias || g.dropout)) return 0;
+  // two epilogues are worth a pass of their own behind the library's product on the 3072 x 3072 class: the projection
+  // dropout (same mask: element index m N + n; the value is rounded to bf16 once more before the 1 / keep scaling) and the
+  // bias-gradient column sums of the weight gradient (82 -> ~45 + 10 us, 116 -> ~85 + 8 us)
+  const bool huge = (long long)g.M * g.N * g.K >= (1ll << 34);
+  if (g.dropout && !(huge && g.ldc == g.N && ((long long)g.M * g.N) % 4 == 0)) return 0;
+  if (g.colsum && !(huge && c_float && ((g.colsum_side == 1 && g.sAm == 1) || (g.colsum_side == 2 && g.sBn == 1)))) return 0;
+  // sizes where the library measured faster: both output extents >= 512, K >= 512, and for the fp32-accumulating weight
+  // gradients only the 3072 x 3072 class (768 x 768: vu_gemm 45.7 us, library 71.9)
+  if (g.K < 512 || g.N < 512 || g.M < 512) return 0;
+  if (c_float ? ((long long)g.M * g.N < (4ll << 20)) : ((long long)g.M * g.N * g.K < (1ll << 32))) return 0;
+  // operand storage: A (M,K) row-major (sAk == 1) or (K,M) (sAm == 1); B (K,N) row-major (sBn == 1) or (N,K) (sBk == 1)
+  if (!((g.sAk == 1) != (g.sAm == 1)) || !((g.sBn == 1) != (g.sBk == 1))) return 0;
+  const bool a_mk = g.sAk == 1, b_kn = g.sBn == 1;
+  const long long lda_row = a_mk ? g.sAm : g.sAk, ldb_row = b_kn ? g.sBk : g.sBn;
+  if (lda_row < (a_mk ? g.K : g.M) || ldb_row < (b_kn ? g.N : g.K) || g.ldc < g.N) return 0;
+  if (((uintptr_t)g.A | (uintptr_t)g.B | (uintptr_t)g.C) & 15) return 0;
+  // C^T (N x M, column-major, ld = ldc) = op(B') op(A'):  first operand from B, second from A
+  const hipblasOperation_t opA = b_kn ? HIPBLAS_OP_N : HIPBLAS_OP_T;        // B stored (K,N) row-major = (N x K) column-major
+  const hipblasOperation_t opB = a_mk ? HIPBLAS_OP_N : HIPBLAS_OP_T;        // A stored (M,K) row-major = (K x M) column-major
+  const int m = g.N, n = g.M, k = g.K;
+  State& s = state();
+  std::lock_guard<std::mutex> lock(s.mu);
+  if (s.dead) return 0;
+  const Key key{m, n, k, (int)opA, (int)opB, ldb_row, lda_row, g.ldc, c_float, g.accumulate, g.bias ? 1 : 0};
+  auto it = s.plans.find(key);
+  if (it == s.plans.end()) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return 0;      // no plan yet: not inside a capture
+    Plan p;
+    if (!make_plan(s, p, m, n, k, opA, opB, ldb_row, lda_row, g.ldc, c_float, g.bias ? 1 : 0)) p.ok = false;
+    it = s.plans.emplace(key, p).first;
+  }
+  Plan& p = it->second;
+  if (!p.ok) return 0;
+  if (g.bias) {
+    const void* bp = g.bias;
+    if (hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bp, sizeof(bp)) != HIPBLAS_STATUS_SUCCESS) return 0;
+  }
+  const float alpha = 1.f, beta = (c_float && g.accumulate) ? 1.f : 0.f;
+  const hipblasStatus_t rs = hipblasLtMatmul(s.handle, p.desc, &alpha, g.B, p.a, g.A, p.b, &beta, g.C, p.c, g.C, p.c, &p.algo, s.ws, p.ws, st);
+  if (rs != HIPBLAS_STATUS_SUCCESS) {
+    vu_set_error("vu_gemm (hipBLASLt route): hipblasLtMatmul failed with status %d for M=%d N=%d K=%d", (int)rs, g.M, g.N, g.K);
+    return VU_ELAUNCH;
+  }
+  if (vu_prof_on()) vu_prof_note(c_float ? "hipblaslt_gemm<f32 acc>" : "hipblaslt_gemm<bf16>", 2.0 * g.M * g.N * g.K,
+                                 2.0 * ((double)g.M * g.K + (double)g.K * g.N) + (c_float ? 8.0 : 2.0) * g.M * g.N);
+  int rc = vu_check_launch("vu_gemm (hipBLASLt route)");
+  if (rc < 0) return rc;
+  if (g.dropout) rc = vu_k_dropout(1, g.C, g.C, (long long)g.M * g.N, g.rng, st);
+  if (rc < 0) return rc;
+  if (g.colsum) rc = g.colsum_side == 1 ? vu_k_colsum(1, g.A, g.colsum, g.K, g.M, g.sAk, st) : vu_k_colsum(1, g.B, g.colsum, g.K, g.N, g.sBk, st);
+  return rc < 0 ? rc : 1;
+}

@@ -316,8 +316,13 @@ __global__ __launch_bounds__(256) void conv_qkv_dgrad_mm_kernel(const bf16_t* __
   }
 }
 
-// VU_CONV_MM: 0 = never, 1 = wherever instantiated (measurements), unset = where it measured faster (forward, C = 3, s >= 16)
-inline int mm_mode() { static const int v = [] { const char* e = getenv("VU_CONV_MM"); return !e ? -1 : (e[0] == '0' ? 0 : 1); }(); return v; }
+// NOT TAKEN by default (VU_CONV_MM=1 enables it wherever instantiated, for measurements): the tap gather is bound by its
+// 2-byte LDS reads (8 per MFMA, ~6 cycles each with the bank conflicts of four tap groups), so back to back on 64 images the
+// forward takes 28.4 / 24.3 / 25.4 us at patch size 8 / 16 / 32 against 29.0 / 29.1 / 28.2 for the stencil form and the data
+// gradient (24 reads per group) 45 - 112 us against 35; on the Base step the forward at s >= 16 was worth +0.3 %, inside the
+// noise, and its differently rounded q / k moved the ill-conditioned first level-1 decoder block ("saturated rows")
+// from 0.05 to 0.09 in the teacher-forced dx check.  Kept as the measured answer to "convolutions on the matrix cores".
+inline int mm_mode() { static const int v = [] { const char* e = getenv("VU_CONV_MM"); return (e && e[0] == '1') ? 1 : 0; }(); return v; }
 
 template <typename K>
 inline int reserve(K kern, size_t lds) {
@@ -376,8 +381,8 @@ int launch_dgrad(const bf16_t* dq, const bf16_t* dk, const bf16_t* dv, const flo
 // covered: bf16 storage, C in {1, 3}, patch size 8 / 16 / 32, 16-byte aligned tensors
 bool vu_conv_mm_ok(int dtype, int C, int s, int backward) {
   const bool inst = dtype == 1 && (C == 1 || C == 3) && (s == 8 || s == 16 || s == 32);
-  const int m = mm_mode();
-  return inst && m != 0 && (m == 1 || (!backward && C == 3 && s >= 16));
+  (void)backward;
+  return inst && mm_mode() == 1;
 }
 
 #define VU_CONV_MM_DISPATCH(FN, ...)                                                          \
