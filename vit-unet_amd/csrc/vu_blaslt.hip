@@ -12,6 +12,7 @@
 #include <hipblaslt/hipblaslt.h>
 #include <map>
 #include <mutex>
+#include <stdio.h>
 #include <stdlib.h>
 #include <tuple>
 #include "vu_kernels.h"
@@ -38,6 +39,12 @@ State& state() { static State s; return s; }
 
 inline int lt_mode() {        // VU_GEMM_LT: 0 = never, unset / 1 = where eligible
   static const int v = [] { const char* e = getenv("VU_GEMM_LT"); return (e && e[0] == '0') ? 0 : 1; }();
+  return v;
+}
+// smallest M N K for which a product with a dropout / residual epilogue goes to the library + a pass of its own
+// (VU_GEMM_LT_POST_LOG2 overrides the exponent for measurements)
+inline long long lt_post_min() {
+  static const long long v = [] { const char* e = getenv("VU_GEMM_LT_POST_LOG2"); return 1ll << (e ? atoi(e) : 34); }();
   return v;
 }
 constexpr size_t WS_BYTES = 32u << 20;
@@ -80,19 +87,38 @@ bool make_plan(State& s, Plan& p, int m, int n, int k, hipblasOperation_t opA, h
   return true;
 }
 
+// y = dropout(y) + addend in one pass behind the library's product (same mask as the fused epilogue of vu_gemm: element
+// index m N + n through vu_keep; thr == 0: no dropout); 8 elements per thread
+__global__ __launch_bounds__(256) void lt_post_kernel(bf16_t* __restrict__ y, const bf16_t* __restrict__ addend, long long n8, vu_rng rng_in) {
+  const vu_rng rng = vu_rng_resolve(rng_in);
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n8; t += (long long)gridDim.x * blockDim.x) {
+    union U8 { uint4 u; bf16_t h[8]; } a, b;
+    a.u = *reinterpret_cast<const uint4*>(y + t * 8);
+    b.u = addend ? *reinterpret_cast<const uint4*>(addend + t * 8) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float v = (float)a.h[e];
+      if (rng.thr) v = vu_keep(rng, (uint64_t)(t * 8 + e)) ? v * rng.inv_keep : 0.f;
+      a.h[e] = (bf16_t)(v + (float)b.h[e]);
+    }
+    *reinterpret_cast<uint4*>(y + t * 8) = a.u;
+  }
+}
+
 }  // namespace
 
 // 1 = done by the library, 0 = not eligible (caller goes on with vu_gemm), < 0 = error
 int vu_lt_try(const vu_gemm_args& g, int c_float, hipStream_t st) {
   if (!lt_mode()) return 0;
-  if (g.Z1 * g.Z2 != 1 || g.act != VU_ACT_NONE || g.aux || g.addend || g.alpha != 1.f) return 0;
+  if (g.Z1 * g.Z2 != 1 || g.act != VU_ACT_NONE || g.aux || g.alpha != 1.f) return 0;
   if (!c_float && g.accumulate) return 0;
-  if (c_float && (g.bias || g.dropout)) return 0;
+  if (c_float && (g.bias || g.dropout || g.addend)) return 0;
   // two epilogues are worth a pass of their own behind the library's product on the 3072 x 3072 class: the projection
   // dropout (same mask: element index m N + n; the value is rounded to bf16 once more before the 1 / keep scaling) and the
   // bias-gradient column sums of the weight gradient (82 -> ~45 + 10 us, 116 -> ~85 + 8 us)
   const bool huge = (long long)g.M * g.N * g.K >= (1ll << 34);
-  if (g.dropout && !(huge && g.ldc == g.N && ((long long)g.M * g.N) % 4 == 0)) return 0;
+  const bool post = g.dropout || g.addend;          // dropout and / or the block residual: one pass over C behind the product
+  if (post && !(lt_post_min() <= (long long)g.M * g.N * g.K && g.ldc == g.N && ((long long)g.M * g.N) % 8 == 0 && !(((uintptr_t)g.addend) & 15))) return 0;
   if (g.colsum && !(huge && c_float && ((g.colsum_side == 1 && g.sAm == 1) || (g.colsum_side == 2 && g.sBn == 1)))) return 0;
   // sizes where the library measured faster: both output extents >= 512, K >= 512, and for the fp32-accumulating weight
   // gradients only the 3072 x 3072 class (768 x 768: vu_gemm 45.7 us, library 71.9)
@@ -132,11 +158,24 @@ int vu_lt_try(const vu_gemm_args& g, int c_float, hipStream_t st) {
     vu_set_error("vu_gemm (hipBLASLt route): hipblasLtMatmul failed with status %d for M=%d N=%d K=%d", (int)rs, g.M, g.N, g.K);
     return VU_ELAUNCH;
   }
-  if (vu_prof_on()) vu_prof_note(c_float ? "hipblaslt_gemm<f32 acc>" : "hipblaslt_gemm<bf16>", 2.0 * g.M * g.N * g.K,
-                                 2.0 * ((double)g.M * g.K + (double)g.K * g.N) + (c_float ? 8.0 : 2.0) * g.M * g.N);
+  if (vu_prof_on()) {
+    static const bool shapes = getenv("VU_PROF_SHAPES") != nullptr;
+    char tag[96];
+    if (shapes) snprintf(tag, sizeof(tag), "hipblaslt_gemm<%s> M%d N%d K%d%s%s", c_float ? "f32 acc" : "bf16", g.M, g.N, g.K, g.dropout ? " +dropout" : "", g.colsum ? " +colsum" : "");
+    else snprintf(tag, sizeof(tag), "hipblaslt_gemm<%s>", c_float ? "f32 acc" : "bf16");
+    vu_prof_note(tag, 2.0 * g.M * g.N * g.K, 2.0 * ((double)g.M * g.K + (double)g.K * g.N) + (c_float ? 8.0 : 2.0) * g.M * g.N);
+  }
   int rc = vu_check_launch("vu_gemm (hipBLASLt route)");
   if (rc < 0) return rc;
-  if (g.dropout) rc = vu_k_dropout(1, g.C, g.C, (long long)g.M * g.N, g.rng, st);
+  if (post) {
+    const long long n8 = (long long)g.M * g.N / 8;
+    vu_rng r = g.rng;
+    if (!g.dropout) r.thr = 0;
+    const long long grid = (n8 + 255) / 256;
+    hipLaunchKernelGGL(lt_post_kernel, dim3((unsigned)(grid > 8192 ? 8192 : grid)), dim3(256), 0, st, (bf16_t*)g.C, (const bf16_t*)g.addend, n8, r);
+    if (vu_prof_on()) vu_prof_note("lt_post_kernel", 0.0, (double)n8 * 16 * (g.addend ? 3 : 2));
+    rc = vu_check_launch("vu_gemm (hipBLASLt route: dropout / residual pass)");
+  }
   if (rc < 0) return rc;
   if (g.colsum) rc = g.colsum_side == 1 ? vu_k_colsum(1, g.A, g.colsum, g.K, g.M, g.sAk, st) : vu_k_colsum(1, g.B, g.colsum, g.K, g.N, g.sBk, st);
   return rc < 0 ? rc : 1;
