@@ -7,7 +7,7 @@ TAG=${1:-r02}; shift
 cd $GRAFT_REPO_ROOT
 OUT=$GRAFT_REPO_ROOT/gpurun_out/rocprof_$TAG
 rm -rf $OUT; cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-host-input --no-graph --no-roofline "$@" > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_trace_bench.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-host-input --no-graph --no-roofline --no-sustained "$@" > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_trace_bench.log 2>&1
 tail -c 300 $GRAFT_REPO_ROOT/gpurun_out/${TAG}_trace_bench.log
 cd $GRAFT_REPO_ROOT
 python - "$TAG" <<'PY'

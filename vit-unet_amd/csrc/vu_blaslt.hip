@@ -41,10 +41,8 @@ inline int lt_mode() {        // VU_GEMM_LT: 0 = never, unset / 1 = where eligib
   static const int v = [] { const char* e = getenv("VU_GEMM_LT"); return (e && e[0] == '0') ? 0 : 1; }();
   return v;
 }
-// smallest M N K for which a product with a dropout / residual epilogue goes to the library + a pass of its own
-// (VU_GEMM_LT_POST_LOG2 overrides the exponent for measurements)
-inline long long lt_post_min() {
-  static const long long v = [] { const char* e = getenv("VU_GEMM_LT_POST_LOG2"); return 1ll << (e ? atoi(e) : 34); }();
+inline bool post_forced() {      // VU_GEMM_LT_POST=1: every eligible product with a dropout / residual epilogue (measurements)
+  static const bool v = [] { const char* e = getenv("VU_GEMM_LT_POST"); return e && e[0] == '1'; }();
   return v;
 }
 constexpr size_t WS_BYTES = 32u << 20;
@@ -113,13 +111,14 @@ int vu_lt_try(const vu_gemm_args& g, int c_float, hipStream_t st) {
   if (g.Z1 * g.Z2 != 1 || g.act != VU_ACT_NONE || g.aux || g.alpha != 1.f) return 0;
   if (!c_float && g.accumulate) return 0;
   if (c_float && (g.bias || g.dropout || g.addend)) return 0;
-  // two epilogues are worth a pass of their own behind the library's product on the 3072 x 3072 class: the projection
-  // dropout (same mask: element index m N + n; the value is rounded to bf16 once more before the 1 / keep scaling) and the
-  // bias-gradient column sums of the weight gradient (82 -> ~45 + 10 us, 116 -> ~85 + 8 us)
-  const bool huge = (long long)g.M * g.N * g.K >= (1ll << 34);
-  const bool post = g.dropout || g.addend;          // dropout and / or the block residual: one pass over C behind the product
-  if (post && !(lt_post_min() <= (long long)g.M * g.N * g.K && g.ldc == g.N && ((long long)g.M * g.N) % 8 == 0 && !(((uintptr_t)g.addend) & 15))) return 0;
-  if (g.colsum && !(huge && c_float && ((g.colsum_side == 1 && g.sAm == 1) || (g.colsum_side == 2 && g.sBn == 1)))) return 0;
+  // two epilogues are worth a pass of their own behind the library's product on the 3072 x 3072 WEIGHTS (K and N >= 2048,
+  // any token count): the projection dropout + block residual (same mask: element index m N + n; the value is rounded to
+  // bf16 once more before the 1 / keep scaling) and the bias-gradient column sums of the weight gradient.  Measured in the
+  // Base step, 64 images: forward 130 -> 59 + 12 us, weight gradient 116 -> 80 + 8 us; 16 images: forward 79 -> 38 + 5 us.
+  // The 768-class (K = 768) does not pay: 43.7 us against 26.7 + 10.
+  const bool post = g.dropout || g.addend;          // one pass over C behind the product
+  if (post && !(((g.K >= 2048 && g.N >= 2048) || post_forced()) && g.ldc == g.N && ((long long)g.M * g.N) % 8 == 0 && !(((uintptr_t)g.addend) & 15))) return 0;
+  if (g.colsum && !(g.M >= 2048 && g.N >= 2048 && c_float && ((g.colsum_side == 1 && g.sAm == 1) || (g.colsum_side == 2 && g.sBn == 1)))) return 0;
   // sizes where the library measured faster: both output extents >= 512, K >= 512, and for the fp32-accumulating weight
   // gradients only the 3072 x 3072 class (768 x 768: vu_gemm 45.7 us, library 71.9)
   if (g.K < 512 || g.N < 512 || g.M < 512) return 0;

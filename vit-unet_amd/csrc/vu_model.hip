@@ -295,8 +295,13 @@ inline SideLane* side_lane() {
   if (!tried) {
     tried = true;
     const char* ev = getenv("VU_SIDE_LANE");
-    bool ok = ev && ev[0] == '1';
-    ok = ok && hipStreamCreateWithFlags(&sl.s, hipStreamNonBlocking) == hipSuccess;
+    bool ok = ev && (ev[0] == '1' || ev[0] == '2');
+    if (ok && ev[0] == '2') {          // 2: a LOW-PRIORITY side lane (its kernels only take what the main chain leaves idle)
+      int lo = 0, hi = 0;
+      ok = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hipStreamCreateWithPriority(&sl.s, hipStreamNonBlocking, lo) == hipSuccess;
+    } else {
+      ok = ok && hipStreamCreateWithFlags(&sl.s, hipStreamNonBlocking) == hipSuccess;
+    }
     for (int i = 0; ok && i < 3; ++i) ok = hipEventCreateWithFlags(&sl.e[i], hipEventDisableTiming) == hipSuccess;
     sl.ok = ok;
   }
