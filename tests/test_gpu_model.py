@@ -413,3 +413,14 @@ def test_two_rank_data_parallel_rehearsal():
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count("identical parameters across ranks: True") == 2
+    # the same two ranks on the Base preset in bf16 (recompute attention at level 2, dropout on), one step: identical
+    # parameters, and the all-reduced gradient arena is bit for bit the sum of the two ranks' stand-alone gradients
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(root, "tools", "dp_rehearsal.py"), "--base"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("identical parameters across ranks: True") == 2
+    assert "bit for bit: True" in r.stdout

@@ -31,6 +31,20 @@ with open(f"gpurun_out/{tag}_by_grid.csv", "w") as o:
     for (k, gx, gy, gz), (n, us) in rows[:120]:
         o.write('"%s",%s,%s,%s,%.1f,%.1f,%.1f,%.4f\n' % (k, gx, gy, gz, n / steps, us / n, us / steps, us / tot))
 print("total us per step (all launches / %d steps): %.1f" % (steps, tot / steps))
+# idle time between consecutive kernels of the compute stream (end of one -> start of the next), second half of the trace
+ev = []
+for f in glob.glob(root + "/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"][:60]))
+ev.sort()
+ev = ev[len(ev) // 2:]
+gaps = sorted((b[0] - a[1]) / 1e3 for a, b in zip(ev, ev[1:]))
+small = [g for g in gaps if g < 200.0]
+busy = sum((e[1] - e[0]) for e in ev) / 1e3
+with open(f"gpurun_out/{tag}_gaps.txt", "w") as o:
+    o.write("launches %d  busy %.1f us  gaps(<200us) %.1f us  = %.1f %% of busy+gaps\n" % (len(ev), busy, sum(small), 100.0 * sum(small) / (busy + sum(small))))
+    o.write("gap us: p10 %.2f  median %.2f  p90 %.2f  max(<200) %.2f  overlapping (<0): %d\n" % (gaps[len(gaps) // 10], gaps[len(gaps) // 2], gaps[9 * len(gaps) // 10], max(small), sum(1 for g in gaps if g < 0)))
+print(open(f"gpurun_out/{tag}_gaps.txt").read())
 shutil.rmtree(root, ignore_errors=True)
 PY
 head -45 gpurun_out/${TAG}_by_grid.csv

@@ -103,6 +103,28 @@ __global__ __launch_bounds__(256) void lt_post_kernel(bf16_t* __restrict__ y, co
   }
 }
 
+// colsum[n] += sum over the rows of in[row ld + n], one workgroup per 64 columns, every row, fixed order: the bias gradient
+// behind the library's weight-gradient product must stay bit-reproducible (vu_k_colsum's row blocks end in float atomics)
+__global__ __launch_bounds__(1024) void lt_colsum_kernel(const bf16_t* __restrict__ in, float* __restrict__ out, int rows, int ncols, long long ld) {
+  __shared__ float red[128][65];
+  const int v = threadIdx.x & 7, rl = threadIdx.x >> 3, c0 = blockIdx.x * 64 + v * 8;
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c0 < ncols)
+    for (int r = rl; r < rows; r += 128) {
+      const bf16x8 x = *reinterpret_cast<const bf16x8*>(in + (long long)r * ld + c0);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) a[i] += (float)x[i];
+    }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) red[rl][v * 8 + i] = a[i];
+  __syncthreads();
+  if (threadIdx.x < 64 && blockIdx.x * 64 + threadIdx.x < ncols) {
+    float t = 0.f;
+    for (int r = 0; r < 128; ++r) t += red[r][threadIdx.x];
+    out[blockIdx.x * 64 + threadIdx.x] += t;
+  }
+}
+
 }  // namespace
 
 // 1 = done by the library, 0 = not eligible (caller goes on with vu_gemm), < 0 = error
@@ -118,7 +140,8 @@ int vu_lt_try(const vu_gemm_args& g, int c_float, hipStream_t st) {
   // The 768-class (K = 768) does not pay: 43.7 us against 26.7 + 10.
   const bool post = g.dropout || g.addend;          // one pass over C behind the product
   if (post && !(((g.K >= 2048 && g.N >= 2048) || post_forced()) && g.ldc == g.N && ((long long)g.M * g.N) % 8 == 0 && !(((uintptr_t)g.addend) & 15))) return 0;
-  if (g.colsum && !(g.M >= 2048 && g.N >= 2048 && c_float && ((g.colsum_side == 1 && g.sAm == 1) || (g.colsum_side == 2 && g.sBn == 1)))) return 0;
+  if (g.colsum && !(g.M >= 2048 && g.N >= 2048 && c_float && ((g.colsum_side == 1 && g.sAm == 1 && g.M % 8 == 0 && g.sAk % 8 == 0) ||
+                                                                 (g.colsum_side == 2 && g.sBn == 1 && g.N % 8 == 0 && g.sBk % 8 == 0)))) return 0;
   // sizes where the library measured faster: both output extents >= 512, K >= 512, and for the fp32-accumulating weight
   // gradients only the 3072 x 3072 class (768 x 768: vu_gemm 45.7 us, library 71.9)
   if (g.K < 512 || g.N < 512 || g.M < 512) return 0;
@@ -176,6 +199,12 @@ int vu_lt_try(const vu_gemm_args& g, int c_float, hipStream_t st) {
     rc = vu_check_launch("vu_gemm (hipBLASLt route: dropout / residual pass)");
   }
   if (rc < 0) return rc;
-  if (g.colsum) rc = g.colsum_side == 1 ? vu_k_colsum(1, g.A, g.colsum, g.K, g.M, g.sAk, st) : vu_k_colsum(1, g.B, g.colsum, g.K, g.N, g.sBk, st);
+  if (g.colsum) {
+    const bool a_side = g.colsum_side == 1;
+    const int nc = a_side ? g.M : g.N;
+    hipLaunchKernelGGL(lt_colsum_kernel, dim3((unsigned)((nc + 63) / 64)), dim3(1024), 0, st, (const bf16_t*)(a_side ? g.A : g.B), g.colsum, g.K, nc, a_side ? g.sAk : g.sBk);
+    if (vu_prof_on()) vu_prof_note("lt_colsum_kernel", 0.0, (double)g.K * nc * 2.0);
+    rc = vu_check_launch("vu_gemm (hipBLASLt route: bias-gradient sums)");
+  }
   return rc < 0 ? rc : 1;
 }
