@@ -25,6 +25,9 @@ import pytest
 import torch
 
 import vit_unet_oracle as O
+import ctypes as C
+
+from vit_unet.torch import _lib
 from vit_unet.torch import model as M
 from vit_unet.torch.engine import TrainStep
 
@@ -212,6 +215,54 @@ def _one_block_model(cfg, lvl, dtype):
     return M.HViT_UNet(depth=0, depth_te=1, size_bottleneck=1, preprocessing="none", im_size=cfg.im_size, patch_size=s,
                        num_channels=cfg.num_channels, hidden_dim=hid, num_heads=cfg.num_heads, attn_drop=cfg.attn_drop,
                        proj_drop=cfg.proj_drop, linear_drop=0.0, dtype=dtype, attn_operands=cfg.attn_operands).to(DEV).train()
+
+
+def test_level0_block_at_a_token_count_that_takes_the_library_route(attn_form, monkeypatch):
+    """The level-0 block of Base (49 tokens x 3072 features) at 12 images = 588 token rows: its 3072 x 3072 projection runs
+    through hipBLASLt with the dropout + residual pass and the deterministic bias-gradient sums behind it
+    (csrc/vu_blaslt.hip; at the 2 images of the teacher-forced test above the products stay on vu_gemm).  Same block, same
+    bounds: output 3e-2, dx and every parameter gradient 5e-2 of their range against the oracle's bf16-storage restatement."""
+    monkeypatch.setattr(O, "FLASH_FILL_RULE", False)
+    dt, B, seed, lvl = torch.bfloat16, 12, 4321, 0
+    cfg = O.Config(**O.PRESETS["base"])
+    w = O.make_weights(cfg, seed=0)
+    N, D, hid, s = cfg.level(lvl)
+    pre = [k for k in w if k.endswith("ReAttn.proj.weight") and tuple(w[k].shape) == (D, D) and "Skip" not in k][0][:-len("ReAttn.proj.weight")]
+    assert D == 3072 and B * N >= 512
+    m = _one_block_model(cfg, lvl, dt)
+    sdict = {"PE.position_embedding.weight": torch.zeros(N, D)}
+    for k in BLOCK_KEYS + BN_BUFS:
+        sdict["BottleNeck.0." + k] = w[pre + k].clone()
+    sdict["BottleNeck.0.ReAttn.var_norm.num_batches_tracked"] = torch.zeros((), dtype=torch.int64)
+    m.load_state_dict(sdict, strict=True)
+    m.zero_grad(set_to_none=False)
+    m._shadow_clean = False
+    m._step_seed = seed
+    gen = torch.Generator().manual_seed(9)
+    xin = torch.randn(B, N, D, generator=gen).to(dt).float()
+    G = torch.randn(B, N, D, generator=gen).to(dt).float()
+    C_ = cfg.num_channels
+    L = _lib.lib()
+    L.vu_prof_enable(C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    X = O.unpatchify(xin, C_).to(DEV).requires_grad_(True)
+    out = m(X)
+    out.backward(O.unpatchify(G, C_).to(DEV))
+    torch.cuda.synchronize()
+    rep = json.loads(L.vu_prof_report().decode())
+    assert "lt_post_kernel" in rep and "lt_colsum_kernel" in rep and "hipblaslt_gemm<bf16>" in rep and "hipblaslt_gemm<f32 acc>" in rep, rep.keys()
+    wr = {pre + k: w[pre + k].clone().requires_grad_(True) for k in BLOCK_KEYS}
+    for k in BN_BUFS:
+        wr[pre + k] = w[pre + k].clone()
+    xr = xin.clone().requires_grad_(True)
+    ref = O.te_block(xr, wr, pre, cfg, training=True, seed=seed, stream=0, storage=torch.bfloat16)
+    (ref * G).sum().backward()
+    assert serr(O.patchify(out.detach().cpu(), s), ref) < 3e-2
+    assert serr(O.patchify(X.grad.cpu(), s), xr.grad) < 5e-2
+    sd = dict(m.named_parameters())
+    for k in BLOCK_KEYS:
+        if k.endswith("reatten_matrix.bias"):
+            continue                                        # analytically zero in train mode
+        assert serr(sd["BottleNeck.0." + k].grad, wr[pre + k].grad) < 5e-2, k
 
 
 @pytest.mark.parametrize("name,dt", [("base", torch.bfloat16), ("large", torch.bfloat16), ("lite", torch.bfloat16),
