@@ -22,10 +22,14 @@ def golden_dir():
 
 @pytest.fixture
 def attn_form():
-    """Set the process-level re-attention form for one test (vu_set_attn_form) and restore the default afterwards."""
+    """Set the process-level re-attention form for one test (vu_set_attn_form) and restore the default afterwards.
+    key_split: the recompute form's split of the streamed axis over wave pairs (vu_set_flash_key_split).  A test that forces
+    the form runs the UNSPLIT sweeps (1: the default) unless it asks for 2; 0 = the library's default."""
     from vit_unet.torch import _lib
 
-    def setter(flash=-1, centered=0):
+    def setter(flash=-1, centered=0, key_split=None):
         _lib.set_attn_form(flash, centered)
+        _lib.set_flash_key_split((1 if flash == 1 else 0) if key_split is None else key_split)
     yield setter
     _lib.set_attn_form(-1, 0)
+    _lib.set_flash_key_split(0)

@@ -265,12 +265,13 @@ def test_level0_block_at_a_token_count_that_takes_the_library_route(attn_form, m
         assert serr(sd["BottleNeck.0." + k].grad, wr[pre + k].grad) < 5e-2, k
 
 
-@pytest.mark.parametrize("name,dt", [("base", torch.bfloat16), ("large", torch.bfloat16), ("lite", torch.bfloat16),
-                                     ("base", torch.float32), ("seg512", torch.bfloat16)])
-def test_teacher_forced_blocks_bf16_full_size(name, dt, attn_form, monkeypatch):
+@pytest.mark.parametrize("name,dt,ks", [("base", torch.bfloat16, 1), ("large", torch.bfloat16, 1), ("lite", torch.bfloat16, 1),
+                                        ("base", torch.float32, 1), ("seg512", torch.bfloat16, 1), ("base", torch.bfloat16, 2)])
+def test_teacher_forced_blocks_bf16_full_size(name, dt, ks, attn_form, monkeypatch):
     # the benchmarked batch runs every covered level in the recompute ("flash") form; at this test's batch the fill rule
-    # would pick the materialising kernels for most levels, so force the form the bench line is made of
-    attn_form(flash=1)
+    # would pick the materialising kernels for most levels, so force the form the bench line is made of (ks = 1: the unsplit
+    # sweeps every batch size runs by default; ks = 2: the opt-in split form, kept correct)
+    attn_form(flash=1, key_split=ks)
     monkeypatch.setattr(O, "FLASH_FILL_RULE", False)
     B = 1 if name in ("lite", "seg512") else 2
     cfg = O.Config(**_preset(name))                  # dropout 0.2 / 0.2 as benchmarked

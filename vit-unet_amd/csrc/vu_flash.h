@@ -28,6 +28,8 @@ vu_rng vu_flash_quad_rng(vu_rng r);
 // true when the backward of this shape, launched eagerly (outside a stream capture), overlaps its dv sweep with the tails of the
 // dq / dk sweeps on a low-priority stream (vu_flash.hip "Tail overlap")
 bool vu_flash_tail_overlap(int B, int N, int H);
+// 1 or 2: waves of a workgroup that share one own tile and split the streamed axis (small launches; vu_flash.hip)
+int vu_flash_key_split(int B, int N);
 bool vu_flash_ok(int dtype, int B, int N, int D, int H);
 // the recompute form only pays when its grid (B x ceil(N/64) work groups of 4 waves) puts a work group on most CUs; below that
 // the materialising kernels (which parallelise over heads too) are faster.  Measured on Base (N = 784: 13 groups per sample)

@@ -377,7 +377,31 @@ __global__ __launch_bounds__(WPB * 64) void flash_stats_kernel(const bf16_t* __r
 // Row statistics alone, ONE sweep (the v2 forward's first pass): every lane carries a running (max, sum) pair per head
 // over its own keys (4 per tile) in the log2 domain and rescales the sum when its maximum moves; the four lane groups of a
 // query are merged at the end.  The next K chunk is fetched into registers while the current one is consumed.
-template <int H, int DH, int WPB, int CK>
+
+// ---- split of the streamed axis over the waves of a workgroup (KS = 2) ------------------------------------------------
+// At small batches the sweeps launch fewer workgroups than CUs (Base level 2 at 16 images: 208) and every SIMD runs ONE
+// wave of a latency-bound chain.  With KS = 2 a workgroup owns two tiles instead of four: waves 2p and 2p + 1 share own
+// tile p and take the even / odd tiles of the streamed operand (the chunk staging stays cooperative and unchanged), so the
+// grid doubles and every SIMD gets two waves.  At the end the odd wave parks its accumulators in LDS (the operand images are
+// dead by then), the even wave adds them and runs the epilogue alone.  Sums are re-associated (even tiles + odd tiles), so
+// results differ from KS = 1 by rounding; a forward and its backward always run with the same split only by convention of
+// the launcher - nothing depends on it (lse, rinv, pk are stored values).
+template <int NV>
+__device__ __forceinline__ void pair_park(const f32x4 (&v)[NV], float* scratch, int lane) {
+#pragma unroll
+  for (int i = 0; i < NV; ++i) reinterpret_cast<f32x4*>(scratch)[i * 64 + lane] = v[i];
+}
+template <int NV>
+__device__ __forceinline__ void pair_take(f32x4 (&v)[NV], const float* scratch, int lane) {
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const f32x4 x = reinterpret_cast<const f32x4*>(scratch)[i * 64 + lane];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[i][r] += x[r];
+  }
+}
+
+template <int H, int DH, int WPB, int CK, int KS = 1>
 // row_norm_note: every later sweep recomputes P = exp2(c s - lse) from the ONE stored float lse = m + log2(sum).  When the
 // logits are huge (un-normalised skip outputs through saturating e4m3 operands reach c s ~ 1.6e6, where a float resolves
 // 0.125) the rounding of that sum leaves every P of the row off by one common factor g = sum 2^(m - lse) (up to 4.4 % at
@@ -394,10 +418,11 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash_rowstats_kernel(const bf16_
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* Kc = reinterpret_cast<bf16_t*>(smem_raw);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
-  const int ntiles = N >> 4, per = (ntiles + WPB - 1) / WPB;
+  constexpr int TPB = WPB / KS;
+  const int ntiles = N >> 4, per = (ntiles + TPB - 1) / TPB;
   int b, grp;
   work_item(blockIdx.x, B, per, b, grp);
-  const int t = grp * WPB + wave;
+  const int t = grp * TPB + wave / KS, ksh = wave % KS;
   const bool active = t < ntiles;
   const int tq = active ? t : ntiles - 1;
   const int qrow = tq * 16 + l15;
@@ -421,7 +446,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash_rowstats_kernel(const bf16_
       st_Kc.fetch(kb + (long long)cn * CK * 16 * C::D, min(CK, ntiles - cn * CK) * 16, tid);
     }
     if (active)
-      for (int kc = 0; kc < nt; ++kc) {
+      for (int kc = (KS == 1 ? 0 : ((ch * CK) & 1) ^ ksh); kc < nt; kc += KS) {
         f32x4 acc[H];
         tile_logits<H, DH>(acc, Kc, kc, qf, l15, g4);
 #pragma unroll
@@ -436,6 +461,24 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash_rowstats_kernel(const bf16_
         }
       }
   }
+  if constexpr (KS == 2) {                  // merge the odd wave's running (max, sum) into the even wave's
+    __syncthreads();
+    float* cs = reinterpret_cast<float*>(smem_raw) + (wave >> 1) * (2 * H * 64);
+    if (ksh) {
+#pragma unroll
+      for (int h = 0; h < H; ++h) { cs[h * 64 + lane] = mx[h]; cs[(H + h) * 64 + lane] = sm[h]; }
+    }
+    __syncthreads();
+    if (!ksh) {
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        const float m2 = cs[h * 64 + lane], s2 = cs[(H + h) * 64 + lane];
+        const float mn = fmaxf(mx[h], m2);
+        sm[h] = sm[h] * fexp2(mx[h] - mn) + s2 * fexp2(m2 - mn);
+        mx[h] = mn;
+      }
+    }
+  }
 #pragma unroll
   for (int h = 0; h < H; ++h) {
     float m = mx[h], s_ = sm[h];
@@ -446,7 +489,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash_rowstats_kernel(const bf16_
       s_ = s_ * fexp2(m - mn) + s2 * fexp2(m2 - mn);
       m = mn;
     }
-    if (active && g4 == 0) {
+    if (active && g4 == 0 && ksh == 0) {
       const float l = m + log2f(s_);
       lse2[((long long)b * H + h) * N + qrow] = l;
       rinv[((long long)b * H + h) * N + qrow] = 1.0f / (s_ * fexp2(m - l));
@@ -1256,7 +1299,7 @@ template <int DH> constexpr int tr_strip_elems() { return ((3 * DH + 8 * ((DH + 
 
 // ---- stats pass, sweep 3 only (sweeps 1 / 2 are the v1 code): moments of the MIXED map directly -------------------
 // per lane 4 heads x (sum, sum of squares) of A_g - shift_g, shift_g = sum_h W[g,h] / N (the exact mean without dropout)
-template <int DH, int WPB, int CK>
+template <int DH, int WPB, int CK, int KS = 1>
 __global__ __launch_bounds__(WPB * 64, 2) void flash2_moments_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                                       const float* __restrict__ lse2, const float* __restrict__ W,
                                                                       float* __restrict__ partials, float* __restrict__ pk_out,
@@ -1275,10 +1318,11 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_moments_kernel(const bf16_
   const vu_rng rng = vu_rng_resolve(rng_in);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
   if (SPARE) for (int i = tid; i < ONES; i += WPB * 64) ones[i] = (bf16_t)1.0f;
-  const int ntiles = N >> 4, per = (ntiles + WPB - 1) / WPB;
+  constexpr int TPB = WPB / KS;
+  const int ntiles = N >> 4, per = (ntiles + TPB - 1) / TPB;
   int b, grp;
   work_item(blockIdx.x, B, per, b, grp);
-  const int t = grp * WPB + wave;
+  const int t = grp * TPB + wave / KS, ksh = wave % KS;
   const bool active = t < ntiles;
   const int tq = active ? t : ntiles - 1;
   const int qrow = tq * 16 + l15;
@@ -1335,7 +1379,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_moments_kernel(const bf16_
       st_Kc.fetch(kb + (long long)cn * CK * 16 * C::D, min(CK, ntiles - cn * CK) * 16, tid);
     }
     if (active)
-      for (int kc = 0; kc < nt; ++kc) {
+      for (int kc = (KS == 1 ? 0 : ((ch * CK) & 1) ^ ksh); kc < nt; kc += KS) {
         f32x4 S[H];
         tile_logits<H, DH>(S, Kc, kc, qf, l15, g4);
         tag_probs<H>(S, lse, c, rng, wlane + 4u * (uint32_t)(ch * CK + kc), hstride);
@@ -1367,7 +1411,26 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_moments_kernel(const bf16_
             for (int j = 0; j < 4; ++j) { s1[j] += A[half][r][j]; s2[j] = fmaf(A[half][r][j], A[half][r][j], s2[j]); }
       }
   }
-  if (active) {
+  if constexpr (KS == 2) {                  // (pair_park / pair_take: the odd wave's P k partial and row sums into the even wave's)
+    __syncthreads();
+    float* cs = reinterpret_cast<float*>(smem_raw) + (wave >> 1) * ((H * C::DT + 2) * 256);
+    f32x4 sb4[2] = {f32x4{sb[0], sb[1], sb[2], sb[3]}, f32x4{sb[4], sb[5], sb[6], sb[7]}};
+    if (ksh) {
+#pragma unroll
+      for (int h = 0; h < H; ++h) pair_park(pacc[h], cs + h * C::DT * 256, lane);
+      pair_park(sb4, cs + H * C::DT * 256, lane);
+    }
+    __syncthreads();
+    if (!ksh) {
+#pragma unroll
+      for (int h = 0; h < H; ++h) pair_take(pacc[h], cs + h * C::DT * 256, lane);
+      pair_take(sb4, cs + H * C::DT * 256, lane);
+#pragma unroll
+      for (int h = 0; h < H; ++h) sb[h] = sb4[h >> 2][h & 3];
+    }
+  }
+  const bool writer = active && ksh == 0;
+  if (writer) {
     float* prow = pk_out + ((long long)b * N + qrow) * C::D;
 #pragma unroll
     for (int h = 0; h < H; ++h)
@@ -1380,14 +1443,14 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_moments_kernel(const bf16_
   if constexpr (SPARE) {              // the spare rows of the last feature block (lane group 2, register 0) hold sum_k bf16(P)
 #pragma unroll
     for (int h = 0; h < H; ++h)
-      if (active && g4 == 2) rinv[((long long)b * H + h) * N + qrow] = 1.0f / pacc[h][C::DT - 1][0];
+      if (writer && g4 == 2) rinv[((long long)b * H + h) * N + qrow] = 1.0f / pacc[h][C::DT - 1][0];
   } else {
 #pragma unroll
     for (int h = 0; h < H; ++h) {     // the four lane groups of a query hold its four key quarters
       float x = sb[h];
       x += __shfl_xor(x, 16, 64);
       x += __shfl_xor(x, 32, 64);
-      if (active && g4 == 0) rinv[((long long)b * H + h) * N + qrow] = 1.0f / x;
+      if (writer && g4 == 0) rinv[((long long)b * H + h) * N + qrow] = 1.0f / x;
     }
   }
   // lanes with the same head half (g4 & 1) hold the same 4 heads: reduce over q (16 lanes) and over a (g4 >> 1)
@@ -1410,7 +1473,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_moments_kernel(const bf16_
 }
 
 // ---- apply pass --------------------------------------------------------------------------------------------------
-template <int DH, int WPB, int CK>
+template <int DH, int WPB, int CK, int KS = 1>
 __global__ __launch_bounds__(WPB * 64, 2) void flash2_apply_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, const float* __restrict__ lse2,
     const float* __restrict__ stats, bf16_t* __restrict__ O, int B, int N, float c, vu_rng rng_in) {
@@ -1422,10 +1485,11 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_apply_kernel(
   bf16_t* Zr = Vc + CK * 16 * C::PITCH;                                   // zero region for the dead operand halves
   const vu_rng rng = vu_rng_resolve(rng_in);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
-  const int ntiles = N >> 4, per = (ntiles + WPB - 1) / WPB;
+  constexpr int TPB = WPB / KS;
+  const int ntiles = N >> 4, per = (ntiles + TPB - 1) / TPB;
   int b, grp;
   work_item(blockIdx.x, B, per, b, grp);
-  const int t = grp * WPB + wave;
+  const int t = grp * TPB + wave / KS, ksh = wave % KS;
   const bool active = t < ntiles;
   const int tq = active ? t : ntiles - 1;
   const int qrow = tq * 16 + l15;
@@ -1468,7 +1532,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_apply_kernel(
       st_Vc.fetch(vb + (long long)cn * CK * 16 * C::D, min(CK, ntiles - cn * CK) * 16, tid);
     }
     if (active)
-      for (int kc = 0; kc < nt; ++kc) {
+      for (int kc = (KS == 1 ? 0 : ((ch * CK) & 1) ^ ksh); kc < nt; kc += KS) {
         f32x4 S[H];
         tile_logits<H, DH>(S, Kc, kc, qf, l15, g4);
         tag_probs<H, true>(S, lse, c, rng, wlane + 4u * (uint32_t)(ch * CK + kc), hstride);      // P~ (dropped = 0)
@@ -1488,7 +1552,20 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_apply_kernel(
           }
       }
   }
-  if (active) {   // accumulator row 4 g4 + jj: head 4 (g4 >> 1) + j, feature 8 fb + 4 (g4 & 1) + jj
+  if constexpr (KS == 2) {
+    __syncthreads();
+    float* cs = reinterpret_cast<float*>(smem_raw) + (wave >> 1) * (4 * FB * 256);
+    if (ksh) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) pair_park(oacc[j], cs + j * FB * 256, lane);
+    }
+    __syncthreads();
+    if (!ksh) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) pair_take(oacc[j], cs + j * FB * 256, lane);
+    }
+  }
+  if (active && ksh == 0) {   // accumulator row 4 g4 + jj: head 4 (g4 >> 1) + j, feature 8 fb + 4 (g4 & 1) + jj
     bf16_t* orow = O + ((long long)b * N + qrow) * C::D;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -1784,7 +1861,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_bwd_dq_kernel(
 // second one for dq (each recomputing the chain), accumulate U = sum_k (P~ dP~) k here and take V = sum_k P k from the
 // forward (flash2_moments_kernel): dq = scale (U - delta V).  The u = P~ dP~ terms go to the matrix cores as single bf16
 // values like dS did; U - delta V is the covariance form of the same sum.
-template <int DH, int WPB, int CK>
+template <int DH, int WPB, int CK, int KS = 1>
 __global__ __launch_bounds__(WPB * 64, 2) void flash2_bwd_dqx_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, const bf16_t* __restrict__ dO,
     const float* __restrict__ lse2, const float* __restrict__ rinv, const float* __restrict__ pkv, const float* __restrict__ stats,
@@ -1804,10 +1881,11 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_bwd_dqx_kernel(
   float* red = reinterpret_cast<float*>(Kc);                              // [WPB][NT], after the last tile (aliases the K chunk)
   const vu_rng rng = vu_rng_resolve(rng_in);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
-  const int ntiles = N >> 4, per = (ntiles + WPB - 1) / WPB;
+  constexpr int TPB = WPB / KS;
+  const int ntiles = N >> 4, per = (ntiles + TPB - 1) / TPB;
   int b, grp;
   work_item(blockIdx.x, B, per, b, grp);
-  const int t = grp * WPB + wave;
+  const int t = grp * TPB + wave / KS, ksh = wave % KS;
   const bool active = t < ntiles;
   const int tq = active ? t : ntiles - 1;
   const int qrow = tq * 16 + l15;
@@ -1857,7 +1935,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_bwd_dqx_kernel(
       st_Vc.fetch(vb + (long long)cn * CK * 16 * C::D, min(CK, ntiles - cn * CK) * 16, tid);
     }
     if (active)
-      for (int kc = 0; kc < nt; ++kc) {
+      for (int kc = (KS == 1 ? 0 : ((ch * CK) & 1) ^ ksh); kc < nt; kc += KS) {
         f32x4 S[H], T[2][4], E[2][4];
         tile_prod<H, DH, true>(S, Kc, kc, nullptr, Qs, nullptr, l15, g4);
         bwd2_chain<H, DH, true, true>(S, Vc, kc, dOs, lse, c, rng, wlane + 4u * (uint32_t)(ch * CK + kc), hstride, ops, T, E, l15, g4);
@@ -1915,6 +1993,25 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_bwd_dqx_kernel(
         }
       }
   }
+  if constexpr (KS == 2) {                  // the odd wave's partial U, row sums and head-mix gradient sums into the even wave's
+    __syncthreads();
+    float* cs = reinterpret_cast<float*>(smem_raw) + (wave >> 1) * ((4 * FB + 4) * 256);
+    f32x4 misc[4] = {dl, dlb, tc, Tacc};
+    if (ksh) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) pair_park(acc[j], cs + j * FB * 256, lane);
+      pair_park(misc, cs + 4 * FB * 256, lane);
+    }
+    __syncthreads();
+    if (!ksh) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) pair_take(acc[j], cs + j * FB * 256, lane);
+      pair_take(misc, cs + 4 * FB * 256, lane);
+      dl = misc[0]; dlb = misc[1]; tc = misc[2]; Tacc = misc[3];
+    }
+    __syncthreads();                                  // (red below aliases the same LDS)
+  }
+  const bool writer = active && ksh == 0;
   // delta: the lanes (q, hh) and (q, hh + 2) hold the two key groups of the same 4 heads; the accumulators of this lane
   // belong to heads 4 (g4 >> 1) + j, whose delta sits in the lanes with hh = g4 >> 1
   f32x4 dsel;
@@ -1924,10 +2021,10 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_bwd_dqx_kernel(
     d += __shfl_xor(d, 32, 64);
     db += __shfl_xor(db, 32, 64);
     const float rs = rinv[((long long)b * H + 4 * hh + j) * N + qrow];    // row_norm_note: 1 / sum_k bf16(P) (moments sweep)
-    if (active && g4 < 2) delta[((long long)b * H + 4 * hh + j) * N + qrow] = d * rs;
+    if (writer && g4 < 2) delta[((long long)b * H + 4 * hh + j) * N + qrow] = d * rs;
     dsel[j] = __shfl(db * rs, l15 + 16 * (g4 >> 1), 64);
   }
-  if (active) {
+  if (writer) {
     bf16_t* orow = dq + ((long long)b * N + qrow) * C::D;
     const float* vrow = pkv + ((long long)b * N + qrow) * C::D;
 #pragma unroll
@@ -1947,11 +2044,11 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_bwd_dqx_kernel(
 #pragma unroll
   for (int jj = 0; jj < 4; ++jj) {
     const int g = 4 * g4 + jj;
-    if (g < 8 && l15 >= 8) red[wave * NT + g * H + (l15 - 8)] = active ? Tacc[jj] : 0.f;
+    if (g < 8 && l15 >= 8) red[wave * NT + g * H + (l15 - 8)] = writer ? Tacc[jj] : 0.f;
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    float x = active ? tc[j] : 0.f;
+    float x = writer ? tc[j] : 0.f;
 #pragma unroll
     for (int m = 8; m >= 1; m >>= 1) x += __shfl_xor(x, m, 64);
     x += __shfl_xor(x, 32, 64);
@@ -1967,7 +2064,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_bwd_dqx_kernel(
 }
 
 // ---- sweeps 3 / 4: dk (DV = false) and dv (DV = true), key-major loop ------------------------------------------------
-template <int DH, int WPB, int CK, bool DV>
+template <int DH, int WPB, int CK, bool DV, int KS = 1>
 __global__ __launch_bounds__(WPB * 64, DV ? 3 : 2) void flash2_bwd_dkv_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, const bf16_t* __restrict__ dO,
     const float* __restrict__ lse2, const float* __restrict__ delta, const float* __restrict__ stats, bf16_t* __restrict__ out,
@@ -1984,10 +2081,11 @@ __global__ __launch_bounds__(WPB * 64, DV ? 3 : 2) void flash2_bwd_dkv_kernel(
   bf16_t* img = Dc + CK * 16 * C::PITCH + WPB * SROWS * C::PITCH + (threadIdx.x >> 6) * 640;     // 2 x [16 q][IMP]
   const vu_rng rng = vu_rng_resolve(rng_in);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
-  const int ntiles = N >> 4, per = (ntiles + WPB - 1) / WPB;
+  constexpr int TPB = WPB / KS;
+  const int ntiles = N >> 4, per = (ntiles + TPB - 1) / TPB;
   int b, grp;
   work_item(blockIdx.x, B, per, b, grp);
-  const int t = grp * WPB + wave;
+  const int t = grp * TPB + wave / KS, ksh = wave % KS;
   const bool active = t < ntiles;
   const int tk = active ? t : ntiles - 1;
   const bf16_t* qb = q + (long long)b * N * C::D;
@@ -2037,7 +2135,7 @@ __global__ __launch_bounds__(WPB * 64, DV ? 3 : 2) void flash2_bwd_dkv_kernel(
       st_Dc.fetch(dob + (long long)cn * CK * 16 * C::D, min(CK, ntiles - cn * CK) * 16, tid);
     }
     if (active)
-      for (int qc = 0; qc < nt; ++qc) {
+      for (int qc = (KS == 1 ? 0 : ((ch * CK) & 1) ^ ksh); qc < nt; qc += KS) {
         // row constants of the tile's queries (log-sum-exp of all heads, delta of the lane's 4 heads): L2-resident
         const long long qg = (long long)(ch * CK + qc) * 16 + l15;
         float lse[H];
@@ -2089,7 +2187,20 @@ __global__ __launch_bounds__(WPB * 64, DV ? 3 : 2) void flash2_bwd_dkv_kernel(
         }
       }
   }
-  if (active) {
+  if constexpr (KS == 2) {                  // (query split: the odd wave's partial dk / dv into the even wave's)
+    __syncthreads();
+    float* cs = reinterpret_cast<float*>(smem_raw) + (wave >> 1) * (H * C::DT * 256);
+    if (ksh) {
+#pragma unroll
+      for (int h = 0; h < H; ++h) pair_park(oa[h], cs + h * C::DT * 256, lane);
+    }
+    __syncthreads();
+    if (!ksh) {
+#pragma unroll
+      for (int h = 0; h < H; ++h) pair_take(oa[h], cs + h * C::DT * 256, lane);
+    }
+  }
+  if (active && ksh == 0) {
     bf16_t* orow = out + ((long long)b * N + tk * 16 + l15) * C::D;
 #pragma unroll
     for (int h = 0; h < H; ++h)
@@ -2280,7 +2391,7 @@ inline bool tail_overlap(const ForkPool* fp, int nblk, hipStream_t st, bool chec
   return true;
 }
 
-template <int DH>
+template <int DH, int KS>
 int launch_forward_v2(const vu_flash_args& a, hipStream_t st) {
 #ifndef VU_CKF
 #define VU_CKF 4
@@ -2290,16 +2401,18 @@ int launch_forward_v2(const vu_flash_args& a, hipStream_t st) {
 #endif
   constexpr int H = 8, WPB = 4, CK = VU_CKF;
   typedef FC<H, DH> C;
-  const int ntiles = a.N >> 4, per = (ntiles + WPB - 1) / WPB;
+  constexpr int TPB = WPB / KS;                                          // own tiles per workgroup (pair_park / pair_take)
+  const int ntiles = a.N >> 4, per = (ntiles + TPB - 1) / TPB;
   const int nblk = a.B * per;
   const float c = a.scale * 1.44269504088896340736f;
   const size_t rowb = (size_t)16 * C::PITCH * 2;
   const size_t lds1 = CK * rowb + (size_t)WPB * C::NMOM * 4;
-  const size_t ldsm = CK * rowb + (size_t)WPB * 16 * 4 + (size_t)(7 * DH + 16) * 2 + 16;
+  size_t ldsm = CK * rowb + (size_t)WPB * 16 * 4 + (size_t)(7 * DH + 16) * 2 + 16;
+  if (KS == 2 && ldsm < (size_t)(WPB / 2) * (H * C::DT + 2) * 1024) ldsm = (size_t)(WPB / 2) * (H * C::DT + 2) * 1024;      // the pair-combine scratch
   const size_t lds2 = 2 * CK * rowb + (size_t)tr_zero_elems<H, DH>() * 2;
-  auto k1 = flash_rowstats_kernel<H, DH, WPB, CK>;
-  auto km = flash2_moments_kernel<DH, WPB, CK>;
-  auto k2 = flash2_apply_kernel<DH, WPB, CK>;
+  auto k1 = flash_rowstats_kernel<H, DH, WPB, CK, KS>;
+  auto km = flash2_moments_kernel<DH, WPB, CK, KS>;
+  auto k2 = flash2_apply_kernel<DH, WPB, CK, KS>;
   VU_TRY(reserve_lds(k1, lds1)); VU_TRY(reserve_lds(km, ldsm)); VU_TRY(reserve_lds(k2, lds2));
   const double E = (double)a.B * H * a.N * a.N, act = (double)a.B * a.N * C::D * 2.0;
   const bf16_t *q = (const bf16_t*)a.q, *k = (const bf16_t*)a.k, *v = (const bf16_t*)a.v;
@@ -2320,11 +2433,12 @@ int launch_forward_v2(const vu_flash_args& a, hipStream_t st) {
   return vu_check_launch("flash2_apply");
 }
 
-template <int DH>
+template <int DH, int KS>
 int launch_backward_v2(const vu_flash_args& a, hipStream_t st) {
   constexpr int H = 8, WPB = 4, CK = 4, CK2 = 2, NT = H * H + H;
   typedef FC<H, DH> C;
-  const int ntiles = a.N >> 4, per = (ntiles + WPB - 1) / WPB;
+  constexpr int TPB = WPB / KS;
+  const int ntiles = a.N >> 4, per = (ntiles + TPB - 1) / TPB;
   const int nblk = a.B * per;
   const float c = a.scale * 1.44269504088896340736f;
   const size_t rowb = (size_t)16 * C::PITCH * 2;
@@ -2336,20 +2450,21 @@ int launch_backward_v2(const vu_flash_args& a, hipStream_t st) {
   const size_t lds3 = (2 * CKK + 2 * WPB) * rowb + (size_t)WPB * 1280;
   static_assert((size_t)WPB * NT * 4 <= (size_t)CK2 * 16 * C::PITCH * 2, "reduction scratch must fit the K chunk");
   const size_t lds4 = (2 * CK + 2 * WPB) * rowb + (size_t)2 * H * CK * 16 * 4 + (size_t)WPB * 1024;
-  constexpr int CKX = 1;
+  constexpr int CKX = KS == 2 ? 2 : 1;       // (split form: a chunk must hold a tile for each wave of a pair)
   const size_t lds2x = (2 * CKX + 2 * WPB) * rowb + (size_t)WPB * 1024 + (size_t)tr_strip_elems<DH>() * 2;
   auto k1 = flash2_bwd_delta_kernel<DH, WPB, CK2>;
   auto k2 = flash2_bwd_dq_kernel<DH, WPB, CK2>;
-  auto k2x = flash2_bwd_dqx_kernel<DH, WPB, CKX>;
+  auto k2x = flash2_bwd_dqx_kernel<DH, WPB, CKX, KS>;
   // The fused sweep takes V = sum_k P k from the TRAINING forward (flash2_moments_kernel); with running statistics (eval
   // mode + autograd) no moments sweep ran and pk holds nothing, so that case takes the separate delta and dq sweeps.
   // (VU_FLASH_UNFUSED=1, read once: diagnostic switch that takes the separate sweeps in training too)
   static const bool unfused_dbg = [] { const char* e = getenv("VU_FLASH_UNFUSED"); return e && e[0] == '1'; }();
   const bool fused = a.pk != nullptr && a.training && !unfused_dbg;
+  if (KS != 1 && !fused) { vu_set_error("flash attention: the split backward exists for the fused training form only"); return VU_EUNSUPPORTED; }
   VU_TRY(reserve_lds(k2x, lds2x));
-  auto k3 = flash2_bwd_dkv_kernel<DH, WPB, CKK, false>;
-  constexpr int CKV = 1;                 // dv: one tile per chunk, 16 stationary rows per wave: 43.5 KB, three workgroups per CU
-  auto k4 = flash2_bwd_dkv_kernel<DH, WPB, CKV, true>;
+  auto k3 = flash2_bwd_dkv_kernel<DH, WPB, CKK, false, KS>;
+  constexpr int CKV = KS == 2 ? 2 : 1;   // dv: one tile per chunk, 16 stationary rows per wave: 43.5 KB, three workgroups per CU (split form: two)
+  auto k4 = flash2_bwd_dkv_kernel<DH, WPB, CKV, true, KS>;
   const size_t lds3v = (2 * CKV + WPB) * rowb + (size_t)WPB * 1280;
   VU_TRY(reserve_lds(k1, lds1)); VU_TRY(reserve_lds(k2, lds2)); VU_TRY(reserve_lds(k3, lds3)); VU_TRY(reserve_lds(k4, lds3v));
   (void)lds4;
@@ -2431,8 +2546,26 @@ bool vu_flash_ok(int dtype, int B, int N, int D, int H) {
   return inst && N % 16 == 0 && N >= 256 && (double)B * H * N * N < 17179869184.0;
 }
 
+// Split of the streamed axis over wave pairs ("split of the streamed axis" above).  MEASURED, NOT TAKEN BY DEFAULT (round 3):
+// one Base level-2 module, forward + backward, unsplit -> split: 16 images 735 -> 735 us (dq+delta 147 -> 145, dk 131 -> 119,
+// moments 77 -> 67, dv 83 -> 98..111, apply / row statistics unchanged), 8 images 694 -> 578.  The two waves of a pair run in
+// lock-step through the two barriers of every streamed chunk and both still do their share of the chunk staging, so the second
+// wave on the SIMD hides little (two INDEPENDENT workgroups per CU deliver 1.56x); and where it does gain (8 - 12 images) the
+// materialising kernels are still faster (Base step at 8 images: 5.82 ms materialised, 6.02 split, 6.49 unsplit; at 12:
+// 6.32 / 6.52 / 6.62).  So the rule is "never"; vu_set_flash_key_split(2) / VU_FLASH_KS=2 run it (tests keep it correct).
+static int g_key_split = [] { const char* e = getenv("VU_FLASH_KS"); return (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0; }();
+extern "C" int vu_set_flash_key_split(int ks) {
+  if (ks < 0 || ks > 2) { vu_set_error("vu_set_flash_key_split: 0 (default), 1 or 2"); return VU_EINVAL; }
+  g_key_split = ks;
+  return VU_OK;
+}
+int vu_flash_key_split(int B, int N) {
+  (void)B; (void)N;
+  return g_key_split ? g_key_split : 1;
+}
+
 size_t vu_flash_partials_floats(int B, int N, int H) {
-  const int ntiles = N >> 4, per = (ntiles + 3) / 4;
+  const int ntiles = N >> 4, per = (ntiles + 1) / 2;          // (rows of the split form: two own tiles per workgroup)
   return (size_t)B * per * (H * H + H) + 64;          // forward: H + H (H + 1) / 2 moments; backward: H H + H mix-gradient sums
 }
 
@@ -2440,9 +2573,14 @@ int vu_k_flash_forward(const vu_flash_args& a, hipStream_t st) {
   VU_REQUIRE(vu_flash_ok(1, a.B, a.N, a.D, a.H), "flash attention: shape not covered");
   if (a.H == 8) {       // head mixes on the matrix cores (v2 tile body)
     const int dh = a.D / a.H;
-    if (dh == 24) return launch_forward_v2<24>(a, st);
-    if (dh == 8) return launch_forward_v2<8>(a, st);
-    if (dh == 32) return launch_forward_v2<32>(a, st);
+    if (vu_flash_key_split(a.B, a.N) == 2) {
+      if (dh == 24) return launch_forward_v2<24, 2>(a, st);
+      if (dh == 8) return launch_forward_v2<8, 2>(a, st);
+      if (dh == 32) return launch_forward_v2<32, 2>(a, st);
+    }
+    if (dh == 24) return launch_forward_v2<24, 1>(a, st);
+    if (dh == 8) return launch_forward_v2<8, 1>(a, st);
+    if (dh == 32) return launch_forward_v2<32, 1>(a, st);
   }
   VU_FLASH_DISPATCH(launch_forward, a, st);
 }
@@ -2451,9 +2589,14 @@ int vu_k_flash_backward(const vu_flash_args& a, hipStream_t st) {
   VU_REQUIRE(vu_flash_ok(1, a.B, a.N, a.D, a.H), "flash attention: shape not covered");
   if (a.H == 8) {
     const int dh = a.D / a.H;
-    if (dh == 24) return launch_backward_v2<24>(a, st);
-    if (dh == 8) return launch_backward_v2<8>(a, st);
-    if (dh == 32) return launch_backward_v2<32>(a, st);
+    if (vu_flash_key_split(a.B, a.N) == 2 && a.pk != nullptr && a.training) {      // (the eval-mode backward keeps the unsplit sweeps)
+      if (dh == 24) return launch_backward_v2<24, 2>(a, st);
+      if (dh == 8) return launch_backward_v2<8, 2>(a, st);
+      if (dh == 32) return launch_backward_v2<32, 2>(a, st);
+    }
+    if (dh == 24) return launch_backward_v2<24, 1>(a, st);
+    if (dh == 8) return launch_backward_v2<8, 1>(a, st);
+    if (dh == 32) return launch_backward_v2<32, 1>(a, st);
   }
   VU_FLASH_DISPATCH(launch_backward, a, st);
 }

@@ -61,6 +61,7 @@ SIGNATURES = {
     "vu_model_num_attn": (_i, [_cfgp]),
     "vu_model_workspace_bytes": (_sz, [_cfgp, _i]),
     "vu_model_prefers_eager": (_i, [_cfgp, _i]),
+    "vu_set_flash_key_split": (_i, [_i]),
     "vu_model_forward": (_i, [_cfgp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _u64, _vp, _vp]),
     "vu_model_backward": (_i, [_cfgp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _u64, _vp, _i, _vp]),
     "vu_model_num_backward_units": (_i, [_cfgp]),
@@ -182,6 +183,12 @@ def set_attn_form(flash: int = -1, centered: int = 0) -> None:
     """Process-level choice of the re-attention form (include/vit_unet_amd.h: vu_set_attn_form): flash -1 auto / 0 never /
     1 wherever covered; centered 1: the stand-alone op in the centred-map form.  Tests and experiments only."""
     check(lib().vu_set_attn_form(int(flash), int(centered)), "vu_set_attn_form")
+
+
+def set_flash_key_split(ks: int = 0) -> None:
+    """Recompute attention only: waves of a workgroup that share one tile and split the streamed keys / queries (0 = by launch
+    size, 1, 2; include/vit_unet_amd.h: vu_set_flash_key_split).  Tests and experiments only."""
+    check(lib().vu_set_flash_key_split(int(ks)), "vu_set_flash_key_split")
 
 
 def make_config(depth, depth_te, size_bottleneck, preprocessing, im_size, patch_size, num_channels,
