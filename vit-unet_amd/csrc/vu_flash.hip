@@ -1235,6 +1235,13 @@ __device__ __forceinline__ bf16x8 relu_packed(const bf16x8& x) {
 __device__ __forceinline__ f32x4 mfma32(const bf16x8& a, const bf16x8& b, const f32x4& c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
+// Two K = 16 contractions into the same accumulator as ONE K = 32 instruction: the lane's four k-slots of each become its eight
+// (any assignment of k-slots is fine as long as both operands use the same one).  v_mfma_f32_16x16x16_bf16 occupies the matrix
+// pipe for the same 16 cycles as v_mfma_f32_16x16x32_bf16 (SQ_VALU_MFMA_BUSY_CYCLES / SQ_INSTS_MFMA = 16.0 on sweeps that mix both).
+__device__ __forceinline__ bf16x8 join_k(const s16x4& a, const s16x4& b) {
+  const s16x8 t = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return __builtin_bit_cast(bf16x8, t);
+}
 // ML tile X[half][r] (f32x4 over j) = cin + (op.hi + op.lo) . pk[r]
 __device__ __forceinline__ void mix_ml(f32x4 (&X)[2][4], const MixOp& op, const bf16x8 (&pk)[4], const f32x4& cin) {
 #pragma unroll
@@ -1542,14 +1549,13 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_apply_kernel(
         mix_ml(A, op, pk, cin);                       // A^ in ML
         const int tb = src.base(kc);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j) {                // the two key halves of the tile as the two k-blocks of one K = 32 product (join_k)
+          const f32x4 a0 = {A[0][0][j], A[0][1][j], A[0][2][j], A[0][3][j]}, a1 = {A[1][0][j], A[1][1][j], A[1][2][j], A[1][3][j]};
+          const bf16x8 b8 = join_k(pack4s(a0), pack4s(a1));
 #pragma unroll
-          for (int half = 0; half < 2; ++half) {
-            const f32x4 a4 = {A[half][0][j], A[half][1][j], A[half][2][j], A[half][3][j]};
-            const s16x4 bop = pack4s(a4);
-#pragma unroll
-            for (int fb = 0; fb < FB; ++fb) oacc[j][fb] = mfma16(tr_half<H, DH>(Vc, tb, half, j, fb), bop, oacc[j][fb]);
-          }
+          for (int fb = 0; fb < FB; ++fb)
+            oacc[j][fb] = mfma32(join_k(tr_half<H, DH>(Vc, tb, 0, j, fb), tr_half<H, DH>(Vc, tb, 1, j, fb)), b8, oacc[j][fb]);
+        }
       }
   }
   if constexpr (KS == 2) {
@@ -1623,6 +1629,9 @@ __device__ __forceinline__ void bwd2_chain(f32x4 (&S)[H], const bf16_t* Dc, int 
 __device__ __forceinline__ f32x4 bwd2_dp(const f32x4& e, const BackOp& bk) {
   const s16x4 b = pack4s(e);
   const s16x4 bl = pack4s(residual4(e, b));
+  // (round 3: hi b + hi bl as one K = 32 product (hi | hi) (b | bl) followed by the K = 16 product lo b gave WRONG results - an
+  // accumulator chained from a 16x16x32 into a 16x16x16 instruction - and, with both as K = 32 instructions, two more operand
+  // registers in sweeps that sit at the cap: dq+delta 408 -> 419 us.  Three K = 16 products stay.)
   f32x4 dp = mfma16(bk.hi, b, f32x4{0.f, 0.f, 0.f, 0.f});
   dp = mfma16(bk.lo, b, dp);
   return mfma16(bk.hi, bl, dp);
@@ -1958,16 +1967,16 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_bwd_dqx_kernel(
             const f32x4 elo4 = residual4(E[half][r], ehi);
             *reinterpret_cast<s16x4*>(im_e) = ehi;
             *reinterpret_cast<s16x4*>(im_p) = pack4s(ph);
-#pragma unroll
-            for (int pb = 0; pb < 2; ++pb) {       // 32 positions = 2 k-blocks of 16
-              const s16x4 x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(im_r + 16 * pb * IMP));
-              Tacc = mfma16(x, x, Tacc);
+            {                                      // 32 positions = 2 k-blocks of 16 = one K = 32 product (join_k)
+              const bf16x8 x = join_k(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)im_r),
+                                      __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(im_r + 16 * IMP)));
+              Tacc = mfma32(x, x, Tacc);
             }
             *reinterpret_cast<s16x4*>(im_e) = pack4s(elo4);
-#pragma unroll
-            for (int pb = 0; pb < 2; ++pb) {
-              const s16x4 x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(im_r + 16 * pb * IMP));
-              Tacc = mfma16(x, x, Tacc);
+            {
+              const bf16x8 x = join_k(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)im_r),
+                                      __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(im_r + 16 * IMP)));
+              Tacc = mfma32(x, x, Tacc);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -1976,19 +1985,22 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_bwd_dqx_kernel(
               T[half][r][j] = u;
             }
           }
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-          const int tb = src.base(kc, half);
+        {                                          // the two key halves of the tile as the two k-blocks of one K = 32 product (join_k)
+          const int tb0 = src.base(kc, 0), tb1 = src.base(kc, 1);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const f32x4 d4 = {T[half][0][j], T[half][1][j], T[half][2][j], T[half][3][j]};
-            const s16x4 bop = pack4s(d4);
-            {
-              const u32x2_t bw = __builtin_bit_cast(u32x2_t, bop);
+            s16x4 bop[2];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+              const f32x4 d4 = {T[half][0][j], T[half][1][j], T[half][2][j], T[half][3][j]};
+              bop[half] = pack4s(d4);
+              const u32x2_t bw = __builtin_bit_cast(u32x2_t, bop[half]);
               dlb[j] = sum2_bf16(bw[1], sum2_bf16(bw[0], dlb[j]));
             }
+            const bf16x8 b8 = join_k(bop[0], bop[1]);
 #pragma unroll
-            for (int fb = 0; fb < FB; ++fb) acc[j][fb] = mfma16(tr_rel<DH>(Kc, tb, j, fb), bop, acc[j][fb]);
+            for (int fb = 0; fb < FB; ++fb)
+              acc[j][fb] = mfma32(join_k(tr_rel<DH>(Kc, tb0, j, fb), tr_rel<DH>(Kc, tb1, j, fb)), b8, acc[j][fb]);
           }
         }
       }
