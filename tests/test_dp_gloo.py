@@ -51,6 +51,16 @@ def _worker(rank, world, port, ret):
     flat /= world
     ref = sum(_flat_grads(cfg, table, total, w, x[r * 2:r * 2 + 2], y[r * 2:r * 2 + 2]) for r in range(world)) / world
     ok = torch.allclose(flat, ref, rtol=1e-5, atol=1e-7)
+    # the bf16 wire option: same schedule, buckets cast to bf16 for the collective: within bf16 rounding of the fp32 result
+    flat16 = _flat_grads(cfg, table, total, w, x[shard], y[shard])
+    for _first, _last, ranges in dp_unit_buckets(_lib.backward_unit_ranges(ccfg), cap_bytes=64 << 10):
+        for lo, hi in ranges:
+            allreduce_bucket(flat16, lo, hi, wire_dtype=torch.bfloat16)
+    flat16 /= world
+    ok = ok and bool(((flat16 - ref).abs() <= 2.0 ** -7 * ref.abs().max()).all()) and not torch.equal(flat16, flat)
+    g16 = [torch.zeros_like(flat16) for _ in range(world)]
+    dist.all_gather(g16, flat16)
+    ok = ok and all(torch.equal(g16[0], g) for g in g16)
     # identical update on every rank
     p = torch.cat([w[n].reshape(-1) for n, *_ in table])
     gathered = [torch.zeros_like(flat) for _ in range(world)]

@@ -70,18 +70,32 @@ def dp_unit_buckets(unit_ranges, cap_bytes: int = 48 << 20, elem_bytes: int = 4)
     return out
 
 
-def allreduce_bucket(flat: torch.Tensor, lo: int, hi: int, group=None):
+def allreduce_bucket(flat: torch.Tensor, lo: int, hi: int, group=None, wire_dtype=None):
     """Sum one bucket of the flat gradient arena over the data-parallel group (RCCL on GPU
-    tensors, gloo on CPU tensors in the tests).  The 1/world average is applied by AdamW."""
-    if hi > lo:
+    tensors, gloo on CPU tensors in the tests).  The 1/world average is applied by AdamW.
+    `wire_dtype=torch.bfloat16`: the bucket crosses the links as bf16 (half the bytes on the per-link-bound xGMI ring):
+    cast, all-reduce, cast back into the fp32 arena - every rank ends with the same values (the sum is formed from the
+    same bf16 operands everywhere), each gradient carries one more rounding to 8 bits."""
+    if hi <= lo:
+        return
+    if wire_dtype is None or wire_dtype == flat.dtype:
         torch.distributed.all_reduce(flat[lo:hi], group=group)
+    else:
+        wire = flat[lo:hi].to(wire_dtype)
+        torch.distributed.all_reduce(wire, group=group)
+        flat[lo:hi].copy_(wire)
 
 
 class TrainStep:
     def __init__(self, model, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
-                 process_group=None, seed: int = 0, overlap: bool = True, loss: str = "mse", bucket_mb: Optional[int] = None):
+                 process_group=None, seed: int = 0, overlap: bool = True, loss: str = "mse", bucket_mb: Optional[int] = None,
+                 grad_wire_dtype: Optional[torch.dtype] = None):
         """`loss`: "mse" (run_denoising.py:80) or "dice" (README.md:91-101 on sigmoid(model output),
-        the segmentation configuration of BASELINE config 5)."""
+        the segmentation configuration of BASELINE config 5).  `grad_wire_dtype=torch.bfloat16`: data-parallel gradient
+        buckets are all-reduced in bf16 (allreduce_bucket); default: fp32, as the reference's DDP would."""
+        if grad_wire_dtype not in (None, torch.float32, torch.bfloat16):
+            raise ValueError("grad_wire_dtype must be None, torch.float32 or torch.bfloat16")
+        self.grad_wire_dtype = None if grad_wire_dtype == torch.float32 else grad_wire_dtype
         if loss not in ("mse", "dice"):
             raise ValueError(f"loss must be 'mse' or 'dice', got {loss!r}")
         self.loss_kind = loss
@@ -165,10 +179,10 @@ class TrainStep:
             self.comm_stream.wait_stream(cur)
             with torch.cuda.stream(self.comm_stream):
                 for lo, hi in ranges:
-                    allreduce_bucket(self.model._garena, lo, hi, self.pg)
+                    allreduce_bucket(self.model._garena, lo, hi, self.pg, self.grad_wire_dtype)
         else:
             for lo, hi in ranges:
-                allreduce_bucket(self.model._garena, lo, hi, self.pg)
+                allreduce_bucket(self.model._garena, lo, hi, self.pg, self.grad_wire_dtype)
 
     def _enqueue(self, x, y, out, dout):
         self._enqueue_head(x, y, out, dout)
