@@ -7,6 +7,8 @@
 // product, the skinny shapes and the fp32-accumulating weight gradients below 3072 x 3072 stay on csrc/vu_gemm.hip /
 // vu_tsgemm.hip / vu_pgemm.hip.
 // Row-major C (M x N) = A B is handed over as the column-major product C^T = B^T A^T.
+// ONE 32 MB workspace serves every call: the products are issued on the caller's compute stream, one after the other (the side
+// lanes of the backward carry no library product); a caller that put them on several streams at once would need one per stream.
 // Plans (descriptors + the heuristic's first algorithm) are cached per shape; a plan is never CREATED while the stream is
 // being captured (the heuristic query and the workspace allocation are not capturable) - such a call falls back to vu_gemm.
 #include <hipblaslt/hipblaslt.h>
@@ -33,7 +35,6 @@ struct State {
   void* ws = nullptr;
   size_t ws_bytes = 0;
   std::map<Key, Plan> plans;
-  bool dead = false;
 };
 State& state() { static State s; return s; }
 
@@ -158,7 +159,6 @@ int vu_lt_try(const vu_gemm_args& g, int c_float, hipStream_t st) {
   const int m = g.N, n = g.M, k = g.K;
   State& s = state();
   std::lock_guard<std::mutex> lock(s.mu);
-  if (s.dead) return 0;
   const Key key{m, n, k, (int)opA, (int)opB, ldb_row, lda_row, g.ldc, c_float, g.accumulate, g.bias ? 1 : 0};
   auto it = s.plans.find(key);
   if (it == s.plans.end()) {

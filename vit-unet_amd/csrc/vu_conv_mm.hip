@@ -96,7 +96,7 @@ __device__ __forceinline__ void tap_offsets(int g4, int (&koff)[8]) {
 }
 // hi / lo bf16 halves of the lane's 8 weights of column n: w[k] for k = 8 g4 .. 8 g4 + 7 (nullptr / k >= 9 C: zeros)
 template <int C, bool FLIP>
-__device__ __forceinline__ void weight_op(const float* __restrict__ w, int stride_co, int col, int g4, bf16x8& hi, bf16x8& lo) {
+__device__ __forceinline__ void weight_op(const float* __restrict__ w, int col, int g4, bf16x8& hi, bf16x8& lo) {
   // forward: w[co = col][k]                       -> w + col * 9 C + k
   // data gradient (FLIP): k = co 9 + a 3 + b, w[co][ci = col][2 - a][2 - b] -> w + (co C + col) 9 + 8 - (a 3 + b)
   float v[8];
@@ -153,8 +153,8 @@ __global__ __launch_bounds__(256) void conv_qkv_mm_kernel(const bf16_t* __restri
   const int t = l15 / C, co = l15 % C;
   const float* wsel = t == 0 ? wq : (t == 1 ? wk : (t == 2 ? wv : nullptr));
   bf16x8 bh0, bl0, bh1, bl1;
-  weight_op<C, false>(NIN == 1 ? wsel : (t == 0 ? wq : nullptr), 0, co, g4, bh0, bl0);
-  if (NIN == 2) weight_op<C, false>(t == 1 ? wk : (t == 2 ? wv : nullptr), 0, co, g4, bh1, bl1);
+  weight_op<C, false>(NIN == 1 ? wsel : (t == 0 ? wq : nullptr), co, g4, bh0, bl0);
+  if (NIN == 2) weight_op<C, false>(t == 1 ? wk : (t == 2 ? wv : nullptr), co, g4, bh1, bl1);
   const bool ocol = l15 < 3 * C;
   const int pixoff = (l15 / M::PXR) * M::PITCH + (l15 % M::PXR);
   const int lo_w = l15 * OS::LP + 4 * g4;                   // the lane's slot in line (set 0, column l15)
@@ -242,9 +242,9 @@ __global__ __launch_bounds__(256) void conv_qkv_dgrad_mm_kernel(const bf16_t* __
   // columns: ci (all three gradients) or, CROSS, ci for dq and C + ci for dk / dv
   const int half = l15 / C, ci = l15 % C;
   bf16x8 bh[3], bl[3];
-  weight_op<C, true>(half == 0 ? wq : nullptr, 0, ci, g4, bh[0], bl[0]);
-  weight_op<C, true>(half == (CROSS ? 1 : 0) ? wk : nullptr, 0, ci, g4, bh[1], bl[1]);
-  weight_op<C, true>(half == (CROSS ? 1 : 0) ? wv : nullptr, 0, ci, g4, bh[2], bl[2]);
+  weight_op<C, true>(half == 0 ? wq : nullptr, ci, g4, bh[0], bl[0]);
+  weight_op<C, true>(half == (CROSS ? 1 : 0) ? wk : nullptr, ci, g4, bh[1], bl[1]);
+  weight_op<C, true>(half == (CROSS ? 1 : 0) ? wv : nullptr, ci, g4, bh[2], bl[2]);
   const bool ocol = l15 < NC;
   const bf16_t* abase = half == 0 ? add0 : add1;
   const int pixoff = (l15 / M::PXR) * M::PITCH + (l15 % M::PXR);
