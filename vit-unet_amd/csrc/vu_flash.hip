@@ -1629,9 +1629,10 @@ __device__ __forceinline__ void bwd2_chain(f32x4 (&S)[H], const bf16_t* Dc, int 
 __device__ __forceinline__ f32x4 bwd2_dp(const f32x4& e, const BackOp& bk) {
   const s16x4 b = pack4s(e);
   const s16x4 bl = pack4s(residual4(e, b));
-  // (round 3: hi b + hi bl as one K = 32 product (hi | hi) (b | bl) followed by the K = 16 product lo b gave WRONG results - an
-  // accumulator chained from a 16x16x32 into a 16x16x16 instruction - and, with both as K = 32 instructions, two more operand
-  // registers in sweeps that sit at the cap: dq+delta 408 -> 419 us.  Three K = 16 products stay.)
+  // (round 3: hi b + hi bl as one K = 32 product (hi | hi)(b | bl) followed by the K = 16 product lo b gave WRONG results - an
+  // accumulator chained from a 16x16x32 into a 16x16x16 instruction; with lo b as the K = 32 product (lo | 0)(b | b) the
+  // results are right and the sweeps slower - dk 367 -> 373 us, dq+delta 408 -> 416: the operand copies cost more than the
+  // eight matrix instructions per tile return.  Three K = 16 products stay.)
   f32x4 dp = mfma16(bk.hi, b, f32x4{0.f, 0.f, 0.f, 0.f});
   dp = mfma16(bk.lo, b, dp);
   return mfma16(bk.hi, bl, dp);
