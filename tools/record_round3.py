@@ -11,7 +11,7 @@ G, P = os.path.join(R, "gpurun_out"), os.path.join(R, "profiles")
 for f in glob.glob(os.path.join(G, "r03_bench_*.json")):
     shutil.copy(f, P)
 for src, dst in [("r03_kernel_stats.csv", "r03_kernel_stats.csv"), ("r03_by_grid.csv", "r03_by_grid.csv"),
-                 ("pmc_mfma_summary.csv", "r03_pmc_mfma_util_summary.csv"), ("r03_flash_pmc_sq_summary.csv", "r03_flash_pmc_sq_summary.csv")]:
+                 ("pmc_mfma_summary.csv", "r03_pmc_mfma_util_summary.csv"), ("r03_gaps.txt", "r03_gaps.txt"), ("r03_flash_pmc_sq_summary.csv", "r03_flash_pmc_sq_summary.csv")]:
     if os.path.exists(os.path.join(G, src)):
         shutil.copy(os.path.join(G, src), os.path.join(P, dst))
     else:
