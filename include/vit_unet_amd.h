@@ -66,6 +66,9 @@ int vu_model_num_params(const vu_config* cfg);
 int vu_model_param_table(const vu_config* cfg, vu_param_entry* out, int capacity);
 int vu_model_num_attn(const vu_config* cfg);                    /* BatchNorm modules           */
 size_t vu_model_workspace_bytes(const vu_config* cfg, int B);
+/* Diagnostic (no reference counterpart): the carve of that workspace as text, one "name offset bytes" line per buffer, the
+ * forward's buffers in execution order.  Returns the length of the full text (snprintf convention), < 0 on a bad config. */
+int vu_model_workspace_describe(const vu_config* cfg, int B, char* out, int cap);
 /* 1 when a training step of this configuration at B images per GPU is faster launched eagerly than replayed from a captured
  * graph: the recompute attention's backward then runs its dv sweep on a low-priority stream in the tails of the dq / dk
  * sweeps (more workgroups than the chip holds at once), and a captured kernel node carries no stream priority.  Needs a

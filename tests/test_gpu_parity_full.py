@@ -268,6 +268,12 @@ def test_level0_block_at_a_token_count_that_takes_the_library_route(attn_form, m
 @pytest.mark.parametrize("name,dt,ks", [("base", torch.bfloat16, 1), ("large", torch.bfloat16, 1), ("lite", torch.bfloat16, 1),
                                         ("base", torch.float32, 1), ("seg512", torch.bfloat16, 1), ("base", torch.bfloat16, 2)])
 def test_teacher_forced_blocks_bf16_full_size(name, dt, ks, attn_form, monkeypatch):
+    teacher_forced_blocks(name, dt, ks, attn_form, monkeypatch)
+
+
+def teacher_forced_blocks(name, dt, ks, attn_form, monkeypatch, one_per_level=False):
+    """Body of the teacher-forced block test.  `one_per_level`: only the FIRST block met at each level (the hot-path file that
+    collects first runs one block per level of every preset in about a minute; the full sweep over all blocks is the test above)."""
     # the benchmarked batch runs every covered level in the recompute ("flash") form; at this test's batch the fill rule
     # would pick the materialising kernels for most levels, so force the form the bench line is made of (ks = 1: the unsplit
     # sweeps every batch size runs by default; ks = 2: the opt-in split form, kept correct)
@@ -281,8 +287,12 @@ def test_teacher_forced_blocks_bf16_full_size(name, dt, ks, attn_form, monkeypat
     models = {}
     gen = torch.Generator().manual_seed(5)
     worst = {"fwd": 0.0, "bwd": 0.0}
+    nrun = 0
     for pre, xin, lvl, _stream in taps["blocks"]:
         N, D, hid, s = cfg.level(lvl)
+        if one_per_level and lvl in models:
+            continue
+        nrun += 1
         if lvl not in models:
             models[lvl] = _one_block_model(cfg, lvl, dt)
         m = models[lvl]
@@ -348,7 +358,7 @@ def test_teacher_forced_blocks_bf16_full_size(name, dt, ks, attn_form, monkeypat
         bufs = dict(m.named_buffers())
         assert serr(bufs["BottleNeck.0.ReAttn.var_norm.running_var"], wr[pre + "ReAttn.var_norm.running_var"]) < 2e-2, pre
         worst["fwd"], worst["bwd"] = max(worst["fwd"], ef), max(worst["bwd"], eb)
-    print(f"teacher-forced {name} {dt}: {len(taps['blocks'])} blocks, worst scaled error fwd {worst['fwd']:.3e} bwd {worst['bwd']:.3e}")
+    print(f"teacher-forced {name} {dt}: {nrun} of {len(taps['blocks'])} blocks, worst scaled error fwd {worst['fwd']:.3e} bwd {worst['bwd']:.3e}")
 
 
 ATTN_KEYS = ["reatten_matrix.weight", "reatten_matrix.bias", "var_norm.weight", "var_norm.bias", "qconv2d.weight",

@@ -1,0 +1,122 @@
+"""Which kernel loses run-to-run bit-identity when ANOTHER PROCESS uses the same GPU?  (round 4)
+
+    python tools/contention_ops.py [--load 60] [--iters 300] [--B 20]
+
+The round-3 two-rank rehearsal went red because the Base bf16 forward differed between two runs once a second process was
+computing on the same GPU; tools/nondet_check.py --ws-diff named the q / k / v buffers as the first to differ.  This runs the
+stand-alone ops at Base level shapes back to back under that load and counts repetitions whose output bytes differ from the
+first.  Each op is deterministic by construction (no atomics on these paths), so any count > 0 is a bug in that op."""
+import argparse
+import ctypes as C
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ap = argparse.ArgumentParser()
+ap.add_argument("--load", type=float, default=60.0)
+ap.add_argument("--iters", type=int, default=300)
+ap.add_argument("--B", type=int, default=20)
+args = ap.parse_args()
+child = None
+if args.load > 0:
+    child = subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "nondet_check.py"), "--as-load", str(args.load), "--B", str(args.B)])
+sys.path.insert(0, os.path.join(ROOT, "vit-unet_amd"))
+import torch  # noqa: E402
+from vit_unet.torch import _lib  # noqa: E402
+from vit_unet.torch._lib import check, lib, ptr  # noqa: E402
+
+L = lib()
+dev = "cuda"
+bf = torch.bfloat16
+if child is not None:
+    import glob
+    t0 = time.time()
+    while not glob.glob(f"/tmp/nondet_load_{child.pid}") and time.time() - t0 < 180:
+        time.sleep(0.2)
+    print(f"load process running after {time.time() - t0:.1f} s", flush=True)
+st = _lib.stream_ptr()
+B = args.B
+g = torch.Generator(device="cpu").manual_seed(3)
+total_bad = 0
+
+
+def conv_detail(s_):
+    def show(outs, ref):
+        for name_, o, r in zip("qkv", outs, ref):
+            d = (o.view(torch.int16) != r.view(torch.int16)).reshape(-1)
+            idx = d.nonzero().reshape(-1)
+            if idx.numel() == 0:
+                continue
+            ss = s_ * s_
+            print(f"    {name_}: {idx.numel()} elements differ; first 12:", flush=True)
+            for i in idx[:12].tolist():
+                patch, rem = divmod(i, 3 * ss)
+                ch, rem2 = divmod(rem, ss)
+                y_, x_ = divmod(rem2, s_)
+                quad = (patch * 3 * ss + ch * ss + y_ * s_ + x_) // 4
+                print(f"      elem {i}: patch {patch} ch {ch} y {y_} x {x_}  got {o.reshape(-1)[i].item():.5f} ref {r.reshape(-1)[i].item():.5f}", flush=True)
+            quads = torch.unique(idx // 4)
+            print(f"      {quads.numel()} quads; distinct patches {torch.unique(idx // (3 * ss)).numel()}; channels {torch.unique((idx % (3 * ss)) // ss).tolist()}; "
+                  f"runs of consecutive elements: {int((idx[1:] - idx[:-1] != 1).sum()) + 1}", flush=True)
+    return show
+
+
+def repeat(name, fn, outs, detail=None):
+    """fn() launches; outs: tensors it writes"""
+    global total_bad
+    for o in outs:
+        o.zero_()
+    fn()
+    torch.cuda.synchronize()
+    ref = [o.clone() for o in outs]
+    bad, worst = 0, 0
+    for _ in range(args.iters):
+        for o in outs:
+            o.fill_(7)              # (a stale value would show as well)
+        fn()
+        torch.cuda.synchronize()
+        nd = sum(int((o.view(torch.uint8) != r.view(torch.uint8)).sum()) for o, r in zip(outs, ref))
+        if nd:
+            bad += 1
+            worst = max(worst, nd)
+            if bad <= 2 and detail is not None:
+                detail(outs, ref)
+    total_bad += bad
+    print(f"{name:48s} {bad:4d} of {args.iters} repetitions differ (worst: {worst} bytes)", flush=True)
+
+
+for s, N in ((32, 49), (16, 196), (8, 784)):
+    D = 3 * s * s
+    npatch = B * N
+    x = torch.randn(B, N, D, generator=g).to(bf).to(dev)
+    w = [(torch.randn(3, 3, 3, 3, generator=g) / 5).to(dev) for _ in range(3)]
+    q, k, v = (torch.empty_like(x) for _ in range(3))
+    repeat(f"conv3x3_qkv_fwd s={s} npatch={npatch}",
+           lambda: check(L.vu_conv3x3_qkv_fwd(1, ptr(x), ptr(x), ptr(w[0]), ptr(w[1]), ptr(w[2]), ptr(q), ptr(k), ptr(v), npatch, 3, s, st)), [q, k, v], detail=conv_detail(s))
+    dq, dk, dv = (torch.randn(B, N, D, generator=g).to(bf).to(dev) for _ in range(3))
+    dx = torch.empty_like(x)
+    repeat(f"conv3x3_qkv_dgrad s={s}",
+           lambda: check(L.vu_conv3x3_qkv_dgrad(1, ptr(dq), ptr(dk), ptr(dv), ptr(w[0]), ptr(w[1]), ptr(w[2]), None, None, ptr(dx), None, npatch, 3, s, st)), [dx])
+    # residual add + LayerNorm over (N, D)
+    P = N * D
+    a = torch.randn(B, N, D, generator=g).to(bf).to(dev)
+    lw, lb = torch.randn(P, generator=g).to(dev), torch.randn(P, generator=g).to(dev)
+    z, y = torch.empty_like(a), torch.empty_like(a)
+    lws = torch.empty(L.vu_layernorm_workspace_floats(B, P), dtype=torch.float32, device=dev)
+    stats = torch.empty(2 * B, dtype=torch.float32, device=dev)
+    repeat(f"add_layernorm_fwd P={P}", lambda: check(L.vu_add_layernorm_fwd(1, ptr(a), ptr(x), ptr(z), ptr(lw), ptr(lb), ptr(y), ptr(lws), ptr(stats), B, P, st)), [z, y, stats])
+    # re-tiling to the next level
+    if s > 8:
+        o = torch.empty_like(x)
+        repeat(f"retile s={s}->{s // 2}", lambda: check(L.vu_retile(1, 0, 0, ptr(x), ptr(o), None, B, 3, 224, s, s // 2, st)), [o])
+    # the level's projection: y = x W^T + b
+    M = B * N
+    wt = (torch.randn(D, D, generator=g) / D ** 0.5).to(bf).to(dev)
+    yo = torch.empty(M, D, dtype=bf, device=dev)
+    repeat(f"gemm M={M} N={D} K={D}", lambda: check(L.vu_gemm(1, 0, ptr(x), ptr(wt), ptr(yo), M, D, D, D, 1, 1, D, D, 1, 1, 0, 0, 0, 0, 0, 0, 1.0, None, 0, st)), [yo])
+if child is not None:
+    child.wait()
+print("CONTENTION_OPS", "CLEAN" if total_bad == 0 else f"{total_bad} bad repetitions", flush=True)
+sys.exit(0 if total_bad == 0 else 1)

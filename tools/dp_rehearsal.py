@@ -42,6 +42,7 @@ if "--base" in sys.argv:
     assert ts.dp and ts.world == world
     ts.step(*base_batch(rank))
     torch.cuda.synchronize()
+    dp_out = ts._gout.detach().clone()
     summed = m._garena.detach().clone()               # after the bucketed all-reduces: the SUM over the ranks (AdamW folds 1 / world in)
     arena = m._arena.detach().clone()
     gathered = [torch.empty_like(arena) for _ in range(world)]
@@ -59,6 +60,10 @@ if "--base" in sys.argv:
             tr._enqueue_head(x, y, out, dout)
             tr._enqueue_units(dout, 0, tr._nunits - 1)
             torch.cuda.synchronize()
+            if r == 0:       # the forward of rank 0's data-parallel step against the same forward without data parallelism
+                nfw = int((out != dp_out).sum().item())
+                print(f"  forward output of rank 0: {nfw} of {out.numel()} elements differ from the data-parallel step's "
+                      f"(max |diff| {(out - dp_out).abs().max().item():.3e})", flush=True)
             total = mr._garena.detach().clone() if total is None else total + mr._garena
             del mr, tr
         nbad = int((total != summed).sum().item())

@@ -88,14 +88,32 @@ __device__ __forceinline__ void quad_coords(long long qid, int s, long long& pat
 
 // ---- forward ---------------------------------------------------------------------------------
 // NOUT = 1: out0 = conv(in0, w0) (+bias)      NOUT = 3: q = conv(in0,w0), k = conv(in1,w1), v = conv(in1,w2)
-template <typename TI, typename TO, int C, int NOUT, int SH = 0>
+// WL: where the weights of the rolled (o, co) loops come from.  0: scalar loads off the kernel-argument pointers inside the
+// loops (rounds 1 - 3).  1: all NOUT * 9 C C weights staged ONCE per workgroup into LDS by vector loads, each (o, co) trip
+// reads its 9 C weights back as broadcast ds_read_b128s (every lane the same address).  Round 4 found the scalar form
+// returning WRONG results for whole waves (one pixel of every quad of the wave) in 4 - 10 % of the launches whenever a SECOND
+// PROCESS was computing on the same GPU (tools/contention_ops.py; the idle-GPU suites never saw it) - the cause of the red
+// two-rank rehearsal of round 3.  The LDS form is the default; VU_CONV_W=smem selects the scalar form for the A/B record.
+template <typename TI, typename TO, int C, int NOUT, int SH = 0, int WL = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((SH == 1 && NOUT == 3) ? 4 : 1, 8))) void conv_fwd_kernel(const TI* __restrict__ in0, const TI* __restrict__ in1,
                                                        const float* __restrict__ w0, const float* __restrict__ w1,
                                                        const float* __restrict__ w2, const float* __restrict__ bias,
                                                        TO* __restrict__ o0, TO* __restrict__ o1, TO* __restrict__ o2,
                                                        long long nquads, int s) {
-  // weights are wave-uniform: indexed with compile-time constants off a kernel-argument pointer
+  // WL = 0: weights are wave-uniform: indexed with compile-time constants off a kernel-argument pointer
   // they come through scalar loads into SGPRs (no LDS, no VGPRs)
+  constexpr int NWC = 9 * C * C, NWP = (9 * C + 3) / 4 * 4;       // weights per convolution; per output channel, padded to 16 B
+  __shared__ __attribute__((aligned(16))) float wl[WL ? NOUT * C * NWP : 4];
+  __shared__ float bl[WL ? 4 : 1];
+  if constexpr (WL != 0) {
+    for (int i = threadIdx.x; i < NOUT * NWC; i += 256) {
+      const int o = i / NWC, r = i - o * NWC, co = r / (9 * C), t = r - co * (9 * C);
+      const float* wp = o == 0 ? w0 : (o == 1 ? w1 : w2);
+      wl[(o * C + co) * NWP + t] = wp[r];
+    }
+    if (threadIdx.x < 4) bl[threadIdx.x] = (bias && threadIdx.x < C) ? bias[threadIdx.x] : 0.f;
+    __syncthreads();
+  }
   const int ss = s * s;
   const bool same = (in0 == in1);
   for (long long qid = blockIdx.x * (long long)blockDim.x + threadIdx.x; qid < nquads;
@@ -118,7 +136,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((SH == 1 &&
 #pragma unroll 1
       for (int co = 0; co < C; ++co) {     // (rolled: 27 weights live at a time; unrolled, the 81 of a convolution sit in VGPRs)
         vu_f4 acc;
-        const float b0 = bias ? bias[co] : 0.f;
+        float wr[NWP];
+        float b0;
+        if constexpr (WL != 0) {
+          const f32x4* wv4 = reinterpret_cast<const f32x4*>(wl + (o * C + co) * NWP);
+#pragma unroll
+          for (int t4 = 0; t4 < NWP / 4; ++t4) {
+            const f32x4 x4 = wv4[t4];
+            wr[4 * t4] = x4[0]; wr[4 * t4 + 1] = x4[1]; wr[4 * t4 + 2] = x4[2]; wr[4 * t4 + 3] = x4[3];
+          }
+          b0 = bl[co];
+        } else {
+#pragma unroll
+          for (int t = 0; t < 9 * C; ++t) wr[t] = wp[co * C * 9 + t];
+          b0 = bias ? bias[co] : 0.f;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc.v[i] = b0;
 #pragma unroll
@@ -127,7 +159,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((SH == 1 &&
           for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
-              const float wv = wp[(co * C + ci) * 9 + ky * 3 + kx];
+              const float wv = wr[ci * 9 + ky * 3 + kx];
 #pragma unroll
               for (int i = 0; i < 4; ++i) acc.v[i] += wv * win[ci][ky][i + kx];
             }
@@ -469,6 +501,9 @@ __global__ __launch_bounds__(1024) void conv_wgrad_mm_reduce_kernel(const float*
   }
 }
 
+// VU_CONV_W=smem: the forward kernels read their weights with scalar loads inside the rolled loops (the form of rounds 1 - 3,
+// kept for the A/B record: wrong under GPU sharing, see conv_fwd_kernel); default: weights staged in LDS
+inline bool weights_smem() { static const bool v = [] { const char* e = getenv("VU_CONV_W"); return e && e[0] == 's'; }(); return v; }
 // A/B switch for measurements: VU_CONV_SHUFFLE=0 keeps the all-loads window
 inline bool shuffle_off() { static const bool v = [] { const char* e = getenv("VU_CONV_SHUFFLE"); return e && e[0] == '0'; }(); return v; }
 
@@ -494,10 +529,12 @@ int vu_k_conv3x3_fwd(int dtype, int out_f32, const void* in, const float* w, con
   if (nq == 0) return VU_OK;
   const int grid = grid_for(nq, 256 * 16);
   const bool fo = out_f32 || dtype == 0;
-  VU_CONV_C(C,
-    if (dtype == 0) hipLaunchKernelGGL((conv_fwd_kernel<float, float, CC, 1>), dim3(grid), dim3(256), 0, st, (const float*)in, (const float*)in, w, w, w, bias, (float*)out, (float*)out, (float*)out, nq, s);
-    else if (fo) hipLaunchKernelGGL((conv_fwd_kernel<bf16_t, float, CC, 1>), dim3(grid), dim3(256), 0, st, (const bf16_t*)in, (const bf16_t*)in, w, w, w, bias, (float*)out, (float*)out, (float*)out, nq, s);
-    else hipLaunchKernelGGL((conv_fwd_kernel<bf16_t, bf16_t, CC, 1>), dim3(grid), dim3(256), 0, st, (const bf16_t*)in, (const bf16_t*)in, w, w, w, bias, (bf16_t*)out, (bf16_t*)out, (bf16_t*)out, nq, s);)
+#define VU_FWD1(WLV) \
+    if (dtype == 0) hipLaunchKernelGGL((conv_fwd_kernel<float, float, CC, 1, 0, WLV>), dim3(grid), dim3(256), 0, st, (const float*)in, (const float*)in, w, w, w, bias, (float*)out, (float*)out, (float*)out, nq, s); \
+    else if (fo) hipLaunchKernelGGL((conv_fwd_kernel<bf16_t, float, CC, 1, 0, WLV>), dim3(grid), dim3(256), 0, st, (const bf16_t*)in, (const bf16_t*)in, w, w, w, bias, (float*)out, (float*)out, (float*)out, nq, s); \
+    else hipLaunchKernelGGL((conv_fwd_kernel<bf16_t, bf16_t, CC, 1, 0, WLV>), dim3(grid), dim3(256), 0, st, (const bf16_t*)in, (const bf16_t*)in, w, w, w, bias, (bf16_t*)out, (bf16_t*)out, (bf16_t*)out, nq, s);
+  VU_CONV_C(C, if (weights_smem()) { VU_FWD1(0) } else { VU_FWD1(1) })
+#undef VU_FWD1
   if (vu_prof_on()) vu_prof_note("conv_fwd_kernel<1>", 0.0, (double)nq * 4 * C * ((dtype == 0 ? 4.0 : 2.0) + (fo ? 4.0 : 2.0)));
   return vu_check_launch("vu_conv3x3_fwd");
 }
@@ -516,11 +553,12 @@ int vu_k_conv3x3_qkv_fwd(int dtype, const void* xq, const void* xkv, const float
   const int grid = grid_for(nq, 256 * 16);
   int sh = shuffle_off() ? 0 : conv_shuffle_form(s);
   if (sh == 2) sh = 1;      // forward: VALU-bound (243 MACs per pixel), the extra DPP moves of the one-load form cost more than its loads (37.9 vs 30.9 us)
-#define VU_QKV_FWD(SHV) \
-    if (dtype == 0) hipLaunchKernelGGL((conv_fwd_kernel<float, float, CC, 3, SHV>), dim3(grid), dim3(256), 0, st, (const float*)xq, (const float*)xkv, wq, wk, wv, (const float*)nullptr, (float*)q, (float*)k, (float*)v, nq, s); \
-    else hipLaunchKernelGGL((conv_fwd_kernel<bf16_t, bf16_t, CC, 3, SHV>), dim3(grid), dim3(256), 0, st, (const bf16_t*)xq, (const bf16_t*)xkv, wq, wk, wv, (const float*)nullptr, (bf16_t*)q, (bf16_t*)k, (bf16_t*)v, nq, s);
+#define VU_QKV_FWD(SHV, WLV) \
+    if (dtype == 0) hipLaunchKernelGGL((conv_fwd_kernel<float, float, CC, 3, SHV, WLV>), dim3(grid), dim3(256), 0, st, (const float*)xq, (const float*)xkv, wq, wk, wv, (const float*)nullptr, (float*)q, (float*)k, (float*)v, nq, s); \
+    else hipLaunchKernelGGL((conv_fwd_kernel<bf16_t, bf16_t, CC, 3, SHV, WLV>), dim3(grid), dim3(256), 0, st, (const bf16_t*)xq, (const bf16_t*)xkv, wq, wk, wv, (const float*)nullptr, (bf16_t*)q, (bf16_t*)k, (bf16_t*)v, nq, s);
   VU_CONV_C(C,
-    if (sh == 2) { VU_QKV_FWD(2) } else if (sh == 1) { VU_QKV_FWD(1) } else { VU_QKV_FWD(0) })
+    if (weights_smem()) { if (sh == 1) { VU_QKV_FWD(1, 0) } else { VU_QKV_FWD(0, 0) } }
+    else { if (sh == 1) { VU_QKV_FWD(1, 1) } else { VU_QKV_FWD(0, 1) } })
 #undef VU_QKV_FWD
   if (vu_prof_on()) vu_prof_note("conv_fwd_kernel<3>", 0.0, (double)nq * 4 * C * (dtype == 0 ? 4.0 : 2.0) * (xq == xkv ? 4 : 5));
   return vu_check_launch("vu_conv3x3_qkv_fwd");

@@ -895,6 +895,48 @@ size_t vu_model_workspace_bytes(const vu_config* cfg, int B) {
   return w.bytes;
 }
 
+// Diagnostic: the carve of the model workspace as text, one "name offset bytes" line per buffer in carve order (the forward's
+// buffers come in execution order), for tools that diff two runs' workspaces (tools/nondet_check.py --ws-diff).  Returns the
+// number of characters the full text needs (snprintf convention); `out` receives at most cap - 1 of them.
+int vu_model_workspace_describe(const vu_config* cfg, int B, char* out, int cap) {
+  Plan pl;
+  if (!cfg || B <= 0 || build_plan(*cfg, pl) != VU_OK) return -1;
+  ModelWS w;
+  char* const fake = reinterpret_cast<char*>(4096);            // (a null base makes every take() return null: carve from a fake one)
+  carve_model(pl, B, fake, w);
+  std::vector<std::pair<std::string, size_t>> ents;
+  auto add = [&](const std::string& n, const void* p) { if (p) ents.push_back({n, (size_t)((const char*)p - fake)}); };
+  auto add_attn = [&](const std::string& pre, const AttnBuf& a) {
+    add(pre + "q", a.q); add(pre + "k", a.k); add(pre + "v", a.v); add(pre + "O", a.O); add(pre + "Ps", a.Ps); add(pre + "Ah", a.Ah);
+    add(pre + "stats", a.stats); add(pre + "lse2", a.lse2); add(pre + "rinv", a.rinv); add(pre + "delta", a.delta); add(pre + "pk", a.pk);
+  };
+  auto add_block = [&](const std::string& pre, const BlockBuf& b) {
+    add_attn(pre + "attn.", b.at);
+    add(pre + "z1", b.z1); add(pre + "x1", b.x1); add(pre + "hpre", b.hpre); add(pre + "hact", b.hact); add(pre + "z2", b.z2);
+    add(pre + "out", b.out); add(pre + "ln1s", b.ln1s); add(pre + "ln2s", b.ln2s);
+  };
+  ents.push_back({"tok0", 0});
+  for (size_t i = 0; i < w.enc.size(); ++i) add_block("enc" + std::to_string(i) + ".", w.enc[i]);
+  for (size_t i = 0; i < w.bot.size(); ++i) add_block("bot" + std::to_string(i) + ".", w.bot[i]);
+  for (size_t i = 0; i < w.dec.size(); ++i) add_block("dec" + std::to_string(i) + ".", w.dec[i]);
+  for (size_t j = 0; j < w.skip.size(); ++j) add_attn("skip" + std::to_string(j) + ".", w.skip[j]);
+  for (size_t j = 0; j < w.skip_out.size(); ++j) {
+    add("skip_out" + std::to_string(j), w.skip_out[j]); add("down_out" + std::to_string(j), w.down_out[j]); add("up_out" + std::to_string(j), w.up_out[j]);
+  }
+  add("img", w.img); add("y_attn", w.y_attn); add("f_ff", w.f_ff);
+  add("gx0", w.gx0); add("gx1", w.gx1); add("ga", w.ga); add("gb", w.gb); add("gc", w.gc); add("gh", w.gh);
+  add("asc.dO", w.asc.dO); add("asc.dq", w.asc.dq); add("asc.dk", w.asc.dk); add("asc.dv", w.asc.dv); add("asc.dA", w.asc.dA);
+  for (size_t j = 0; j < w.dskip.size(); ++j) add("dskip" + std::to_string(j), w.dskip[j]);
+  add("partials", w.partials); add("lnp", w.lnp); add("lnp2", w.lnp2); add("wgs", w.wgs);
+  std::string text;
+  for (size_t i = 0; i < ents.size(); ++i) {
+    const size_t end = i + 1 < ents.size() ? ents[i + 1].second : w.bytes;
+    text += ents[i].first + " " + std::to_string(ents[i].second) + " " + std::to_string(end - ents[i].second) + "\n";
+  }
+  if (out && cap > 0) { const size_t n = std::min(text.size(), (size_t)cap - 1); memcpy(out, text.data(), n); out[n] = 0; }
+  return (int)text.size();
+}
+
 int vu_model_prefers_eager(const vu_config* cfg, int B) {
   Plan pl;
   if (!cfg || B <= 0 || build_plan(*cfg, pl) != VU_OK) return 0;

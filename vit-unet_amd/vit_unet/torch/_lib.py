@@ -60,6 +60,7 @@ SIGNATURES = {
     "vu_model_param_table": (_i, [_cfgp, C.POINTER(vu_param_entry), _i]),
     "vu_model_num_attn": (_i, [_cfgp]),
     "vu_model_workspace_bytes": (_sz, [_cfgp, _i]),
+    "vu_model_workspace_describe": (_i, [_cfgp, _i, C.c_char_p, _i]),
     "vu_model_prefers_eager": (_i, [_cfgp, _i]),
     "vu_set_flash_key_split": (_i, [_i]),
     "vu_model_forward": (_i, [_cfgp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _u64, _vp, _vp]),
