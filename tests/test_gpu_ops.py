@@ -165,34 +165,43 @@ def test_gemm_forms(dt, M, N, K):
     assert serr(out.view(M, N), ref + base.double()) < ft * (4 if dt == torch.bfloat16 else 40)
 
 
-def test_gemm_library_route_for_plain_big_products():
-    """Plain big bf16 products (no fused epilogue beyond a bias; both output extents and K >= 512) go to hipBLASLt
-    (csrc/vu_blaslt.hip): the three layouts the Linear layers use - forward x W^T + b, data gradient dy W, fp32-accumulating
-    weight gradient dy^T x - against float64 on the bf16-rounded operands, and the launch profiler shows the route taken."""
+@pytest.mark.parametrize("M,N,K", [(3136, 3072, 3072),      # Base level 0 at 64 images: 14 x 16 exact tiles of 224 x 192, XCD rectangles
+                                   (2176, 1536, 1600),      # ragged rows (9.7 tiles), 8 column tiles
+                                   (980, 3072, 3072),       # 20 images: M % 8 != 0 (k-contiguous A: any M)
+                                   (1568, 2048, 2048),      # 32 images: the weight gradient's K = 1568 = 24.5 k-steps (zeroed tail k-slots)
+                                   (2104, 1544, 1368)])     # ragged everything: N = 8 tiles + 8 columns, K % 64 = 24 forward, 8 in the data gradient
+def test_gemm_big_tile_kernel_for_plain_big_products(M, N, K):
+    """Plain big bf16 products (no fused GELU; both output extents and K >= 512, M N K >= 2^32 or a >= 2048 x 2048 fp32 output) run
+    on csrc/vu_bgemm.hip (one 512-thread workgroup per CU, 224 x 192 tile, LDS-DMA ring): the three layouts the Linear layers
+    use - forward x W^T + b, data gradient dy W, fp32-accumulating weight gradient dy^T x - against float64 on the bf16-rounded
+    operands, and the launch profiler shows the kernel that ran (no vendor GEMM on any route: the library links no BLAS)."""
     import json
     dt = torch.bfloat16
     g = torch.Generator().manual_seed(17)
-    M, N, K = 2176, 1536, 1600
     x = torch.randn(M, K, generator=g).to(dt)
     w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dt)
     dy = torch.randn(M, N, generator=g).to(dt)
     bias = torch.randn(N, generator=g)
     L = lib()
     L.vu_prof_enable(C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    big = M * N * K >= 2 ** 32
     y = _gemm(dt, dev(x), dev(w), M, N, K, K, 1, 1, K, bias=dev(bias))                      # B stored (N, K)
     assert serr(y.view(M, N), x.double() @ w.double().t() + bias.double()) < 8e-3
     dx = _gemm(dt, dev(dy), dev(w), M, K, N, N, 1, K, 1)                                      # B stored (K', N') = (N, K) row-major
     assert serr(dx.view(M, K), dy.double() @ w.double()) < 8e-3
-    M2, N2, K2 = 2048, 2048, 1111                                                             # weight gradient: A stored (K2, M2)
-    a = torch.randn(K2, M2, generator=g).to(dt)
-    b = torch.randn(K2, N2, generator=g).to(dt)
-    acc0 = torch.randn(M2, N2, generator=g)
+    # weight gradient: C (N, K) fp32 += dy^T x: A stored (tokens, N) = (k, m), B stored (tokens, K) = (k, n)
+    wg = N % 8 == 0 and M % 8 == 0 and N * K >= 4 << 20
+    acc0 = torch.randn(N, K, generator=g)
     out = dev(acc0).clone().reshape(-1)
-    _gemm(dt, dev(a), dev(b), M2, N2, K2, 1, M2, N2, 1, c_float=1, accumulate=1, out=out)
-    assert serr(out.view(M2, N2), acc0.double() + a.double().t() @ b.double()) < 2e-5
+    _gemm(dt, dev(dy), dev(x), N, K, M, 1, N, K, 1, c_float=1, accumulate=1, out=out)
+    assert serr(out.view(N, K), acc0.double() + dy.double().t() @ x.double()) < 2e-5
     torch.cuda.synchronize()
     rep = json.loads(L.vu_prof_report().decode())
-    assert rep.get("hipblaslt_gemm<bf16>", {}).get("count") == 2 and rep.get("hipblaslt_gemm<f32 acc>", {}).get("count") == 1, rep.keys()
+    assert not any("hipblaslt" in k or k.startswith("Cijk") for k in rep), rep.keys()
+    if big:
+        assert rep.get("bgemm_kernel<NN,bf16,224x192>", {}).get("count") == 1 and rep.get("bgemm_kernel<NT,bf16,224x192>", {}).get("count") == 1, rep.keys()
+    if wg:
+        assert rep.get("bgemm_kernel<TT,f32 acc,224x192>", {}).get("count") == 1, rep.keys()
 
 
 @pytest.mark.parametrize("M,N,K", [(48, 16, 3137), (200, 72, 1500), (192, 192, 4100), (64, 768, 2049), (3072, 128, 1100)])

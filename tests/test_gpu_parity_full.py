@@ -217,13 +217,14 @@ def _one_block_model(cfg, lvl, dtype):
                        proj_drop=cfg.proj_drop, linear_drop=0.0, dtype=dtype, attn_operands=cfg.attn_operands).to(DEV).train()
 
 
-def test_level0_block_at_a_token_count_that_takes_the_library_route(attn_form, monkeypatch):
-    """The level-0 block of Base (49 tokens x 3072 features) at 12 images = 588 token rows: its 3072 x 3072 projection runs
-    through hipBLASLt with the dropout + residual pass and the deterministic bias-gradient sums behind it
-    (csrc/vu_blaslt.hip; at the 2 images of the teacher-forced test above the products stay on vu_gemm).  Same block, same
-    bounds: output 3e-2, dx and every parameter gradient 5e-2 of their range against the oracle's bf16-storage restatement."""
+def test_level0_block_at_a_token_count_that_takes_the_big_tile_kernel(attn_form, monkeypatch):
+    """The level-0 block of Base (49 tokens x 3072 features) at 16 images = 784 token rows: its 3072 x 3072 projection runs
+    on csrc/vu_bgemm.hip with bias + projection dropout + block residual fused in the epilogue, the data gradient and the
+    fp32-accumulating weight gradient (ragged K = 784 = 12 k-steps + 16: 48 tail k-slots zeroed) with the deterministic
+    bias-gradient sums behind it (at the 2 images of the teacher-forced test above the products stay on vu_gemm).  Same block, same bounds: output 3e-2,
+    dx and every parameter gradient 5e-2 of their range against the oracle's bf16-storage restatement."""
     monkeypatch.setattr(O, "FLASH_FILL_RULE", False)
-    dt, B, seed, lvl = torch.bfloat16, 12, 4321, 0
+    dt, B, seed, lvl = torch.bfloat16, 16, 4321, 0
     cfg = O.Config(**O.PRESETS["base"])
     w = O.make_weights(cfg, seed=0)
     N, D, hid, s = cfg.level(lvl)
@@ -249,7 +250,9 @@ def test_level0_block_at_a_token_count_that_takes_the_library_route(attn_form, m
     out.backward(O.unpatchify(G, C_).to(DEV))
     torch.cuda.synchronize()
     rep = json.loads(L.vu_prof_report().decode())
-    assert "lt_post_kernel" in rep and "lt_colsum_kernel" in rep and "hipblaslt_gemm<bf16>" in rep and "hipblaslt_gemm<f32 acc>" in rep, rep.keys()
+    assert ("bg_colsum_kernel" in rep and "bgemm_kernel<NN,bf16,224x192>" in rep and "bgemm_kernel<NT,bf16,224x192>" in rep
+            and "bgemm_kernel<TT,f32 acc,224x192>" in rep), rep.keys()
+    assert not any("hipblaslt" in k or k.startswith("Cijk") for k in rep), rep.keys()
     wr = {pre + k: w[pre + k].clone().requires_grad_(True) for k in BLOCK_KEYS}
     for k in BN_BUFS:
         wr[pre + k] = w[pre + k].clone()

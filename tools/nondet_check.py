@@ -9,7 +9,7 @@ the fused engine and compares the output image and every parameter gradient with
   --fresh  : every repetition builds a new model + engine (what tools/dp_rehearsal.py --base does for its reference sums).
   --load S : a second process runs the same kind of step on the same GPU for S seconds while the repetitions run (the only
              structural difference between the two legs of the two-rank rehearsal that went red on the driver's box).
-Environment switches of the library (VU_GEMM_LT, VU_ATTN_FLASH, ...) are inherited, so the caller bisects with them."""
+Environment switches of the library (VU_BGEMM, VU_CONV_W, VU_ATTN_FLASH, ...) are inherited, so the caller bisects with them."""
 import argparse
 import os
 import subprocess

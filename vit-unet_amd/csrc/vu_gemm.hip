@@ -147,14 +147,14 @@ void vu_gemm_get_scratch(void** p, size_t* bytes) { *p = g_scratch; *bytes = g_s
 
 int vu_tsgemm_try(const vu_gemm_args& g, hipStream_t st);      // vu_tsgemm.hip: long-K, small-output weight gradients
 int vu_pgemm_try(const vu_gemm_args& g, hipStream_t st);       // vu_pgemm.hip: many rows, small resident weight
-int vu_lt_try(const vu_gemm_args& g, int c_float, hipStream_t st);   // vu_blaslt.hip: plain big products through hipBLASLt
+int vu_bgemm_try(const vu_gemm_args& g, int c_float, hipStream_t st);   // vu_bgemm.hip: plain big products, one workgroup per CU (LDS-DMA ring)
 
 // dtype: 0 = fp32 storage, 1 = bf16 storage.
 int vu_gemm_launch(int dtype, int c_float, vu_gemm_args g, hipStream_t st) {
   if (g.M <= 0 || g.N <= 0 || g.Z1 * g.Z2 <= 0) return VU_OK;
   if (g.K <= 0) { vu_set_error("vu_gemm: K must be positive"); return VU_EINVAL; }
-  if (dtype == 1) {       // plain big products: the vendor library (vu_blaslt.hip)
-    const int rc = vu_lt_try(g, c_float, st);
+  if (dtype == 1) {       // plain big products of levels 0 / 1 (vu_bgemm.hip)
+    const int rc = vu_bgemm_try(g, c_float, st);
     if (rc < 0) return rc;
     if (rc > 0) return VU_OK;
   }
