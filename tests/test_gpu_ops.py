@@ -198,8 +198,9 @@ def test_gemm_big_tile_kernel_for_plain_big_products(M, N, K):
     torch.cuda.synchronize()
     rep = json.loads(L.vu_prof_report().decode())
     assert not any("hipblaslt" in k or k.startswith("Cijk") for k in rep), rep.keys()
-    if big:
-        assert rep.get("bgemm_kernel<NN,bf16,224x192>", {}).get("count") == 1 and rep.get("bgemm_kernel<NT,bf16,224x192>", {}).get("count") == 1, rep.keys()
+    if big:      # (224 x 192 tiles where they fill the chip, 112 x 192 with two workgroups per CU below ~160 tiles)
+        assert sum(v["count"] for k, v in rep.items() if k.startswith("bgemm_kernel<NN,bf16,")) == 1, rep.keys()
+        assert sum(v["count"] for k, v in rep.items() if k.startswith("bgemm_kernel<NT,bf16,")) == 1, rep.keys()
     if wg:
         assert rep.get("bgemm_kernel<TT,f32 acc,224x192>", {}).get("count") == 1, rep.keys()
 

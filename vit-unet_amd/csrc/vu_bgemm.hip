@@ -32,7 +32,7 @@ namespace {
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 
-constexpr int BK = 64, NST = 3;
+constexpr int BK = 64;
 
 // one LDS-DMA piece: 64 lanes x 16 bytes from sbase + voff[lane] to LDS bytes [lds_dst, lds_dst + 1024) in lane order.
 // M0 carries the LDS address and is compiler-reserved: saved and restored inside the statement.  Not counted by hipcc:
@@ -42,29 +42,29 @@ __device__ __forceinline__ void dma16(const void* sbase, unsigned voff, unsigned
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "s"(sbase), "v"(voff), "s"(lds_dst) : "memory");
 }
-// the same for 2 - 4 pieces whose LDS destinations are 8 KiB apart (pieces wave, wave + 8, ... of a stage): one save / restore
+// the same for 2 - 4 pieces whose LDS destinations are STRIDE bytes apart (pieces wave, wave + NW, ... of a stage): one save / restore
 // of M0, one s_add per further piece
-__device__ __forceinline__ void dma16x2(const void* b0, unsigned v0, const void* b1, unsigned v1, unsigned lds_dst) {
+template <int STRIDE> __device__ __forceinline__ void dma16x2(const void* b0, unsigned v0, const void* b1, unsigned v1, unsigned lds_dst) {
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\t"
-               "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %3\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "s"(b0), "v"(v0), "s"(b1), "v"(v1), "s"(lds_dst) : "memory", "scc");
+               "s_add_u32 m0, m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %3\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "s"(b0), "v"(v0), "s"(b1), "v"(v1), "s"(lds_dst), "n"(STRIDE) : "memory", "scc");
 }
-__device__ __forceinline__ void dma16x3(const void* b0, unsigned v0, const void* b1, unsigned v1, const void* b2, unsigned v2, unsigned lds_dst) {
+template <int STRIDE> __device__ __forceinline__ void dma16x3(const void* b0, unsigned v0, const void* b1, unsigned v1, const void* b2, unsigned v2, unsigned lds_dst) {
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\t"
-               "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %3\n\t"
-               "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %6, %5\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "s"(b0), "v"(v0), "s"(b1), "v"(v1), "s"(b2), "v"(v2), "s"(lds_dst) : "memory", "scc");
+               "s_add_u32 m0, m0, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %3\n\t"
+               "s_add_u32 m0, m0, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %6, %5\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "s"(b0), "v"(v0), "s"(b1), "v"(v1), "s"(b2), "v"(v2), "s"(lds_dst), "n"(STRIDE) : "memory", "scc");
 }
-__device__ __forceinline__ void dma16x4(const void* b0, unsigned v0, const void* b1, unsigned v1, const void* b2, unsigned v2, const void* b3,
+template <int STRIDE> __device__ __forceinline__ void dma16x4(const void* b0, unsigned v0, const void* b1, unsigned v1, const void* b2, unsigned v2, const void* b3,
                                         unsigned v3, unsigned lds_dst) {
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %9\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\t"
-               "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %3\n\t"
-               "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %6, %5\n\t"
-               "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %8, %7\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "s"(b0), "v"(v0), "s"(b1), "v"(v1), "s"(b2), "v"(v2), "s"(b3), "v"(v3), "s"(lds_dst) : "memory", "scc");
+               "s_add_u32 m0, m0, %10\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %3\n\t"
+               "s_add_u32 m0, m0, %10\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %6, %5\n\t"
+               "s_add_u32 m0, m0, %10\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %8, %7\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "s"(b0), "v"(v0), "s"(b1), "v"(v1), "s"(b2), "v"(v2), "s"(b3), "v"(v3), "s"(lds_dst), "n"(STRIDE) : "memory", "scc");
 }
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
@@ -92,19 +92,20 @@ struct bg_args {
 };
 
 // TA: A stored (K, M) (m-contiguous); TB: B stored (K, N) (n-contiguous); otherwise k-contiguous (M, K) / (N, K).
-template <bool TA, bool TB, bool CF, int TM, int TN>
-__global__ __launch_bounds__(512, 2) void bgemm_kernel(const bg_args g) {
-  constexpr int WM = 2, WN = 4, BM = WM * TM * 16, BN = WN * TN * 16;
+// WM: wave rows (2: 512 threads, one workgroup per CU; 1: 256 threads, two per CU when NST = 2); NST: LDS ring stages
+template <bool TA, bool TB, bool CF, int TM, int TN, int WM, int NST>
+__global__ __launch_bounds__(WM * 256, 2) void bgemm_kernel(const bg_args g) {
+  constexpr int WN = 4, NW = WM * WN, BM = WM * TM * 16, BN = WN * TN * 16;
   constexpr int NPA = BM / 8, NPB = BN / 8, NP = NPA + NPB;               // 1-KiB pieces per stage
   constexpr int STAGE = NP * 1024;
-  constexpr int NJ = (NP + 7) / 8;                                         // pieces per wave (the last one only for waves < NP % 8)
+  constexpr int NJ = (NP + NW - 1) / NW;                                   // pieces per wave (the last one only for waves < NP % NW)
   static_assert(NST * STAGE <= 160 * 1024, "LDS ring too large");
-  static_assert(BM % 32 == 0 && BN % 32 == 0, "tile extents must be multiples of 32");
+  static_assert((TA ? BM % 32 == 0 : BM % 8 == 0) && (TB ? BN % 32 == 0 : BN % 8 == 0), "tile extents: multiples of 32 (row-contiguous operand) / 8");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const unsigned lbase = (unsigned)(size_t)smem;
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
+  const int wm = wave >> 2, wn = wave & 3;          // (WM = 1: wm = 0)
   // ---- tile of this workgroup (XCD rectangles) -------------------------------------------------------------------
   int tile_m, tile_n;
   {
@@ -118,13 +119,13 @@ __global__ __launch_bounds__(512, 2) void bgemm_kernel(const bg_args g) {
   // ---- per-piece source offsets (bytes from the operand base of the k-step) -------------------------------------------
   // kvalid: k-extent of the step (64, or K % 64 in the last step of a ragged K): k-rows / k-chunks beyond it are fetched from the
   // last valid ones (in-bounds, finite) and multiplied by zeroed A fragments in the tile loop
-  constexpr int NJF = NP / 8, NREM = NP % 8;       // every wave issues NJF pieces per stage, waves < NREM one more
+  constexpr int NJF = NP / NW, NREM = NP % NW;     // every wave issues NJF pieces per stage, waves < NREM one more
   const bool has_last = NREM != 0 && wave < NREM;   // (wave-uniform)
   bool isA[NJ];
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) isA[j] = wave + 8 * j < NPA;
+  for (int j = 0; j < NJ; ++j) isA[j] = wave + NW * j < NPA;
   auto piece_off = [&](int j, int kvalid) -> unsigned {
-    const int p = wave + 8 * j;
+    const int p = wave + NW * j;
     const int pp = p < NP ? p : NP - 1;
     const bool a = pp < NPA;
     const int q = a ? pp : pp - NPA;                 // piece within its operand's image
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(512, 2) void bgemm_kernel(const bg_args g) {
   // piece j of k-step `step` (j = NJ - 1: only the waves that have one)
   auto issue_piece = [&](int step, int j) {
     if (j == NJ - 1 && NREM != 0 && !has_last) return;
-    const unsigned st = lbase + (unsigned)(step % NST) * STAGE + (unsigned)(wave + 8 * j) * 1024;
+    const unsigned st = lbase + (unsigned)(step % NST) * STAGE + (unsigned)(wave + NW * j) * 1024;
     const char* sb = (isA[j] ? baseA + step * stepA : baseB + step * stepB);
     if (step == nk - 1 && ktail != BK) dma16(sb, piece_off(j, ktail), st);           // (workgroup-uniform)
     else dma16(sb, voff[j], st);
@@ -175,13 +176,14 @@ __global__ __launch_bounds__(512, 2) void bgemm_kernel(const bg_args g) {
     const unsigned st = lbase + (unsigned)(step % NST) * STAGE + (unsigned)wave * 1024;
     auto bs = [&](int j) -> const char* { return isA[j] ? sa : sb; };
     constexpr int NFULL = NREM ? NJ - 1 : NJ;          // pieces every wave has
+    constexpr int SB = NW * 1024;                       // LDS bytes between a wave's consecutive pieces
     int j = 0;
 #pragma unroll
-    for (; j + 4 <= NFULL; j += 4) dma16x4(bs(j), voff[j], bs(j + 1), voff[j + 1], bs(j + 2), voff[j + 2], bs(j + 3), voff[j + 3], st + j * 8192);
-    if constexpr (NFULL % 4 == 3) dma16x3(bs(NFULL - 3), voff[NFULL - 3], bs(NFULL - 2), voff[NFULL - 2], bs(NFULL - 1), voff[NFULL - 1], st + (NFULL - 3) * 8192);
-    if constexpr (NFULL % 4 == 2) dma16x2(bs(NFULL - 2), voff[NFULL - 2], bs(NFULL - 1), voff[NFULL - 1], st + (NFULL - 2) * 8192);
-    if constexpr (NFULL % 4 == 1) dma16(bs(NFULL - 1), voff[NFULL - 1], st + (NFULL - 1) * 8192);
-    if (NREM != 0 && has_last) dma16(bs(NJ - 1), voff[NJ - 1], st + (NJ - 1) * 8192);
+    for (; j + 4 <= NFULL; j += 4) dma16x4<SB>(bs(j), voff[j], bs(j + 1), voff[j + 1], bs(j + 2), voff[j + 2], bs(j + 3), voff[j + 3], st + j * SB);
+    if constexpr (NFULL % 4 == 3) dma16x3<SB>(bs(NFULL - 3), voff[NFULL - 3], bs(NFULL - 2), voff[NFULL - 2], bs(NFULL - 1), voff[NFULL - 1], st + (NFULL - 3) * SB);
+    if constexpr (NFULL % 4 == 2) dma16x2<SB>(bs(NFULL - 2), voff[NFULL - 2], bs(NFULL - 1), voff[NFULL - 1], st + (NFULL - 2) * SB);
+    if constexpr (NFULL % 4 == 1) dma16(bs(NFULL - 1), voff[NFULL - 1], st + (NFULL - 1) * SB);
+    if (NREM != 0 && has_last) dma16(bs(NJ - 1), voff[NJ - 1], st + (NJ - 1) * SB);
   };
   // wait until at most `steps` whole k-steps of this wave's pieces are still in flight (steps = 0, 1, 2: wave-uniform)
   auto wait_steps = [&](int steps) {
@@ -259,44 +261,52 @@ __global__ __launch_bounds__(512, 2) void bgemm_kernel(const bg_args g) {
   // is the CU's LDS-DMA path beside the fragment reads (52 pieces of 1 KiB per step; the ring alone moves 36 B / clock / CU, the
   // full kernel 14) - a larger share of register staging or a one-wave-per-SIMD tile with fewer LDS bytes per product is the
   // next step, not another ordering of this loop.
-  issue(0);
-  if (nk > 1) issue(1);
+  constexpr int D = NST - 1;                  // k-steps of DMA in flight ahead of the one being multiplied
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+    if (d < nk) issue(d);
   bf16x8 a0[TM], b0[TN];
   for (int t = 0; t < nk; ++t) {
-    wait_steps(t + 1 < nk ? 1 : 0);                                     // stage t has landed (this wave's pieces); step t + 1 may fly
+    { const int ahead = nk - 1 - t; wait_steps(ahead < D - 1 ? ahead : D - 1); }     // stage t has landed (this wave's pieces); later steps may fly
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     const unsigned char* st = smem + (t % NST) * STAGE;
     const bool last = t == nk - 1;
-    if (t + 2 < nk) issue(t + 2);                                       // into the stage every wave finished reading before the barrier
+    if (t + D < nk) issue(t + D);                                       // into the stage every wave finished reading before the barrier
     load_frags(st, 0, last, a0, b0);
     mma(a0, b0);
     load_frags(st, 1, last, a0, b0);
     mma(a0, b0);
   }
   // ---- epilogue: one half of the tile rows (one wm) per pass through an fp32 LDS tile -------------------------------------
-  constexpr int HM = TM * 16, LDC = BN + 4;
+  constexpr int LDC = BN + 4;
+  constexpr int EP = (TM * 16 * LDC * 4 <= NST * STAGE) ? 1 : 2;      // sub-passes over a wave's row tiles when the whole half does not fit
+  constexpr int IP = (TM + EP - 1) / EP, HM = IP * 16;
   static_assert(HM * LDC * 4 <= NST * STAGE, "C staging tile must fit the ring");
   float* Ct = reinterpret_cast<float*>(smem);
   const vu_rng rng = g.dropout ? vu_rng_resolve(g.rng) : g.rng;
 #pragma unroll 1
-  for (int pass = 0; pass < WM; ++pass) {
+  for (int pass = 0; pass < WM * EP; ++pass) {
+    const int pw = pass / EP, i0 = (pass % EP) * IP;
+    const int nrow = ((i0 + IP < TM ? i0 + IP : TM) - i0) * 16;       // rows of this pass
     asm volatile("" ::: "memory");
     __syncthreads();                                   // the ring (pass 0) / the previous pass's tile is no longer read
-    if (wm == pass) {
+    if (wm == pw) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
+        if (i >= i0 && i < i0 + IP) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+          for (int j = 0; j < TN; ++j)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) Ct[(i * 16 + lg * 4 + r) * LDC + wn * TN * 16 + j * 16 + l15] = acc[i][j][r];
+            for (int r = 0; r < 4; ++r) Ct[((i - i0) * 16 + lg * 4 + r) * LDC + wn * TN * 16 + j * 16 + l15] = acc[i][j][r];
+        }
     }
     __syncthreads();
-    const int rbase = m0 + pass * HM;
+    const int rbase = m0 + pw * TM * 16 + i0 * 16;
     if constexpr (CF) {
       constexpr int CPR = BN / 4;                      // float4 items per row
-      for (int it = tid; it < HM * CPR; it += 512) {
+      for (int it = tid; it < nrow * CPR; it += NW * 64) {
         const int rl = it / CPR, c4 = (it - rl * CPR) * 4;
         const int row = rbase + rl, col = n0 + c4;
         if (row < g.M && col < g.N) {
@@ -309,7 +319,7 @@ __global__ __launch_bounds__(512, 2) void bgemm_kernel(const bg_args g) {
       }
     } else {
       constexpr int CPR = BN / 8;                      // 16-byte bf16 items per row
-      for (int it = tid; it < HM * CPR; it += 512) {
+      for (int it = tid; it < nrow * CPR; it += NW * 64) {
         const int rl = it / CPR, c8 = (it - rl * CPR) * 8;
         const int row = rbase + rl, col = n0 + c8;
         if (row < g.M && col < g.N) {
@@ -368,9 +378,9 @@ inline int bg_mode() {        // VU_BGEMM: 0 = never (vu_gemm.h's tile), unset /
   return v;
 }
 
-template <bool TA, bool TB, bool CF, int TM, int TN>
-int launch(const bg_args& a0, hipStream_t st) {
-  constexpr int BM = 2 * TM * 16, BN = 4 * TN * 16;
+template <bool TA, bool TB, bool CF, int TM, int TN, int WM, int NST>
+int launch_tile(const bg_args& a0, hipStream_t st) {
+  constexpr int BM = WM * TM * 16, BN = 4 * TN * 16;
   bg_args a = a0;
   a.tiles_m = vu_cdiv(a.M, BM); a.tiles_n = vu_cdiv(a.N, BN);
   a.gm = 0; a.gn = 0;
@@ -381,7 +391,7 @@ int launch(const bg_args& a0, hipStream_t st) {
       if (a.tiles_m % cand[c][0] == 0 && a.tiles_n % cand[c][1] == 0) { a.gm = cand[c][0]; a.gn = cand[c][1]; break; }
   }
   constexpr size_t lds = (size_t)NST * ((BM + BN) / 8) * 1024;
-  auto kern = bgemm_kernel<TA, TB, CF, TM, TN>;
+  auto kern = bgemm_kernel<TA, TB, CF, TM, TN, WM, NST>;
   static bool reserved = false;            // (per instantiation)
   if (!reserved) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
@@ -390,7 +400,7 @@ int launch(const bg_args& a0, hipStream_t st) {
     }
     reserved = true;
   }
-  hipLaunchKernelGGL(kern, dim3(total), dim3(512), lds, st, a);
+  hipLaunchKernelGGL(kern, dim3(total), dim3(WM * 256), lds, st, a);
   if (vu_prof_on()) {
     static const bool shapes = getenv("VU_PROF_SHAPES") != nullptr;
     char tag[112];
@@ -399,6 +409,21 @@ int launch(const bg_args& a0, hipStream_t st) {
     vu_prof_note(tag, 2.0 * a.M * (double)a.N * a.K, 2.0 * ((double)a.M * a.K + (double)a.K * a.N) + (CF ? 8.0 : 2.0) * a.M * a.N);
   }
   return vu_check_launch("vu_gemm (bgemm)");
+}
+
+template <bool TA, bool TB, bool CF, int TM, int TN>
+int launch(const bg_args& a, hipStream_t st) {
+  // Tile choice.  224 x 192 (8 waves, 3 stages, one workgroup per CU) where it fills the chip (224 tiles at 64 images).  With
+  // fewer than ~160 such tiles (16 - 32 images per GPU: 64 - 112) the k-contiguous-A forms take 112 x 192 (4 waves, 2 stages =
+  // 78 KB: two independent workgroups per CU): measured M 1568 N 3072 K 3072 67 -> 52 us, M 784 63 -> 47 us; equal at 64 images
+  // (76 us both).  VU_BGEMM_TILE = 0 / 1 / 2 forces 224 x 192 / 112 x 192 x 2 stages / 112 x 192 x 3 stages (A/B switch).
+  static const int force = [] { const char* e = getenv("VU_BGEMM_TILE"); return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : -1; }();
+  if constexpr (!TA) {       // (a row-contiguous A needs BM % 32 == 0)
+    const long long big_tiles = (long long)vu_cdiv(a.M, 2 * TM * 16) * vu_cdiv(a.N, 4 * TN * 16);
+    if (force == 1 || (force < 0 && big_tiles < 160)) return launch_tile<TA, TB, CF, TM, TN, 1, 2>(a, st);
+    if (force == 2) return launch_tile<TA, TB, CF, TM, TN, 1, 3>(a, st);
+  }
+  return launch_tile<TA, TB, CF, TM, TN, 2, 3>(a, st);
 }
 
 }  // namespace
