@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-host-input", action="store_true", help="skip the PCIe-inclusive legs (N=1 only)")
     ap.add_argument("--grad-wire", default="fp32", choices=["fp32", "bf16"], help="N > 1: dtype of the gradient buckets on the links")
+    ap.add_argument("--collective", default="all_reduce", choices=["all_reduce", "rs_ag"],
+                    help="N > 1: one all-reduce per gradient bucket, or reduce-scatter + all-gather (engine._sum_over_ranks)")
     ap.add_argument("--no-sustained", action="store_true", help="skip the second, longer timed region (profiler runs)")
     ap.add_argument("--profile-steps", type=int, default=2)
     ap.add_argument("--dump-profile", default=None, help="write the full per-kernel table (JSON) here")
@@ -197,7 +199,12 @@ def main():
         x = (y + 0.1 * torch.randn(y.shape, generator=g)).clamp(0, 1)
     x, y = x.to(dev), y.to(dev)
     ts = TrainStep(model, lr=1e-4, seed=1234 + rank, loss="dice" if seg else "mse",
-                   grad_wire_dtype=torch.bfloat16 if a.grad_wire == "bf16" else None)
+                   grad_wire_dtype=torch.bfloat16 if a.grad_wire == "bf16" else None, collective=a.collective)
+    # what the collective library itself reports, so that the driver can check "RCCL formed N ranks" against n_gpus
+    comm = None
+    if dp:
+        comm = {"backend": torch.distributed.get_backend(), "ranks": torch.distributed.get_world_size(), "collective": a.collective,
+                "buckets": len(ts._ubuckets), "bucket_mb": [round(sum(hi - lo for lo, hi in rs) * 4 / 2 ** 20, 1) for _, _, rs in ts._ubuckets]}
     # eager where the step has tails to fill (TrainStep.prefers_eager: Base at >= 40 images per GPU), a hipGraph elsewhere
     tail_overlap = ts.prefers_eager(a.batch) and not a.force_graph
     use_graph = not a.no_graph and not tail_overlap
@@ -363,7 +370,7 @@ def main():
                "config": {"workload": f"ViT_UNet-{mname} train step: forward + {lossn} + backward + "
                                       f"AdamW on synthetic " + ("CT-style 512x512x1 image/mask pairs" if seg else
                                                                 "SIDD-style 224x224x3 noisy/clean pairs") + ", random-init weights",
-                          "per_gpu_batch": a.batch, "global_batch": a.batch * world, "parallelism": f"dp{world}", "rccl_path": dp, "grad_wire": a.grad_wire,
+                          "per_gpu_batch": a.batch, "global_batch": a.batch * world, "parallelism": f"dp{world}", "rccl_path": dp, "comm": comm, "grad_wire": a.grad_wire,
                           "hip_graph": use_graph, "tail_overlap": bool(not use_graph and ts.prefers_eager(a.batch)), "attn_operands": operands, "final_loss": loss},
                "roofline": roof, "cpu_baseline": cpu, "parity": parity, "host_input": host_in, "sustained": sustained}
         print(json.dumps(out), flush=True)

@@ -61,6 +61,18 @@ def _worker(rank, world, port, ret):
     g16 = [torch.zeros_like(flat16) for _ in range(world)]
     dist.all_gather(g16, flat16)
     ok = ok and all(torch.equal(g16[0], g) for g in g16)
+    # reduce-scatter + all-gather per bucket (SURVEY 8e's collective for the fully connected xGMI mesh): the same sums as the
+    # all-reduce schedule (two ranks: one fp32 addition per element either way - bit-identical), identical on every rank; odd
+    # bucket lengths take the small all-reduce for the remainder
+    flat_rs = _flat_grads(cfg, table, total, w, x[shard], y[shard])
+    for _first, _last, ranges in dp_unit_buckets(_lib.backward_unit_ranges(ccfg), cap_bytes=64 << 10):
+        for lo, hi in ranges:
+            allreduce_bucket(flat_rs, lo, hi, collective="rs_ag")
+    odd = torch.arange(7, dtype=torch.float32) + 10.0 * rank
+    allreduce_bucket(odd, 0, 7, collective="rs_ag")
+    ok = ok and torch.equal(odd, 2 * torch.arange(7, dtype=torch.float32) + 10.0)
+    flat_rs /= world
+    ok = ok and torch.equal(flat_rs, flat)
     # identical update on every rank
     p = torch.cat([w[n].reshape(-1) for n, *_ in table])
     gathered = [torch.zeros_like(flat) for _ in range(world)]

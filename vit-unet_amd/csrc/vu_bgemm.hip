@@ -251,16 +251,23 @@ __global__ __launch_bounds__(WM * 256, 2) void bgemm_kernel(const bg_args g) {
       for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
   };
   // ONE barrier per k-step: before it every wave waits (counted vmcnt) for its own pieces of stage t; behind it stage t is
-  // complete and stage t - 1 is free, so the pieces of step t + 2 are issued there and stay in flight under two steps of
-  // matrix instructions.  Measured on M 3136 N 3072 K 3072 (round 4, us; the library's kernel 53 - 55, vu_gemm.h's 128 x 128
-  // tile 126): this order 73 - 76; the ring alone (no fragments, no products) 34; fragments + products alone 63; and, all
-  // SLOWER than this order: the pieces spread one by one between the rows of matrix instructions 80 - 89; both halves' fragments
-  // requested before the first product 78 (hipcc sinks the reads back next to their uses), with the order pinned by
-  // sched_barrier 94; the barrier between the two halves with the next step's first fragments in flight across it 95; LOAD
-  // and COMPUTE phases with the two waves of a SIMD one phase apart (an extra barrier for half of the waves) 94.  What is left
-  // is the CU's LDS-DMA path beside the fragment reads (52 pieces of 1 KiB per step; the ring alone moves 36 B / clock / CU, the
-  // full kernel 14) - a larger share of register staging or a one-wave-per-SIMD tile with fewer LDS bytes per product is the
-  // next step, not another ordering of this loop.
+  // complete and stage t - 1 is free, so the pieces of step t + D are issued there and stay in flight under D steps of matrix
+  // instructions.
+  // Measured on M 3136 N 3072 K 3072 (round 4, us per launch, random operands; the library's kernel 53 - 55; vu_gemm.h's
+  // 128 x 128 tile 126): THIS ORDER 73 - 81 (boxes differ).  Pieces of it, timed alone (results wrong by construction):
+  //   matrix instructions only (fragments read once)            46   <- the floor of this tile on this chip: 224 CUs, and the
+  //                                                                    clock an MFMA-dense loop holds on random data (~1.6 GHz)
+  //   fragment reads only (160 KB of ds_read_b128 per step)     27.5 <- ~200 B / clock / CU: the LDS is a co-bottleneck
+  //   reads + products, no DMA                                   63   (either hipcc's just-in-time reads or both halves up front)
+  //   the DMA ring alone                                         34
+  // and orders of the whole loop, all SLOWER than this one: pieces spread one by one between the rows of matrix instructions
+  // 80 - 89; both halves' fragments requested before the first product 78 (hipcc sinks the reads back next to their uses), pinned
+  // by sched_barrier 94, spread by sched_group_barrier 74 - 75 (no DMA); the barrier between the two halves with the next step's
+  // first fragments in flight across it 95; LOAD / COMPUTE phases with the two waves of a SIMD one phase apart (an extra
+  // barrier for half of the waves) 94; two independent 4-wave workgroups per CU (112 x 192) 76.  Reads and products add up
+  // instead of overlapping (46 + 27.5 = 73.5): with eight waves of 112 x 48 the tile re-reads every A fragment four times
+  // and every B fragment twice.  The library's shape - four waves, one per SIMD, 128 x 80 each (35 % fewer LDS bytes per
+  // product), operands staged through registers - is the next step; it is a different kernel, not another order of this loop.
   constexpr int D = NST - 1;                  // k-steps of DMA in flight ahead of the one being multiplied
 #pragma unroll
   for (int d = 0; d < D; ++d)

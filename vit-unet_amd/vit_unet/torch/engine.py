@@ -70,31 +70,56 @@ def dp_unit_buckets(unit_ranges, cap_bytes: int = 48 << 20, elem_bytes: int = 4)
     return out
 
 
-def allreduce_bucket(flat: torch.Tensor, lo: int, hi: int, group=None, wire_dtype=None):
+def _sum_over_ranks(t: torch.Tensor, group, collective: str):
+    """In-place sum of a 1-D tensor over the group.  "all_reduce": one ring all-reduce (per-link bound on xGMI: 2 (w-1)/w S
+    through one ~153 GB/s link).  "rs_ag": reduce-scatter + all-gather (on the fully connected xGMI mesh every
+    rank exchanges S/w with each of its w-1 peers concurrently in both phases, so the exposed time is ~2 S / (w link_bw)
+    instead of ~2 S / link_bw); the same sum, the same value on every rank.  The part of the tensor that does not divide by the
+    world size (< w elements) goes through a small all-reduce."""
+    if collective == "all_reduce":
+        torch.distributed.all_reduce(t, group=group)
+        return
+    w = torch.distributed.get_world_size(group)
+    n = t.numel()
+    main = n - n % w
+    if main:
+        shard = torch.empty(main // w, dtype=t.dtype, device=t.device)
+        torch.distributed.reduce_scatter_tensor(shard, t[:main], group=group)
+        torch.distributed.all_gather_into_tensor(t[:main], shard, group=group)
+    if main < n:
+        torch.distributed.all_reduce(t[main:], group=group)
+
+
+def allreduce_bucket(flat: torch.Tensor, lo: int, hi: int, group=None, wire_dtype=None, collective: str = "all_reduce"):
     """Sum one bucket of the flat gradient arena over the data-parallel group (RCCL on GPU
     tensors, gloo on CPU tensors in the tests).  The 1/world average is applied by AdamW.
     `wire_dtype=torch.bfloat16`: the bucket crosses the links as bf16 (half the bytes on the per-link-bound xGMI ring):
     cast, all-reduce, cast back into the fp32 arena - every rank ends with the same values (the sum is formed from the
-    same bf16 operands everywhere), each gradient carries one more rounding to 8 bits."""
+    same bf16 operands everywhere), each gradient carries one more rounding to 8 bits.
+    `collective`: "all_reduce" (default) or "rs_ag" (reduce-scatter + all-gather, `_sum_over_ranks`)."""
     if hi <= lo:
         return
     if wire_dtype is None or wire_dtype == flat.dtype:
-        torch.distributed.all_reduce(flat[lo:hi], group=group)
+        _sum_over_ranks(flat[lo:hi], group, collective)
     else:
         wire = flat[lo:hi].to(wire_dtype)
-        torch.distributed.all_reduce(wire, group=group)
+        _sum_over_ranks(wire, group, collective)
         flat[lo:hi].copy_(wire)
 
 
 class TrainStep:
     def __init__(self, model, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
                  process_group=None, seed: int = 0, overlap: bool = True, loss: str = "mse", bucket_mb: Optional[int] = None,
-                 grad_wire_dtype: Optional[torch.dtype] = None):
+                 grad_wire_dtype: Optional[torch.dtype] = None, collective: str = "all_reduce"):
         """`loss`: "mse" (run_denoising.py:80) or "dice" (README.md:91-101 on sigmoid(model output),
         the segmentation configuration of BASELINE config 5).  `grad_wire_dtype=torch.bfloat16`: data-parallel gradient
-        buckets are all-reduced in bf16 (allreduce_bucket); default: fp32, as the reference's DDP would."""
+        buckets are all-reduced in bf16 (allreduce_bucket); default: fp32, as the reference's DDP would.
+        `collective="rs_ag"`: every bucket as reduce-scatter + all-gather instead of one all-reduce (`_sum_over_ranks`)."""
         if grad_wire_dtype not in (None, torch.float32, torch.bfloat16):
             raise ValueError("grad_wire_dtype must be None, torch.float32 or torch.bfloat16")
+        if collective not in ("all_reduce", "rs_ag"):
+            raise ValueError("collective must be 'all_reduce' or 'rs_ag' (reduce-scatter + all-gather per bucket)")
+        self.collective = collective
         self.grad_wire_dtype = None if grad_wire_dtype == torch.float32 else grad_wire_dtype
         if loss not in ("mse", "dice"):
             raise ValueError(f"loss must be 'mse' or 'dice', got {loss!r}")
@@ -179,10 +204,10 @@ class TrainStep:
             self.comm_stream.wait_stream(cur)
             with torch.cuda.stream(self.comm_stream):
                 for lo, hi in ranges:
-                    allreduce_bucket(self.model._garena, lo, hi, self.pg, self.grad_wire_dtype)
+                    allreduce_bucket(self.model._garena, lo, hi, self.pg, self.grad_wire_dtype, self.collective)
         else:
             for lo, hi in ranges:
-                allreduce_bucket(self.model._garena, lo, hi, self.pg, self.grad_wire_dtype)
+                allreduce_bucket(self.model._garena, lo, hi, self.pg, self.grad_wire_dtype, self.collective)
 
     def _enqueue(self, x, y, out, dout):
         self._enqueue_head(x, y, out, dout)
