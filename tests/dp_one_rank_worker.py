@@ -75,6 +75,22 @@ def main(golden_dir):
     for (k, pc), (_, pd_) in zip(mc.named_parameters(), md.named_parameters()):
         if not k.endswith("reatten_matrix.bias"):
             assert serr(pc, pd_) < 2e-4, k
+    # reduce-scatter + all-gather per bucket over RCCL (collective="rs_ag"): same step as the all-reduce schedule
+    me = build(kw, w).train()
+    te = TrainStep(me, lr=1e-3, seed=5, bucket_mb=0, collective="rs_ag")
+    assert te.dp and te.collective == "rs_ag"
+    mf = build(kw, w).train()
+    os.environ.pop("VU_DP_FORCE", None)
+    tf = TrainStep(mf, lr=1e-3, seed=5)
+    assert not tf.dp
+    os.environ["VU_DP_FORCE"] = "1"
+    for _ in range(2):
+        le, lf = te.step(x, y).item(), tf.step(x, y).item()
+        assert abs(le - lf) < 1e-4 * abs(lf), (le, lf)
+    torch.cuda.synchronize()
+    for (k, pe), (_, pf) in zip(me.named_parameters(), mf.named_parameters()):
+        if not k.endswith("reatten_matrix.bias"):
+            assert serr(pe, pf) < 1e-4, k
     print("DP_ONE_RANK_OK", flush=True)
 
 

@@ -22,6 +22,11 @@ enum { VU_ACT_NONE = 0, VU_ACT_GELU = 1, VU_ACT_DGELU = 2 };
 // fixed order with one small kernel, instead of float atomics on the output.  Per-thread, scoped: set before, cleared after.
 void vu_gemm_set_scratch(void* p, size_t bytes);
 void vu_gemm_get_scratch(void** p, size_t* bytes);
+// A second, larger region for the K-slice partials of the skinny weight gradients (vu_tsgemm.hip): products take pieces of it one
+// after the other and QUEUE their fixed-order reductions; vu_tsgemm_flush launches all queued reductions as one kernel.  Whoever
+// lends the arena flushes before anything outside its call reads the outputs, and before taking the arena back.
+void vu_tsgemm_set_arena(void* p, size_t bytes);
+int vu_tsgemm_flush(hipStream_t st);
 
 struct vu_gemm_args {
   const void* A; const void* B; void* C;

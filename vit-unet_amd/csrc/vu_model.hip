@@ -437,6 +437,7 @@ struct ModelWS {
   std::vector<void*> dskip;
   float *partials, *lnp, *lnp2;
   void* wgs; size_t wgs_bytes;      // split-K slab of the tall-skinny weight gradients (bf16 storage; vu_gemm_set_scratch)
+  void* wga; size_t wga_bytes;      // arena of the deferred (batched) reductions of those gradients (vu_tsgemm_set_arena)
   size_t bytes;
 };
 
@@ -492,6 +493,8 @@ void carve_model(const Plan& pl, int B, char* base, ModelWS& w) {
   w.lnp2 = bp.takef((size_t)B * vu_ln_nbchunks(P) * 2);
   w.wgs_bytes = dt == 1 ? (size_t)40 << 20 : 0;      // (16 K slices of a 768 x 768 output)
   w.wgs = w.wgs_bytes ? bp.take(w.wgs_bytes) : nullptr;
+  w.wga_bytes = dt == 1 ? (size_t)160 << 20 : 0;     // (a Base backward queues ~100 MB of partial tiles: one reduce launch per call)
+  w.wga = w.wga_bytes ? bp.take(w.wga_bytes) : nullptr;
   w.bytes = vu_align_up(bp.off, 256);
 }
 
@@ -927,7 +930,7 @@ int vu_model_workspace_describe(const vu_config* cfg, int B, char* out, int cap)
   add("gx0", w.gx0); add("gx1", w.gx1); add("ga", w.ga); add("gb", w.gb); add("gc", w.gc); add("gh", w.gh);
   add("asc.dO", w.asc.dO); add("asc.dq", w.asc.dq); add("asc.dk", w.asc.dk); add("asc.dv", w.asc.dv); add("asc.dA", w.asc.dA);
   for (size_t j = 0; j < w.dskip.size(); ++j) add("dskip" + std::to_string(j), w.dskip[j]);
-  add("partials", w.partials); add("lnp", w.lnp); add("lnp2", w.lnp2); add("wgs", w.wgs);
+  add("partials", w.partials); add("lnp", w.lnp); add("lnp2", w.lnp2); add("wgs", w.wgs); add("wga", w.wga);
   std::string text;
   for (size_t i = 0; i < ents.size(); ++i) {
     const size_t end = i + 1 < ents.size() ? ents[i + 1].second : w.bytes;
@@ -980,8 +983,11 @@ static int run_backward(const vu_config* cfg, const float* params, const void* s
   VU_REQUIRE(first >= 0 && last < nu && first <= last + 1, "vu_model_backward_units: unit range [%d,%d] outside [0,%d)", first, last, nu);
   Ctx cx{&pl, B, params, shadow, (float*)bn_state, grads, training, seed, rng_salt, (hipStream_t)stream, &w};
   vu_gemm_set_scratch(w.wgs, w.wgs_bytes);          // lent for this call: deterministic split-K of the skinny weight gradients
-  const int rc = model_backward(cx, dy, dx, first, last);
+  vu_tsgemm_set_arena(w.wga, w.wga_bytes);          // ... and the arena of their deferred, batched reductions
+  int rc = model_backward(cx, dy, dx, first, last);
+  if (rc == VU_OK) rc = vu_tsgemm_flush((hipStream_t)stream);
   vu_gemm_set_scratch(nullptr, 0);
+  vu_tsgemm_set_arena(nullptr, 0);
   return rc;
 }
 

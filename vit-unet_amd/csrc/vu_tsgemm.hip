@@ -169,12 +169,17 @@ __global__ __launch_bounds__(64 * WM * WN) void vu_tsgemm_kernel(const bf16_t* _
 // a workgroup takes 16 float4 items x 16 slice lanes (lane sl adds slices sl, sl + 16, ...), then one thread per item adds
 // the 16 lane sums in order.  `tile`: floats between two slices' tiles (padded so that the slices do not all start on the
 // same memory channels).
-__global__ __launch_bounds__(256) void tsgemm_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ slab_cs,
-                                                            float* __restrict__ C, float* __restrict__ colsum, int M, int N, int Mp,
-                                                            int Np, int ldc, int nsplit, long long tile, int nitems) {
+struct RedDesc {
+  const float* slab; const float* slab_cs; float* C; float* colsum;
+  int M, N, Mp, Np, ldc, nsplit, nitems, blk0;       // blk0: first workgroup of this reduction inside a batched launch
+  long long tile;
+};
+__device__ __forceinline__ void tsgemm_reduce_body(const float* __restrict__ slab, const float* __restrict__ slab_cs, float* __restrict__ C,
+                                                   float* __restrict__ colsum, int M, int N, int Mp, int Np, int ldc, int nsplit, long long tile,
+                                                   int nitems, int blk) {
   __shared__ float4 part[16][16];
   const int it = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  const int id = blockIdx.x * 16 + it;
+  const int id = blk * 16 + it;
   const int nq = N >> 2;                                    // N % 8 == 0 (checked by the launcher)
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
   const bool is_c = id < nitems;
@@ -213,6 +218,42 @@ __global__ __launch_bounds__(256) void tsgemm_reduce_kernel(const float* __restr
   }
 }
 
+__global__ __launch_bounds__(256) void tsgemm_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ slab_cs,
+                                                            float* __restrict__ C, float* __restrict__ colsum, int M, int N, int Mp,
+                                                            int Np, int ldc, int nsplit, long long tile, int nitems) {
+  tsgemm_reduce_body(slab, slab_cs, C, colsum, M, N, Mp, Np, ldc, nsplit, tile, nitems, blockIdx.x);
+}
+// The reductions of SEVERAL products in one launch (their slabs sit side by side in the deferred arena lent by the model
+// executor): a workgroup finds its reduction by its index.  29 reduce launches per Base backward were 0.28 ms of tiny
+// dependent launches (~10 us each for ~3 us of work); batched they are one launch per backward call.
+constexpr int RED_MAX = 40;
+struct RedBatch { int n; RedDesc d[RED_MAX]; };
+__global__ __launch_bounds__(256) void tsgemm_reduce_batch_kernel(const RedBatch b) {
+  int i = 0;
+  while (i + 1 < b.n && (int)blockIdx.x >= b.d[i + 1].blk0) ++i;          // (workgroup-uniform)
+  const RedDesc& r = b.d[i];
+  tsgemm_reduce_body(r.slab, r.slab_cs, r.C, r.colsum, r.M, r.N, r.Mp, r.Np, r.ldc, r.nsplit, r.tile, r.nitems, (int)blockIdx.x - r.blk0);
+}
+
+// ---- deferred reductions -------------------------------------------------------------------------------------------------
+// vu_tsgemm_set_arena lends a region for the K-slice partial tiles of MANY products; each product takes the next piece of it
+// and queues its reduction; vu_tsgemm_flush launches them all (the model executor: once per backward call, before anything
+// outside the call reads the gradients).  A product that does not fit flushes first.  Per-thread state, like the scratch.
+struct Arena { char* base = nullptr; size_t bytes = 0, off = 0; RedBatch batch; int blocks = 0; };
+thread_local Arena g_arena;
+int arena_flush(hipStream_t st) {
+  Arena& a = g_arena;
+  if (a.batch.n == 0) { a.off = 0; return VU_OK; }
+  hipLaunchKernelGGL(tsgemm_reduce_batch_kernel, dim3((unsigned)a.blocks), dim3(256), 0, st, a.batch);
+  if (vu_prof_on()) {
+    double bytes = 0.0;
+    for (int i = 0; i < a.batch.n; ++i) bytes += (double)(a.batch.d[i].nsplit + 2) * a.batch.d[i].M * a.batch.d[i].N * 4.0;
+    vu_prof_note("tsgemm_reduce_batch_kernel", 0.0, bytes);
+  }
+  a.batch.n = 0; a.blocks = 0; a.off = 0;
+  return vu_check_launch("vu_tsgemm_reduce (batched)");
+}
+
 inline bool ldc_ok(const vu_gemm_args& g) { return g.ldc % 4 == 0 && ((uintptr_t)g.C & 15) == 0; }
 
 template <int TM, int TN, int WM, int WN, int PD>
@@ -225,6 +266,9 @@ int launch_ts(const vu_gemm_args& g, hipStream_t st) {
   static const bool slab_off = [] { const char* e = getenv("VU_TSGEMM_SLAB"); return e && e[0] == '0'; }();      // A/B switch
   const long long slab_tile = (long long)mt * MT * ((long long)nt * NT) + 1088;        // + 4352 B: spreads the slices over the memory channels
   const size_t per_split = ((size_t)slab_tile + (size_t)mt * MT) * 4;
+  Arena& ar = g_arena;
+  const bool arena_ok = ar.base && !slab_off && ar.bytes >= 2 * per_split && ldc_ok(g);
+  if (arena_ok) { scr = ar.base; scr_bytes = ar.bytes; }          // (sized against the whole arena: a product that does not fit what is left flushes first)
   const bool use_slab = scr && !slab_off && scr_bytes >= 2 * per_split && ldc_ok(g);
   // K slices: enough workgroups to put a stream on every CU and at least 8 k-steps (256 rows) per slice.  With a slab the
   // partial tiles cost a plain write and a read (bounded by half the operand bytes and by the slab); without one they are
@@ -244,6 +288,13 @@ int launch_ts(const vu_gemm_args& g, hipStream_t st) {
   rows = (rows + 31) / 32 * 32;
   const int nsplit = (g.K + rows - 1) / rows;
   const bool slab = use_slab && nsplit > 1;
+  const bool deferred = slab && arena_ok;
+  if (deferred) {
+    const size_t need = (size_t)nsplit * per_split;
+    if (ar.off + need > ar.bytes || ar.batch.n == RED_MAX) { const int rc_ = arena_flush(st); if (rc_) return rc_; }
+    scr = ar.base + ar.off;
+    ar.off += (need + 255) / 256 * 256;
+  }
   float* sl = slab ? (float*)scr : nullptr;
   float* slcs = slab ? sl + (size_t)nsplit * slab_tile : nullptr;
   hipLaunchKernelGGL((vu_tsgemm_kernel<TM, TN, WM, WN, PD>), dim3(nsplit, mt, nt), dim3(64 * WM * WN), 0, st, (const bf16_t*)g.A,
@@ -255,6 +306,15 @@ int launch_ts(const vu_gemm_args& g, hipStream_t st) {
     vu_prof_note(tag, 2.0 * g.M * (double)g.N * g.K, in_bytes + out_bytes);
   }
   { const int rc_ = vu_check_launch("vu_tsgemm"); if (rc_) return rc_; }
+  if (deferred) {
+    const int nitems = g.M * (g.N / 4);
+    const long long items = (long long)nitems + (g.colsum ? (g.M + 3) / 4 : 0);
+    RedDesc& d = ar.batch.d[ar.batch.n++];
+    d.slab = sl; d.slab_cs = slcs; d.C = (float*)g.C; d.colsum = g.colsum; d.M = g.M; d.N = g.N; d.Mp = mt * MT; d.Np = nt * NT;
+    d.ldc = (int)g.ldc; d.nsplit = nsplit; d.nitems = nitems; d.blk0 = ar.blocks; d.tile = slab_tile;
+    ar.blocks += (int)((items + 15) / 16);
+    return VU_OK;
+  }
   if (slab) {
     const int nitems = g.M * (g.N / 4);
     const long long items = (long long)nitems + (g.colsum ? (g.M + 3) / 4 : 0);
@@ -269,6 +329,9 @@ int launch_ts(const vu_gemm_args& g, hipStream_t st) {
 inline int side_class(int n) { return n <= 32 ? 32 : (n <= 64 ? 64 : (n <= 128 ? 128 : 192)); }   // workgroup tile side
 
 }  // namespace
+
+void vu_tsgemm_set_arena(void* p, size_t bytes) { g_arena.base = (char*)p; g_arena.bytes = p ? bytes : 0; g_arena.off = 0; g_arena.batch.n = 0; g_arena.blocks = 0; }
+int vu_tsgemm_flush(hipStream_t st) { return arena_flush(st); }
 
 // 1 = launched, 0 = shape not covered (the caller falls through to the tiled GEMM), < 0 = error
 int vu_tsgemm_try(const vu_gemm_args& g, hipStream_t st) {
