@@ -284,8 +284,9 @@ int vu_add_layernorm_fwd_eps(int dtype, const void* a, const void* x, void* z, c
  * Initial values: the environment variables VU_ATTN_FLASH (0 / 1) and VU_ATTN_CENTERED, read once. */
 int vu_set_attn_form(int flash, int centered);
 /* Recompute form only: how many waves of a workgroup share one 16-row tile and split the streamed keys / queries between them
- * (csrc/vu_flash.hip): 0 = the default (1: measured, the split does not pay where the recompute form is used), 1, 2.  Process-level,
- * for tests and measurements; results differ between 1 and 2 by the order of the fp32 sums only. */
+ * (csrc/vu_flash.hip): 0 = the default (by launch size: 1, or 3 where the unsplit sweeps would leave one wave per SIMD), 1 = unsplit,
+ * 2 = wave pairs in 4-wave workgroups, 3 = wave pairs in 8-wave workgroups (the Base / Large level-2 shape).  Process-level, for
+ * tests and measurements; results differ between the forms by the order of the fp32 sums only. */
 int vu_set_flash_key_split(int ks);
 
 /* In-process launch profiler (bench.py's roofline leg): PROCESS-GLOBAL state, meant for one

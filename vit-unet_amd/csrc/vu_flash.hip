@@ -2404,7 +2404,7 @@ inline bool tail_overlap(const ForkPool* fp, int nblk, hipStream_t st, bool chec
   return true;
 }
 
-template <int DH, int KS>
+template <int DH, int KS, int WPBV = 4>
 int launch_forward_v2(const vu_flash_args& a, hipStream_t st) {
 #ifndef VU_CKF
 #define VU_CKF 4
@@ -2412,7 +2412,7 @@ int launch_forward_v2(const vu_flash_args& a, hipStream_t st) {
 #ifndef VU_CKK
 #define VU_CKK 2
 #endif
-  constexpr int H = 8, WPB = 4, CK = VU_CKF;
+  constexpr int H = 8, WPB = WPBV, CK = VU_CKF;
   typedef FC<H, DH> C;
   constexpr int TPB = WPB / KS;                                          // own tiles per workgroup (pair_park / pair_take)
   const int ntiles = a.N >> 4, per = (ntiles + TPB - 1) / TPB;
@@ -2446,9 +2446,9 @@ int launch_forward_v2(const vu_flash_args& a, hipStream_t st) {
   return vu_check_launch("flash2_apply");
 }
 
-template <int DH, int KS>
+template <int DH, int KS, int WPBV = 4>
 int launch_backward_v2(const vu_flash_args& a, hipStream_t st) {
-  constexpr int H = 8, WPB = 4, CK = 4, CK2 = 2, NT = H * H + H;
+  constexpr int H = 8, WPB = WPBV, CK = 4, CK2 = 2, NT = H * H + H;
   typedef FC<H, DH> C;
   constexpr int TPB = WPB / KS;
   const int ntiles = a.N >> 4, per = (ntiles + TPB - 1) / TPB;
@@ -2566,15 +2566,20 @@ bool vu_flash_ok(int dtype, int B, int N, int D, int H) {
 // wave on the SIMD hides little (two INDEPENDENT workgroups per CU deliver 1.56x); and where it does gain (8 - 12 images) the
 // materialising kernels are still faster (Base step at 8 images: 5.82 ms materialised, 6.02 split, 6.49 unsplit; at 12:
 // 6.32 / 6.52 / 6.62).  So the rule is "never"; vu_set_flash_key_split(2) / VU_FLASH_KS=2 run it (tests keep it correct).
-static int g_key_split = [] { const char* e = getenv("VU_FLASH_KS"); return (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0; }();
+static int g_key_split = [] { const char* e = getenv("VU_FLASH_KS"); return (e && e[0] >= '1' && e[0] <= '3') ? e[0] - '0' : 0; }();
 extern "C" int vu_set_flash_key_split(int ks) {
-  if (ks < 0 || ks > 2) { vu_set_error("vu_set_flash_key_split: 0 (default), 1 or 2"); return VU_EINVAL; }
+  if (ks < 0 || ks > 3) { vu_set_error("vu_set_flash_key_split: 0 (default), 1, 2 or 3 (2 with eight waves per workgroup)"); return VU_EINVAL; }
   g_key_split = ks;
   return VU_OK;
 }
+// Default (no setter, no environment): the unsplit sweeps, except where they would put a single wave on every SIMD - at most
+// one 4-wave workgroup per CU (B ceil(N / 64) <= 256: Base / Large level 2 at 16 images per GPU, the per-GPU batch of BASELINE
+// configs 3 - 4).  There the split form with EIGHT waves per workgroup runs (form 3: the same 13 workgroups per sample, each
+// tile's keys shared by a wave pair, two waves per SIMD): one level-2 module, forward + backward, 16 images: 730 -> 677 us
+// (tools/flash_bench.py; form 2 - the split with four waves per workgroup - 730; at 32 images form 3 is slower: 1024 -> 1145).
 int vu_flash_key_split(int B, int N) {
-  (void)B; (void)N;
-  return g_key_split ? g_key_split : 1;
+  if (g_key_split) return g_key_split;
+  return (long long)B * ((N / 16 + 3) / 4) <= 256 ? 3 : 1;
 }
 
 size_t vu_flash_partials_floats(int B, int N, int H) {
@@ -2586,7 +2591,8 @@ int vu_k_flash_forward(const vu_flash_args& a, hipStream_t st) {
   VU_REQUIRE(vu_flash_ok(1, a.B, a.N, a.D, a.H), "flash attention: shape not covered");
   if (a.H == 8) {       // head mixes on the matrix cores (v2 tile body)
     const int dh = a.D / a.H;
-    if (vu_flash_key_split(a.B, a.N) == 2) {
+    if (vu_flash_key_split(a.B, a.N) == 3 && dh == 24) return launch_forward_v2<24, 2, 8>(a, st);        // (Base / Large level 2 only)
+    if (vu_flash_key_split(a.B, a.N) >= 2) {
       if (dh == 24) return launch_forward_v2<24, 2>(a, st);
       if (dh == 8) return launch_forward_v2<8, 2>(a, st);
       if (dh == 32) return launch_forward_v2<32, 2>(a, st);
@@ -2602,7 +2608,8 @@ int vu_k_flash_backward(const vu_flash_args& a, hipStream_t st) {
   VU_REQUIRE(vu_flash_ok(1, a.B, a.N, a.D, a.H), "flash attention: shape not covered");
   if (a.H == 8) {
     const int dh = a.D / a.H;
-    if (vu_flash_key_split(a.B, a.N) == 2 && a.pk != nullptr && a.training) {      // (the eval-mode backward keeps the unsplit sweeps)
+    if (vu_flash_key_split(a.B, a.N) == 3 && dh == 24 && a.pk != nullptr && a.training) return launch_backward_v2<24, 2, 8>(a, st);
+    if (vu_flash_key_split(a.B, a.N) >= 2 && a.pk != nullptr && a.training) {      // (the eval-mode backward keeps the unsplit sweeps)
       if (dh == 24) return launch_backward_v2<24, 2>(a, st);
       if (dh == 8) return launch_backward_v2<8, 2>(a, st);
       if (dh == 32) return launch_backward_v2<32, 2>(a, st);

@@ -188,7 +188,7 @@ def set_attn_form(flash: int = -1, centered: int = 0) -> None:
 
 def set_flash_key_split(ks: int = 0) -> None:
     """Recompute attention only: waves of a workgroup that share one tile and split the streamed keys / queries (0 = by launch
-    size, 1, 2; include/vit_unet_amd.h: vu_set_flash_key_split).  Tests and experiments only."""
+    size, 1, 2, 3; include/vit_unet_amd.h: vu_set_flash_key_split).  Tests and experiments only."""
     check(lib().vu_set_flash_key_split(int(ks)), "vu_set_flash_key_split")
 
 
