@@ -168,6 +168,7 @@ def test_gemm_forms(dt, M, N, K):
 @pytest.mark.parametrize("M,N,K", [(3136, 3072, 3072),      # Base level 0 at 64 images: 14 x 16 exact tiles of 224 x 192, XCD rectangles
                                    (2176, 1536, 1600),      # ragged rows (9.7 tiles), 8 column tiles
                                    (980, 3072, 3072),       # 20 images: M % 8 != 0 (k-contiguous A: any M)
+                                   (784, 3072, 3072),       # 16 images: 112 x 128 tiles (168 workgroups; 112 x 192 would be 112)
                                    (1568, 2048, 2048),      # 32 images: the weight gradient's K = 1568 = 24.5 k-steps (zeroed tail k-slots)
                                    (2104, 1544, 1368)])     # ragged everything: N = 8 tiles + 8 columns, K % 64 = 24 forward, 8 in the data gradient
 def test_gemm_big_tile_kernel_for_plain_big_products(M, N, K):
@@ -198,9 +199,11 @@ def test_gemm_big_tile_kernel_for_plain_big_products(M, N, K):
     torch.cuda.synchronize()
     rep = json.loads(L.vu_prof_report().decode())
     assert not any("hipblaslt" in k or k.startswith("Cijk") for k in rep), rep.keys()
-    if big:      # (224 x 192 tiles where they fill the chip, 112 x 192 with two workgroups per CU below ~160 tiles)
+    if big:      # (224 x 192 tiles where they fill the chip, 112 x 192 with two workgroups per CU below ~160 tiles, 112 x 128 below 144)
         assert sum(v["count"] for k, v in rep.items() if k.startswith("bgemm_kernel<NN,bf16,")) == 1, rep.keys()
         assert sum(v["count"] for k, v in rep.items() if k.startswith("bgemm_kernel<NT,bf16,")) == 1, rep.keys()
+        if M == 784:
+            assert "bgemm_kernel<NN,bf16,112x128>" in rep and "bgemm_kernel<NT,bf16,112x128>" in rep, rep.keys()
     if wg:
         assert rep.get("bgemm_kernel<TT,f32 acc,224x192>", {}).get("count") == 1, rep.keys()
 

@@ -424,9 +424,14 @@ int launch(const bg_args& a, hipStream_t st) {
   // fewer than ~160 such tiles (16 - 32 images per GPU: 64 - 112) the k-contiguous-A forms take 112 x 192 (4 waves, 2 stages =
   // 78 KB: two independent workgroups per CU): measured M 1568 N 3072 K 3072 67 -> 52 us, M 784 63 -> 47 us; equal at 64 images
   // (76 us both).  VU_BGEMM_TILE = 0 / 1 / 2 forces 224 x 192 / 112 x 192 x 2 stages / 112 x 192 x 3 stages (A/B switch).
-  static const int force = [] { const char* e = getenv("VU_BGEMM_TILE"); return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : -1; }();
+  // 16 images per GPU (M 784): 112 x 192 is 112 workgroups on 256 CUs; 112 x 128 (VU_BGEMM_TILE=3) makes 168 of two thirds the work.
+  static const int force = [] { const char* e = getenv("VU_BGEMM_TILE"); return (e && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : -1; }();
   if constexpr (!TA) {       // (a row-contiguous A needs BM % 32 == 0)
     const long long big_tiles = (long long)vu_cdiv(a.M, 2 * TM * 16) * vu_cdiv(a.N, 4 * TN * 16);
+    if constexpr (TN == 3) {
+      const long long half_tiles = (long long)vu_cdiv(a.M, TM * 16) * vu_cdiv(a.N, 4 * TN * 16);
+      if (force == 3 || (force < 0 && half_tiles < 144)) return launch_tile<TA, TB, CF, TM, 2, 1, 2>(a, st);
+    }
     if (force == 1 || (force < 0 && big_tiles < 160)) return launch_tile<TA, TB, CF, TM, TN, 1, 2>(a, st);
     if (force == 2) return launch_tile<TA, TB, CF, TM, TN, 1, 3>(a, st);
   }
