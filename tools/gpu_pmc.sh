@@ -5,7 +5,7 @@ python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
 cd /tmp && export TMPDIR=/tmp
 # (round 3: one pass per kernel family - with the counters armed on every dispatch of a step this image's rocprofv3 dies with
 # a SIGSEGV in its own dispatch callback; each family alone, 300 - 900 dispatches, runs through)
-FAMILIES=('flash' 'gemm' 'ln_|layernorm' 'map_|scores|mix_' 'conv' 'adamw|retile|bn_|colsum|cast|mse|tsgemm' 'Cijk_|lt_post')
+FAMILIES=('flash' 'gemm' 'ln_|layernorm' 'map_|scores|mix_' 'conv' 'adamw|retile|bn_|colsum|cast|mse|tsgemm')
 for C in FETCH_SIZE WRITE_SIZE; do
   i=0
   for RX in "${FAMILIES[@]}"; do

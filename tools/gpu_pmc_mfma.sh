@@ -2,7 +2,7 @@
 # GRBM_GUI_ACTIVE (sum over the 8 XCDs) - one --pmc pass, kernel-trace only.
 cd /tmp && export TMPDIR=/tmp
 # (one pass per kernel family: see tools/gpu_pmc.sh)
-FAMILIES=('flash' 'gemm' 'ln_|layernorm' 'map_|scores|mix_' 'conv' 'adamw|retile|bn_|colsum|cast|mse|tsgemm' 'Cijk_|lt_post')
+FAMILIES=('flash' 'gemm' 'ln_|layernorm' 'map_|scores|mix_' 'conv' 'adamw|retile|bn_|colsum|cast|mse|tsgemm')
 i=0
 for RX in "${FAMILIES[@]}"; do
   i=$((i+1))

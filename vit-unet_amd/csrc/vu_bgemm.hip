@@ -24,6 +24,7 @@
 // weight (N, K)) or n-contiguous.  K % 64 == 0; M, N, leading dimensions % 8 == 0; 16-byte aligned bases.
 #include <stdio.h>
 #include <stdlib.h>
+#include <type_traits>
 #include "vu_gemm.h"
 #include "vu_kernels.h"
 
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(WM * 256, 2) void bgemm_kernel(const bg_args g) {
   bool isA[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) isA[j] = wave + NW * j < NPA;
-  auto piece_off = [&](int j, int kvalid) -> unsigned {
+  auto piece_off = [&](int j, int kvalid) __attribute__((always_inline)) -> unsigned {
     const int p = wave + NW * j;
     const int pp = p < NP ? p : NP - 1;
     const bool a = pp < NPA;
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(WM * 256, 2) void bgemm_kernel(const bg_args g) {
   const char* baseA = reinterpret_cast<const char*>(g.A);
   const char* baseB = reinterpret_cast<const char*>(g.B);
   // piece j of k-step `step` (j = NJ - 1: only the waves that have one)
-  auto issue_piece = [&](int step, int j) {
+  auto issue_piece = [&](int step, int j) __attribute__((always_inline)) {
     if (j == NJ - 1 && NREM != 0 && !has_last) return;
     const unsigned st = lbase + (unsigned)(step % NST) * STAGE + (unsigned)(wave + NW * j) * 1024;
     const char* sb = (isA[j] ? baseA + step * stepA : baseB + step * stepB);
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(WM * 256, 2) void bgemm_kernel(const bg_args g) {
     else dma16(sb, voff[j], st);
   };
   // all pieces of a k-step: batches of up to four pieces per asm statement
-  auto issue = [&](int step) {
+  auto issue = [&](int step) __attribute__((always_inline)) {
     if (step == nk - 1 && ktail != BK) {             // (workgroup-uniform; ragged last step: clamped offsets, piece by piece)
 #pragma unroll
       for (int j = 0; j < NJ; ++j) issue_piece(step, j);
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(WM * 256, 2) void bgemm_kernel(const bg_args g) {
     const char* sa = baseA + step * stepA;
     const char* sb = baseB + step * stepB;
     const unsigned st = lbase + (unsigned)(step % NST) * STAGE + (unsigned)wave * 1024;
-    auto bs = [&](int j) -> const char* { return isA[j] ? sa : sb; };
+    auto bs = [&](int j) __attribute__((always_inline)) -> const char* { return isA[j] ? sa : sb; };
     constexpr int NFULL = NREM ? NJ - 1 : NJ;          // pieces every wave has
     constexpr int SB = NW * 1024;                       // LDS bytes between a wave's consecutive pieces
     int j = 0;
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(WM * 256, 2) void bgemm_kernel(const bg_args g) {
     if (NREM != 0 && has_last) dma16(bs(NJ - 1), voff[NJ - 1], st + (NJ - 1) * SB);
   };
   // wait until at most `steps` whole k-steps of this wave's pieces are still in flight (steps = 0, 1, 2: wave-uniform)
-  auto wait_steps = [&](int steps) {
+  auto wait_steps = [&](int steps) __attribute__((always_inline)) {
     if (steps == 0) wait_vm<0>();
     else if (steps == 1) { if (has_last) wait_vm<NJF + 1>(); else wait_vm<NJF>(); }
     else { if (has_last) wait_vm<2 * (NJF + 1)>(); else wait_vm<2 * NJF>(); }
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(WM * 256, 2) void bgemm_kernel(const bg_args g) {
     const int col = wn * TN * 16 + j * 16 + 4 * tp, k = 8 * lg + tq;
     tfB[j] = NPA * 1024 + k * (BN * 2) + (((col >> 3) ^ tswz<BN>(k)) << 4) + (col & 7) * 2;
   }
-  auto tr_frag = [&](const unsigned char* p, int pitch) -> bf16x8 {
+  auto tr_frag = [&](const unsigned char* p, int pitch) __attribute__((always_inline)) -> bf16x8 {
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)p);
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p + 4 * pitch));
     const s16x8 t = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -226,7 +227,10 @@ __global__ __launch_bounds__(WM * 256, 2) void bgemm_kernel(const bg_args g) {
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // fragments of one 32-deep half of a k-step; `last`: the ragged last step zeroes the A slots beyond K
-  auto load_frags = [&](const unsigned char* st, int kb, bool last, bf16x8 (&af)[TM], bf16x8 (&bfr)[TN]) {
+  // (`last` is a compile-time constant: the ragged step is peeled off the loop - as a run-time flag the zeroing became 56
+  // v_cndmask per k-step in EVERY step, 40 % of the loop's vector instructions)
+  auto load_frags = [&](const unsigned char* st, int kb, auto lastc, bf16x8 (&af)[TM], bf16x8 (&bfr)[TN]) __attribute__((always_inline)) {
+    constexpr bool last = decltype(lastc)::value;
     const unsigned char* pa = st + (nfA ^ (kb << 6));
     const unsigned char* pb = st + (nfB ^ (kb << 6));
 #pragma unroll
@@ -234,7 +238,7 @@ __global__ __launch_bounds__(WM * 256, 2) void bgemm_kernel(const bg_args g) {
       if constexpr (TA) af[i] = tr_frag(st + tfA[i] + kb * 32 * (BM * 2), BM * 2);
       else af[i] = *reinterpret_cast<const bf16x8*>(pa + i * 2048);
     }
-    if (last && kb * 32 + 8 * lg >= ktail) {          // this lane's 8 k-slots lie beyond K
+    if constexpr (last) if (kb * 32 + 8 * lg >= ktail) {          // this lane's 8 k-slots lie beyond K
 #pragma unroll
       for (int i = 0; i < TM; ++i) af[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
     }
@@ -244,7 +248,7 @@ __global__ __launch_bounds__(WM * 256, 2) void bgemm_kernel(const bg_args g) {
       else bfr[j] = *reinterpret_cast<const bf16x8*>(pb + j * 2048);
     }
   };
-  auto mma = [&](const bf16x8 (&af)[TM], const bf16x8 (&bfr)[TN]) {
+  auto mma = [&](const bf16x8 (&af)[TM], const bf16x8 (&bfr)[TN]) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -273,19 +277,21 @@ __global__ __launch_bounds__(WM * 256, 2) void bgemm_kernel(const bg_args g) {
   for (int d = 0; d < D; ++d)
     if (d < nk) issue(d);
   bf16x8 a0[TM], b0[TN];
-  for (int t = 0; t < nk; ++t) {
+  auto kstep = [&](int t, auto lastc) __attribute__((always_inline)) {
     { const int ahead = nk - 1 - t; wait_steps(ahead < D - 1 ? ahead : D - 1); }     // stage t has landed (this wave's pieces); later steps may fly
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     const unsigned char* st = smem + (t % NST) * STAGE;
-    const bool last = t == nk - 1;
     if (t + D < nk) issue(t + D);                                       // into the stage every wave finished reading before the barrier
-    load_frags(st, 0, last, a0, b0);
+    load_frags(st, 0, lastc, a0, b0);
     mma(a0, b0);
-    load_frags(st, 1, last, a0, b0);
+    load_frags(st, 1, lastc, a0, b0);
     mma(a0, b0);
-  }
+  };
+  for (int t = 0; t < nk - 1; ++t) kstep(t, std::false_type{});
+  if (ktail != BK) kstep(nk - 1, std::true_type{});                       // ragged K: the slots beyond K multiply zeros
+  else kstep(nk - 1, std::false_type{});
   // ---- epilogue: one half of the tile rows (one wm) per pass through an fp32 LDS tile -------------------------------------
   constexpr int LDC = BN + 4;
   constexpr int EP = (TM * 16 * LDC * 4 <= NST * STAGE) ? 1 : 2;      // sub-passes over a wave's row tiles when the whole half does not fit
