@@ -204,3 +204,16 @@ def test_tf_token_pool_index_formula():
                 src = 8 * w + 2 * s_
                 ref = red(torch.stack([x[:, src], x[:, src + 1], x[:, src + 4], x[:, src + 5]]))
                 assert torch.allclose(got[:, m], ref, atol=1e-6), (N, mode, m)
+
+
+def test_no_mixed_opcode_mfma_accumulator_chain_in_the_recompute_sweeps():
+    """tools/probe/mfma_chain_probe.hip (round 4): on gfx950, as hipcc 7.2 schedules them, a v_mfma_f32_16x16x16_bf16 whose
+    accumulator input is the result of a v_mfma_f32_16x16x32_bf16 a few instructions earlier (or the other way round) reads a
+    stale accumulator - wrong sums, no diagnostic (profiles/r04_mfma_chain_probe.txt).  vu_flash.hip is the one file that uses
+    both opcodes; its generated code must not contain that pattern (tools/mfma_chain_scan.py compiles it with hipcc -S)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "mfma_chain_scan.py"), os.path.join(root, "vit-unet_amd", "csrc", "vu_flash.hip")],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "MFMA_CHAIN_SCAN CLEAN" in r.stdout, r.stdout + r.stderr

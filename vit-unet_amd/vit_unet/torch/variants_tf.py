@@ -433,6 +433,13 @@ class HViT_UNet(nn.Module):
         assert resampling_type in ["max", "avg", "standard"], "Resampling type must be either 'max', 'avg' or 'standard'."
         assert all(img_size % p == 0 for p in patch_size), "Patch sizes must divide image size."
         assert all(patch_size[i] < patch_size[i + 1] for i in range(len(patch_size) - 1)), "Patch sizes must be a strictly increasing sequence."
+        if resampling_type in ("max", "avg"):
+            # tf/model.py:24-26 builds the decoder's Resampling on the REVERSED patch sizes, where num_patches[0] // num_patches[1]
+            # is 0 (tf/functions.py:77): the reference model cannot be assembled with a pooling type either (it fails inside the
+            # Keras pooling layer).  Said here, instead of through an assertion about pool sizes further down.
+            raise NotImplementedError("HViT_UNet(resampling_type='max' / 'avg'): the decoder would pool with pool_size 0 "
+                                      "(tf/functions.py:77 on the reversed patch sizes) - the reference model cannot be built this "
+                                      "way either; use 'standard'.  The Resampling LAYER supports 'max' / 'avg' for merging levels.")
         assert (resampling_type in ["max", "avg"] and projection_dim is not None) or (resampling_type == "standard" and projection_dim is None), \
             "If resampling_type is in ['max', 'avg'], projection_dim must be specified. If resampling_type is 'standard', projection_dim is automatically computed."
         if not original_attn:
