@@ -11,7 +11,7 @@ struct vu_flash_args {
   void* O;                     // (B,N,D) bf16: A^ v, heads re-concatenated (model.py:161)
   float* lse2;                 // (B,H,N): log2-domain log-sum-exp of the scaled logits, kept for the backward
   float* rinv;                 // (B,H,N): 1 / (row sum of the probabilities as every sweep recomputes them from lse2), kept for the backward
-  float* pk;                   // (B,N,D) fp32: sum_k P k per head (H = 8 training forward writes it, the backward's dq sweep reads it)
+  float* pk;                   // (B,N,D) fp32: sum_k bf16(P) k per head (the training forward writes it, the backward's fused delta + dq sweep reads it; null: separate sweeps)
   float* partials;             // >= vu_flash_partials_floats()
   float* stats;                // VU_BN_STATS_FLOATS(H): folded tables (vu_kernels.h)
   const float *mix_w, *mix_b, *bn_w, *bn_b;

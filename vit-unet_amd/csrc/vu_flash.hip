@@ -36,6 +36,11 @@ namespace {
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 
+// waves per SIMD the 4-head backward sweeps are compiled for (A/B: -DVU_FLASH_V1_W4=2 restores the 8-head value)
+#ifndef VU_FLASH_V1_W4
+#define VU_FLASH_V1_W4 4
+#endif
+#define VU_FLASH_V1_WAVES(H) ((H) == 4 ? VU_FLASH_V1_W4 : 2)
 template <int H, int DH> struct FC {
   static constexpr int D = H * DH;
   static constexpr int PITCH = D + 8;            // LDS row pitch of a (token x feature) chunk, elements: 16 B of (zeroed) pad
@@ -244,7 +249,7 @@ __device__ __forceinline__ void work_item(int id, int B, int per, int& b, int& g
 template <int H, int DH, int WPB, int CK>
 __global__ __launch_bounds__(WPB * 64) void flash_stats_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                                float* __restrict__ lse2, float* __restrict__ rinv,
-                                                               float* __restrict__ partials, int B, int N,
+                                                               float* __restrict__ partials, float* __restrict__ pk_out, int B, int N,
                                                                float c, vu_rng rng_in, int want_moments) {
   typedef FC<H, DH> C;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -268,7 +273,9 @@ __global__ __launch_bounds__(WPB * 64) void flash_stats_kernel(const bf16_t* __r
   float mx[H], sm[H];
 #pragma unroll
   for (int h = 0; h < H; ++h) { mx[h] = -3.0e38f; sm[h] = 0.f; }
-  // sweep 1: row maxima of the raw logits
+  // sweep 1 (round 4: ONE pass instead of a maxima pass and a sums pass - the recurrence of flash_rowstats_kernel): every lane
+  // carries a running (max, sum) pair per head over its own keys in the log2 domain and rescales the sum when its maximum moves;
+  // the four lane groups of a query are merged at the end (every lane ends up with the row's pair)
   for (int ch = 0; ch < nchunks; ++ch) {
     const int nt = min(CK, ntiles - ch * CK);
     __syncthreads();
@@ -279,40 +286,32 @@ __global__ __launch_bounds__(WPB * 64) void flash_stats_kernel(const bf16_t* __r
         f32x4 acc[H];
         tile_logits<H, DH>(acc, Kc, kc, qf, l15, g4);
 #pragma unroll
-        for (int h = 0; h < H; ++h) mx[h] = fmaxf(fmaxf(mx[h], fmaxf(acc[h][0], acc[h][1])), fmaxf(acc[h][2], acc[h][3]));
-      }
-  }
+        for (int h = 0; h < H; ++h) {
+          const float tm = fmaxf(fmaxf(acc[h][0], acc[h][1]), fmaxf(acc[h][2], acc[h][3])) * c;      // c > 0
+          const float mn = fmaxf(mx[h], tm);
+          float a = sm[h] * fexp2(mx[h] - mn);
 #pragma unroll
-  for (int h = 0; h < H; ++h) {
-    mx[h] = fmaxf(mx[h], __shfl_xor(mx[h], 16, 64));
-    mx[h] = fmaxf(mx[h], __shfl_xor(mx[h], 32, 64));
-    mx[h] *= c;                                                   // c > 0: max and scale commute
-  }
-  // sweep 2: row sums of exp2(c s - max)
-  for (int ch = 0; ch < nchunks; ++ch) {
-    const int nt = min(CK, ntiles - ch * CK);
-    __syncthreads();
-    load_chunk<H, DH>(Kc, kb + (long long)ch * CK * 16 * C::D, nt * 16, tid, WPB * 64);
-    __syncthreads();
-    if (active)
-      for (int kc = 0; kc < nt; ++kc) {
-        f32x4 acc[H];
-        tile_logits<H, DH>(acc, Kc, kc, qf, l15, g4);
-#pragma unroll
-        for (int h = 0; h < H; ++h)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) sm[h] += fexp2(fmaf(acc[h][r], c, -mx[h]));
+          for (int r = 0; r < 4; ++r) a += fexp2(fmaf(acc[h][r], c, -mn));
+          sm[h] = a;
+          mx[h] = mn;
+        }
       }
   }
   float lse[H];
 #pragma unroll
   for (int h = 0; h < H; ++h) {
-    sm[h] += __shfl_xor(sm[h], 16, 64);
-    sm[h] += __shfl_xor(sm[h], 32, 64);
-    lse[h] = mx[h] + log2f(sm[h]);
+    float m = mx[h], s_ = sm[h];
+#pragma unroll
+    for (int o = 16; o <= 32; o <<= 1) {
+      const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s_, o, 64);
+      const float mn = fmaxf(m, m2);
+      s_ = s_ * fexp2(m - mn) + s2 * fexp2(m2 - mn);
+      m = mn;
+    }
+    lse[h] = m + log2f(s_);
     if (active && g4 == 0) {
       lse2[((long long)b * H + h) * N + qrow] = lse[h];
-      rinv[((long long)b * H + h) * N + qrow] = 1.0f / (sm[h] * fexp2(mx[h] - lse[h]));      // (row_norm_note below)
+      rinv[((long long)b * H + h) * N + qrow] = 1.0f / (s_ * fexp2(m - lse[h]));      // (row_norm_note below; overwritten with 1 / sum_k bf16(P) when pk_out)
     }
   }
   if (!want_moments) return;                                      // (uniform: eval mode needs the row statistics only)
@@ -323,6 +322,17 @@ __global__ __launch_bounds__(WPB * 64) void flash_stats_kernel(const bf16_t* __r
   for (int h = 0; h < H; ++h) s1[h] = 0.f;
 #pragma unroll
   for (int i = 0; i < H * (H + 1) / 2; ++i) s2[i] = 0.f;
+  // pk_out (round 4): V = sum_k bf16(P) k per head and s_b = sum_k bf16(P) (row_norm_note) ride on this sweep, as in the 8-head
+  // form's moments sweep, so that the backward forms dq in its delta sweep (dq = scale (U - delta~ V), flash_bwd_delta_kernel<DQ>)
+  const bool want_pk = pk_out != nullptr;          // (kernel-uniform)
+  f32x4 pacc[H][C::DT];
+  float sb[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    sb[h] = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt) pacc[h][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   const float cen = 1.0f / (float)N;
   const uint32_t hstride = (uint32_t)(((unsigned long long)N * N) >> 2);          // quad words per (sample, head) map
   const uint32_t wlane = (uint32_t)((((unsigned long long)b * N + qrow) * (unsigned long long)N) >> 2) + (uint32_t)g4;
@@ -342,10 +352,20 @@ __global__ __launch_bounds__(WPB * 64) void flash_stats_kernel(const bf16_t* __r
           keep4_t kp;
           kp.thr = rng.thr;
           kp.w = rng.thr ? vu_quad_head(base, base_sh, h) : 0u;
+          f32x4 pu;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float p = fexp2(fmaf(acc[h][r], c, -lse[h]));
+            pu[r] = p;
             acc[h][r] = kept(kp, r) ? fmaf(p, rng.inv_keep, -cen) : -cen;
+          }
+          if (want_pk) {           // a logits-shaped tile is the B operand of a key-contracting product as it stands
+            const s16x4 bop = pack4s(pu);
+            const u32x2_t bw = __builtin_bit_cast(u32x2_t, bop);
+            sb[h] = sum2_bf16(bw[1], sum2_bf16(bw[0], sb[h]));
+#pragma unroll
+            for (int dt = 0; dt < C::DT; ++dt)
+              pacc[h][dt] = mfma16(tr_operand<C::PITCH>(Kc, kc * 16, h * DH + 16 * dt, l15, g4), bop, pacc[h][dt]);
           }
         }
         int idx = 0;
@@ -358,6 +378,21 @@ __global__ __launch_bounds__(WPB * 64) void flash_stats_kernel(const bf16_t* __r
             for (int r = 0; r < 4; ++r) s2[idx] = fmaf(acc[h][r], acc[h2][r], s2[idx]);
         }
       }
+  }
+  if (want_pk) {
+    float* prow = pk_out + ((long long)b * N + qrow) * C::D;
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+#pragma unroll
+      for (int dt = 0; dt < C::DT; ++dt) {
+        const int f = 16 * dt + 4 * g4;              // accumulator row = head feature, column = query l15
+        if (active && f < DH) *reinterpret_cast<f32x4*>(prow + h * DH + f) = pacc[h][dt];
+      }
+      float x = sb[h];                                // the four lane groups of a query hold its four key quarters
+      x += __shfl_xor(x, 16, 64);
+      x += __shfl_xor(x, 32, 64);
+      if (active && g4 == 0) rinv[((long long)b * H + h) * N + qrow] = 1.0f / x;
+    }
   }
   // wave -> workgroup -> one partial row per workgroup
   __syncthreads();
@@ -799,11 +834,17 @@ __device__ __forceinline__ f32x4 mix_back(const f32x4 (&E)[H], const RowW<H>& w)
 }
 
 // ---- sweep 1 (q-major): delta_h[i] and the head-mix gradient sums ---------------------------------------------------
-template <int H, int DH, int WPB, int CK>
-__global__ __launch_bounds__(WPB * 64, 2) void flash_bwd_delta_kernel(
+// DQ (round 4; the training backward when the forward saved V = sum_k bf16(P) k): dq leaves the SAME sweep.  dS = P~ dP~ - P delta
+// needs delta of the whole row, so the sweep accumulates U = sum_k bf16(u) k (u = P~ dP~) and uses V from the forward:
+// dq = scale (U - delta~ V) with delta~ = sum_k bf16(u) * rinv, rinv = 1 / sum_k bf16(P): the coefficients bf16(u) - delta~ bf16(P)
+// sum to zero exactly, as the row-wise softmax backward requires (row_norm_note).  The delta written for the dk sweep stays
+// sum_k u * rinv.  One whole chain rebuild (flash_bwd_dq_kernel) less per module.
+template <int H, int DH, int WPB, int CK, bool DQ = false>
+__global__ __launch_bounds__(WPB * 64, VU_FLASH_V1_WAVES(H)) void flash_bwd_delta_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, const bf16_t* __restrict__ dO,
     const float* __restrict__ lse2, const float* __restrict__ rinv, const float* __restrict__ stats, float* __restrict__ delta,
-    float* __restrict__ partials, int B, int N, float c, vu_rng rng_in) {
+    float* __restrict__ partials, int B, int N, float c, vu_rng rng_in, const float* __restrict__ pkv = nullptr,
+    bf16_t* __restrict__ dq = nullptr, float scale = 0.f) {
   typedef FC<H, DH> C;
   constexpr int NT = H * H + H;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -831,6 +872,16 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash_bwd_delta_kernel(
   for (int h = 0; h < H; ++h) { lse[h] = lse2[((long long)b * H + h) * N + qrow]; dl[h] = 0.f; Tc[h] = 0.f; }
 #pragma unroll
   for (int i = 0; i < H * H; ++i) T[i] = 0.f;
+  float dlb[DQ ? H : 1];
+  f32x4 dqa[DQ ? H : 1][C::DT];
+  if constexpr (DQ) {
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      dlb[h] = 0.f;
+#pragma unroll
+      for (int dt = 0; dt < C::DT; ++dt) dqa[h][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
   zero_pads<H, DH>(Kc, 2 * CK * 16 + WPB * 32, tid, WPB * 64);
   load_bwd_tab<H>(tb, stats, tid, WPB * 64);
   const uint32_t hstride = (uint32_t)(((unsigned long long)N * N) >> 2);          // quad words per (sample, head) map
@@ -859,13 +910,28 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash_bwd_delta_kernel(
           RowW<H> wnxt = wcur;
           if (h + 1 < H) wnxt = ld_row<H>(tb->FWkT + (h + 1) * H);
           LDS_FENCE();
+          s16x4 aop[C::DT];
+          if constexpr (DQ) {
+#pragma unroll
+            for (int dt = 0; dt < C::DT; ++dt) aop[dt] = tr_operand<C::PITCH>(Kc, kc * 16, h * DH + 16 * dt, l15, g4);
+            LDS_FENCE();
+          }
           const f32x4 dp = mix_back<H>(E, wcur);
+          f32x4 u;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float ph = fmaxf(S[h][r], 0.f);
-            dl[h] = fmaf(ph, dp[r], dl[h]);
+            u[r] = ph * dp[r];
+            dl[h] += u[r];
 #pragma unroll
             for (int g = 0; g < H; ++g) T[g * H + h] = fmaf(E[g][r], ph, T[g * H + h]);
+          }
+          if constexpr (DQ) {
+            const s16x4 bop = pack4s(u);
+            const u32x2_t bw = __builtin_bit_cast(u32x2_t, bop);
+            dlb[h] = sum2_bf16(bw[1], sum2_bf16(bw[0], dlb[h]));
+#pragma unroll
+            for (int dt = 0; dt < C::DT; ++dt) dqa[h][dt] = mfma16(aop[dt], bop, dqa[h][dt]);       // U_h^T += K_h^T bf16(u_h)^T
           }
           wcur = wnxt;
         }
@@ -875,7 +941,29 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash_bwd_delta_kernel(
   for (int h = 0; h < H; ++h) {
     dl[h] += __shfl_xor(dl[h], 16, 64);
     dl[h] += __shfl_xor(dl[h], 32, 64);
-    if (active && g4 == 0) delta[((long long)b * H + h) * N + qrow] = dl[h] * rinv[((long long)b * H + h) * N + qrow];      // row_norm_note
+    const float rs = rinv[((long long)b * H + h) * N + qrow];                                                               // row_norm_note
+    if (active && g4 == 0) delta[((long long)b * H + h) * N + qrow] = dl[h] * rs;
+    if constexpr (DQ) {
+      float db = dlb[h];
+      db += __shfl_xor(db, 16, 64);
+      db += __shfl_xor(db, 32, 64);
+      const float dt_ = db * rs;                                                    // delta~ of (query l15, head h): in every lane group
+      if (active) {
+        bf16_t* orow = dq + ((long long)b * N + qrow) * C::D;
+        const float* vrow = pkv + ((long long)b * N + qrow) * C::D;
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) {
+          const int f = 16 * dt + 4 * g4;                                           // accumulator row = head feature, column = query
+          if (f < DH) {
+            const f32x4 pv = *reinterpret_cast<const f32x4*>(vrow + h * DH + f);
+            f32x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = scale * fmaf(-dt_, pv[r], dqa[h][dt][r]);
+            *reinterpret_cast<bf16x4*>(orow + h * DH + f) = pack4(o);
+          }
+        }
+      }
+    }
   }
   __syncthreads();
 #pragma unroll
@@ -1018,7 +1106,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash_bwd_dq_kernel(
 // the packed tile goes through a 512-byte wave-private LDS image [query][key] and comes back through the transposing
 // read as the B operand (k = query, column = key); the A operand is the transposing read of the Q / dO chunk.
 template <int H, int DH, int WPB, int CK, bool DV>
-__global__ __launch_bounds__(WPB * 64, 2) void flash_bwd_dkv_kernel(
+__global__ __launch_bounds__(WPB * 64, VU_FLASH_V1_WAVES(H)) void flash_bwd_dkv_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, const bf16_t* __restrict__ dO,
     const float* __restrict__ lse2, const float* __restrict__ delta, const float* __restrict__ stats, bf16_t* __restrict__ out,
     int B, int N, float c, float scale, vu_rng rng_in) {
@@ -2306,14 +2394,29 @@ int launch_backward(const vu_flash_args& a, hipStream_t st) {
   VU_TRY(reserve_lds(k1, lds1)); VU_TRY(reserve_lds(k2, lds2)); VU_TRY(reserve_lds(k3, lds3)); VU_TRY(reserve_lds(k4, lds4));
   const double E = (double)a.B * H * a.N * a.N, act = (double)a.B * a.N * C::D * 2.0;
   const bf16_t *q = (const bf16_t*)a.q, *k = (const bf16_t*)a.k, *v = (const bf16_t*)a.v, *dO = (const bf16_t*)a.dO;
-  hipLaunchKernelGGL(k1, dim3(nblk), dim3(WPB * 64), lds1, st, q, k, v, dO, a.lse2, a.rinv, a.stats, a.delta, a.partials, a.B, a.N, c, a.rng);
-  if (vu_prof_on()) vu_prof_note("flash_bwd_delta_kernel", 4.0 * E * DH + 6.0 * E * H, 4.0 * act);
+  // the training backward behind a forward that saved V = sum_k bf16(P) k: dq leaves the delta sweep (VU_FLASH_FUSE_DQ=0: the
+  // separate dq sweep of rounds 2 - 3, for the A/B record)
+  static const bool fuse_off = [] { const char* e = getenv("VU_FLASH_FUSE_DQ"); return e && e[0] == '0'; }();
+  const bool fused = a.pk != nullptr && a.training && !fuse_off;
+  if (fused) {
+    auto k1q = flash_bwd_delta_kernel<H, DH, WPB, CK2, true>;
+    VU_TRY(reserve_lds(k1q, lds1));
+    hipLaunchKernelGGL(k1q, dim3(nblk), dim3(WPB * 64), lds1, st, q, k, v, dO, a.lse2, a.rinv, a.stats, a.delta, a.partials, a.B, a.N, c, a.rng,
+                       (const float*)a.pk, (bf16_t*)a.dq, a.scale);
+    if (vu_prof_on()) vu_prof_note("flash_bwd_delta_dq_kernel", 6.0 * E * DH + 6.0 * E * H, 6.0 * act);
+  } else {
+    hipLaunchKernelGGL(k1, dim3(nblk), dim3(WPB * 64), lds1, st, q, k, v, dO, a.lse2, a.rinv, a.stats, a.delta, a.partials, a.B, a.N, c, a.rng,
+                       (const float*)nullptr, (bf16_t*)nullptr, 0.f);
+    if (vu_prof_on()) vu_prof_note("flash_bwd_delta_kernel", 4.0 * E * DH + 6.0 * E * H, 4.0 * act);
+  }
   VU_TRY(vu_check_launch("flash_bwd_delta"));
   hipLaunchKernelGGL(flash_bwd_mix_finalize_kernel, dim3((unsigned)((H * H + H + 15) / 16)), dim3(1024), 0, st, a.partials, nblk, a.stats, a.d_mix_w, a.d_mix_b, H, a.rng.inv_keep);
   VU_TRY(vu_check_launch("flash_bwd_mix_finalize"));
-  hipLaunchKernelGGL(k2, dim3(nblk), dim3(WPB * 64), lds2, st, q, k, v, dO, a.lse2, a.delta, a.stats, (bf16_t*)a.dq, a.B, a.N, c, a.scale, a.rng);
-  if (vu_prof_on()) vu_prof_note("flash_bwd_dq_kernel", 6.0 * E * DH + 4.0 * E * H, 5.0 * act);
-  VU_TRY(vu_check_launch("flash_bwd_dq"));
+  if (!fused) {
+    hipLaunchKernelGGL(k2, dim3(nblk), dim3(WPB * 64), lds2, st, q, k, v, dO, a.lse2, a.delta, a.stats, (bf16_t*)a.dq, a.B, a.N, c, a.scale, a.rng);
+    if (vu_prof_on()) vu_prof_note("flash_bwd_dq_kernel", 6.0 * E * DH + 4.0 * E * H, 5.0 * act);
+    VU_TRY(vu_check_launch("flash_bwd_dq"));
+  }
   hipLaunchKernelGGL(k3, dim3(nblk), dim3(WPB * 64), lds3, st, q, k, v, dO, a.lse2, a.delta, a.stats, (bf16_t*)a.dk, a.B, a.N, c, a.scale, a.rng);
   if (vu_prof_on()) vu_prof_note("flash_bwd_dk_kernel", 6.0 * E * DH + 4.0 * E * H, 5.0 * act);
   VU_TRY(vu_check_launch("flash_bwd_dk"));
@@ -2341,9 +2444,9 @@ int launch_forward(const vu_flash_args& a, hipStream_t st) {
     vu_set_error("flash attention: cannot reserve %zu bytes of LDS", lds2); return VU_ELAUNCH;
   }
   const double E = (double)a.B * H * a.N * a.N, act = (double)a.B * a.N * C::D * 2.0;
-  hipLaunchKernelGGL(k1, dim3(nblk), dim3(WPB * 64), lds1, st, (const bf16_t*)a.q, (const bf16_t*)a.k, a.lse2, a.rinv, a.partials, a.B, a.N, c,
-                     a.rng, a.training);
-  if (vu_prof_on()) vu_prof_note("flash_stats_kernel", (a.training ? 3.0 : 2.0) * 2.0 * E * DH, 2.0 * act);
+  hipLaunchKernelGGL(k1, dim3(nblk), dim3(WPB * 64), lds1, st, (const bf16_t*)a.q, (const bf16_t*)a.k, a.lse2, a.rinv, a.partials,
+                     a.training ? a.pk : (float*)nullptr, a.B, a.N, c, a.rng, a.training);
+  if (vu_prof_on()) vu_prof_note("flash_stats_kernel", (a.training ? (a.pk ? 3.0 : 2.0) : 1.0) * 2.0 * E * DH, 2.0 * act);
   VU_TRY(vu_check_launch("flash_stats"));
   hipLaunchKernelGGL(flash_bn_finalize_kernel, dim3(1), dim3(1024), 0, st, a.partials, nblk, a.mix_w, a.mix_b, a.bn_w, a.bn_b, a.run_mean,
                      a.run_var, a.stats, H, a.N, (double)a.B * a.N * a.N, a.training, 0.1f, 1e-5f, a.rng.inv_keep, 0);
@@ -2540,6 +2643,7 @@ int launch_backward_v2(const vu_flash_args& a, hipStream_t st) {
   do {                                                                                 \
     const int dh_ = a.D / a.H;                                                         \
     if (a.H == 4 && dh_ == 32) return FN<4, 32>(__VA_ARGS__);                         \
+    if (a.H == 4 && dh_ == 16) return FN<4, 16>(__VA_ARGS__);                         \
     vu_set_error("flash attention: shape H=%d d=%d not instantiated", a.H, dh_);      \
     return VU_EUNSUPPORTED;                                                            \
   } while (0)
@@ -2554,7 +2658,7 @@ bool vu_flash_pays(int B, int N) { return (long long)B * ((N / 16 + 3) / 4) >= 1
 bool vu_flash_ok(int dtype, int B, int N, int D, int H) {
   if (dtype != 1 || H <= 0 || D % H != 0) return false;
   const int dh = D / H;
-  const bool inst = (H == 8 && (dh == 24 || dh == 8 || dh == 32)) || (H == 4 && dh == 32);
+  const bool inst = (H == 8 && (dh == 24 || dh == 8 || dh == 32)) || (H == 4 && (dh == 32 || dh == 16));
   // the dropout word index of a map element (one word per 4 keys) must fit 32 bits: B H N N < 2^34
   return inst && N % 16 == 0 && N >= 256 && (double)B * H * N * N < 17179869184.0;
 }

@@ -8,6 +8,9 @@ int vu_gemm_launch(int dtype, int c_float, vu_gemm_args g, hipStream_t st);
 
 // a1-a4: token re-tiling of one latent image between patch sizes (image layout = patch size im).
 // in_f32 / out_f32: the tensor is fp32 regardless of dtype (model input / output side).
+// (rows, H, dh_src) -> (rows, H, dh_dst) bf16, per head: the first min(dh_src, dh_dst) features copied, the rest of dst zero (head dims
+// that are multiples of 4).  n <= 4 tensors in one launch.  The recompute attention's zero-padded operands (vu_model.hip, flash_padded).
+int vu_k_head_pad(const void* const* src, void* const* dst, int n, long long rows, int H, int dh_src, int dh_dst, hipStream_t st);
 int vu_k_retile(int dtype, int in_f32, int out_f32, const void* in, void* out, const float* pos,
                 int B, int C, int im, int s_in, int s_out, hipStream_t st);
 // out[r] += sum_b in[b*P + r]   (positional-embedding gradient)

@@ -91,6 +91,29 @@ int vu_k_retile(int dtype, int in_f32, int out_f32, const void* in, void* out, c
   return vu_check_launch("vu_retile");
 }
 
+struct HeadPadArgs { const bf16_t* src[4]; bf16_t* dst[4]; };
+__global__ __launch_bounds__(256) void head_pad_kernel(const HeadPadArgs a, long long groups, int gs, int gd) {
+  const bf16_t* __restrict__ src = a.src[blockIdx.y];
+  bf16_t* __restrict__ dst = a.dst[blockIdx.y];
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < groups; t += (long long)gridDim.x * blockDim.x) {
+    const long long rh = t / gd;                       // (row, head)
+    const int g = (int)(t - rh * gd);                  // 4-feature group of the destination head
+    uint2 v = make_uint2(0u, 0u);
+    if (g < gs) v = *reinterpret_cast<const uint2*>(src + (rh * gs + g) * 4);
+    *reinterpret_cast<uint2*>(dst + t * 4) = v;
+  }
+}
+int vu_k_head_pad(const void* const* src, void* const* dst, int n, long long rows, int H, int dh_src, int dh_dst, hipStream_t st) {
+  VU_REQUIRE(n >= 1 && n <= 4 && rows > 0 && H > 0 && dh_src > 0 && dh_dst > 0 && dh_src % 4 == 0 && dh_dst % 4 == 0, "vu_head_pad: bad argument");
+  HeadPadArgs a;
+  for (int i = 0; i < 4; ++i) { a.src[i] = (const bf16_t*)(i < n ? src[i] : src[0]); a.dst[i] = (bf16_t*)(i < n ? dst[i] : dst[0]); }
+  for (int i = 0; i < n; ++i) VU_REQUIRE(a.src[i] && a.dst[i] && !(((uintptr_t)a.src[i] | (uintptr_t)a.dst[i]) & 7), "vu_head_pad: null or misaligned tensor");
+  const long long groups = rows * H * (dh_dst / 4);
+  hipLaunchKernelGGL(head_pad_kernel, dim3(grid_for(groups), n), dim3(256), 0, st, a, groups, dh_src / 4, dh_dst / 4);
+  if (vu_prof_on()) vu_prof_note("head_pad_kernel", 0.0, (double)n * rows * H * (dh_src + dh_dst) * 2.0);
+  return vu_check_launch("vu_head_pad");
+}
+
 template <typename T>
 __global__ void batch_sum_kernel(const T* __restrict__ in, float* __restrict__ out, int B, long long P) {
   const long long r = (blockIdx.x * (long long)blockDim.x + threadIdx.x) * 4;

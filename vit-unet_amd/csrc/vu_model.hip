@@ -148,14 +148,22 @@ int build_plan(const vu_config& c, Plan& pl) {
 // ---------------------------------------------------------------------------------------------
 // ReAttention / SkipConnection
 // ---------------------------------------------------------------------------------------------
-struct AttnBuf { void *q, *k, *v, *Ps, *Ah, *O; float* stats; float *lse2, *rinv, *delta, *pk; };
-struct AttnScratch { void *dO, *dq, *dk, *dv, *dA; float* partials; int nblocks; };
+struct AttnBuf { void *q, *k, *v, *Ps, *Ah, *O; float* stats; float *lse2, *rinv, *delta, *pk; void *qp = nullptr, *kp = nullptr, *vp = nullptr, *Op = nullptr; };
+struct AttnScratch { void *dO, *dq, *dk, *dv, *dA; float* partials; int nblocks; void* pad = nullptr; };
 
 struct AttnDims { int dtype, B, N, D, H, C, s, ld; int centered = 0; int flash = 0; };
 // non-materialising form (vu_flash.hip): the maps are recomputed from q, k (and v, dO) in every pass
 // flash: 0 = never, 1 = wherever the shape is covered, 2 = covered AND the launch fills enough of the chip (vu_flash_pays)
+// Head dims the recompute kernels do not take (they want a multiple of 8) run on ZERO-PADDED copies of q, k, v (and dO): Lite's
+// finest level has 4 heads of 12 features (N = 3136, D = 48) and runs as d = 16.  The pad features add 0 to every logit and meet
+// zero columns of v / dO, so O, dq, dk, dv of the real features are what the unpadded arithmetic gives and the pad features of
+// the results are 0 (dropped on the way back); the scale stays 12^-0.5.  Four small copies forward, seven backward (~10 MB each
+// at 32 images) against map passes of 2.5 GB each in the materialised form.
+inline int flash_dh(const AttnDims& d) { const int dh = d.D / d.H; return (d.H == 4 && dh == 12) ? 16 : dh; }
+inline int flash_D(const AttnDims& d) { return flash_dh(d) * d.H; }
+inline bool flash_padded(const AttnDims& d) { return flash_D(d) != d.D; }
 inline bool flash_on(const AttnDims& d) {
-  return d.flash && vu_flash_ok(d.dtype, d.B, d.N, d.D, d.H) && (d.flash == 1 || vu_flash_pays(d.B, d.N));
+  return d.flash && vu_flash_ok(d.dtype, d.B, d.N, flash_D(d), d.H) && (d.flash == 1 || vu_flash_pays(d.B, d.N));
 }
 // Which attention form runs is a PROCESS-LEVEL setting (vu_set_attn_form, include/vit_unet_amd.h): -1 = per level by the
 // fill rule (model path) / materialised (stand-alone op), 0 = never the recompute form, 1 = wherever the shape is covered.
@@ -195,7 +203,11 @@ void carve_attn(Bump& bp, const AttnDims& d, AttnBuf& a) {
   a.lse2 = bp.takef((size_t)d.B * d.H * d.N);
   a.rinv = bp.takef((size_t)d.B * d.H * d.N);
   a.delta = bp.takef((size_t)d.B * d.H * d.N);
-  a.pk = (flash_on(d) && d.H == 8) ? bp.takef((size_t)d.B * d.N * d.D) : nullptr;     // sum_k P k of the recompute form (vu_flash.h)
+  a.pk = flash_on(d) ? bp.takef((size_t)d.B * d.N * flash_D(d)) : nullptr;     // sum_k P k of the recompute form (vu_flash.h)
+  if (flash_on(d) && flash_padded(d)) {      // zero-padded q, k, v (kept for the backward) and O of the recompute form
+    const size_t actp = (size_t)d.B * d.N * flash_D(d) * esize(d.dtype);
+    a.qp = bp.take(actp); a.kp = bp.take(actp); a.vp = bp.take(actp); a.Op = bp.take(actp);
+  } else { a.qp = a.kp = a.vp = a.Op = nullptr; }
 }
 inline size_t attn_partials_floats(const AttnDims& d) {
   return std::max((size_t)std::max(stats_blocks(d), d.B) * 2 * d.H + 1024, vu_flash_partials_floats(d.B, d.N, d.H));
@@ -223,7 +235,17 @@ int attn_forward(const AttnDims& d, const vu_attn_params& p, const void* xq, con
   if (flash_on(d)) {   // O = A^ v without ever forming a map
     vu_flash_args fa;
     fill_flash_args(fa, d, p, a, partials, ra, training);
-    VU_TRY(vu_k_flash_forward(fa, st));
+    if (flash_padded(d)) {
+      VU_REQUIRE(a.qp && a.Op, "attention: the padded recompute form needs its padded buffers (workspace carved for another form)");
+      const void* src[4] = {a.q, a.k, a.v, nullptr};
+      void* dst[4] = {a.qp, a.kp, a.vp, nullptr};
+      VU_TRY(vu_k_head_pad(src, dst, 3, npatch, H, dh, flash_dh(d), st));
+      fa.D = flash_D(d); fa.q = a.qp; fa.k = a.kp; fa.v = a.vp; fa.O = a.Op;
+      VU_TRY(vu_k_flash_forward(fa, st));
+      const void* s2[4] = {a.Op, nullptr, nullptr, nullptr};
+      void* d2[4] = {a.O, nullptr, nullptr, nullptr};
+      VU_TRY(vu_k_head_pad(s2, d2, 1, npatch, H, flash_dh(d), dh, st));
+    } else VU_TRY(vu_k_flash_forward(fa, st));
   } else {
   int fused = vu_k_attn_scores(dt, a.q, a.k, a.Ps, B, N, D, H, ld, 1.0f / sqrtf((float)dh), ra, st);
   if (fused < 0) return fused;
@@ -352,6 +374,20 @@ int attn_backward(const AttnDims& d, const vu_attn_params& p, const vu_attn_grad
     vu_flash_args fa;
     fill_flash_args(fa, d, p, a, sc.partials, ra, training);
     fa.dO = sc.dO; fa.dq = sc.dq; fa.dk = sc.dk; fa.dv = sc.dv; fa.d_mix_w = gr.mix_w; fa.d_mix_b = gr.mix_b;
+    if (flash_padded(d)) {      // (a.qp, a.kp, a.vp: the forward's padded copies)
+      VU_REQUIRE(a.qp && sc.pad, "attention: the padded recompute form needs its padded buffers (workspace carved for another form)");
+      const size_t actp = vu_align_up((size_t)rows * flash_D(d) * esize(dt), 256);
+      char* pb = (char*)sc.pad;
+      const void* src[4] = {sc.dO, nullptr, nullptr, nullptr};
+      void* dst[4] = {pb, nullptr, nullptr, nullptr};
+      VU_TRY(vu_k_head_pad(src, dst, 1, rows, H, dh, flash_dh(d), st));
+      fa.D = flash_D(d); fa.q = a.qp; fa.k = a.kp; fa.v = a.vp; fa.O = a.Op;
+      fa.dO = pb; fa.dq = pb + actp; fa.dk = pb + 2 * actp; fa.dv = pb + 3 * actp;
+      VU_TRY(vu_k_flash_backward(fa, st));
+      const void* s2[4] = {fa.dq, fa.dk, fa.dv, nullptr};
+      void* d2[4] = {sc.dq, sc.dk, sc.dv, nullptr};
+      VU_TRY(vu_k_head_pad(s2, d2, 3, rows, H, flash_dh(d), dh, st));
+    } else
     VU_TRY(vu_k_flash_backward(fa, st));
     if (sl) VU_TRY(lane_wait(sl, 1, st, sw));           // dq, dk, dv are ready
     VU_TRY(vu_k_conv3x3_qkv_wgrad(dt, sc.dq, sc.dk, sc.dv, xq, xkv, gr.wq, gr.wk, gr.wv, npatch, d.C, d.s, sw));
@@ -473,18 +509,20 @@ void carve_model(const Plan& pl, int B, char* base, ModelWS& w) {
   w.img = bp.take(act);
   w.y_attn = bp.take(act); w.f_ff = bp.take(act);
   w.gx0 = bp.take(act); w.gx1 = bp.take(act); w.ga = bp.take(act); w.gb = bp.take(act); w.gc = bp.take(act);
-  size_t hh = 0, map = 0, npart = 0;
+  size_t hh = 0, map = 0, npart = 0, padb = 0;
   int nb = 1;
   for (const Level& L : pl.lv) {
     hh = std::max(hh, (size_t)B * L.N * L.hid * esize(dt));
     AttnDims d{dt, B, L.N, L.D, H, c.num_channels, L.s, L.ld, 1, flash_switch()};
     if (!flash_on(d)) map = std::max(map, (size_t)B * H * L.N * L.ld * esize(dt));     // dA^ / dS scratch of the materialised forms
+    else if (flash_padded(d)) padb = std::max(padb, 4 * vu_align_up((size_t)B * L.N * flash_D(d) * esize(dt), 256));   // padded dO, dq, dk, dv
     nb = std::max(nb, stats_blocks(d));
     npart = std::max(npart, attn_partials_floats(d));
   }
   w.gh = bp.take(hh);
   w.asc.dO = bp.take(act); w.asc.dq = bp.take(act); w.asc.dk = bp.take(act); w.asc.dv = bp.take(act);
   w.asc.dA = bp.take(map);
+  w.asc.pad = padb ? bp.take(padb) : nullptr;
   w.asc.nblocks = nb;
   for (int j = 0; j < c.depth; ++j) w.dskip[j] = bp.take(act);
   w.partials = bp.takef(std::max((size_t)std::max(nb, B) * 2 * H + 1024, npart));
@@ -1051,7 +1089,12 @@ int vu_conv3x3_qkv_dgrad(int dtype, const void* dq, const void* dk, const void* 
 
 static void carve_attn_ws(Bump& bp, const AttnDims& d, AttnBuf& a, AttnScratch& sc, void** dzbuf) {
   carve_attn(bp, d, a);
-  if (!a.pk) a.pk = bp.takef((size_t)d.B * d.N * d.D);      // the op's form is chosen after the carve (test switch)
+  if (!a.pk) a.pk = bp.takef((size_t)d.B * d.N * flash_D(d));      // the op's form is chosen after the carve (test switch)
+  if (flash_padded(d) && !a.qp) {
+    const size_t actp = (size_t)d.B * d.N * flash_D(d) * esize(d.dtype);
+    a.qp = bp.take(actp); a.kp = bp.take(actp); a.vp = bp.take(actp); a.Op = bp.take(actp);
+  }
+  sc.pad = flash_padded(d) ? bp.take(4 * vu_align_up((size_t)d.B * d.N * flash_D(d) * esize(d.dtype), 256)) : nullptr;
   const size_t act = (size_t)d.B * d.N * d.D * esize(d.dtype);
   const size_t map = (size_t)d.B * d.H * d.N * d.ld * esize(d.dtype);
   sc.dO = bp.take(act); sc.dq = bp.take(act); sc.dk = bp.take(act); sc.dv = bp.take(act); sc.dA = bp.take(map);
