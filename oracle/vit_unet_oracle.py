@@ -218,7 +218,7 @@ def flash_shape(B: int, N: int, D: int, h: int) -> bool:
     if h <= 0 or D % h:
         return False
     d = D // h
-    inst = (h == 8 and d in (24, 8, 32)) or (h == 4 and d in (32, 16, 12))      # (d = 12: Lite's finest level, run as d = 16 on zero-padded operands)
+    inst = (h == 8 and d in (24, 8, 32)) or (h == 4 and d in (32, 16, 12, 48))      # (d = 12: Lite's finest level, run as d = 16 on zero-padded operands; d = 48: Lite level 1)
     fills = (not FLASH_FILL_RULE) or B * ((N // 16 + 3) // 4) >= 192
     return inst and fills and N % 16 == 0 and N >= 256 and B * h * N * N < 2 ** 34
 

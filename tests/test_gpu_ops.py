@@ -293,7 +293,7 @@ def test_attention_centred_map_form(N, Cn, s, H, mode, attn_form):
 
 
 @pytest.mark.parametrize("N,Cn,s,H", [(784, 3, 8, 8), (1024, 1, 8, 8), (1024, 1, 16, 8), (256, 2, 8, 4), (272, 3, 8, 8), (4096, 1, 8, 8),
-                                      (256, 1, 8, 4),                      # 4 heads, d = 16
+                                      (256, 1, 8, 4), (784, 3, 8, 4),      # 4 heads, d = 16; d = 48 (Lite level 1: two k-steps per logits product)
                                       (784, 3, 4, 4), (3136, 3, 4, 4)])    # 4 heads, d = 12 (Lite level 2): d = 16 on zero-padded operands
 @pytest.mark.parametrize("mode", ["eval", "train", "train_drop"])
 @pytest.mark.parametrize("cross", [False, True])

@@ -94,9 +94,11 @@ struct bg_args {
 
 // TA: A stored (K, M) (m-contiguous); TB: B stored (K, N) (n-contiguous); otherwise k-contiguous (M, K) / (N, K).
 // WM: wave rows (2: 512 threads, one workgroup per CU; 1: 256 threads, two per CU when NST = 2); NST: LDS ring stages
-template <bool TA, bool TB, bool CF, int TM, int TN, int WM, int NST>
-__global__ __launch_bounds__(WM * 256, 2) void bgemm_kernel(const bg_args g) {
-  constexpr int WN = 4, NW = WM * WN, BM = WM * TM * 16, BN = WN * TN * 16;
+// WN: wave columns (4: eight waves of 112 x 48 or four of 112 x 48 / 112 x 32; 2: FOUR waves of 112 x 96, one per SIMD - half the
+// waves re-reading each fragment, 35 % fewer LDS bytes per product, accumulators in the AGPR half of a 512-register budget)
+template <bool TA, bool TB, bool CF, int TM, int TN, int WM, int NST, int WN = 4>
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TM * TN > 24) ? 1 : 2) void bgemm_kernel(const bg_args g) {
+  constexpr int NW = WM * WN, BM = WM * TM * 16, BN = WN * TN * 16;
   constexpr int NPA = BM / 8, NPB = BN / 8, NP = NPA + NPB;               // 1-KiB pieces per stage
   constexpr int STAGE = NP * 1024;
   constexpr int NJ = (NP + NW - 1) / NW;                                   // pieces per wave (the last one only for waves < NP % NW)
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(WM * 256, 2) void bgemm_kernel(const bg_args g) {
   const unsigned lbase = (unsigned)(size_t)smem;
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;          // (WM = 1: wm = 0)
+  const int wm = wave / WN, wn = wave % WN;          // (WM = 1: wm = 0)
   // ---- tile of this workgroup (XCD rectangles) -------------------------------------------------------------------
   int tile_m, tile_n;
   {
@@ -391,9 +393,9 @@ inline int bg_mode() {        // VU_BGEMM: 0 = never (vu_gemm.h's tile), unset /
   return v;
 }
 
-template <bool TA, bool TB, bool CF, int TM, int TN, int WM, int NST>
+template <bool TA, bool TB, bool CF, int TM, int TN, int WM, int NST, int WN = 4>
 int launch_tile(const bg_args& a0, hipStream_t st) {
-  constexpr int BM = WM * TM * 16, BN = 4 * TN * 16;
+  constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
   bg_args a = a0;
   a.tiles_m = vu_cdiv(a.M, BM); a.tiles_n = vu_cdiv(a.N, BN);
   a.gm = 0; a.gn = 0;
@@ -404,7 +406,7 @@ int launch_tile(const bg_args& a0, hipStream_t st) {
       if (a.tiles_m % cand[c][0] == 0 && a.tiles_n % cand[c][1] == 0) { a.gm = cand[c][0]; a.gn = cand[c][1]; break; }
   }
   constexpr size_t lds = (size_t)NST * ((BM + BN) / 8) * 1024;
-  auto kern = bgemm_kernel<TA, TB, CF, TM, TN, WM, NST>;
+  auto kern = bgemm_kernel<TA, TB, CF, TM, TN, WM, NST, WN>;
   static bool reserved = false;            // (per instantiation)
   if (!reserved) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
@@ -413,12 +415,13 @@ int launch_tile(const bg_args& a0, hipStream_t st) {
     }
     reserved = true;
   }
-  hipLaunchKernelGGL(kern, dim3(total), dim3(WM * 256), lds, st, a);
+  hipLaunchKernelGGL(kern, dim3(total), dim3(WM * WN * 64), lds, st, a);
   if (vu_prof_on()) {
     static const bool shapes = getenv("VU_PROF_SHAPES") != nullptr;
     char tag[112];
-    if (shapes) snprintf(tag, sizeof(tag), "bgemm_kernel<%c%c,%s,%dx%d> M%d N%d K%d%s", TA ? 'T' : 'N', TB ? 'T' : 'N', CF ? "f32 acc" : "bf16", BM, BN, a.M, a.N, a.K, a.dropout ? " +dropout" : "");
-    else snprintf(tag, sizeof(tag), "bgemm_kernel<%c%c,%s,%dx%d>", TA ? 'T' : 'N', TB ? 'T' : 'N', CF ? "f32 acc" : "bf16", BM, BN);
+    const char* w4 = (WM * WN == 4 && BM == 224) ? ",4 waves" : "";
+    if (shapes) snprintf(tag, sizeof(tag), "bgemm_kernel<%c%c,%s,%dx%d%s> M%d N%d K%d%s", TA ? 'T' : 'N', TB ? 'T' : 'N', CF ? "f32 acc" : "bf16", BM, BN, w4, a.M, a.N, a.K, a.dropout ? " +dropout" : "");
+    else snprintf(tag, sizeof(tag), "bgemm_kernel<%c%c,%s,%dx%d%s>", TA ? 'T' : 'N', TB ? 'T' : 'N', CF ? "f32 acc" : "bf16", BM, BN, w4);
     vu_prof_note(tag, 2.0 * a.M * (double)a.N * a.K, 2.0 * ((double)a.M * a.K + (double)a.K * a.N) + (CF ? 8.0 : 2.0) * a.M * a.N);
   }
   return vu_check_launch("vu_gemm (bgemm)");
@@ -431,7 +434,10 @@ int launch(const bg_args& a, hipStream_t st) {
   // 78 KB: two independent workgroups per CU): measured M 1568 N 3072 K 3072 67 -> 52 us, M 784 63 -> 47 us; equal at 64 images
   // (76 us both).  VU_BGEMM_TILE = 0 / 1 / 2 forces 224 x 192 / 112 x 192 x 2 stages / 112 x 192 x 3 stages (A/B switch).
   // 16 images per GPU (M 784): 112 x 192 is 112 workgroups on 256 CUs; 112 x 128 (VU_BGEMM_TILE=3) makes 168 of two thirds the work.
-  static const int force = [] { const char* e = getenv("VU_BGEMM_TILE"); return (e && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : -1; }();
+  static const int force = [] { const char* e = getenv("VU_BGEMM_TILE"); return (e && e[0] >= '0' && e[0] <= '4') ? e[0] - '0' : -1; }();
+  if constexpr (TN == 3) {
+    if (force == 4) return launch_tile<TA, TB, CF, TM, 6, 2, 3, 2>(a, st);          // 224 x 192 by four waves of 112 x 96 (one per SIMD)
+  }
   if constexpr (!TA) {       // (a row-contiguous A needs BM % 32 == 0)
     const long long big_tiles = (long long)vu_cdiv(a.M, 2 * TM * 16) * vu_cdiv(a.N, 4 * TN * 16);
     if constexpr (TN == 3) {

@@ -40,11 +40,12 @@ typedef __attribute__((ext_vector_type(8))) short s16x8;
 #ifndef VU_FLASH_V1_W4
 #define VU_FLASH_V1_W4 4
 #endif
-#define VU_FLASH_V1_WAVES(H) ((H) == 4 ? VU_FLASH_V1_W4 : 2)
+#define VU_FLASH_V1_WAVES(H, DH) (((H) == 4 && (DH) <= 32) ? VU_FLASH_V1_W4 : 2)      // (d = 48: LDS allows two workgroups per CU anyway)
 template <int H, int DH> struct FC {
   static constexpr int D = H * DH;
   static constexpr int PITCH = D + 8;            // LDS row pitch of a (token x feature) chunk, elements: 16 B of (zeroed) pad
-  static constexpr int KS = DH / 8;              // valid 8-feature k-slots of the QK^T MFMA (k = 32 >= DH)
+  static constexpr int KS = DH / 8;              // valid 8-feature k-slots of the QK^T product (NK MFMAs of k = 32 each)
+  static constexpr int NK = (DH + 31) / 32;      // k-steps of a logits-shaped product (1 for d <= 32; d = 48: 32 + 16)
   static constexpr int DT = (DH + 15) / 16;      // 16-row tiles of the head dim in the transposed products
   static constexpr int VPR = D / 8;              // 16-byte vectors per row
   static constexpr int NMOM = H + H * (H + 1) / 2;
@@ -133,26 +134,55 @@ struct ChunkStage {
 
 // B operand of the logits product for one 16-token tile held in registers: lane (token l15, k-slot g4) has features
 // h DH + 8 g4 .. + 7 of its token, zero where 8 g4 >= DH (so whatever the other operand holds there is multiplied by 0).
-template <int H, int DH>
-__device__ __forceinline__ void load_stationary(bf16x8 (&f)[H], const bf16_t* __restrict__ rowp, int g4) {
+// (f[h NK + kh]: k-step kh of head h)
+template <int H, int DH, int NF>
+__device__ __forceinline__ void load_stationary(bf16x8 (&f)[NF], const bf16_t* __restrict__ rowp, int g4) {
   typedef FC<H, DH> C;
+  static_assert(NF == H * C::NK, "one fragment per (head, k-step)");
+  if constexpr (C::NK == 1) {
 #pragma unroll
-  for (int h = 0; h < H; ++h) {
-    if (g4 < C::KS) f[h] = *reinterpret_cast<const bf16x8*>(rowp + h * DH + 8 * g4);
-    else f[h] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    for (int h = 0; h < H; ++h) {
+      if (g4 < C::KS) f[h] = *reinterpret_cast<const bf16x8*>(rowp + h * DH + 8 * g4);
+      else f[h] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    return;
   }
+#pragma unroll
+  for (int h = 0; h < H; ++h)
+#pragma unroll
+    for (int kh = 0; kh < C::NK; ++kh) {
+      if (4 * kh + g4 < C::KS) f[h * C::NK + kh] = *reinterpret_cast<const bf16x8*>(rowp + h * DH + 32 * kh + 8 * g4);
+      else f[h * C::NK + kh] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
 }
 
 // S^T tile of every head: A = chunk rows (tokens 16 kc + l15 of the chunk), B = stationary fragments.
-template <int H, int DH>
-__device__ __forceinline__ void tile_logits(f32x4 (&acc)[H], const bf16_t* Kc, int kc, const bf16x8 (&qf)[H], int l15, int g4) {
+template <int H, int DH, int NF>
+__device__ __forceinline__ void tile_logits(f32x4 (&acc)[H], const bf16_t* Kc, int kc, const bf16x8 (&qf)[NF], int l15, int g4) {
   typedef FC<H, DH> C;
-  const int gk = g4 < C::KS ? g4 : C::KS - 1;                 // slots >= KS meet zeros: re-read a valid slot (finite data)
-  const bf16_t* krow = Kc + (kc * 16 + l15) * C::PITCH + 8 * gk;
+  static_assert(NF == H * C::NK, "one fragment per (head, k-step)");
+  if constexpr (C::NK == 1) {      // d <= 32: one MFMA is the whole k-loop (kept verbatim: the 8-head sweeps sit at their register limit)
+    const int gk = g4 < C::KS ? g4 : C::KS - 1;                 // slots >= KS meet zeros: re-read a valid slot (finite data)
+    const bf16_t* krow1 = Kc + (kc * 16 + l15) * C::PITCH + 8 * gk;
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(krow1 + h * DH);
+      acc[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[h], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    }
+    return;
+  }
+  const bf16_t* krow = Kc + (kc * 16 + l15) * C::PITCH;
 #pragma unroll
   for (int h = 0; h < H; ++h) {
-    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(krow + h * DH);
-    acc[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[h], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kh = 0; kh < C::NK; ++kh) {
+      const int ks = C::KS - 4 * kh < 4 ? C::KS - 4 * kh : 4;   // valid slots of this k-step (compile time after unrolling)
+      const int gk = g4 < ks ? g4 : ks - 1;                     // slots >= ks meet zeros: re-read a valid slot (finite data)
+      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(krow + h * DH + 32 * kh + 8 * gk);
+      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[h * C::NK + kh], a, 0, 0, 0);
+    }
+    acc[h] = a;
   }
 }
 
@@ -265,7 +295,7 @@ __global__ __launch_bounds__(WPB * 64) void flash_stats_kernel(const bf16_t* __r
   const int tq = active ? t : ntiles - 1;
   const int qrow = tq * 16 + l15;
   const bf16_t* kb = k + (long long)b * N * C::D;
-  bf16x8 qf[H];
+  bf16x8 qf[H * C::NK];
   load_stationary<H, DH>(qf, q + ((long long)b * N + qrow) * C::D, g4);
   zero_pads<H, DH>(Kc, CK * 16, tid, WPB * 64);
   const int nchunks = (ntiles + CK - 1) / CK;
@@ -462,7 +492,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash_rowstats_kernel(const bf16_
   const int tq = active ? t : ntiles - 1;
   const int qrow = tq * 16 + l15;
   const bf16_t* kb = k + (long long)b * N * C::D;
-  bf16x8 qf[H];
+  bf16x8 qf[H * C::NK];
   load_stationary<H, DH>(qf, q + ((long long)b * N + qrow) * C::D, g4);
   zero_pads<H, DH>(Kc, CK * 16, tid, WPB * 64);
   const int nchunks = (ntiles + CK - 1) / CK;
@@ -641,7 +671,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash_apply_kernel(
   const int qrow = tq * 16 + l15;
   const bf16_t* kb = k + (long long)b * N * C::D;
   const bf16_t* vb = v + (long long)b * N * C::D;
-  bf16x8 qf[H];
+  bf16x8 qf[H * C::NK];
   load_stationary<H, DH>(qf, q + ((long long)b * N + qrow) * C::D, g4);
   float lse[H];
 #pragma unroll
@@ -755,24 +785,48 @@ template <int H, int DH, bool STREAM_A>
 __device__ __forceinline__ void tile_prod(f32x4 (&acc)[H], const bf16_t* Xc, int kc, const bf16x8* sf, const bf16_t* sl, const float* cin,
                                           int l15, int g4) {
   typedef FC<H, DH> C;
-  const int gk = g4 < C::KS ? g4 : C::KS - 1;
-  const bf16_t* xrow = Xc + (kc * 16 + l15) * C::PITCH + 8 * gk;
-  // k-slots >= KS of the stationary operand must be zero: those lanes read the row's zeroed 16-byte pad for every head (a
-  // per-lane head stride of 0) instead of a valid slot followed by 4 selects per head (32 VALU instructions per product)
-  const bool dead = C::KS < 4 && g4 >= C::KS;
-  const int hs = dead ? 0 : DH;
-  const bf16_t* srow = sl ? sl + l15 * C::PITCH + (dead ? C::D : 8 * g4) : nullptr;
+  if constexpr (C::NK == 1) {      // (verbatim single-product form, see tile_logits)
+    const int gk = g4 < C::KS ? g4 : C::KS - 1;
+    const bf16_t* xrow = Xc + (kc * 16 + l15) * C::PITCH + 8 * gk;
+    // k-slots >= KS of the stationary operand must be zero: those lanes read the row's zeroed 16-byte pad for every head (a
+    // per-lane head stride of 0) instead of a valid slot followed by 4 selects per head (32 VALU instructions per product)
+    const bool dead = C::KS < 4 && g4 >= C::KS;
+    const int hs = dead ? 0 : DH;
+    const bf16_t* srow = sl ? sl + l15 * C::PITCH + (dead ? C::D : 8 * g4) : nullptr;
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xrow + h * DH);
+      bf16x8 st;
+      if (sl) {
+        st = *reinterpret_cast<const bf16x8*>(srow + h * hs);
+      } else st = sf[h];
+      const float ci = cin ? cin[h] : 0.f;
+      const f32x4 c0 = {ci, ci, ci, ci};
+      acc[h] = STREAM_A ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, st, c0, 0, 0, 0)
+                        : __builtin_amdgcn_mfma_f32_16x16x32_bf16(st, xf, c0, 0, 0, 0);
+    }
+    return;
+  }
+  const bf16_t* xrow0 = Xc + (kc * 16 + l15) * C::PITCH;
 #pragma unroll
   for (int h = 0; h < H; ++h) {
-    const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xrow + h * DH);
-    bf16x8 st;
-    if (sl) {
-      st = *reinterpret_cast<const bf16x8*>(srow + h * hs);
-    } else st = sf[h];
     const float ci = cin ? cin[h] : 0.f;
-    const f32x4 c0 = {ci, ci, ci, ci};
-    acc[h] = STREAM_A ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, st, c0, 0, 0, 0)
-                      : __builtin_amdgcn_mfma_f32_16x16x32_bf16(st, xf, c0, 0, 0, 0);
+    f32x4 a = {ci, ci, ci, ci};
+#pragma unroll
+    for (int kh = 0; kh < C::NK; ++kh) {
+      const int ks = C::KS - 4 * kh < 4 ? C::KS - 4 * kh : 4;   // valid 8-feature slots of this k-step
+      const int gk = g4 < ks ? g4 : ks - 1;
+      const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xrow0 + h * DH + 32 * kh + 8 * gk);
+      // k-slots >= ks of the stationary operand must be zero: those lanes read the row's zeroed 16-byte pad for every head (a
+      // per-lane head stride of 0) instead of a valid slot followed by 4 selects per head (32 VALU instructions per product)
+      const bool dead = ks < 4 && g4 >= ks;
+      bf16x8 st;
+      if (sl) st = *reinterpret_cast<const bf16x8*>(sl + l15 * C::PITCH + (dead ? C::D : h * DH + 32 * kh + 8 * g4));
+      else st = sf[h * C::NK + kh];
+      a = STREAM_A ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, st, a, 0, 0, 0)
+                   : __builtin_amdgcn_mfma_f32_16x16x32_bf16(st, xf, a, 0, 0, 0);
+    }
+    acc[h] = a;
   }
 }
 // the wave's own 16 token rows -> its LDS image [16][PITCH] (wave-private: no barrier, LDS operations of a wave are ordered)
@@ -840,7 +894,7 @@ __device__ __forceinline__ f32x4 mix_back(const f32x4 (&E)[H], const RowW<H>& w)
 // sum to zero exactly, as the row-wise softmax backward requires (row_norm_note).  The delta written for the dk sweep stays
 // sum_k u * rinv.  One whole chain rebuild (flash_bwd_dq_kernel) less per module.
 template <int H, int DH, int WPB, int CK, bool DQ = false>
-__global__ __launch_bounds__(WPB * 64, VU_FLASH_V1_WAVES(H)) void flash_bwd_delta_kernel(
+__global__ __launch_bounds__(WPB * 64, VU_FLASH_V1_WAVES(H, DH)) void flash_bwd_delta_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, const bf16_t* __restrict__ dO,
     const float* __restrict__ lse2, const float* __restrict__ rinv, const float* __restrict__ stats, float* __restrict__ delta,
     float* __restrict__ partials, int B, int N, float c, vu_rng rng_in, const float* __restrict__ pkv = nullptr,
@@ -1106,7 +1160,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash_bwd_dq_kernel(
 // the packed tile goes through a 512-byte wave-private LDS image [query][key] and comes back through the transposing
 // read as the B operand (k = query, column = key); the A operand is the transposing read of the Q / dO chunk.
 template <int H, int DH, int WPB, int CK, bool DV>
-__global__ __launch_bounds__(WPB * 64, VU_FLASH_V1_WAVES(H)) void flash_bwd_dkv_kernel(
+__global__ __launch_bounds__(WPB * 64, VU_FLASH_V1_WAVES(H, DH)) void flash_bwd_dkv_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, const bf16_t* __restrict__ dO,
     const float* __restrict__ lse2, const float* __restrict__ delta, const float* __restrict__ stats, bf16_t* __restrict__ out,
     int B, int N, float c, float scale, vu_rng rng_in) {
@@ -1132,7 +1186,7 @@ __global__ __launch_bounds__(WPB * 64, VU_FLASH_V1_WAVES(H)) void flash_bwd_dkv_
   const int krow = tk * 16 + l15;
   const bf16_t* qb = q + (long long)b * N * C::D;
   const bf16_t* dob = dO + (long long)b * N * C::D;
-  bf16x8 kf[H];
+  bf16x8 kf[H * C::NK];
   if (DV) load_stationary<H, DH>(kf, k + ((long long)b * N + krow) * C::D, g4);
   else {
     stage_own_rows<H, DH>(Ks, k + ((long long)b * N + tk * 16) * C::D, lane);
@@ -1422,7 +1476,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_moments_kernel(const bf16_
   const int tq = active ? t : ntiles - 1;
   const int qrow = tq * 16 + l15;
   const bf16_t* kb = k + (long long)b * N * C::D;
-  bf16x8 qf[H];
+  bf16x8 qf[H * C::NK];
   load_stationary<H, DH>(qf, q + ((long long)b * N + qrow) * C::D, g4);
   float lse[H];
 #pragma unroll
@@ -1590,7 +1644,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_apply_kernel(
   const int qrow = tq * 16 + l15;
   const bf16_t* kb = k + (long long)b * N * C::D;
   const bf16_t* vb = v + (long long)b * N * C::D;
-  bf16x8 qf[H];
+  bf16x8 qf[H * C::NK];
   load_stationary<H, DH>(qf, q + ((long long)b * N + qrow) * C::D, g4);
   float lse[H];
 #pragma unroll
@@ -2644,6 +2698,7 @@ int launch_backward_v2(const vu_flash_args& a, hipStream_t st) {
     const int dh_ = a.D / a.H;                                                         \
     if (a.H == 4 && dh_ == 32) return FN<4, 32>(__VA_ARGS__);                         \
     if (a.H == 4 && dh_ == 16) return FN<4, 16>(__VA_ARGS__);                         \
+    if (a.H == 4 && dh_ == 48) return FN<4, 48>(__VA_ARGS__);                         \
     vu_set_error("flash attention: shape H=%d d=%d not instantiated", a.H, dh_);      \
     return VU_EUNSUPPORTED;                                                            \
   } while (0)
@@ -2658,7 +2713,7 @@ bool vu_flash_pays(int B, int N) { return (long long)B * ((N / 16 + 3) / 4) >= 1
 bool vu_flash_ok(int dtype, int B, int N, int D, int H) {
   if (dtype != 1 || H <= 0 || D % H != 0) return false;
   const int dh = D / H;
-  const bool inst = (H == 8 && (dh == 24 || dh == 8 || dh == 32)) || (H == 4 && (dh == 32 || dh == 16));
+  const bool inst = (H == 8 && (dh == 24 || dh == 8 || dh == 32)) || (H == 4 && (dh == 32 || dh == 16 || dh == 48));
   // the dropout word index of a map element (one word per 4 keys) must fit 32 bits: B H N N < 2^34
   return inst && N % 16 == 0 && N >= 256 && (double)B * H * N * N < 17179869184.0;
 }
