@@ -95,7 +95,11 @@ __device__ __forceinline__ void quad_coords(long long qid, int s, long long& pat
 // PROCESS was computing on the same GPU (tools/contention_ops.py; the idle-GPU suites never saw it) - the cause of the red
 // two-rank rehearsal of round 3.  The LDS form is the default; VU_CONV_W=smem selects the scalar form for the A/B record.
 template <typename TI, typename TO, int C, int NOUT, int SH = 0, int WL = 0>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((SH == 1 && NOUT == 3) ? 4 : 1, 8))) void conv_fwd_kernel(const TI* __restrict__ in0, const TI* __restrict__ in1,
+#ifndef VU_CONV_WL_WAVES
+#define VU_CONV_WL_WAVES 3
+#endif
+// (waves per SIMD the shuffle form is held to: 4 with scalar-load weights; the LDS-weight form spills 19 registers at 4 - VU_CONV_WL_WAVES)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((SH == 1 && NOUT == 3) ? (WL ? VU_CONV_WL_WAVES : 4) : 1, 8))) void conv_fwd_kernel(const TI* __restrict__ in0, const TI* __restrict__ in1,
                                                        const float* __restrict__ w0, const float* __restrict__ w1,
                                                        const float* __restrict__ w2, const float* __restrict__ bias,
                                                        TO* __restrict__ o0, TO* __restrict__ o1, TO* __restrict__ o2,
