@@ -12,6 +12,7 @@ struct vu_flash_args {
   float* lse2;                 // (B,H,N): log2-domain log-sum-exp of the scaled logits, kept for the backward
   float* rinv;                 // (B,H,N): 1 / (row sum of the probabilities as every sweep recomputes them from lse2), kept for the backward
   float* pk;                   // (B,N,D) fp32: sum_k bf16(P) k per head (the training forward writes it, the backward's fused delta + dq sweep reads it; null: separate sweeps)
+  float* rinv_b;               // (B,H,N) 4-head form only: 1 / sum_k bf16(P) of the moments sweep (the fused dq's delta~; rinv keeps the fp32 row sum for the dk sweep)
   float* partials;             // >= vu_flash_partials_floats()
   float* stats;                // VU_BN_STATS_FLOATS(H): folded tables (vu_kernels.h)
   const float *mix_w, *mix_b, *bn_w, *bn_b;

@@ -279,7 +279,8 @@ __device__ __forceinline__ void work_item(int id, int B, int per, int& b, int& g
 template <int H, int DH, int WPB, int CK>
 __global__ __launch_bounds__(WPB * 64) void flash_stats_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                                float* __restrict__ lse2, float* __restrict__ rinv,
-                                                               float* __restrict__ partials, float* __restrict__ pk_out, int B, int N,
+                                                               float* __restrict__ partials, float* __restrict__ pk_out,
+                                                               float* __restrict__ rinv_b, int B, int N,
                                                                float c, vu_rng rng_in, int want_moments) {
   typedef FC<H, DH> C;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -341,7 +342,7 @@ __global__ __launch_bounds__(WPB * 64) void flash_stats_kernel(const bf16_t* __r
     lse[h] = m + log2f(s_);
     if (active && g4 == 0) {
       lse2[((long long)b * H + h) * N + qrow] = lse[h];
-      rinv[((long long)b * H + h) * N + qrow] = 1.0f / (s_ * fexp2(m - lse[h]));      // (row_norm_note below; overwritten with 1 / sum_k bf16(P) when pk_out)
+      rinv[((long long)b * H + h) * N + qrow] = 1.0f / (s_ * fexp2(m - lse[h]));      // (row_norm_note below)
     }
   }
   if (!want_moments) return;                                      // (uniform: eval mode needs the row statistics only)
@@ -421,7 +422,9 @@ __global__ __launch_bounds__(WPB * 64) void flash_stats_kernel(const bf16_t* __r
       float x = sb[h];                                // the four lane groups of a query hold its four key quarters
       x += __shfl_xor(x, 16, 64);
       x += __shfl_xor(x, 32, 64);
-      if (active && g4 == 0) rinv[((long long)b * H + h) * N + qrow] = 1.0f / x;
+      // rinv keeps the fp32 form (the dk sweep multiplies fp32 probabilities: its delta must be divided by THEIR row sum,
+      // section 2 "saturated rows" point 2); 1 / sum_k bf16(P) - the divisor of delta~ in the fused dq form - goes to rinv_b
+      if (active && g4 == 0) rinv_b[((long long)b * H + h) * N + qrow] = 1.0f / x;
     }
   }
   // wave -> workgroup -> one partial row per workgroup
@@ -898,7 +901,7 @@ __global__ __launch_bounds__(WPB * 64, VU_FLASH_V1_WAVES(H, DH)) void flash_bwd_
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, const bf16_t* __restrict__ dO,
     const float* __restrict__ lse2, const float* __restrict__ rinv, const float* __restrict__ stats, float* __restrict__ delta,
     float* __restrict__ partials, int B, int N, float c, vu_rng rng_in, const float* __restrict__ pkv = nullptr,
-    bf16_t* __restrict__ dq = nullptr, float scale = 0.f) {
+    bf16_t* __restrict__ dq = nullptr, float scale = 0.f, const float* __restrict__ rinv_b = nullptr) {
   typedef FC<H, DH> C;
   constexpr int NT = H * H + H;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -926,12 +929,13 @@ __global__ __launch_bounds__(WPB * 64, VU_FLASH_V1_WAVES(H, DH)) void flash_bwd_
   for (int h = 0; h < H; ++h) { lse[h] = lse2[((long long)b * H + h) * N + qrow]; dl[h] = 0.f; Tc[h] = 0.f; }
 #pragma unroll
   for (int i = 0; i < H * H; ++i) T[i] = 0.f;
-  float dlb[DQ ? H : 1];
+  float dlb[DQ ? H : 1], rsb[DQ ? H : 1];
   f32x4 dqa[DQ ? H : 1][C::DT];
   if constexpr (DQ) {
 #pragma unroll
     for (int h = 0; h < H; ++h) {
       dlb[h] = 0.f;
+      rsb[h] = rinv_b[((long long)b * H + h) * N + qrow];       // 1 / sum_k bf16(P) of the forward's moments sweep
 #pragma unroll
       for (int dt = 0; dt < C::DT; ++dt) dqa[h][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -1001,7 +1005,7 @@ __global__ __launch_bounds__(WPB * 64, VU_FLASH_V1_WAVES(H, DH)) void flash_bwd_
       float db = dlb[h];
       db += __shfl_xor(db, 16, 64);
       db += __shfl_xor(db, 32, 64);
-      const float dt_ = db * rs;                                                    // delta~ of (query l15, head h): in every lane group
+      const float dt_ = db * rsb[h];                                               // delta~ of (query l15, head h): in every lane group
       if (active) {
         bf16_t* orow = dq + ((long long)b * N + qrow) * C::D;
         const float* vrow = pkv + ((long long)b * N + qrow) * C::D;
@@ -2451,16 +2455,16 @@ int launch_backward(const vu_flash_args& a, hipStream_t st) {
   // the training backward behind a forward that saved V = sum_k bf16(P) k: dq leaves the delta sweep (VU_FLASH_FUSE_DQ=0: the
   // separate dq sweep of rounds 2 - 3, for the A/B record)
   static const bool fuse_off = [] { const char* e = getenv("VU_FLASH_FUSE_DQ"); return e && e[0] == '0'; }();
-  const bool fused = a.pk != nullptr && a.training && !fuse_off;
+  const bool fused = a.pk != nullptr && a.rinv_b != nullptr && a.training && !fuse_off;
   if (fused) {
     auto k1q = flash_bwd_delta_kernel<H, DH, WPB, CK2, true>;
     VU_TRY(reserve_lds(k1q, lds1));
     hipLaunchKernelGGL(k1q, dim3(nblk), dim3(WPB * 64), lds1, st, q, k, v, dO, a.lse2, a.rinv, a.stats, a.delta, a.partials, a.B, a.N, c, a.rng,
-                       (const float*)a.pk, (bf16_t*)a.dq, a.scale);
+                       (const float*)a.pk, (bf16_t*)a.dq, a.scale, (const float*)a.rinv_b);
     if (vu_prof_on()) vu_prof_note("flash_bwd_delta_dq_kernel", 6.0 * E * DH + 6.0 * E * H, 6.0 * act);
   } else {
     hipLaunchKernelGGL(k1, dim3(nblk), dim3(WPB * 64), lds1, st, q, k, v, dO, a.lse2, a.rinv, a.stats, a.delta, a.partials, a.B, a.N, c, a.rng,
-                       (const float*)nullptr, (bf16_t*)nullptr, 0.f);
+                       (const float*)nullptr, (bf16_t*)nullptr, 0.f, (const float*)nullptr);
     if (vu_prof_on()) vu_prof_note("flash_bwd_delta_kernel", 4.0 * E * DH + 6.0 * E * H, 4.0 * act);
   }
   VU_TRY(vu_check_launch("flash_bwd_delta"));
@@ -2499,7 +2503,7 @@ int launch_forward(const vu_flash_args& a, hipStream_t st) {
   }
   const double E = (double)a.B * H * a.N * a.N, act = (double)a.B * a.N * C::D * 2.0;
   hipLaunchKernelGGL(k1, dim3(nblk), dim3(WPB * 64), lds1, st, (const bf16_t*)a.q, (const bf16_t*)a.k, a.lse2, a.rinv, a.partials,
-                     a.training ? a.pk : (float*)nullptr, a.B, a.N, c, a.rng, a.training);
+                     (a.training && a.rinv_b) ? a.pk : (float*)nullptr, a.rinv_b, a.B, a.N, c, a.rng, a.training);
   if (vu_prof_on()) vu_prof_note("flash_stats_kernel", (a.training ? (a.pk ? 3.0 : 2.0) : 1.0) * 2.0 * E * DH, 2.0 * act);
   VU_TRY(vu_check_launch("flash_stats"));
   hipLaunchKernelGGL(flash_bn_finalize_kernel, dim3(1), dim3(1024), 0, st, a.partials, nblk, a.mix_w, a.mix_b, a.bn_w, a.bn_b, a.run_mean,
