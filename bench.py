@@ -336,8 +336,12 @@ def main():
                 import glob
                 for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{a.model}_pmc_traffic.json")) or
                                 glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))[::-1]:
+                    pj = json.load(open(f))
+                    wl = pj.get("workload", {"model": "base", "batch": 64})      # (the PMC passes run the default bench.py workload)
+                    if wl.get("model") != a.model or wl.get("batch") != a.batch:
+                        continue          # counters of another workload say nothing about this launch: traffic stays null
                     # several template instances can share the name: the dominant launch is the one with most traffic
-                    for sym, rec in json.load(open(f))["kernels"].items():
+                    for sym, rec in pj["kernels"].items():
                         if name.split("<")[0] in sym and rec.get("traffic_bytes") and rec["traffic_bytes"] > (traffic or 0):
                             traffic, tsrc = rec["traffic_bytes"], os.path.basename(f)
                     if traffic:

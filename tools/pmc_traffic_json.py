@@ -15,6 +15,7 @@ out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/
                "all launches of the symbol (a symbol that runs at several token levels averages over them); "
                "traffic_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: on gfx950 FETCH_SIZE counts half the bytes of wide "
                "coalesced reads (MI355X_MICROARCH.md, HBM)",
+       "workload": {"model": "base", "batch": 64},      # tools/gpu_pmc.sh profiles the default bench.py run
        "kernels": {}}
 missing = []
 for name, v in sorted(k.items()):
