@@ -576,15 +576,17 @@ def test_long_rows_4096_bf16_tracks_fp32(drop):
         assert serr(g16[k], g32[k]) < bt, k
 
 
-def test_flash_backward_tail_overlap_is_bit_identical_to_the_serial_order(attn_form):
+@pytest.mark.parametrize("N,Cn,s,H,B", [(784, 3, 8, 8, 44), (3136, 3, 4, 4, 22)])
+def test_flash_backward_tail_overlap_is_bit_identical_to_the_serial_order(N, Cn, s, H, B, attn_form):
     """Where the serial order would start a nearly empty round (44 images x 13 groups = 572 workgroups on 512 slots) an
     EAGER backward of the recompute form runs its dv sweep on a low-priority stream beside the dq / dk sweeps
     (csrc/vu_flash.hip "Tail overlap"); inside a stream capture the serial order is kept.  Same kernels, same operands,
     disjoint outputs: bit-identical dx and parameter gradients (the convolution and projection weight gradients of the STAND-ALONE op end in
     float atomics, so those are held to 1e-5), and the rule itself (vu_model_prefers_eager) says Base at 64 images, not at 32
-    or 128, never Lite."""
+    or 128.  Round 4: the 4-head form (Lite's finest level, 49 groups per image) overlaps whenever it launches more than 1024
+    workgroups - 22 images here; Lite at 32 and 64 images per GPU, not at 8."""
     attn_form(flash=1)
-    dt, N, Cn, s, H, B = torch.bfloat16, 784, 3, 8, 8, 44
+    dt = torch.bfloat16
     p, xq, _, dy, D = _attn_case(N, Cn, s, H, B=B)
     L = lib()
     d = {k: dev(v) for k, v in p.items()}
@@ -630,4 +632,6 @@ def test_flash_backward_tail_overlap_is_bit_identical_to_the_serial_order(attn_f
     assert L.vu_model_prefers_eager(C.byref(base._cfg), 64) == 1
     assert L.vu_model_prefers_eager(C.byref(base._cfg), 32) == 0
     assert L.vu_model_prefers_eager(C.byref(base._cfg), 128) == 0
-    assert L.vu_model_prefers_eager(C.byref(lite._cfg), 64) == 0
+    assert L.vu_model_prefers_eager(C.byref(lite._cfg), 64) == 1
+    assert L.vu_model_prefers_eager(C.byref(lite._cfg), 32) == 1
+    assert L.vu_model_prefers_eager(C.byref(lite._cfg), 8) == 0

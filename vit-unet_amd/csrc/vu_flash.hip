@@ -2424,97 +2424,6 @@ int launch_center_dk(const vu_flash_args& a, hipStream_t st) {
   return vu_check_launch("flash_center_dk");
 }
 
-template <typename K>
-int reserve_lds(K kern, size_t lds) {
-  if (lds > 48 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-    vu_set_error("flash attention: cannot reserve %zu bytes of LDS", lds);
-    return VU_ELAUNCH;
-  }
-  return VU_OK;
-}
-
-template <int H, int DH>
-int launch_backward(const vu_flash_args& a, hipStream_t st) {
-  typedef FC<H, DH> C;
-  constexpr int WPB = 4, CK = 4, CK2 = 2, NT = H * H + H;     // CK2: sweeps that keep BOTH stationary tiles in LDS
-  const int ntiles = a.N >> 4, per = (ntiles + WPB - 1) / WPB;
-  const int nblk = a.B * per;
-  const float c = a.scale * 1.44269504088896340736f;
-  const size_t rowb = (size_t)16 * C::PITCH * 2;                                      // one 16-row image
-  const size_t lds1 = (2 * CK2 + 2 * WPB) * rowb + sizeof(BwdTab<H>) + (size_t)WPB * NT * 4;
-  const size_t lds2 = (2 * CK2 + 2 * WPB) * rowb + sizeof(BwdTab<H>) + (size_t)WPB * 2 * H * 16 * 4;
-  const size_t lds3 = (2 * CK2 + 2 * WPB) * rowb + (size_t)2 * H * CK2 * 16 * 4 + sizeof(BwdTab<H>) + (size_t)(H * H + H) * 4 + (size_t)WPB * 512;
-  const size_t lds4 = (2 * CK) * rowb + (size_t)2 * H * CK * 16 * 4 + sizeof(BwdTab<H>) + (size_t)(H * H + H) * 4 + (size_t)WPB * 512;
-  auto k1 = flash_bwd_delta_kernel<H, DH, WPB, CK2>;
-  auto k2 = flash_bwd_dq_kernel<H, DH, WPB, CK2>;
-  auto k3 = flash_bwd_dkv_kernel<H, DH, WPB, CK2, false>;
-  auto k4 = flash_bwd_dkv_kernel<H, DH, WPB, CK, true>;
-  VU_TRY(reserve_lds(k1, lds1)); VU_TRY(reserve_lds(k2, lds2)); VU_TRY(reserve_lds(k3, lds3)); VU_TRY(reserve_lds(k4, lds4));
-  const double E = (double)a.B * H * a.N * a.N, act = (double)a.B * a.N * C::D * 2.0;
-  const bf16_t *q = (const bf16_t*)a.q, *k = (const bf16_t*)a.k, *v = (const bf16_t*)a.v, *dO = (const bf16_t*)a.dO;
-  // the training backward behind a forward that saved V = sum_k bf16(P) k: dq leaves the delta sweep (VU_FLASH_FUSE_DQ=0: the
-  // separate dq sweep of rounds 2 - 3, for the A/B record)
-  static const bool fuse_off = [] { const char* e = getenv("VU_FLASH_FUSE_DQ"); return e && e[0] == '0'; }();
-  const bool fused = a.pk != nullptr && a.rinv_b != nullptr && a.training && !fuse_off;
-  if (fused) {
-    auto k1q = flash_bwd_delta_kernel<H, DH, WPB, CK2, true>;
-    VU_TRY(reserve_lds(k1q, lds1));
-    hipLaunchKernelGGL(k1q, dim3(nblk), dim3(WPB * 64), lds1, st, q, k, v, dO, a.lse2, a.rinv, a.stats, a.delta, a.partials, a.B, a.N, c, a.rng,
-                       (const float*)a.pk, (bf16_t*)a.dq, a.scale, (const float*)a.rinv_b);
-    if (vu_prof_on()) vu_prof_note("flash_bwd_delta_dq_kernel", 6.0 * E * DH + 6.0 * E * H, 6.0 * act);
-  } else {
-    hipLaunchKernelGGL(k1, dim3(nblk), dim3(WPB * 64), lds1, st, q, k, v, dO, a.lse2, a.rinv, a.stats, a.delta, a.partials, a.B, a.N, c, a.rng,
-                       (const float*)nullptr, (bf16_t*)nullptr, 0.f, (const float*)nullptr);
-    if (vu_prof_on()) vu_prof_note("flash_bwd_delta_kernel", 4.0 * E * DH + 6.0 * E * H, 4.0 * act);
-  }
-  VU_TRY(vu_check_launch("flash_bwd_delta"));
-  hipLaunchKernelGGL(flash_bwd_mix_finalize_kernel, dim3((unsigned)((H * H + H + 15) / 16)), dim3(1024), 0, st, a.partials, nblk, a.stats, a.d_mix_w, a.d_mix_b, H, a.rng.inv_keep);
-  VU_TRY(vu_check_launch("flash_bwd_mix_finalize"));
-  if (!fused) {
-    hipLaunchKernelGGL(k2, dim3(nblk), dim3(WPB * 64), lds2, st, q, k, v, dO, a.lse2, a.delta, a.stats, (bf16_t*)a.dq, a.B, a.N, c, a.scale, a.rng);
-    if (vu_prof_on()) vu_prof_note("flash_bwd_dq_kernel", 6.0 * E * DH + 4.0 * E * H, 5.0 * act);
-    VU_TRY(vu_check_launch("flash_bwd_dq"));
-  }
-  hipLaunchKernelGGL(k3, dim3(nblk), dim3(WPB * 64), lds3, st, q, k, v, dO, a.lse2, a.delta, a.stats, (bf16_t*)a.dk, a.B, a.N, c, a.scale, a.rng);
-  if (vu_prof_on()) vu_prof_note("flash_bwd_dk_kernel", 6.0 * E * DH + 4.0 * E * H, 5.0 * act);
-  VU_TRY(vu_check_launch("flash_bwd_dk"));
-  VU_TRY(launch_center_dk(a, st));
-  hipLaunchKernelGGL(k4, dim3(nblk), dim3(WPB * 64), lds4, st, q, k, v, dO, a.lse2, (const float*)nullptr, a.stats, (bf16_t*)a.dv, a.B, a.N, c, a.scale, a.rng);
-  if (vu_prof_on()) vu_prof_note("flash_bwd_dv_kernel", 4.0 * E * DH + 2.0 * E * H, 4.0 * act);
-  return vu_check_launch("flash_bwd_dv");
-}
-
-template <int H, int DH>
-int launch_forward(const vu_flash_args& a, hipStream_t st) {
-  typedef FC<H, DH> C;
-  constexpr int WPB = 4, CK = 4;
-  const int ntiles = a.N >> 4, per = (ntiles + WPB - 1) / WPB;
-  const int nblk = a.B * per;
-  const float c = a.scale * 1.44269504088896340736f;
-  const size_t lds1 = (size_t)CK * 16 * C::PITCH * 2 + (size_t)WPB * C::NMOM * 4;
-  const size_t lds2 = (size_t)2 * CK * 16 * C::PITCH * 2 + (size_t)(H * H + H) * 4;
-  auto k1 = flash_stats_kernel<H, DH, WPB, CK>;
-  auto k2 = flash_apply_kernel<H, DH, WPB, CK>;
-  if (lds1 > 48 * 1024 && hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1) != hipSuccess) {
-    vu_set_error("flash attention: cannot reserve %zu bytes of LDS", lds1); return VU_ELAUNCH;
-  }
-  if (lds2 > 48 * 1024 && hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess) {
-    vu_set_error("flash attention: cannot reserve %zu bytes of LDS", lds2); return VU_ELAUNCH;
-  }
-  const double E = (double)a.B * H * a.N * a.N, act = (double)a.B * a.N * C::D * 2.0;
-  hipLaunchKernelGGL(k1, dim3(nblk), dim3(WPB * 64), lds1, st, (const bf16_t*)a.q, (const bf16_t*)a.k, a.lse2, a.rinv, a.partials,
-                     (a.training && a.rinv_b) ? a.pk : (float*)nullptr, a.rinv_b, a.B, a.N, c, a.rng, a.training);
-  if (vu_prof_on()) vu_prof_note("flash_stats_kernel", (a.training ? (a.pk ? 3.0 : 2.0) : 1.0) * 2.0 * E * DH, 2.0 * act);
-  VU_TRY(vu_check_launch("flash_stats"));
-  hipLaunchKernelGGL(flash_bn_finalize_kernel, dim3(1), dim3(1024), 0, st, a.partials, nblk, a.mix_w, a.mix_b, a.bn_w, a.bn_b, a.run_mean,
-                     a.run_var, a.stats, H, a.N, (double)a.B * a.N * a.N, a.training, 0.1f, 1e-5f, a.rng.inv_keep, 0);
-  VU_TRY(vu_check_launch("flash_bn_finalize"));
-  hipLaunchKernelGGL(k2, dim3(nblk), dim3(WPB * 64), lds2, st, (const bf16_t*)a.q, (const bf16_t*)a.k, (const bf16_t*)a.v, a.lse2,
-                     a.stats, (bf16_t*)a.O, a.B, a.N, c, a.rng);
-  if (vu_prof_on()) vu_prof_note("flash_apply_kernel", 4.0 * E * DH + 2.0 * E * H, 4.0 * act);
-  return vu_check_launch("flash_apply");
-}
-
 // Tail overlap of the backward (round 3).  The dv sweep needs nothing of the dq / dk sweeps and writes only dv, so it can
 // be enqueued FIRST, on a LOW-PRIORITY stream forked from `st`, and joined back at the end: the dispatcher serves the dq
 // and dk sweeps first and dv's workgroups take the slots their last, partly filled round leaves empty.  Measured on one
@@ -2563,6 +2472,127 @@ inline bool tail_overlap(const ForkPool* fp, int nblk, hipStream_t st, bool chec
     if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;
   }
   return true;
+}
+
+// the same for the 4-head sweeps (3 - 5 workgroups per CU): VU_FLASH_FORK=2 forces it; the default rule is the measurement below
+inline bool tail_overlap_v1(const ForkPool* fp, int nblk, hipStream_t st, bool check_capture) {
+  if (!fp || fp->mode == 1 || fp->mode == 0) return false;
+  static const bool v1_on = [] { const char* e = getenv("VU_FLASH_FORK_V1"); return !(e && e[0] == '0'); }();
+  if (fp->mode != 2 && !(v1_on && nblk > 2 * fp->slots)) return false;
+  if (check_capture) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;
+  }
+  return true;
+}
+
+template <typename K>
+int reserve_lds(K kern, size_t lds) {
+  if (lds > 48 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    vu_set_error("flash attention: cannot reserve %zu bytes of LDS", lds);
+    return VU_ELAUNCH;
+  }
+  return VU_OK;
+}
+
+template <int H, int DH>
+int launch_backward(const vu_flash_args& a, hipStream_t st) {
+  typedef FC<H, DH> C;
+  constexpr int WPB = 4, CK = 4, CK2 = 2, NT = H * H + H;     // CK2: sweeps that keep BOTH stationary tiles in LDS
+  const int ntiles = a.N >> 4, per = (ntiles + WPB - 1) / WPB;
+  const int nblk = a.B * per;
+  const float c = a.scale * 1.44269504088896340736f;
+  const size_t rowb = (size_t)16 * C::PITCH * 2;                                      // one 16-row image
+  const size_t lds1 = (2 * CK2 + 2 * WPB) * rowb + sizeof(BwdTab<H>) + (size_t)WPB * NT * 4;
+  const size_t lds2 = (2 * CK2 + 2 * WPB) * rowb + sizeof(BwdTab<H>) + (size_t)WPB * 2 * H * 16 * 4;
+  const size_t lds3 = (2 * CK2 + 2 * WPB) * rowb + (size_t)2 * H * CK2 * 16 * 4 + sizeof(BwdTab<H>) + (size_t)(H * H + H) * 4 + (size_t)WPB * 512;
+  const size_t lds4 = (2 * CK) * rowb + (size_t)2 * H * CK * 16 * 4 + sizeof(BwdTab<H>) + (size_t)(H * H + H) * 4 + (size_t)WPB * 512;
+  auto k1 = flash_bwd_delta_kernel<H, DH, WPB, CK2>;
+  auto k2 = flash_bwd_dq_kernel<H, DH, WPB, CK2>;
+  auto k3 = flash_bwd_dkv_kernel<H, DH, WPB, CK2, false>;
+  auto k4 = flash_bwd_dkv_kernel<H, DH, WPB, CK, true>;
+  VU_TRY(reserve_lds(k1, lds1)); VU_TRY(reserve_lds(k2, lds2)); VU_TRY(reserve_lds(k3, lds3)); VU_TRY(reserve_lds(k4, lds4));
+  const double E = (double)a.B * H * a.N * a.N, act = (double)a.B * a.N * C::D * 2.0;
+  const bf16_t *q = (const bf16_t*)a.q, *k = (const bf16_t*)a.k, *v = (const bf16_t*)a.v, *dO = (const bf16_t*)a.dO;
+  // tail overlap as in the 8-head form (launch_backward_v2): the dv sweep first, on the low-priority stream, joined at the end
+  ForkPool* fp = vu_prof_on() ? nullptr : fork_pool();
+  hipStream_t s_dv = st;
+  const bool early_dv = tail_overlap_v1(fp, nblk, st, true);
+  auto launch_dv = [&]() -> int {
+    hipLaunchKernelGGL(k4, dim3(nblk), dim3(WPB * 64), lds4, s_dv, q, k, v, dO, a.lse2, (const float*)nullptr, a.stats, (bf16_t*)a.dv, a.B, a.N, c, a.scale, a.rng);
+    if (vu_prof_on()) vu_prof_note("flash_bwd_dv_kernel", 4.0 * E * DH + 2.0 * E * H, 4.0 * act);
+    return vu_check_launch("flash_bwd_dv");
+  };
+  if (early_dv) {
+    bool ok = hipEventRecord(fp->e[0], st) == hipSuccess && hipStreamWaitEvent(fp->s[1], fp->e[0], 0) == hipSuccess;
+    if (!ok) { vu_set_error("flash attention: stream fork failed"); return VU_ELAUNCH; }
+    s_dv = fp->s[1];
+    VU_TRY(launch_dv());
+  }
+  // the training backward behind a forward that saved V = sum_k bf16(P) k: dq leaves the delta sweep (VU_FLASH_FUSE_DQ=0: the
+  // separate dq sweep of rounds 2 - 3, for the A/B record)
+  static const bool fuse_off = [] { const char* e = getenv("VU_FLASH_FUSE_DQ"); return e && e[0] == '0'; }();
+  const bool fused = a.pk != nullptr && a.rinv_b != nullptr && a.training && !fuse_off;
+  if (fused) {
+    auto k1q = flash_bwd_delta_kernel<H, DH, WPB, CK2, true>;
+    VU_TRY(reserve_lds(k1q, lds1));
+    hipLaunchKernelGGL(k1q, dim3(nblk), dim3(WPB * 64), lds1, st, q, k, v, dO, a.lse2, a.rinv, a.stats, a.delta, a.partials, a.B, a.N, c, a.rng,
+                       (const float*)a.pk, (bf16_t*)a.dq, a.scale, (const float*)a.rinv_b);
+    if (vu_prof_on()) vu_prof_note("flash_bwd_delta_dq_kernel", 6.0 * E * DH + 6.0 * E * H, 6.0 * act);
+  } else {
+    hipLaunchKernelGGL(k1, dim3(nblk), dim3(WPB * 64), lds1, st, q, k, v, dO, a.lse2, a.rinv, a.stats, a.delta, a.partials, a.B, a.N, c, a.rng,
+                       (const float*)nullptr, (bf16_t*)nullptr, 0.f, (const float*)nullptr);
+    if (vu_prof_on()) vu_prof_note("flash_bwd_delta_kernel", 4.0 * E * DH + 6.0 * E * H, 4.0 * act);
+  }
+  VU_TRY(vu_check_launch("flash_bwd_delta"));
+  hipLaunchKernelGGL(flash_bwd_mix_finalize_kernel, dim3((unsigned)((H * H + H + 15) / 16)), dim3(1024), 0, st, a.partials, nblk, a.stats, a.d_mix_w, a.d_mix_b, H, a.rng.inv_keep);
+  VU_TRY(vu_check_launch("flash_bwd_mix_finalize"));
+  if (!fused) {
+    hipLaunchKernelGGL(k2, dim3(nblk), dim3(WPB * 64), lds2, st, q, k, v, dO, a.lse2, a.delta, a.stats, (bf16_t*)a.dq, a.B, a.N, c, a.scale, a.rng);
+    if (vu_prof_on()) vu_prof_note("flash_bwd_dq_kernel", 6.0 * E * DH + 4.0 * E * H, 5.0 * act);
+    VU_TRY(vu_check_launch("flash_bwd_dq"));
+  }
+  hipLaunchKernelGGL(k3, dim3(nblk), dim3(WPB * 64), lds3, st, q, k, v, dO, a.lse2, a.delta, a.stats, (bf16_t*)a.dk, a.B, a.N, c, a.scale, a.rng);
+  if (vu_prof_on()) vu_prof_note("flash_bwd_dk_kernel", 6.0 * E * DH + 4.0 * E * H, 5.0 * act);
+  VU_TRY(vu_check_launch("flash_bwd_dk"));
+  VU_TRY(launch_center_dk(a, st));
+  if (!early_dv) return launch_dv();
+  if (!(hipEventRecord(fp->e[2], fp->s[1]) == hipSuccess && hipStreamWaitEvent(st, fp->e[2], 0) == hipSuccess)) {
+    vu_set_error("flash attention: stream join failed");
+    return VU_ELAUNCH;
+  }
+  return VU_OK;
+}
+
+template <int H, int DH>
+int launch_forward(const vu_flash_args& a, hipStream_t st) {
+  typedef FC<H, DH> C;
+  constexpr int WPB = 4, CK = 4;
+  const int ntiles = a.N >> 4, per = (ntiles + WPB - 1) / WPB;
+  const int nblk = a.B * per;
+  const float c = a.scale * 1.44269504088896340736f;
+  const size_t lds1 = (size_t)CK * 16 * C::PITCH * 2 + (size_t)WPB * C::NMOM * 4;
+  const size_t lds2 = (size_t)2 * CK * 16 * C::PITCH * 2 + (size_t)(H * H + H) * 4;
+  auto k1 = flash_stats_kernel<H, DH, WPB, CK>;
+  auto k2 = flash_apply_kernel<H, DH, WPB, CK>;
+  if (lds1 > 48 * 1024 && hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1) != hipSuccess) {
+    vu_set_error("flash attention: cannot reserve %zu bytes of LDS", lds1); return VU_ELAUNCH;
+  }
+  if (lds2 > 48 * 1024 && hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess) {
+    vu_set_error("flash attention: cannot reserve %zu bytes of LDS", lds2); return VU_ELAUNCH;
+  }
+  const double E = (double)a.B * H * a.N * a.N, act = (double)a.B * a.N * C::D * 2.0;
+  hipLaunchKernelGGL(k1, dim3(nblk), dim3(WPB * 64), lds1, st, (const bf16_t*)a.q, (const bf16_t*)a.k, a.lse2, a.rinv, a.partials,
+                     (a.training && a.rinv_b) ? a.pk : (float*)nullptr, a.rinv_b, a.B, a.N, c, a.rng, a.training);
+  if (vu_prof_on()) vu_prof_note("flash_stats_kernel", (a.training ? (a.pk ? 3.0 : 2.0) : 1.0) * 2.0 * E * DH, 2.0 * act);
+  VU_TRY(vu_check_launch("flash_stats"));
+  hipLaunchKernelGGL(flash_bn_finalize_kernel, dim3(1), dim3(1024), 0, st, a.partials, nblk, a.mix_w, a.mix_b, a.bn_w, a.bn_b, a.run_mean,
+                     a.run_var, a.stats, H, a.N, (double)a.B * a.N * a.N, a.training, 0.1f, 1e-5f, a.rng.inv_keep, 0);
+  VU_TRY(vu_check_launch("flash_bn_finalize"));
+  hipLaunchKernelGGL(k2, dim3(nblk), dim3(WPB * 64), lds2, st, (const bf16_t*)a.q, (const bf16_t*)a.k, (const bf16_t*)a.v, a.lse2,
+                     a.stats, (bf16_t*)a.O, a.B, a.N, c, a.rng);
+  if (vu_prof_on()) vu_prof_note("flash_apply_kernel", 4.0 * E * DH + 2.0 * E * H, 4.0 * act);
+  return vu_check_launch("flash_apply");
 }
 
 template <int DH, int KS, int WPBV = 4>
@@ -2708,7 +2738,7 @@ int launch_backward_v2(const vu_flash_args& a, hipStream_t st) {
   } while (0)
 
 bool vu_flash_tail_overlap(int B, int N, int H) {
-  if (H != 8) return false;                 // (the 4-head form keeps the serial backward)
+  if (H != 8) return tail_overlap_v1(fork_pool(), B * (((N >> 4) + 3) / 4), nullptr, false);
   return tail_overlap(fork_pool(), B * (((N >> 4) + 3) / 4), nullptr, false);
 }
 
