@@ -2498,7 +2498,12 @@ int reserve_lds(K kern, size_t lds) {
 template <int H, int DH>
 int launch_backward(const vu_flash_args& a, hipStream_t st) {
   typedef FC<H, DH> C;
-  constexpr int WPB = 4, CK = 4, CK2 = 2, NT = H * H + H;     // CK2: sweeps that keep BOTH stationary tiles in LDS
+#ifndef VU_FLASH_V1_CK2
+#define VU_FLASH_V1_CK2 4
+#endif
+  // CK2: sweeps that keep BOTH stationary tiles in LDS (4 heads of <= 16 features: 2.3 KB per 16-row image, so four streamed tiles
+  // per barrier pair still leave four workgroups per CU)
+  constexpr int WPB = 4, CK = 4, CK2 = (H == 4 && DH <= 16) ? VU_FLASH_V1_CK2 : 2, NT = H * H + H;      // (dv with 8 tiles per chunk: slower, 2006 vs 2027 images/s)
   const int ntiles = a.N >> 4, per = (ntiles + WPB - 1) / WPB;
   const int nblk = a.B * per;
   const float c = a.scale * 1.44269504088896340736f;
@@ -2567,7 +2572,10 @@ int launch_backward(const vu_flash_args& a, hipStream_t st) {
 template <int H, int DH>
 int launch_forward(const vu_flash_args& a, hipStream_t st) {
   typedef FC<H, DH> C;
-  constexpr int WPB = 4, CK = 4;
+#ifndef VU_FLASH_V1_CKF
+#define VU_FLASH_V1_CKF 8
+#endif
+  constexpr int WPB = 4, CK = (H == 4 && DH <= 16) ? VU_FLASH_V1_CKF : 4;      // streamed tiles per barrier pair
   const int ntiles = a.N >> 4, per = (ntiles + WPB - 1) / WPB;
   const int nblk = a.B * per;
   const float c = a.scale * 1.44269504088896340736f;
