@@ -2579,9 +2579,13 @@ int launch_forward(const vu_flash_args& a, hipStream_t st) {
   const int ntiles = a.N >> 4, per = (ntiles + WPB - 1) / WPB;
   const int nblk = a.B * per;
   const float c = a.scale * 1.44269504088896340736f;
-  const size_t lds1 = (size_t)CK * 16 * C::PITCH * 2 + (size_t)WPB * C::NMOM * 4;
+#ifndef VU_FLASH_V1_CKS
+#define VU_FLASH_V1_CKS 16
+#endif
+  constexpr int CKS = (H == 4 && DH <= 16) ? VU_FLASH_V1_CKS : CK;             // (the statistics sweep stages K only)
+  const size_t lds1 = (size_t)CKS * 16 * C::PITCH * 2 + (size_t)WPB * C::NMOM * 4;
   const size_t lds2 = (size_t)2 * CK * 16 * C::PITCH * 2 + (size_t)(H * H + H) * 4;
-  auto k1 = flash_stats_kernel<H, DH, WPB, CK>;
+  auto k1 = flash_stats_kernel<H, DH, WPB, CKS>;
   auto k2 = flash_apply_kernel<H, DH, WPB, CK>;
   if (lds1 > 48 * 1024 && hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1) != hipSuccess) {
     vu_set_error("flash attention: cannot reserve %zu bytes of LDS", lds1); return VU_ELAUNCH;
