@@ -2615,7 +2615,8 @@ int launch_forward_v2(const vu_flash_args& a, hipStream_t st) {
 #ifndef VU_CKK
 #define VU_CKK 2
 #endif
-  constexpr int H = 8, WPB = WPBV, CK = VU_CKF;
+  // (eight waves per workgroup - the small-batch form, one workgroup per CU: every barrier pair is fully exposed, so twice the tiles per chunk)
+  constexpr int H = 8, WPB = WPBV, CK = WPBV == 8 ? 2 * VU_CKF : VU_CKF;
   typedef FC<H, DH> C;
   constexpr int TPB = WPB / KS;                                          // own tiles per workgroup (pair_park / pair_take)
   const int ntiles = a.N >> 4, per = (ntiles + TPB - 1) / TPB;
@@ -2662,11 +2663,11 @@ int launch_backward_v2(const vu_flash_args& a, hipStream_t st) {
   // two workgroups per CU: every one of these must stay <= 80 KB (81920 B)
   const size_t lds1 = (2 * CK2 + 2 * WPB) * rowb + (size_t)WPB * 1280;          // (the final [WPB][NT] reduction aliases the K chunk)
   const size_t lds2 = (2 * CK2 + 2 * WPB) * rowb + zr;
-  constexpr int CKK = VU_CKK;
+  constexpr int CKK = WPBV == 8 ? 4 : VU_CKK;      // (eight waves, one workgroup per CU: the whole 160 KB, four tiles per barrier pair)
   const size_t lds3 = (2 * CKK + 2 * WPB) * rowb + (size_t)WPB * 1280;
   static_assert((size_t)WPB * NT * 4 <= (size_t)CK2 * 16 * C::PITCH * 2, "reduction scratch must fit the K chunk");
   const size_t lds4 = (2 * CK + 2 * WPB) * rowb + (size_t)2 * H * CK * 16 * 4 + (size_t)WPB * 1024;
-  constexpr int CKX = KS == 2 ? 2 : 1;       // (split form: a chunk must hold a tile for each wave of a pair)
+  constexpr int CKX = WPBV == 8 ? 4 : (KS == 2 ? 2 : 1);       // (split form: a chunk must hold a tile for each wave of a pair)
   const size_t lds2x = (2 * CKX + 2 * WPB) * rowb + (size_t)WPB * 1024 + (size_t)tr_strip_elems<DH>() * 2;
   auto k1 = flash2_bwd_delta_kernel<DH, WPB, CK2>;
   auto k2 = flash2_bwd_dq_kernel<DH, WPB, CK2>;
@@ -2679,7 +2680,7 @@ int launch_backward_v2(const vu_flash_args& a, hipStream_t st) {
   if (KS != 1 && !fused) { vu_set_error("flash attention: the split backward exists for the fused training form only"); return VU_EUNSUPPORTED; }
   VU_TRY(reserve_lds(k2x, lds2x));
   auto k3 = flash2_bwd_dkv_kernel<DH, WPB, CKK, false, KS>;
-  constexpr int CKV = KS == 2 ? 2 : 1;   // dv: one tile per chunk, 16 stationary rows per wave: 43.5 KB, three workgroups per CU (split form: two)
+  constexpr int CKV = WPBV == 8 ? 4 : (KS == 2 ? 2 : 1);   // dv: one tile per chunk, 16 stationary rows per wave: 43.5 KB, three workgroups per CU (split form: two)
   auto k4 = flash2_bwd_dkv_kernel<DH, WPB, CKV, true, KS>;
   const size_t lds3v = (2 * CKV + WPB) * rowb + (size_t)WPB * 1280;
   VU_TRY(reserve_lds(k1, lds1)); VU_TRY(reserve_lds(k2, lds2)); VU_TRY(reserve_lds(k3, lds3)); VU_TRY(reserve_lds(k4, lds3v));
