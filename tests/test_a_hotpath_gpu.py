@@ -80,3 +80,28 @@ def test_base_bf16_step_is_bit_reproducible_on_poisoned_memory(B):
         out1, g1 = _run_step(m, ts, x, y)
         nout, ng = int((out1 != out0).sum()), int((g1 != g0).sum())
         assert nout == 0 and ng == 0, f"pattern {pattern:#x}: {nout} output elements and {ng} gradient elements differ"
+
+
+def test_default_base_step_runs_no_vendor_blas_kernel():
+    """A default Base bf16 train step (16 images: the per-GPU batch of BASELINE configs 3 - 4) through the launch profiler: every
+    kernel of the step is one of this library's (no `Cijk_*` Tensile kernel, nothing tagged hipblaslt / rocblas), the plain big
+    products run on csrc/vu_bgemm.hip and the level-2 attention on the recompute sweeps."""
+    import ctypes as C
+    import json
+    from vit_unet.torch._lib import lib
+    B = 16
+    cfg = O.Config(**O.PRESETS["base"])
+    x, y = O.make_batch(cfg, B=B, seed=3)
+    m, ts = _base_step(B)
+    L = lib()
+    ts.step(x.to(DEV), y.to(DEV))                                    # warm-up (allocations, attribute calls)
+    torch.cuda.synchronize()
+    L.vu_prof_enable(C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    ts.step(x.to(DEV), y.to(DEV))
+    torch.cuda.synchronize()
+    rep = json.loads(L.vu_prof_report().decode())              # (stops the profiler)
+    assert len(rep) > 30, rep.keys()
+    bad = [k for k in rep if k.startswith("Cijk") or "hipblaslt" in k.lower() or "rocblas" in k.lower() or "tensile" in k.lower()]
+    assert not bad, bad
+    assert any(k.startswith("bgemm_kernel<") for k in rep), rep.keys()
+    assert any(k.startswith("flash2_bwd_dqx_kernel") for k in rep), rep.keys()

@@ -217,3 +217,14 @@ def test_no_mixed_opcode_mfma_accumulator_chain_in_the_recompute_sweeps():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "mfma_chain_scan.py"), os.path.join(root, "vit-unet_amd", "csrc", "vu_flash.hip")],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "MFMA_CHAIN_SCAN CLEAN" in r.stdout, r.stdout + r.stderr
+
+
+def test_library_links_no_vendor_blas():
+    """The product library depends on the HIP runtime only: no hipBLASLt / rocBLAS / MIOpen in its NEEDED entries (round 3 linked
+    hipBLASLt for the big GEMMs; round 4 runs them on csrc/vu_bgemm.hip)."""
+    import subprocess
+    so = os.path.join(os.path.dirname(_lib.__file__), "libvitunet_amd.so")
+    out = subprocess.run(["readelf", "-d", so], capture_output=True, text=True).stdout
+    needed = [l.split("[")[1].split("]")[0] for l in out.splitlines() if "(NEEDED)" in l]
+    assert needed, out
+    assert not [n for n in needed if any(t in n.lower() for t in ("blas", "miopen", "tensile", "rccl"))], needed
