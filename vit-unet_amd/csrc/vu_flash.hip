@@ -1,5 +1,6 @@
 // Non-materialising re-attention (model.py:155-161) for long rows and small head dims: bf16 storage, N % 16 == 0,
-// head dim a multiple of 8 and <= 32, 4 or 8 heads (Base / Large level 2: N = 784, d = 24; 512x512 inputs: d = 8 / 32).
+// 8 heads of 8 / 24 / 32 features (Base / Large level 2: N = 784, d = 24; 512x512 inputs: d = 8 / 32) or 4 heads of 16 / 32 / 48
+// (Lite: N = 3136 with d = 12 zero-padded to 16 by the caller, N = 784 with d = 48 as two k-steps per logits product).
 //
 // The (B,h,N,N) attention maps never exist in HBM.  BatchNorm over the head-mixed maps needs batch statistics of
 // A_g = sum_h W[g,h] P~_h + c_g BEFORE the PV product (SURVEY 7 hard part 1), so the forward is two recompute passes:
