@@ -951,6 +951,7 @@ int vu_model_workspace_describe(const vu_config* cfg, int B, char* out, int cap)
   auto add_attn = [&](const std::string& pre, const AttnBuf& a) {
     add(pre + "q", a.q); add(pre + "k", a.k); add(pre + "v", a.v); add(pre + "O", a.O); add(pre + "Ps", a.Ps); add(pre + "Ah", a.Ah);
     add(pre + "stats", a.stats); add(pre + "lse2", a.lse2); add(pre + "rinv", a.rinv); add(pre + "delta", a.delta); add(pre + "pk", a.pk);
+    add(pre + "rinvb", a.rinvb); add(pre + "qp", a.qp); add(pre + "kp", a.kp); add(pre + "vp", a.vp); add(pre + "Op", a.Op);
   };
   auto add_block = [&](const std::string& pre, const BlockBuf& b) {
     add_attn(pre + "attn.", b.at);
@@ -967,7 +968,7 @@ int vu_model_workspace_describe(const vu_config* cfg, int B, char* out, int cap)
   }
   add("img", w.img); add("y_attn", w.y_attn); add("f_ff", w.f_ff);
   add("gx0", w.gx0); add("gx1", w.gx1); add("ga", w.ga); add("gb", w.gb); add("gc", w.gc); add("gh", w.gh);
-  add("asc.dO", w.asc.dO); add("asc.dq", w.asc.dq); add("asc.dk", w.asc.dk); add("asc.dv", w.asc.dv); add("asc.dA", w.asc.dA);
+  add("asc.dO", w.asc.dO); add("asc.dq", w.asc.dq); add("asc.dk", w.asc.dk); add("asc.dv", w.asc.dv); add("asc.dA", w.asc.dA); add("asc.pad", w.asc.pad);
   for (size_t j = 0; j < w.dskip.size(); ++j) add("dskip" + std::to_string(j), w.dskip[j]);
   add("partials", w.partials); add("lnp", w.lnp); add("lnp2", w.lnp2); add("wgs", w.wgs); add("wga", w.wga);
   std::string text;
