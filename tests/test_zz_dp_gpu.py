@@ -67,3 +67,20 @@ def test_ops_are_bit_reproducible_while_another_process_uses_the_gpu():
                        capture_output=True, text=True, timeout=420, env=env)
     assert "CONTENTION_OPS CLEAN" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
     assert r.returncode == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.xfail(strict=False, reason="known (DESIGN 2a, round 4): the dq / dk sweeps of the 4-head recompute form (Lite) differ in "
+                   "1 - 2 % of their 16-token tiles, in the last bits, when another process shares the GPU; bit-identical on an idle GPU")
+def test_four_head_recompute_attention_under_gpu_sharing():
+    """The same check for the recompute attention op at Lite's two long-row levels (4 heads, d = 12 / 48) and at Base level 2
+    (8 heads: clean).  Recorded as an expected failure until the cause is found: ruled out so far are scratch memory
+    (tools/probe/scratch_probe.hip), uninitialised LDS (VU_FLASH_V1_CLEAR=1), hazard waits behind the logits products and the fused
+    dq form (the separate delta / dq sweeps of rounds 2 - 3 show the same)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CONTENTION_ATTN_ONLY="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "contention_ops.py"), "--load", "40", "--iters", "20", "--B", "16", "--attn", "all"],
+                       capture_output=True, text=True, timeout=420, env=env)
+    assert "CONTENTION_OPS CLEAN" in r.stdout, r.stdout[-2000:]

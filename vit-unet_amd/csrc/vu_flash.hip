@@ -902,10 +902,14 @@ __global__ __launch_bounds__(WPB * 64, VU_FLASH_V1_WAVES(H, DH)) void flash_bwd_
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, const bf16_t* __restrict__ dO,
     const float* __restrict__ lse2, const float* __restrict__ rinv, const float* __restrict__ stats, float* __restrict__ delta,
     float* __restrict__ partials, int B, int N, float c, vu_rng rng_in, const float* __restrict__ pkv = nullptr,
-    bf16_t* __restrict__ dq = nullptr, float scale = 0.f, const float* __restrict__ rinv_b = nullptr) {
+    bf16_t* __restrict__ dq = nullptr, float scale = 0.f, const float* __restrict__ rinv_b = nullptr, int lds_clear = 0) {
   typedef FC<H, DH> C;
   constexpr int NT = H * H + H;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  if (lds_clear) {            // diagnostic (VU_FLASH_V1_CLEAR=1): no value of the sweep may depend on what the LDS held before
+    for (int i = threadIdx.x; i < lds_clear / 4; i += WPB * 64) reinterpret_cast<unsigned*>(smem_raw)[i] = 0x7f7f7f7fu;
+    __syncthreads();
+  }
   bf16_t* Kc = reinterpret_cast<bf16_t*>(smem_raw);
   bf16_t* Vc = Kc + CK * 16 * C::PITCH;
   bf16_t* Qs = Vc + CK * 16 * C::PITCH + (threadIdx.x >> 6) * 32 * C::PITCH;             // this wave's q rows, then its dO rows
@@ -1168,9 +1172,13 @@ template <int H, int DH, int WPB, int CK, bool DV>
 __global__ __launch_bounds__(WPB * 64, VU_FLASH_V1_WAVES(H, DH)) void flash_bwd_dkv_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, const bf16_t* __restrict__ dO,
     const float* __restrict__ lse2, const float* __restrict__ delta, const float* __restrict__ stats, bf16_t* __restrict__ out,
-    int B, int N, float c, float scale, vu_rng rng_in) {
+    int B, int N, float c, float scale, vu_rng rng_in, int lds_clear = 0) {
   typedef FC<H, DH> C;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  if (lds_clear) {            // diagnostic (VU_FLASH_V1_CLEAR=1), see flash_bwd_delta_kernel
+    for (int i = threadIdx.x; i < lds_clear / 4; i += WPB * 64) reinterpret_cast<unsigned*>(smem_raw)[i] = 0x7f7f7f7fu;
+    __syncthreads();
+  }
   bf16_t* Qc = reinterpret_cast<bf16_t*>(smem_raw);
   bf16_t* Dc = Qc + CK * 16 * C::PITCH;                                   // dO chunk
   bf16_t* Ks = Dc + CK * 16 * C::PITCH + (threadIdx.x >> 6) * 32 * C::PITCH;             // dk form: this wave's k rows, then its v rows
@@ -2525,7 +2533,7 @@ int launch_backward(const vu_flash_args& a, hipStream_t st) {
   hipStream_t s_dv = st;
   const bool early_dv = tail_overlap_v1(fp, nblk, st, true);
   auto launch_dv = [&]() -> int {
-    hipLaunchKernelGGL(k4, dim3(nblk), dim3(WPB * 64), lds4, s_dv, q, k, v, dO, a.lse2, (const float*)nullptr, a.stats, (bf16_t*)a.dv, a.B, a.N, c, a.scale, a.rng);
+    hipLaunchKernelGGL(k4, dim3(nblk), dim3(WPB * 64), lds4, s_dv, q, k, v, dO, a.lse2, (const float*)nullptr, a.stats, (bf16_t*)a.dv, a.B, a.N, c, a.scale, a.rng, 0);
     if (vu_prof_on()) vu_prof_note("flash_bwd_dv_kernel", 4.0 * E * DH + 2.0 * E * H, 4.0 * act);
     return vu_check_launch("flash_bwd_dv");
   };
@@ -2538,16 +2546,17 @@ int launch_backward(const vu_flash_args& a, hipStream_t st) {
   // the training backward behind a forward that saved V = sum_k bf16(P) k: dq leaves the delta sweep (VU_FLASH_FUSE_DQ=0: the
   // separate dq sweep of rounds 2 - 3, for the A/B record)
   static const bool fuse_off = [] { const char* e = getenv("VU_FLASH_FUSE_DQ"); return e && e[0] == '0'; }();
+  static const bool clr = [] { const char* e = getenv("VU_FLASH_V1_CLEAR"); return e && e[0] == '1'; }();
   const bool fused = a.pk != nullptr && a.rinv_b != nullptr && a.training && !fuse_off;
   if (fused) {
     auto k1q = flash_bwd_delta_kernel<H, DH, WPB, CK2, true>;
     VU_TRY(reserve_lds(k1q, lds1));
     hipLaunchKernelGGL(k1q, dim3(nblk), dim3(WPB * 64), lds1, st, q, k, v, dO, a.lse2, a.rinv, a.stats, a.delta, a.partials, a.B, a.N, c, a.rng,
-                       (const float*)a.pk, (bf16_t*)a.dq, a.scale, (const float*)a.rinv_b);
+                       (const float*)a.pk, (bf16_t*)a.dq, a.scale, (const float*)a.rinv_b, clr ? (int)lds1 : 0);
     if (vu_prof_on()) vu_prof_note("flash_bwd_delta_dq_kernel", 6.0 * E * DH + 6.0 * E * H, 6.0 * act);
   } else {
     hipLaunchKernelGGL(k1, dim3(nblk), dim3(WPB * 64), lds1, st, q, k, v, dO, a.lse2, a.rinv, a.stats, a.delta, a.partials, a.B, a.N, c, a.rng,
-                       (const float*)nullptr, (bf16_t*)nullptr, 0.f, (const float*)nullptr);
+                       (const float*)nullptr, (bf16_t*)nullptr, 0.f, (const float*)nullptr, clr ? (int)lds1 : 0);
     if (vu_prof_on()) vu_prof_note("flash_bwd_delta_kernel", 4.0 * E * DH + 6.0 * E * H, 4.0 * act);
   }
   VU_TRY(vu_check_launch("flash_bwd_delta"));
@@ -2558,14 +2567,21 @@ int launch_backward(const vu_flash_args& a, hipStream_t st) {
     if (vu_prof_on()) vu_prof_note("flash_bwd_dq_kernel", 6.0 * E * DH + 4.0 * E * H, 5.0 * act);
     VU_TRY(vu_check_launch("flash_bwd_dq"));
   }
-  hipLaunchKernelGGL(k3, dim3(nblk), dim3(WPB * 64), lds3, st, q, k, v, dO, a.lse2, a.delta, a.stats, (bf16_t*)a.dk, a.B, a.N, c, a.scale, a.rng);
+  hipLaunchKernelGGL(k3, dim3(nblk), dim3(WPB * 64), lds3, st, q, k, v, dO, a.lse2, a.delta, a.stats, (bf16_t*)a.dk, a.B, a.N, c, a.scale, a.rng, clr ? (int)lds3 : 0);
   if (vu_prof_on()) vu_prof_note("flash_bwd_dk_kernel", 6.0 * E * DH + 4.0 * E * H, 5.0 * act);
   VU_TRY(vu_check_launch("flash_bwd_dk"));
   VU_TRY(launch_center_dk(a, st));
-  if (!early_dv) return launch_dv();
-  if (!(hipEventRecord(fp->e[2], fp->s[1]) == hipSuccess && hipStreamWaitEvent(st, fp->e[2], 0) == hipSuccess)) {
+  if (!early_dv) VU_TRY(launch_dv());
+  else if (!(hipEventRecord(fp->e[2], fp->s[1]) == hipSuccess && hipStreamWaitEvent(st, fp->e[2], 0) == hipSuccess)) {
     vu_set_error("flash attention: stream join failed");
     return VU_ELAUNCH;
+  }
+  {   // bisect switch (tools/contention_ops.py): VU_FLASH_V1_ZERO = bit mask of outputs overwritten with zeros (1 dq, 2 dk, 4 dv)
+    static const int zmask = [] { const char* e = getenv("VU_FLASH_V1_ZERO"); return e ? atoi(e) : 0; }();
+    const size_t nb = (size_t)a.B * a.N * C::D * 2;
+    if (zmask & 1) (void)hipMemsetAsync(a.dq, 0, nb, st);
+    if (zmask & 2) (void)hipMemsetAsync(a.dk, 0, nb, st);
+    if (zmask & 4) (void)hipMemsetAsync(a.dv, 0, nb, st);
   }
   return VU_OK;
 }
