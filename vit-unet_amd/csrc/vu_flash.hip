@@ -70,6 +70,22 @@ __device__ __forceinline__ RowW<H> ld_row(const float* p) {
   return r;
 }
 #define LDS_FENCE() asm volatile("" ::: "memory")
+// The transposed-mix table FWkT of the 4-head backward sweeps lives in REGISTERS (16 per lane), not in the LDS struct: with its rows
+// prefetched from LDS inside the head loop (rounds 2 - 3) the delta / dq / dk sweeps lost bit-reproducibility whenever ANOTHER
+// PROCESS computed on the same GPU - delta (and with it dq, dk) of 1 - 2 % of the 16-query tiles off in the last bits, every other
+// buffer of the module identical (tools/attn_ws_diff.py).  Same arithmetic, same order; -DVU_V1_FW_LDS=1 restores the LDS
+// rows for the A/B record.  (8 heads: 64 registers would not fit; that instantiation is not used - the 8-head form is flash2_*.)
+#if defined(VU_V1_FW_LDS) && VU_V1_FW_LDS
+#define VU_V1_FW_DECL ((void)0)
+#define VU_V1_FW_ROW(i) ld_row<H>(tb->FWkT + (i) * H)
+#else
+#define VU_V1_FW_DECL \
+  RowW<H> fwr[H <= 4 ? H : 1]; \
+  if constexpr (H <= 4) { \
+    _Pragma("unroll") for (int hh_ = 0; hh_ < H; ++hh_) { _Pragma("unroll") for (int gg_ = 0; gg_ < H; ++gg_) fwr[hh_].w[gg_] = stats[VU_BN_STATS_FWK(H) + gg_ * H + hh_]; } \
+  }
+#define VU_V1_FW_ROW(i) (H <= 4 ? fwr[H <= 4 ? (i) : 0] : ld_row<H>(tb->FWkT + (i) * H))
+#endif
 
 // rows [0, nrows) of a row-major (., D) bf16 matrix -> LDS chunk with pitch PITCH.  Four independent 16-byte loads in
 // flight per thread (named registers and clamped unconditional loads: an indexed array or a load-or-skip select ends up
@@ -947,6 +963,7 @@ __global__ __launch_bounds__(WPB * 64, VU_FLASH_V1_WAVES(H, DH)) void flash_bwd_
   }
   zero_pads<H, DH>(Kc, 2 * CK * 16 + WPB * 32, tid, WPB * 64);
   load_bwd_tab<H>(tb, stats, tid, WPB * 64);
+  VU_V1_FW_DECL;
   const uint32_t hstride = (uint32_t)(((unsigned long long)N * N) >> 2);          // quad words per (sample, head) map
   const uint32_t wlane = (uint32_t)((((unsigned long long)b * N + qrow) * (unsigned long long)N) >> 2) + (uint32_t)g4;
   const int nchunks = (ntiles + CK - 1) / CK;
@@ -967,11 +984,11 @@ __global__ __launch_bounds__(WPB * 64, VU_FLASH_V1_WAVES(H, DH)) void flash_bwd_
 #pragma unroll
         for (int g = 0; g < H; ++g) Tc[g] += (E[g][0] + E[g][1]) + (E[g][2] + E[g][3]);
         LDS_FENCE();
-        RowW<H> wcur = ld_row<H>(tb->FWkT);
+        RowW<H> wcur = VU_V1_FW_ROW(0);
 #pragma unroll
         for (int h = 0; h < H; ++h) {
           RowW<H> wnxt = wcur;
-          if (h + 1 < H) wnxt = ld_row<H>(tb->FWkT + (h + 1) * H);
+          if (h + 1 < H) wnxt = VU_V1_FW_ROW(h + 1);
           LDS_FENCE();
           s16x4 aop[C::DT];
           if constexpr (DQ) {
@@ -1096,6 +1113,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash_bwd_dq_kernel(
   }
   zero_pads<H, DH>(Kc, 2 * CK * 16 + WPB * 32, tid, WPB * 64);
   load_bwd_tab<H>(tb, stats, tid, WPB * 64);
+  VU_V1_FW_DECL;
   f32x4 dqa[H][C::DT];
 #pragma unroll
   for (int h = 0; h < H; ++h)
@@ -1124,11 +1142,11 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash_bwd_dq_kernel(
         }
         mix_to_e<H>(E, S, tb);
         LDS_FENCE();
-        RowW<H> wcur = ld_row<H>(tb->FWkT);
+        RowW<H> wcur = VU_V1_FW_ROW(0);
 #pragma unroll
         for (int h = 0; h < H; ++h) {
           RowW<H> wnxt = wcur;
-          if (h + 1 < H) wnxt = ld_row<H>(tb->FWkT + (h + 1) * H);
+          if (h + 1 < H) wnxt = VU_V1_FW_ROW(h + 1);
           const float dlh = rowc[(H + h) * 16 + l15];
           s16x4 aop[C::DT];
 #pragma unroll
@@ -1207,6 +1225,7 @@ __global__ __launch_bounds__(WPB * 64, VU_FLASH_V1_WAVES(H, DH)) void flash_bwd_
   }
   zero_pads<H, DH>(Qc, 2 * CK * 16 + (DV ? 0 : WPB * 32), tid, WPB * 64);
   load_bwd_tab<H>(tb, stats, tid, WPB * 64);
+  VU_V1_FW_DECL;
   for (int i = tid; i < H * H + H; i += WPB * 64) ftab[i] = i < H * H ? stats[VU_BN_STATS_FWK(H) + i] : stats[H * H + (i - H * H)];
   f32x4 oa[H][C::DT];
 #pragma unroll
@@ -1271,11 +1290,11 @@ __global__ __launch_bounds__(WPB * 64, VU_FLASH_V1_WAVES(H, DH)) void flash_bwd_
           tile_prod<H, DH, false>(E, Dc, qc, nullptr, Vs, tb->cin, l15, g4);
           mix_to_e<H>(E, S, tb);
           LDS_FENCE();
-          RowW<H> wcur = ld_row<H>(tb->FWkT);
+          RowW<H> wcur = VU_V1_FW_ROW(0);
 #pragma unroll
           for (int h = 0; h < H; ++h) {
             RowW<H> wnxt = wcur;
-            if (h + 1 < H) wnxt = ld_row<H>(tb->FWkT + (h + 1) * H);
+            if (h + 1 < H) wnxt = VU_V1_FW_ROW(h + 1);
             s16x4 aop[C::DT];
 #pragma unroll
             for (int dt = 0; dt < C::DT; ++dt) aop[dt] = tr_operand<C::PITCH>(Qc, qc * 16, h * DH + 16 * dt, l15, g4);
