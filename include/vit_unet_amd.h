@@ -288,6 +288,13 @@ int vu_set_attn_form(int flash, int centered);
  * 2 = wave pairs in 4-wave workgroups, 3 = wave pairs in 8-wave workgroups (the Base / Large level-2 shape).  Process-level, for
  * tests and measurements; results differ between the forms by the order of the fp32 sums only. */
 int vu_set_flash_key_split(int ks);
+/* Recompute form, 8 heads: probability cache (csrc/vu_flash.hip "probability cache").  1: the training forward's moments sweep stores
+ * the packed sign-tagged bf16 probabilities of every 16 x 16 tile (B h N^2 2 bytes per attention module, part of the workspace) and
+ * the apply / dq / dk / dv sweeps stream them instead of rebuilding logits -> exp2 -> mask -> pack; 0: every sweep recomputes (the
+ * round 2 - 4 form); -1: the build's default.  Results are bit-identical either way.  Process-level like vu_set_attn_form: it changes
+ * vu_model_workspace_bytes / vu_attn_workspace_bytes, so set it before sizing a workspace, never between a forward and its backward.
+ * Initial value: VU_FLASH_PCACHE (0 / 1), read once. */
+int vu_set_flash_pcache(int on);
 
 /* In-process launch profiler (bench.py's roofline leg): PROCESS-GLOBAL state, meant for one
  * instrumented stream at a time.  After vu_prof_enable(stream) an event is
@@ -295,6 +302,11 @@ int vu_set_flash_key_split(int ks);
  * {"<kernel tag>": {"count","ms","flops","bytes"}} with ALGORITHMIC flops / bytes per tag. */
 int vu_prof_enable(void* stream);
 const char* vu_prof_report(void);
+/* Holds the profiled stream for `usec` microseconds (0 .. 200000) with a one-wave kernel, so that the launches the host enqueues
+ * behind it execute back to back: without it an interval between two events also contains the time the GPU waited for the host
+ * (small batches: launches of 5 - 20 us are faster than the eager host).  Its own interval is not reported.  The report's
+ * "flops_strict" counts the model's own products only (no recomputation, no padding); "flops" is the launch's work. */
+int vu_prof_gate(int usec);
 
 #ifdef __cplusplus
 }

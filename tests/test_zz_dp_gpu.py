@@ -82,3 +82,33 @@ def test_four_head_recompute_attention_under_gpu_sharing():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "contention_ops.py"), "--load", "60", "--iters", "30", "--B", "16", "--attn", "all"],
                        capture_output=True, text=True, timeout=420, env=env)
     assert "CONTENTION_OPS CLEAN" in r.stdout, r.stdout[-2000:]
+
+
+def test_bench_launches_its_own_ranks_over_rccl():
+    """`python bench.py --gpus N` as the driver calls it (no torchrun around it): bench.py starts its ranks itself as a child
+    `python -m torch.distributed.run` before touching the GPU and relays rank 0's line.  On this one-GPU box: VU_DP_FORCE=1 sends
+    --gpus 1 through that path - the line must report the RCCL process group it formed; and --gpus 2 must fail with the CHILD's
+    error (no second device), not with a message about torchrun."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", VU_DP_FORCE="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                        "--no-host-input", "--no-sustained"], capture_output=True, text=True, timeout=420, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["config"]["rccl_path"] is True
+    comm = out["config"]["comm"]
+    assert comm["backend"] == "nccl" and comm["ranks"] == 1 and comm["buckets"] >= 1
+    assert out["value"] > 0 and out["roofline"] is not None
+    import torch
+    if torch.cuda.device_count() == 1:
+        env.pop("VU_DP_FORCE")
+        r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
+                             "--no-roofline"], capture_output=True, text=True, timeout=300, env=env)
+        assert r2.returncode != 0
+        assert "needs torchrun" not in (r2.stdout + r2.stderr)

@@ -12,6 +12,8 @@ struct vu_flash_args {
   float* lse2;                 // (B,H,N): log2-domain log-sum-exp of the scaled logits, kept for the backward
   float* rinv;                 // (B,H,N): 1 / (row sum of the probabilities as every sweep recomputes them from lse2), kept for the backward
   float* pk;                   // (B,N,D) fp32: sum_k bf16(P) k per head (the training forward writes it, the backward's fused delta + dq sweep reads it; null: separate sweeps)
+  void* pcache;                // 8-head form, optional: B (N/16)^2 tiles of 4 KB - the sign-tagged bf16 probabilities of every (query tile, key tile) as
+                               // the moments sweep packed them (vu_flash_pcache_bytes); the later sweeps stream it instead of rebuilding logits -> exp2 -> mask -> pack
   float* rinv_b;               // (B,H,N) 4-head form only: 1 / sum_k bf16(P) of the moments sweep (the fused dq's delta~; rinv keeps the fp32 row sum for the dk sweep)
   float* partials;             // >= vu_flash_partials_floats()
   float* stats;                // VU_BN_STATS_FLOATS(H): folded tables (vu_kernels.h)
@@ -37,5 +39,8 @@ bool vu_flash_ok(int dtype, int B, int N, int D, int H);
 // after the round-2 ISA pass: 8 images -9 %, 16 +3 %, 24 +6 %, 32 +4 %, 64 +12 %; Large at 16: +3 %  ->  threshold 192 groups
 bool vu_flash_pays(int B, int N);
 size_t vu_flash_partials_floats(int B, int N, int H);
+// bytes of the probability cache of one module (0: this shape / this process does not use one).  Process-level switch, read once:
+// VU_FLASH_PCACHE=0 / 1, vu_set_flash_pcache()
+size_t vu_flash_pcache_bytes(int B, int N, int D, int H);
 int vu_k_flash_forward(const vu_flash_args& a, hipStream_t st);
 int vu_k_flash_backward(const vu_flash_args& a, hipStream_t st);

@@ -21,6 +21,7 @@
 // B operand with no lane movement, their A operands come out of the row-major K / V chunk through ds_read_b64_tr_b16.
 // Algorithmic HBM traffic: q, k, v, O (+ dO, dq, dk, dv) only: ~10 B N D per module instead of 11 E.
 #include <stdio.h>
+#include <algorithm>
 #include <stdlib.h>
 #include <string.h>
 #include "vu_kernels.h"
@@ -1478,13 +1479,101 @@ __device__ __forceinline__ s16x4 tr_rel(const bf16_t* Xc, int base, int j, int f
 }
 template <int DH> constexpr int tr_strip_elems() { return ((3 * DH + 8 * ((DH + 7) / 8) + 8 + 7) / 8) * 8; }
 
+
+// ---- probability cache (round 5) --------------------------------------------------------------------------------------
+// The training forward's moments sweep packs the sign-tagged probabilities of every 16 x 16 tile of ALL heads to bf16 anyway
+// (pack_heads: the operand of the head mix).  With a cache (vu_flash_args::pcache) it also STORES those four registers per lane:
+// tile (b, query tile qt, key tile kt) = 4 KB as [r][lane] 16-byte vectors - lane (query l15, key quad g4) holds the 8 heads of key
+// 4 g4 + r - and the four sweeps after it (apply, dq + delta, dk, dv) stream the tile back instead of rebuilding logits -> exp2 ->
+// mask hash -> compare / select -> pack (measured round 3: ~half of a sweep).  Same bits as the recomputed operand, so every
+// result is identical to the recompute form's.  The query-major sweeps walk a query tile's row of tiles (contiguous), the
+// key-major ones a column (4 KB pieces, stride N / 16 tiles).  2 bytes per map element per module: B h N^2 2 (Base level 2 at 64
+// images: 630 MB), written once, read four times, non-temporal on both sides.
+struct PTile { u32x4_t r[4]; };
+// The two sweeps that do little besides streaming the cache (apply, dv) take their tiles through a wave-private LDS RING filled by
+// LDS-DMA (global_load_lds_dwordx4, as in vu_bgemm.hip): a tile's [r][lane] layout is four linear 1 KiB pieces, exactly what one DMA
+// instruction writes, so VU_PC_RING tiles are in flight per wave with no staging registers, and the waits are explicit
+// (s_waitcnt vmcnt(4 * tiles younger than the one wanted)).  hipcc does not count these loads: wherever it waits for loads of its own
+// (the register-staged chunk at a chunk boundary) it waits for the ring as well - correct, and the reason for longer chunks here.
+// With register-staged tiles instead (round 5, first form) hipcc's own waits drained the prefetch at every loop head
+// (s_waitcnt vmcnt(0) behind the reload): 144 us per sweep at 64 images where the bare stream takes 94 (tools/probe/tile_stream_probe).
+#ifndef VU_PC_RING
+#define VU_PC_RING 2
+#endif
+// one tile: four pieces of 1 KiB, global byte offsets v[r] = lane * 16 + r * 1024 from `tile`, LDS destinations 1 KiB apart (M0 carries
+// the LDS address and is compiler-reserved: saved and restored inside the statement - the idiom of vu_bgemm.hip's dma16x4)
+__device__ __forceinline__ void pc_dma4(const void* tile, unsigned v0, unsigned v1, unsigned v2, unsigned v3, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1 nt\n\t"
+               "s_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1 nt\n\t"
+               "s_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %1 nt\n\t"
+               "s_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %1 nt\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "s"(tile), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(lds_dst) : "memory", "scc");
+}
+#ifndef VU_DQX_ABLATE
+#define VU_DQX_ABLATE 0         // measurement builds of the cached dq sweep: 1 no head-mix-gradient images, 2 no dq product, 4 no transposed mix, 8 no chunk staging / barriers after the first chunk, 16 no dA^ product / mix
+#endif
+#ifndef VU_PC_ABLATE
+#define VU_PC_ABLATE 0          // measurement builds (results wrong by construction): 1 no cache stream, 2 no chunk staging / barriers after the first chunk, 4 no PV products
+#endif
+template <int RD>
+struct PRing {
+  const unsigned char* base;   // the wave's slot 0 (generic LDS pointer for the reads)
+  unsigned lds0, v0;           // its LDS byte address; lane * 16
+  int seq;                     // tiles taken so far
+  __device__ __forceinline__ void init(unsigned char* ring, int wave, int lane) {
+    base = ring + wave * (RD * 4096);
+    lds0 = (unsigned)(size_t)base; v0 = (unsigned)lane * 16u; seq = 0;
+  }
+  __device__ __forceinline__ void issue(const void* pc, long long tile, int slot) const {
+    if (VU_PC_ABLATE & 1) return;
+    // (wave-uniform values that hipcc cannot prove uniform - they derive from threadIdx.x >> 6: made scalar explicitly)
+    const unsigned long long a = (unsigned long long)(reinterpret_cast<const char*>(pc) + tile * 4096);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    const void* tp = reinterpret_cast<const void*>(((unsigned long long)hi << 32) | lo);
+    pc_dma4(tp, v0, v0 + 1024u, v0 + 2048u, v0 + 3072u, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)slot * 4096u));
+  }
+  // the oldest tile in flight -> registers (its RD - 1 successors stay in flight), then the slot is free for `refill`
+  __device__ __forceinline__ int take(bf16x8 (&pk)[4], int lane) {
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"((RD - 1) * 4) : "memory");
+    const int slot = seq % RD;
+    const unsigned char* p = base + slot * 4096 + lane * 16;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pk[r] = *reinterpret_cast<const bf16x8*>(p + r * 1024);
+    ++seq;
+    return slot;
+  }
+  // after the registers of `take` have arrived (s_waitcnt lgkmcnt(0): a DMA write must not overtake the LDS reads of its slot)
+  __device__ __forceinline__ void refill(const void* pc, long long tile, int slot) const {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    issue(pc, tile, slot);
+  }
+  __device__ __forceinline__ static void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+};
+__device__ __forceinline__ const u32x4_t* pc_tile(const void* pc, int b, int nt, int qt, int kt, int lane) {
+  return reinterpret_cast<const u32x4_t*>(pc) + ((((long long)b * nt + qt) * nt + kt) * 4) * 64 + lane;
+}
+__device__ __forceinline__ void pc_load(PTile& t, const u32x4_t* p) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) t.r[r] = __builtin_nontemporal_load(p + r * 64);
+}
+__device__ __forceinline__ void pc_store(const bf16x8 (&pk)[4], u32x4_t* p) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) __builtin_nontemporal_store(__builtin_bit_cast(u32x4_t, pk[r]), p + r * 64);
+}
+__device__ __forceinline__ void pc_take(bf16x8 (&pk)[4], const PTile& t) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) pk[r] = __builtin_bit_cast(bf16x8, t.r[r]);
+}
+
 // ---- stats pass, sweep 3 only (sweeps 1 / 2 are the v1 code): moments of the MIXED map directly -------------------
 // per lane 4 heads x (sum, sum of squares) of A_g - shift_g, shift_g = sum_h W[g,h] / N (the exact mean without dropout)
-template <int DH, int WPB, int CK, int KS = 1>
+template <int DH, int WPB, int CK, int KS = 1, bool PC = false>
 __global__ __launch_bounds__(WPB * 64, 2) void flash2_moments_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                                       const float* __restrict__ lse2, const float* __restrict__ W,
                                                                       float* __restrict__ partials, float* __restrict__ pk_out,
-                                                                      float* __restrict__ rinv, int B, int N, float c, vu_rng rng_in) {
+                                                                      float* __restrict__ rinv, int B, int N, float c, vu_rng rng_in,
+                                                                      void* __restrict__ pcache) {
   constexpr int H = 8;
   typedef FC<H, DH> C;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1566,6 +1655,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_moments_kernel(const bf16_
         tag_probs<H>(S, lse, c, rng, wlane + 4u * (uint32_t)(ch * CK + kc), hstride);
         bf16x8 pk[4];
         pack_heads(S, pk);
+        if constexpr (PC) pc_store(pk, const_cast<u32x4_t*>(pc_tile(pcache, b, ntiles, tq, ch * CK + kc, lane)));
         const int last_kc = last_base + (spare_lane ? 0 : kc * 16 * C::PITCH);
 #pragma unroll
         for (int h = 0; h < H; ++h) {                  // a logits-shaped tile is the B operand of a key-contracting product as it stands
@@ -1654,15 +1744,17 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_moments_kernel(const bf16_
 }
 
 // ---- apply pass --------------------------------------------------------------------------------------------------
-template <int DH, int WPB, int CK, int KS = 1>
+// PC: the sign-tagged probabilities come from the cache the moments sweep wrote (one 4 KB tile per step, the next one in flight
+// during the mix / PV products of the current one): no q, no K chunk, no logits, exp2, hash or pack
+template <int DH, int WPB, int CK, int KS = 1, bool PC = false>
 __global__ __launch_bounds__(WPB * 64, 2) void flash2_apply_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, const float* __restrict__ lse2,
-    const float* __restrict__ stats, bf16_t* __restrict__ O, int B, int N, float c, vu_rng rng_in) {
+    const float* __restrict__ stats, bf16_t* __restrict__ O, int B, int N, float c, vu_rng rng_in, const void* __restrict__ pcache) {
   constexpr int H = 8, FB = DH / 8;
   typedef FC<H, DH> C;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* Kc = reinterpret_cast<bf16_t*>(smem_raw);
-  bf16_t* Vc = Kc + CK * 16 * C::PITCH;
+  bf16_t* Vc = PC ? Kc : Kc + CK * 16 * C::PITCH;
   bf16_t* Zr = Vc + CK * 16 * C::PITCH;                                   // zero region for the dead operand halves
   const vu_rng rng = vu_rng_resolve(rng_in);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
@@ -1677,10 +1769,17 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_apply_kernel(
   const bf16_t* kb = k + (long long)b * N * C::D;
   const bf16_t* vb = v + (long long)b * N * C::D;
   bf16x8 qf[H * C::NK];
-  load_stationary<H, DH>(qf, q + ((long long)b * N + qrow) * C::D, g4);
   float lse[H];
+  if constexpr (!PC) {
+    load_stationary<H, DH>(qf, q + ((long long)b * N + qrow) * C::D, g4);
 #pragma unroll
-  for (int h = 0; h < H; ++h) lse[h] = lse2[((long long)b * H + h) * N + qrow];
+    for (int h = 0; h < H; ++h) lse[h] = lse2[((long long)b * H + h) * N + qrow];
+  }
+  // PC: the wave's next tile(s) of row tq (it takes tiles ksh, ksh + KS, ...).  Unsplit sweeps keep TWO tiles in flight (the sweep is
+  // bound by the cache stream: 4 KB per tile and wave), even tiles in nx, odd ones in nx1 (every chunk starts at an even tile)
+  constexpr int RD = VU_PC_RING;
+  PRing<RD> ring;
+  if constexpr (PC) ring.init(reinterpret_cast<unsigned char*>(Zr + tr_zero_elems<H, DH>()), wave, lane);
   for (int i = tid; i < tr_zero_elems<H, DH>() / 8; i += WPB * 64) *reinterpret_cast<uint4*>(Zr + i * 8) = make_uint4(0, 0, 0, 0);
   MixOp op;                                                               // gamma rstd W / keep
   make_mix_op(op, stats + VU_BN_STATS_FWK(H), nullptr, l15, g4);
@@ -1698,30 +1797,52 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_apply_kernel(
   const uint32_t wlane = (uint32_t)((((unsigned long long)b * N + qrow) * (unsigned long long)N) >> 2) + (uint32_t)g4;
   const int nchunks = (ntiles + CK - 1) / CK;
   ChunkStage<H, DH, CK * 16, WPB * 64> st_Kc;
-  st_Kc.fetch(kb, min(CK, ntiles) * 16, tid);
+  if constexpr (!PC) st_Kc.fetch(kb, min(CK, ntiles) * 16, tid);
   ChunkStage<H, DH, CK * 16, WPB * 64> st_Vc;
   st_Vc.fetch(vb, min(CK, ntiles) * 16, tid);
+  const long long trow = ((long long)b * ntiles + tq) * ntiles;      // PC: first tile of the wave's row of the cache
+  if constexpr (PC) {
+    if (active) {
+#pragma unroll
+      for (int i = 0; i < RD; ++i) ring.issue(pcache, trow + min(ksh + i * KS, ntiles - 1), i);
+    }
+  }
   for (int ch = 0; ch < nchunks; ++ch) {
     const int nt = min(CK, ntiles - ch * CK);
+    if (!(PC && (VU_PC_ABLATE & 2) && ch > 0)) {
     __syncthreads();                                  // every wave has finished with the previous chunk
-    st_Kc.commit(Kc, nt * 16, tid);
+    if constexpr (!PC) st_Kc.commit(Kc, nt * 16, tid);
     st_Vc.commit(Vc, nt * 16, tid);
     __syncthreads();
     {                                               // next chunk in flight during the tile loop (the last trip re-fetches its own)
       const int cn = ch + 1 < nchunks ? ch + 1 : ch;
-      st_Kc.fetch(kb + (long long)cn * CK * 16 * C::D, min(CK, ntiles - cn * CK) * 16, tid);
+      if constexpr (!PC) st_Kc.fetch(kb + (long long)cn * CK * 16 * C::D, min(CK, ntiles - cn * CK) * 16, tid);
       st_Vc.fetch(vb + (long long)cn * CK * 16 * C::D, min(CK, ntiles - cn * CK) * 16, tid);
+    }
     }
     if (active)
       for (int kc = (KS == 1 ? 0 : ((ch * CK) & 1) ^ ksh); kc < nt; kc += KS) {
-        f32x4 S[H];
-        tile_logits<H, DH>(S, Kc, kc, qf, l15, g4);
-        tag_probs<H, true>(S, lse, c, rng, wlane + 4u * (uint32_t)(ch * CK + kc), hstride);      // P~ (dropped = 0)
         bf16x8 pk[4];
-        pack_heads(S, pk);
+        int slot = 0;
+        if constexpr (PC) {
+          slot = ring.take(pk, lane);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pk[r] = relu_packed(pk[r]);         // P~ (dropped = 0)
+        } else {
+          f32x4 S[H];
+          tile_logits<H, DH>(S, Kc, kc, qf, l15, g4);
+          tag_probs<H, true>(S, lse, c, rng, wlane + 4u * (uint32_t)(ch * CK + kc), hstride);      // P~ (dropped = 0)
+          pack_heads(S, pk);
+        }
         f32x4 A[2][4];
         mix_ml(A, op, pk, cin);                       // A^ in ML
+        if constexpr (PC) ring.refill(pcache, trow + min(ch * CK + kc + RD * KS, ntiles - 1), slot);
         const int tb = src.base(kc);
+        if (PC && (VU_PC_ABLATE & 4)) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) oacc[j][0] += A[0][j] + A[1][j];
+          continue;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {                // the two key halves of the tile as the two k-blocks of one K = 32 product (join_k)
           const f32x4 a0 = {A[0][0][j], A[0][1][j], A[0][2][j], A[0][3][j]}, a1 = {A[1][0][j], A[1][1][j], A[1][2][j], A[1][3][j]};
@@ -1732,6 +1853,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_apply_kernel(
         }
       }
   }
+  if constexpr (PC) ring.drain();           // (the clamped refills behind the last tiles: nothing may land in LDS after the wave has left)
   if constexpr (KS == 2) {
     __syncthreads();
     float* cs = reinterpret_cast<float*>(smem_raw) + (wave >> 1) * (4 * FB * 256);
@@ -1790,6 +1912,28 @@ __device__ __forceinline__ void bwd2_chain(f32x4 (&S)[H], const bf16_t* Dc, int 
 #pragma unroll
     for (int r = 0; r < 4; ++r) pk[r] = relu_packed(pk[r]);
   }
+  mix_ml(E, o.xk2, pk, o.cin);                           // -m1 - m2 x^
+  LDS_FENCE();
+  f32x4 Dh[H];
+  tile_prod<H, DH, STREAM_A>(Dh, Dc, kc, nullptr, dst, nullptr, l15, g4);
+  pack_heads(Dh, pk);
+  convert_ml(E, o.id, pk, true);                         // + dA^  = e
+}
+// The same chain behind cached probabilities (PC sweeps), in two pieces so that the caller can issue the load of its next cache tile
+// between them (after the last use of the registers the tile arrived in):
+//   head: pk = the cached tags (KEPT_ONLY: already max(tag, 0) = P~) -> T (ML); pk <- P~
+//   tail: E = -m1 - m2 x^ + dA^ (dA^ formed here from the streamed chunk and the stationary image)
+template <bool KEPT_ONLY>
+__device__ __forceinline__ void bwd2_head_pk(bf16x8 (&pk)[4], const Bwd2Ops& o, f32x4 (&T)[2][4]) {
+  convert_ml(T, o.id, pk, false);
+  if constexpr (!KEPT_ONLY) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pk[r] = relu_packed(pk[r]);
+  }
+}
+template <int H, int DH, bool STREAM_A>
+__device__ __forceinline__ void bwd2_tail_pk(bf16x8 (&pk)[4], const bf16_t* Dc, int kc, const bf16_t* dst, const Bwd2Ops& o, f32x4 (&E)[2][4],
+                                             int l15, int g4) {
   mix_ml(E, o.xk2, pk, o.cin);                           // -m1 - m2 x^
   LDS_FENCE();
   f32x4 Dh[H];
@@ -2045,23 +2189,25 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_bwd_dq_kernel(
 // second one for dq (each recomputing the chain), accumulate U = sum_k (P~ dP~) k here and take V = sum_k P k from the
 // forward (flash2_moments_kernel): dq = scale (U - delta V).  The u = P~ dP~ terms go to the matrix cores as single bf16
 // values like dS did; U - delta V is the covariance form of the same sum.
-template <int DH, int WPB, int CK, int KS = 1>
+// PC: probabilities from the cache (see flash2_apply_kernel): no q image, no logits; the wave keeps only its dO rows
+template <int DH, int WPB, int CK, int KS = 1, bool PC = false>
 __global__ __launch_bounds__(WPB * 64, 2) void flash2_bwd_dqx_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, const bf16_t* __restrict__ dO,
     const float* __restrict__ lse2, const float* __restrict__ rinv, const float* __restrict__ pkv, const float* __restrict__ stats,
     bf16_t* __restrict__ dq, float* __restrict__ delta, float* __restrict__ partials, int B, int N, float c, float scale,
-    vu_rng rng_in, int want_dc) {
+    vu_rng rng_in, int want_dc, const void* __restrict__ pcache) {
   constexpr int H = 8, FB = DH / 8, NT = H * H + H, IMP = 16;
+  constexpr int SR = PC ? 16 : 32;                  // stationary rows per wave: (q and) dO
   typedef FC<H, DH> C;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* Kc = reinterpret_cast<bf16_t*>(smem_raw);
   bf16_t* Vc = Kc + CK * 16 * C::PITCH;
-  bf16_t* Qs = Vc + CK * 16 * C::PITCH + (threadIdx.x >> 6) * 32 * C::PITCH;
-  bf16_t* dOs = Qs + 16 * C::PITCH;
+  bf16_t* Qs = Vc + CK * 16 * C::PITCH + (threadIdx.x >> 6) * SR * C::PITCH;
+  bf16_t* dOs = PC ? Qs : Qs + 16 * C::PITCH;
   // [32 positions][16: e_0..7 | P^_0..7], 8-byte column blocks XOR-swizzled with (row >> 2) & 3 (pitch 32 B: unswizzled,
   // rows 4 apart would meet on the same banks in the stores)
-  bf16_t* img = Vc + CK * 16 * C::PITCH + WPB * 32 * C::PITCH + (threadIdx.x >> 6) * (32 * IMP);
-  bf16_t* Zr = Vc + CK * 16 * C::PITCH + WPB * 32 * C::PITCH + WPB * (32 * IMP);
+  bf16_t* img = Vc + CK * 16 * C::PITCH + WPB * SR * C::PITCH + (threadIdx.x >> 6) * (32 * IMP);
+  bf16_t* Zr = Vc + CK * 16 * C::PITCH + WPB * SR * C::PITCH + WPB * (32 * IMP);
   float* red = reinterpret_cast<float*>(Kc);                              // [WPB][NT], after the last tile (aliases the K chunk)
   const vu_rng rng = vu_rng_resolve(rng_in);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
@@ -2075,13 +2221,17 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_bwd_dqx_kernel(
   const int qrow = tq * 16 + l15;
   const bf16_t* kb = k + (long long)b * N * C::D;
   const bf16_t* vb = v + (long long)b * N * C::D;
-  zero_pads<H, DH>(Vc + CK * 16 * C::PITCH, WPB * 32, tid, WPB * 64);       // (tile_prod reads the pads of the stationary images as zeros)
-  stage_own_rows<H, DH>(Qs, q + ((long long)b * N + tq * 16) * C::D, lane);
+  zero_pads<H, DH>(Vc + CK * 16 * C::PITCH, WPB * SR, tid, WPB * 64);       // (tile_prod reads the pads of the stationary images as zeros)
+  if constexpr (!PC) stage_own_rows<H, DH>(Qs, q + ((long long)b * N + tq * 16) * C::D, lane);
   stage_own_rows<H, DH>(dOs, dO + ((long long)b * N + tq * 16) * C::D, lane);
   for (int i = tid; i < tr_strip_elems<DH>() / 8; i += WPB * 64) *reinterpret_cast<uint4*>(Zr + i * 8) = make_uint4(0, 0, 0, 0);
   float lse[H];
+  if constexpr (!PC) {
 #pragma unroll
-  for (int h = 0; h < H; ++h) lse[h] = lse2[((long long)b * H + h) * N + qrow];
+    for (int h = 0; h < H; ++h) lse[h] = lse2[((long long)b * H + h) * N + qrow];
+  }
+  PTile nx;
+  if constexpr (PC) pc_load(nx, pc_tile(pcache, b, ntiles, tq, min(ksh, ntiles - 1), lane));
   Bwd2Ops ops;
   make_bwd2_ops(ops, stats, l15, g4);
   TrSrc2<H, DH> src;
@@ -2109,6 +2259,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_bwd_dqx_kernel(
   st_Vc.fetch(vb, min(CK, ntiles) * 16, tid);
   for (int ch = 0; ch < nchunks; ++ch) {
     const int nt = min(CK, ntiles - ch * CK);
+    if (!(PC && (VU_DQX_ABLATE & 8) && ch > 0)) {
     __syncthreads();                                  // every wave has finished with the previous chunk
     st_Kc.commit(Kc, nt * 16, tid);
     st_Vc.commit(Vc, nt * 16, tid);
@@ -2118,16 +2269,34 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_bwd_dqx_kernel(
       st_Kc.fetch(kb + (long long)cn * CK * 16 * C::D, min(CK, ntiles - cn * CK) * 16, tid);
       st_Vc.fetch(vb + (long long)cn * CK * 16 * C::D, min(CK, ntiles - cn * CK) * 16, tid);
     }
+    }
     if (active)
       for (int kc = (KS == 1 ? 0 : ((ch * CK) & 1) ^ ksh); kc < nt; kc += KS) {
-        f32x4 S[H], T[2][4], E[2][4];
-        tile_prod<H, DH, true>(S, Kc, kc, nullptr, Qs, nullptr, l15, g4);
-        bwd2_chain<H, DH, true, true>(S, Vc, kc, dOs, lse, c, rng, wlane + 4u * (uint32_t)(ch * CK + kc), hstride, ops, T, E, l15, g4);
+        f32x4 T[2][4], E[2][4];
+        if constexpr (PC) {
+          bf16x8 pk[4];
+          pc_take(pk, nx);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pk[r] = relu_packed(pk[r]);         // the kept probabilities P~
+          pc_load(nx, pc_tile(pcache, b, ntiles, tq, min(ch * CK + kc + KS, ntiles - 1), lane));
+          bwd2_head_pk<true>(pk, ops, T);
+          if (VU_DQX_ABLATE & 16) {                      // (measurement build: no dA^ product, no mix)
+#pragma unroll
+            for (int half = 0; half < 2; ++half)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) E[half][r] = T[half][r] + ops.cin;
+          } else
+          bwd2_tail_pk<H, DH, true>(pk, Vc, kc, dOs, ops, E, l15, g4);
+        } else {
+          f32x4 S[H];
+          tile_prod<H, DH, true>(S, Kc, kc, nullptr, Qs, nullptr, l15, g4);
+          bwd2_chain<H, DH, true, true>(S, Vc, kc, dOs, lse, c, rng, wlane + 4u * (uint32_t)(ch * CK + kc), hstride, ops, T, E, l15, g4);
+        }
 #pragma unroll
         for (int half = 0; half < 2; ++half)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const f32x4 dp = bwd2_dp(E[half][r], ops.back);
+            const f32x4 dp = (PC && (VU_DQX_ABLATE & 4)) ? E[half][r] : bwd2_dp(E[half][r], ops.back);
             f32x4 ph;
 #pragma unroll
             for (int j = 0; j < 4; ++j) ph[j] = T[half][r][j];                 // (already the kept probabilities: bwd2_chain<KEPT_ONLY>)
@@ -2140,6 +2309,11 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_bwd_dqx_kernel(
             // sum over positions of e_g P^_h as X^T X (see flash2_bwd_delta_kernel): e as a bf16 hi + lo pair in two rounds
             const s16x4 ehi = pack4s(E[half][r]);
             const f32x4 elo4 = residual4(E[half][r], ehi);
+            if (PC && (VU_DQX_ABLATE & 1)) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) { const float u = ph[j] * dp[j]; dl[j] += u + elo4[j]; T[half][r][j] = u; }
+              continue;
+            }
             *reinterpret_cast<s16x4*>(im_e) = ehi;
             *reinterpret_cast<s16x4*>(im_p) = pack4s(ph);
             {                                      // 32 positions = 2 k-blocks of 16 = one K = 32 product (join_k)
@@ -2160,6 +2334,10 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_bwd_dqx_kernel(
               T[half][r][j] = u;
             }
           }
+        if (PC && (VU_DQX_ABLATE & 2)) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[j][0] += f32x4{T[0][0][j], T[0][1][j], T[1][2][j], T[1][3][j]};
+        } else
         {                                          // the two key halves of the tile as the two k-blocks of one K = 32 product (join_k)
           const int tb0 = src.base(kc, 0), tb1 = src.base(kc, 1);
 #pragma unroll
@@ -2251,21 +2429,29 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_bwd_dqx_kernel(
 }
 
 // ---- sweeps 3 / 4: dk (DV = false) and dv (DV = true), key-major loop ------------------------------------------------
-template <int DH, int WPB, int CK, bool DV, int KS = 1>
-__global__ __launch_bounds__(WPB * 64, DV ? 3 : 2) void flash2_bwd_dkv_kernel(
+// PC: probabilities from the cache (column tk of the sample's tile grid): no key image, no logits; the dv sweep streams dO only
+#ifndef VU_PC_DV_WAVES
+#define VU_PC_DV_WAVES 2        // (cached form: dO chunk 25.6 KB + images 20 KB + tile ring 32 KB per workgroup: two workgroups per CU)
+#endif
+template <int DH, int WPB, int CK, bool DV, int KS = 1, bool PC = false>
+__global__ __launch_bounds__(WPB * 64, DV ? (PC ? VU_PC_DV_WAVES : 3) : 2) void flash2_bwd_dkv_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, const bf16_t* __restrict__ dO,
     const float* __restrict__ lse2, const float* __restrict__ delta, const float* __restrict__ stats, bf16_t* __restrict__ out,
-    int B, int N, float c, float scale, vu_rng rng_in) {
+    int B, int N, float c, float scale, vu_rng rng_in, const void* __restrict__ pcache) {
   constexpr int H = 8;
   constexpr int IMP = 20, IMS = 16 * IMP;         // image row pitch 40 B: the 16 rows of a store cover the 32 banks once
   typedef FC<H, DH> C;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr bool NEEDQ = !(PC && DV);             // the q chunk: logits (recompute form) and the dk product
   bf16_t* Qc = reinterpret_cast<bf16_t*>(smem_raw);
-  bf16_t* Dc = Qc + CK * 16 * C::PITCH;
-  constexpr int SROWS = DV ? 16 : 32;            // stationary rows per wave: the keys, and (dk only) their v rows
+  bf16_t* Dc = NEEDQ ? Qc + CK * 16 * C::PITCH : Qc;
+  constexpr int SROWS = PC ? (DV ? 0 : 16) : (DV ? 16 : 32);      // stationary rows per wave: the keys (recompute form), and (dk only) their v rows
   bf16_t* Ks = Dc + CK * 16 * C::PITCH + (threadIdx.x >> 6) * SROWS * C::PITCH;
-  bf16_t* Vs = Ks + 16 * C::PITCH;
-  bf16_t* img = Dc + CK * 16 * C::PITCH + WPB * SROWS * C::PITCH + (threadIdx.x >> 6) * 640;     // 2 x [16 q][IMP]
+  bf16_t* Vs = PC ? Ks : Ks + 16 * C::PITCH;
+  // wave-private transposition images, 2 x [16 q][IMP] per set.  PC: one set per head pair j (LDS is no longer scarce), so that a tile's
+  // eight stores, eight transposing reads and sixteen products are three batches instead of four store -> read -> product round trips
+  constexpr int IMGS = PC ? 4 : 1;
+  bf16_t* img = Dc + CK * 16 * C::PITCH + WPB * SROWS * C::PITCH + (threadIdx.x >> 6) * (640 * IMGS);
   const vu_rng rng = vu_rng_resolve(rng_in);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
   constexpr int TPB = WPB / KS;
@@ -2277,9 +2463,23 @@ __global__ __launch_bounds__(WPB * 64, DV ? 3 : 2) void flash2_bwd_dkv_kernel(
   const int tk = active ? t : ntiles - 1;
   const bf16_t* qb = q + (long long)b * N * C::D;
   const bf16_t* dob = dO + (long long)b * N * C::D;
-  stage_own_rows<H, DH>(Ks, k + ((long long)b * N + tk * 16) * C::D, lane);
+  if constexpr (!PC) stage_own_rows<H, DH>(Ks, k + ((long long)b * N + tk * 16) * C::D, lane);
   if (!DV) stage_own_rows<H, DH>(Vs, v + ((long long)b * N + tk * 16) * C::D, lane);
-  zero_pads<H, DH>(Qc, 2 * CK * 16 + WPB * SROWS, tid, WPB * 64);
+  zero_pads<H, DH>(Qc, (NEEDQ ? 2 : 1) * CK * 16 + WPB * SROWS, tid, WPB * 64);
+  // PC: the tiles of column tk of the sample's grid.  dk (a long chain per tile): the next tile in registers; dv (little besides the
+  // stream): the LDS-DMA ring (PRing)
+  constexpr bool RING = PC && DV;
+  constexpr int RD = VU_PC_RING;
+  PTile nx;
+  PRing<RD> ring;
+  const long long tcol = (long long)b * ntiles * ntiles + tk;      // tile (b, qt, tk) = tcol + qt * ntiles
+  if constexpr (RING) {
+    ring.init(reinterpret_cast<unsigned char*>(Dc + CK * 16 * C::PITCH + WPB * SROWS * C::PITCH + WPB * (640 * IMGS)), wave, lane);
+    if (active) {
+#pragma unroll
+      for (int i = 0; i < RD; ++i) ring.issue(pcache, tcol + (long long)min(ksh + i * KS, ntiles - 1) * ntiles, i);
+    }
+  } else if constexpr (PC) pc_load(nx, pc_tile(pcache, b, ntiles, min(ksh, ntiles - 1), tk, lane));
   Bwd2Ops ops;
   MixOp fw;
   f32x4 fcin = {0.f, 0.f, 0.f, 0.f};
@@ -2302,23 +2502,23 @@ __global__ __launch_bounds__(WPB * 64, DV ? 3 : 2) void flash2_bwd_dkv_kernel(
   constexpr bool PRE = DV && CK > 1;
   ChunkStage<H, DH, CK * 16, WPB * 64> st_Qc, st_Dc;
   if constexpr (PRE) {
-    st_Qc.fetch(qb, min(CK, ntiles) * 16, tid);
+    if constexpr (NEEDQ) st_Qc.fetch(qb, min(CK, ntiles) * 16, tid);
     st_Dc.fetch(dob, min(CK, ntiles) * 16, tid);
   }
   for (int ch = 0; ch < nchunks; ++ch) {
     const int nt = min(CK, ntiles - ch * CK);
     __syncthreads();
     if constexpr (PRE) {
-      st_Qc.commit(Qc, nt * 16, tid);
+      if constexpr (NEEDQ) st_Qc.commit(Qc, nt * 16, tid);
       st_Dc.commit(Dc, nt * 16, tid);
     } else {
-      load_chunk<H, DH>(Qc, qb + (long long)ch * CK * 16 * C::D, nt * 16, tid, WPB * 64);
+      if constexpr (NEEDQ) load_chunk<H, DH>(Qc, qb + (long long)ch * CK * 16 * C::D, nt * 16, tid, WPB * 64);
       load_chunk<H, DH>(Dc, dob + (long long)ch * CK * 16 * C::D, nt * 16, tid, WPB * 64);
     }
     __syncthreads();
     if constexpr (PRE) {
       const int cn = ch + 1 < nchunks ? ch + 1 : ch;
-      st_Qc.fetch(qb + (long long)cn * CK * 16 * C::D, min(CK, ntiles - cn * CK) * 16, tid);
+      if constexpr (NEEDQ) st_Qc.fetch(qb + (long long)cn * CK * 16 * C::D, min(CK, ntiles - cn * CK) * 16, tid);
       st_Dc.fetch(dob + (long long)cn * CK * 16 * C::D, min(CK, ntiles - cn * CK) * 16, tid);
     }
     if (active)
@@ -2326,23 +2526,40 @@ __global__ __launch_bounds__(WPB * 64, DV ? 3 : 2) void flash2_bwd_dkv_kernel(
         // row constants of the tile's queries (log-sum-exp of all heads, delta of the lane's 4 heads): L2-resident
         const long long qg = (long long)(ch * CK + qc) * 16 + l15;
         float lse[H];
+        if constexpr (!PC) {
 #pragma unroll
-        for (int h = 0; h < H; ++h) lse[h] = lse2[((long long)b * H + h) * N + qg];
+          for (int h = 0; h < H; ++h) lse[h] = lse2[((long long)b * H + h) * N + qg];
+        }
         f32x4 dlt = {0.f, 0.f, 0.f, 0.f};
         if (!DV) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) dlt[j] = delta[((long long)b * H + 4 * hh + j) * N + qg];
         }
         f32x4 S[H], T[2][4];
-        tile_prod<H, DH, false>(S, Qc, qc, nullptr, Ks, nullptr, l15, g4);
+        if constexpr (!PC) tile_prod<H, DH, false>(S, Qc, qc, nullptr, Ks, nullptr, l15, g4);
         const uint32_t wt = wkey + (uint32_t)((ch * CK + qc) * 16 + l15) * wq;
         if constexpr (DV) {
-          tag_probs<H, true>(S, lse, c, rng, wt, hstride);       // P~ (dropped = 0)
           bf16x8 pk[4];
-          pack_heads(S, pk);
+          int slot = 0;
+          if constexpr (PC) {
+            slot = ring.take(pk, lane);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pk[r] = relu_packed(pk[r]);       // P~ (dropped = 0)
+          } else {
+            tag_probs<H, true>(S, lse, c, rng, wt, hstride);       // P~ (dropped = 0)
+            pack_heads(S, pk);
+          }
           mix_ml(T, fw, pk, fcin);                     // A^ (ML)
+          if constexpr (PC) ring.refill(pcache, tcol + (long long)min(ch * CK + qc + RD * KS, ntiles - 1) * ntiles, slot);
         } else {
           f32x4 E[2][4];
+          if constexpr (PC) {
+            bf16x8 pk[4];
+            pc_take(pk, nx);
+            bwd2_head_pk<false>(pk, ops, T);           // T: the signed tags; pk: P~
+            pc_load(nx, pc_tile(pcache, b, ntiles, min(ch * CK + qc + KS, ntiles - 1), tk, lane));
+            bwd2_tail_pk<H, DH, false>(pk, Dc, qc, Vs, ops, E, l15, g4);
+          } else
           bwd2_chain<H, DH, false>(S, Dc, qc, Vs, lse, c, rng, wt, hstride, ops, T, E, l15, g4);
 #pragma unroll
           for (int half = 0; half < 2; ++half)
@@ -2355,6 +2572,31 @@ __global__ __launch_bounds__(WPB * 64, DV ? 3 : 2) void flash2_bwd_dkv_kernel(
         }
         // contraction over the query (lane) index: per j the two heads j (lanes hh = 0) and 4 + j (hh = 1) go through
         // wave-private [query][key] images and come back transposed
+        if constexpr (IMGS == 4) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            bf16_t* im = img + j * 640 + hh * IMS;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+              const f32x4 x4 = {T[half][0][j], T[half][1][j], T[half][2][j], T[half][3][j]};
+              *reinterpret_cast<s16x4*>(im + l15 * IMP + 8 * half + 4 * a2) = pack4s(x4);
+            }
+          }
+          s16x4 bop[4][2];
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) bop[j][h2] = tr_operand<IMP>(img + j * 640 + h2 * IMS, 0, 0, l15, g4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+              const int h = 4 * h2 + j;
+#pragma unroll
+              for (int dt = 0; dt < C::DT; ++dt)
+                oa[h][dt] = mfma16(tr_operand<C::PITCH>(DV ? Dc : Qc, qc * 16, h * DH + 16 * dt, l15, g4), bop[j][h2], oa[h][dt]);
+            }
+        } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           bf16_t* im = img + hh * IMS;
@@ -2372,8 +2614,10 @@ __global__ __launch_bounds__(WPB * 64, DV ? 3 : 2) void flash2_bwd_dkv_kernel(
               oa[h][dt] = mfma16(tr_operand<C::PITCH>(DV ? Dc : Qc, qc * 16, h * DH + 16 * dt, l15, g4), bop, oa[h][dt]);
           }
         }
+        }
       }
   }
+  if constexpr (RING) ring.drain();         // (the clamped refills behind the last tiles: nothing may land in LDS after the wave has left)
   if constexpr (KS == 2) {                  // (query split: the odd wave's partial dk / dv into the even wave's)
     __syncthreads();
     float* cs = reinterpret_cast<float*>(smem_raw) + (wave >> 1) * (H * C::DT * 256);
@@ -2652,37 +2896,49 @@ int launch_forward_v2(const vu_flash_args& a, hipStream_t st) {
 #define VU_CKK 2
 #endif
   // (eight waves per workgroup - the small-batch form, one workgroup per CU: every barrier pair is fully exposed, so twice the tiles per chunk)
-  constexpr int H = 8, WPB = WPBV, CK = WPBV == 8 ? 2 * VU_CKF : VU_CKF;
+#ifndef VU_CKM
+#define VU_CKM 2
+#endif
+  // streamed tiles per barrier pair.  Round 5: the row-statistics and moments sweeps of the 4-wave form take TWO (the moments sweep
+  // sits at 256 registers and a 4-tile chunk costs it 12 more staging registers than a 2-tile one: 214 -> 200 us at 64 images,
+  // row statistics 97 -> 91), the apply sweep keeps four (142 against 154 us with two)
+  constexpr int H = 8, WPB = WPBV, CK = WPBV == 8 ? 2 * VU_CKF : VU_CKF, CKM = (WPBV == 8 || KS != 1) ? CK : VU_CKM;
   typedef FC<H, DH> C;
   constexpr int TPB = WPB / KS;                                          // own tiles per workgroup (pair_park / pair_take)
   const int ntiles = a.N >> 4, per = (ntiles + TPB - 1) / TPB;
   const int nblk = a.B * per;
   const float c = a.scale * 1.44269504088896340736f;
   const size_t rowb = (size_t)16 * C::PITCH * 2;
-  const size_t lds1 = CK * rowb + (size_t)WPB * C::NMOM * 4;
-  size_t ldsm = CK * rowb + (size_t)WPB * 16 * 4 + (size_t)(7 * DH + 16) * 2 + 16;
+  const size_t lds1 = CKM * rowb + (size_t)WPB * C::NMOM * 4;
+  size_t ldsm = CKM * rowb + (size_t)WPB * 16 * 4 + (size_t)(7 * DH + 16) * 2 + 16;
   if (KS == 2 && ldsm < (size_t)(WPB / 2) * (H * C::DT + 2) * 1024) ldsm = (size_t)(WPB / 2) * (H * C::DT + 2) * 1024;      // the pair-combine scratch
-  const size_t lds2 = 2 * CK * rowb + (size_t)tr_zero_elems<H, DH>() * 2;
-  auto k1 = flash_rowstats_kernel<H, DH, WPB, CK, KS>;
-  auto km = flash2_moments_kernel<DH, WPB, CK, KS>;
-  auto k2 = flash2_apply_kernel<DH, WPB, CK, KS>;
+  // probability cache (round 5): the training forward writes it in the moments sweep and reads it back in the apply sweep
+  const bool pc = a.pcache != nullptr && a.training;
+  size_t lds2 = (pc ? 1 : 2) * CK * rowb + (size_t)tr_zero_elems<H, DH>() * 2 + (pc ? (size_t)WPB * VU_PC_RING * 4096 : 0);
+  if (pc && KS == 2) lds2 = std::max(lds2, (size_t)(WPB / 2) * 4 * (DH / 8) * 1024);      // (pair-combine scratch of the split form)
+  auto k1 = flash_rowstats_kernel<H, DH, WPB, CKM, KS>;
+  auto km = pc ? flash2_moments_kernel<DH, WPB, CKM, KS, true> : flash2_moments_kernel<DH, WPB, CKM, KS, false>;
+  auto k2 = pc ? flash2_apply_kernel<DH, WPB, CK, KS, true> : flash2_apply_kernel<DH, WPB, CK, KS, false>;
   VU_TRY(reserve_lds(k1, lds1)); VU_TRY(reserve_lds(km, ldsm)); VU_TRY(reserve_lds(k2, lds2));
   const double E = (double)a.B * H * a.N * a.N, act = (double)a.B * a.N * C::D * 2.0;
   const bf16_t *q = (const bf16_t*)a.q, *k = (const bf16_t*)a.k, *v = (const bf16_t*)a.v;
   hipLaunchKernelGGL(k1, dim3(nblk), dim3(WPB * 64), lds1, st, q, k, a.lse2, a.rinv, a.B, a.N, c);
   if (vu_prof_on()) vu_prof_note("flash_rowstats_kernel", 4.0 * E * DH, 2.0 * act);
+  if (vu_prof_on()) vu_prof_note_strict(2.0 * E * DH);
   VU_TRY(vu_check_launch("flash_rowstats"));
   if (a.training) {
     VU_REQUIRE(a.pk != nullptr, "flash attention: the training forward needs the P k buffer");
-    hipLaunchKernelGGL(km, dim3(nblk), dim3(WPB * 64), ldsm, st, q, k, a.lse2, a.mix_w, a.partials, a.pk, a.rinv, a.B, a.N, c, a.rng);
-    if (vu_prof_on()) vu_prof_note("flash2_moments_kernel", 4.0 * E * DH + 2.0 * E * H, 4.0 * act);
+    hipLaunchKernelGGL(km, dim3(nblk), dim3(WPB * 64), ldsm, st, q, k, a.lse2, a.mix_w, a.partials, a.pk, a.rinv, a.B, a.N, c, a.rng, a.pcache);
+    if (vu_prof_on()) vu_prof_note("flash2_moments_kernel", 4.0 * E * DH + 2.0 * E * H, 4.0 * act + (pc ? 2.0 * E : 0.0));
+    if (vu_prof_on()) vu_prof_note_strict(2.0 * E * H);
     VU_TRY(vu_check_launch("flash2_moments"));
   }
   hipLaunchKernelGGL(flash_bn_finalize_kernel, dim3(1), dim3(1024), 0, st, a.partials, nblk, a.mix_w, a.mix_b, a.bn_w, a.bn_b, a.run_mean,
                      a.run_var, a.stats, H, a.N, (double)a.B * a.N * a.N, a.training, 0.1f, 1e-5f, a.rng.inv_keep, 1);
   VU_TRY(vu_check_launch("flash_bn_finalize"));
-  hipLaunchKernelGGL(k2, dim3(nblk), dim3(WPB * 64), lds2, st, q, k, v, a.lse2, a.stats, (bf16_t*)a.O, a.B, a.N, c, a.rng);
-  if (vu_prof_on()) vu_prof_note("flash2_apply_kernel", 4.0 * E * DH + 2.0 * E * H, 4.0 * act);
+  hipLaunchKernelGGL(k2, dim3(nblk), dim3(WPB * 64), lds2, st, q, k, v, a.lse2, a.stats, (bf16_t*)a.O, a.B, a.N, c, a.rng, (const void*)a.pcache);
+  if (vu_prof_on()) vu_prof_note("flash2_apply_kernel", (pc ? 2.0 : 4.0) * E * DH + 2.0 * E * H, pc ? 2.0 * act + 2.0 * E : 4.0 * act);
+  if (vu_prof_on()) vu_prof_note_strict(2.0 * E * DH);      // (per module 12 E d + 6 E h = 3 x forward; the mix counts once, in the moments sweep)
   return vu_check_launch("flash2_apply");
 }
 
@@ -2700,14 +2956,17 @@ int launch_backward_v2(const vu_flash_args& a, hipStream_t st) {
   const size_t lds1 = (2 * CK2 + 2 * WPB) * rowb + (size_t)WPB * 1280;          // (the final [WPB][NT] reduction aliases the K chunk)
   const size_t lds2 = (2 * CK2 + 2 * WPB) * rowb + zr;
   constexpr int CKK = WPBV == 8 ? 4 : VU_CKK;      // (eight waves, one workgroup per CU: the whole 160 KB, four tiles per barrier pair)
-  const size_t lds3 = (2 * CKK + 2 * WPB) * rowb + (size_t)WPB * 1280;
+  size_t lds3 = (2 * CKK + 2 * WPB) * rowb + (size_t)WPB * 1280;
   static_assert((size_t)WPB * NT * 4 <= (size_t)CK2 * 16 * C::PITCH * 2, "reduction scratch must fit the K chunk");
   const size_t lds4 = (2 * CK + 2 * WPB) * rowb + (size_t)2 * H * CK * 16 * 4 + (size_t)WPB * 1024;
   constexpr int CKX = WPBV == 8 ? 4 : (KS == 2 ? 2 : 1);       // (split form: a chunk must hold a tile for each wave of a pair)
-  const size_t lds2x = (2 * CKX + 2 * WPB) * rowb + (size_t)WPB * 1024 + (size_t)tr_strip_elems<DH>() * 2;
+  const size_t lds2xr = (2 * CKX + 2 * WPB) * rowb + (size_t)WPB * 1024 + (size_t)tr_strip_elems<DH>() * 2;
   auto k1 = flash2_bwd_delta_kernel<DH, WPB, CK2>;
   auto k2 = flash2_bwd_dq_kernel<DH, WPB, CK2>;
-  auto k2x = flash2_bwd_dqx_kernel<DH, WPB, CKX, KS>;
+  const bool pc = a.pcache != nullptr && a.training && a.pk != nullptr;      // (the cache holds what the TRAINING forward's moments sweep packed)
+  size_t lds2x = pc ? (2 * CKX + WPB) * rowb + (size_t)WPB * 1024 + (size_t)tr_strip_elems<DH>() * 2 : lds2xr;
+  if (pc && KS == 2) lds2x = std::max(lds2x, (size_t)(WPB / 2) * (4 * (DH / 8) + 4) * 1024);
+  auto k2x = pc ? flash2_bwd_dqx_kernel<DH, WPB, CKX, KS, true> : flash2_bwd_dqx_kernel<DH, WPB, CKX, KS, false>;
   // The fused sweep takes V = sum_k P k from the TRAINING forward (flash2_moments_kernel); with running statistics (eval
   // mode + autograd) no moments sweep ran and pk holds nothing, so that case takes the separate delta and dq sweeps.
   // (VU_FLASH_UNFUSED=1, read once: diagnostic switch that takes the separate sweeps in training too)
@@ -2715,10 +2974,21 @@ int launch_backward_v2(const vu_flash_args& a, hipStream_t st) {
   const bool fused = a.pk != nullptr && a.training && !unfused_dbg;
   if (KS != 1 && !fused) { vu_set_error("flash attention: the split backward exists for the fused training form only"); return VU_EUNSUPPORTED; }
   VU_TRY(reserve_lds(k2x, lds2x));
-  auto k3 = flash2_bwd_dkv_kernel<DH, WPB, CKK, false, KS>;
+#ifndef VU_PC_CKV
+#define VU_PC_CKV 4
+#endif
   constexpr int CKV = WPBV == 8 ? 4 : (KS == 2 ? 2 : 1);   // dv: one tile per chunk, 16 stationary rows per wave: 43.5 KB, three workgroups per CU (split form: two)
-  auto k4 = flash2_bwd_dkv_kernel<DH, WPB, CKV, true, KS>;
-  const size_t lds3v = (2 * CKV + WPB) * rowb + (size_t)WPB * 1280;
+  // cached form: the dv sweep stages dO only and keeps no stationary rows - four tiles per chunk (register-prefetched) still leave
+  // three workgroups per CU
+  constexpr int CKVP = WPBV == 8 ? 4 : (KS == 2 ? 2 : VU_PC_CKV);
+  auto k3 = pc ? flash2_bwd_dkv_kernel<DH, WPB, CKK, false, KS, true> : flash2_bwd_dkv_kernel<DH, WPB, CKK, false, KS, false>;
+  auto k4 = pc ? flash2_bwd_dkv_kernel<DH, WPB, CKVP, true, KS, true> : flash2_bwd_dkv_kernel<DH, WPB, CKV, true, KS, false>;
+  size_t lds3v = pc ? CKVP * rowb + (size_t)WPB * 5120 + (size_t)WPB * VU_PC_RING * 4096 : (2 * CKV + WPB) * rowb + (size_t)WPB * 1280;
+  if (pc) lds3 = (2 * CKK + WPB) * rowb + (size_t)WPB * 5120;
+  if (pc && KS == 2) {      // the pair-combine scratch at the end of a split sweep (pair_park / pair_take) aliases the chunk area: it must fit
+    const size_t pair = (size_t)(WPB / 2) * H * C::DT * 1024;
+    lds3v = std::max(lds3v, pair); lds3 = std::max(lds3, pair);
+  }
   VU_TRY(reserve_lds(k1, lds1)); VU_TRY(reserve_lds(k2, lds2)); VU_TRY(reserve_lds(k3, lds3)); VU_TRY(reserve_lds(k4, lds3v));
   (void)lds4;
   const double E = (double)a.B * H * a.N * a.N, act = (double)a.B * a.N * C::D * 2.0;
@@ -2727,8 +2997,10 @@ int launch_backward_v2(const vu_flash_args& a, hipStream_t st) {
   hipStream_t s_dk = st, s_dv = st;
   const bool early_dv = tail_overlap(fp, nblk, st, true);
   auto launch_dv = [&]() -> int {
-    hipLaunchKernelGGL(k4, dim3(nblk), dim3(WPB * 64), lds3v, s_dv, q, k, v, dO, a.lse2, (const float*)nullptr, a.stats, (bf16_t*)a.dv, a.B, a.N, c, a.scale, a.rng);
-    if (vu_prof_on()) vu_prof_note("flash2_bwd_dv_kernel", 4.0 * E * DH + 2.0 * E * H, 4.0 * act);
+    hipLaunchKernelGGL(k4, dim3(nblk), dim3(WPB * 64), lds3v, s_dv, q, k, v, dO, a.lse2, (const float*)nullptr, a.stats, (bf16_t*)a.dv, a.B, a.N, c, a.scale, a.rng,
+                       (const void*)a.pcache);
+    if (vu_prof_on()) vu_prof_note("flash2_bwd_dv_kernel", (pc ? 2.0 : 4.0) * E * DH + 2.0 * E * H, pc ? 2.0 * act + 2.0 * E : 4.0 * act);
+    if (vu_prof_on()) vu_prof_note_strict(2.0 * E * DH);
     return vu_check_launch("flash2_bwd_dv");
   };
   if (early_dv) {
@@ -2739,8 +3011,9 @@ int launch_backward_v2(const vu_flash_args& a, hipStream_t st) {
   }
   if (fused) {
     hipLaunchKernelGGL(k2x, dim3(nblk), dim3(WPB * 64), lds2x, st, q, k, v, dO, a.lse2, a.rinv, a.pk, a.stats, (bf16_t*)a.dq, a.delta, a.partials, a.B,
-                       a.N, c, a.scale, a.rng, a.training ? 0 : 1);
-    if (vu_prof_on()) vu_prof_note("flash2_bwd_dqx_kernel", 6.0 * E * DH + 8.0 * E * H, 7.0 * act);
+                       a.N, c, a.scale, a.rng, a.training ? 0 : 1, (const void*)a.pcache);
+    if (vu_prof_on()) vu_prof_note("flash2_bwd_dqx_kernel", (pc ? 4.0 : 6.0) * E * DH + 8.0 * E * H, pc ? 6.0 * act + 2.0 * E : 7.0 * act);
+    if (vu_prof_on()) vu_prof_note_strict(4.0 * E * DH + 4.0 * E * H);      // dA^ = dO v^T, dq = dS k, dP~ = W^T e, dW = e P~^T
     VU_TRY(vu_check_launch("flash2_bwd_dqx"));
   } else {
     hipLaunchKernelGGL(k1, dim3(nblk), dim3(WPB * 64), lds1, st, q, k, v, dO, a.lse2, a.rinv, a.stats, a.delta, a.partials, a.B, a.N, c, a.rng);
@@ -2761,8 +3034,9 @@ int launch_backward_v2(const vu_flash_args& a, hipStream_t st) {
     if (vu_prof_on()) vu_prof_note("flash2_bwd_dq_kernel", 6.0 * E * DH + 4.0 * E * H, 5.0 * act);
     VU_TRY(vu_check_launch("flash2_bwd_dq"));
   }
-  hipLaunchKernelGGL(k3, dim3(nblk), dim3(WPB * 64), lds3, s_dk, q, k, v, dO, a.lse2, a.delta, a.stats, (bf16_t*)a.dk, a.B, a.N, c, a.scale, a.rng);
-  if (vu_prof_on()) vu_prof_note("flash2_bwd_dk_kernel", 6.0 * E * DH + 4.0 * E * H, 5.0 * act);
+  hipLaunchKernelGGL(k3, dim3(nblk), dim3(WPB * 64), lds3, s_dk, q, k, v, dO, a.lse2, a.delta, a.stats, (bf16_t*)a.dk, a.B, a.N, c, a.scale, a.rng, (const void*)a.pcache);
+  if (vu_prof_on()) vu_prof_note("flash2_bwd_dk_kernel", (pc ? 4.0 : 6.0) * E * DH + 4.0 * E * H, pc ? 4.0 * act + 2.0 * E : 5.0 * act);
+  if (vu_prof_on()) vu_prof_note_strict(2.0 * E * DH);
   VU_TRY(vu_check_launch("flash2_bwd_dk"));
   VU_TRY(launch_center_dk(a, s_dk));
   if (!early_dv) VU_TRY(launch_dv());
@@ -2822,6 +3096,23 @@ extern "C" int vu_set_flash_key_split(int ks) {
 int vu_flash_key_split(int B, int N) {
   if (g_key_split) return g_key_split;
   return (long long)B * ((N / 16 + 3) / 4) <= 256 ? 3 : 1;
+}
+
+// Probability cache of the 8-head form: process-level switch (like the attention form: it changes the workspace layout, so set it
+// between steps, before the workspace is sized).  VU_FLASH_PCACHE=0 / 1, read once; default in VU_FLASH_PCACHE_DEFAULT.
+#ifndef VU_FLASH_PCACHE_DEFAULT
+#define VU_FLASH_PCACHE_DEFAULT 1
+#endif
+static int g_pcache = [] { const char* e = getenv("VU_FLASH_PCACHE"); return e ? (e[0] == '0' ? 0 : 1) : VU_FLASH_PCACHE_DEFAULT; }();
+extern "C" int vu_set_flash_pcache(int on) {
+  if (on < -1 || on > 1) { vu_set_error("vu_set_flash_pcache: -1 (default), 0 or 1"); return VU_EINVAL; }
+  g_pcache = on < 0 ? VU_FLASH_PCACHE_DEFAULT : on;
+  return VU_OK;
+}
+size_t vu_flash_pcache_bytes(int B, int N, int D, int H) {
+  if (!g_pcache || H != 8 || !vu_flash_ok(1, B, N, D, H)) return 0;
+  const size_t nt = (size_t)(N >> 4);
+  return (size_t)B * nt * nt * 4096;
 }
 
 size_t vu_flash_partials_floats(int B, int N, int H) {

@@ -148,7 +148,7 @@ int build_plan(const vu_config& c, Plan& pl) {
 // ---------------------------------------------------------------------------------------------
 // ReAttention / SkipConnection
 // ---------------------------------------------------------------------------------------------
-struct AttnBuf { void *q, *k, *v, *Ps, *Ah, *O; float* stats; float *lse2, *rinv, *delta, *pk; void *qp = nullptr, *kp = nullptr, *vp = nullptr, *Op = nullptr; float* rinvb = nullptr; };
+struct AttnBuf { void *q, *k, *v, *Ps, *Ah, *O; float* stats; float *lse2, *rinv, *delta, *pk; void *qp = nullptr, *kp = nullptr, *vp = nullptr, *Op = nullptr; float* rinvb = nullptr; void* pc = nullptr; };
 struct AttnScratch { void *dO, *dq, *dk, *dv, *dA; float* partials; int nblocks; void* pad = nullptr; };
 
 struct AttnDims { int dtype, B, N, D, H, C, s, ld; int centered = 0; int flash = 0; };
@@ -205,6 +205,10 @@ void carve_attn(Bump& bp, const AttnDims& d, AttnBuf& a) {
   a.delta = bp.takef((size_t)d.B * d.H * d.N);
   a.rinvb = bp.takef((size_t)d.B * d.H * d.N);
   a.pk = flash_on(d) ? bp.takef((size_t)d.B * d.N * flash_D(d)) : nullptr;     // sum_k P k of the recompute form (vu_flash.h)
+  {   // probability cache of the recompute form (written by the training forward's moments sweep, streamed by the four sweeps after it)
+    const size_t pcb = flash_on(d) ? vu_flash_pcache_bytes(d.B, d.N, flash_D(d), d.H) : 0;
+    a.pc = pcb ? bp.take(pcb) : nullptr;
+  }
   if (flash_on(d) && flash_padded(d)) {      // zero-padded q, k, v (kept for the backward) and O of the recompute form
     const size_t actp = (size_t)d.B * d.N * flash_D(d) * esize(d.dtype);
     a.qp = bp.take(actp); a.kp = bp.take(actp); a.vp = bp.take(actp); a.Op = bp.take(actp);
@@ -217,7 +221,7 @@ void fill_flash_args(vu_flash_args& fa, const AttnDims& d, const vu_attn_params&
   memset(&fa, 0, sizeof(fa));
   fa.B = d.B; fa.N = d.N; fa.D = d.D; fa.H = d.H; fa.scale = 1.0f / sqrtf((float)(d.D / d.H)); fa.training = training;
   fa.rng = vu_flash_quad_rng(ra);
-  fa.q = a.q; fa.k = a.k; fa.v = a.v; fa.O = a.O; fa.lse2 = a.lse2; fa.rinv = a.rinv; fa.pk = a.pk; fa.rinv_b = a.rinvb; fa.delta = a.delta; fa.partials = partials; fa.stats = a.stats;
+  fa.q = a.q; fa.k = a.k; fa.v = a.v; fa.O = a.O; fa.lse2 = a.lse2; fa.rinv = a.rinv; fa.pk = a.pk; fa.pcache = a.pc; fa.rinv_b = a.rinvb; fa.delta = a.delta; fa.partials = partials; fa.stats = a.stats;
   fa.mix_w = p.mix_w; fa.mix_b = p.mix_b; fa.bn_w = p.bn_w; fa.bn_b = p.bn_b; fa.run_mean = p.run_mean; fa.run_var = p.run_var;
 }
 
@@ -1092,6 +1096,7 @@ int vu_conv3x3_qkv_dgrad(int dtype, const void* dq, const void* dk, const void* 
 static void carve_attn_ws(Bump& bp, const AttnDims& d, AttnBuf& a, AttnScratch& sc, void** dzbuf) {
   carve_attn(bp, d, a);
   if (!a.pk) a.pk = bp.takef((size_t)d.B * d.N * flash_D(d));      // the op's form is chosen after the carve (test switch)
+  if (!a.pc) { const size_t pcb = vu_flash_pcache_bytes(d.B, d.N, flash_D(d), d.H); if (pcb) a.pc = bp.take(pcb); }
   if (flash_padded(d) && !a.qp) {
     const size_t actp = (size_t)d.B * d.N * flash_D(d) * esize(d.dtype);
     a.qp = bp.take(actp); a.kp = bp.take(actp); a.vp = bp.take(actp); a.Op = bp.take(actp);

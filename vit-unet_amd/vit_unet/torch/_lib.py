@@ -13,7 +13,9 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvitunet_amd.so")
+# VU_LIB_PATH: a measurement build of the same sources (tools/build_variant.sh: -D switches of csrc/vu_flash.hip etc.); the product
+# and the tests load the in-tree library
+LIB_PATH = os.environ.get("VU_LIB_PATH") or os.path.join(_HERE, "libvitunet_amd.so")
 
 VU_OK = 0
 ABI_VERSION = 200        # include/vit_unet_amd.h: vu_version()
@@ -63,6 +65,7 @@ SIGNATURES = {
     "vu_model_workspace_describe": (_i, [_cfgp, _i, C.c_char_p, _i]),
     "vu_model_prefers_eager": (_i, [_cfgp, _i]),
     "vu_set_flash_key_split": (_i, [_i]),
+    "vu_set_flash_pcache": (_i, [_i]),
     "vu_model_forward": (_i, [_cfgp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _u64, _vp, _vp]),
     "vu_model_backward": (_i, [_cfgp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _u64, _vp, _i, _vp]),
     "vu_model_num_backward_units": (_i, [_cfgp]),
@@ -114,6 +117,7 @@ SIGNATURES = {
     "vu_set_attn_form": (_i, [_i, _i]),
     "vu_prof_enable": (_i, [_vp]),
     "vu_prof_report": (C.c_char_p, []),
+    "vu_prof_gate": (_i, [_i]),
 }
 
 _lib: Optional[C.CDLL] = None
@@ -190,6 +194,12 @@ def set_flash_key_split(ks: int = 0) -> None:
     """Recompute attention only: waves of a workgroup that share one tile and split the streamed keys / queries (0 = by launch
     size, 1, 2, 3; include/vit_unet_amd.h: vu_set_flash_key_split).  Tests and experiments only."""
     check(lib().vu_set_flash_key_split(int(ks)), "vu_set_flash_key_split")
+
+
+def set_flash_pcache(on: int = -1) -> None:
+    """Recompute attention, 8 heads: the probability cache (include/vit_unet_amd.h: vu_set_flash_pcache; -1 default, 0 off, 1 on).
+    Changes the workspace size: call it before a workspace is sized, never between a forward and its backward."""
+    check(lib().vu_set_flash_pcache(int(on)), "vu_set_flash_pcache")
 
 
 def make_config(depth, depth_te, size_bottleneck, preprocessing, im_size, patch_size, num_channels,
