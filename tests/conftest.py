@@ -27,9 +27,11 @@ def attn_form():
     the form runs the UNSPLIT sweeps (1: the default) unless it asks for 2; 0 = the library's default."""
     from vit_unet.torch import _lib
 
-    def setter(flash=-1, centered=0, key_split=None):
+    def setter(flash=-1, centered=0, key_split=None, pcache=-1):
         _lib.set_attn_form(flash, centered)
         _lib.set_flash_key_split((1 if flash == 1 else 0) if key_split is None else key_split)
+        _lib.set_flash_pcache(pcache)               # -1: the build's default (on); 0: every sweep recomputes (the round 2 - 4 form)
     yield setter
     _lib.set_attn_form(-1, 0)
     _lib.set_flash_key_split(0)
+    _lib.set_flash_pcache(-1)

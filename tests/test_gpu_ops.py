@@ -297,18 +297,25 @@ def test_attention_centred_map_form(N, Cn, s, H, mode, attn_form):
                                       (784, 3, 4, 4), (3136, 3, 4, 4)])    # 4 heads, d = 12 (Lite level 2): d = 16 on zero-padded operands
 @pytest.mark.parametrize("mode", ["eval", "train", "train_drop"])
 @pytest.mark.parametrize("cross", [False, True])
-@pytest.mark.parametrize("ks", [1, 2, 3])
+@pytest.mark.parametrize("ks", [1, 2, 3, -1])
 def test_attention_flash_form(N, Cn, s, H, mode, cross, ks, attn_form):
     """The non-materialising form (csrc/vu_flash.hip: no (B,h,N,N) map in HBM, everything recomputed per pass from
     q, k, v) against the same oracle and tolerances as the materialised forms; vu_set_attn_form(flash=1) switches the stand-alone op.
     Shapes: Base / Large level 2 (N = 784, d = 24), the 512x512 levels (d = 8, d = 32), 4 heads, an odd tile count."""
     # ks = 2: two waves share a 16-row tile and split the streamed keys / queries (opt-in form, vu_set_flash_key_split: measured,
     # not faster); every mode at the Base shape, the training mode with dropout at the others
+    # ks = -1: the unsplit sweeps WITHOUT the probability cache (round 5: the cache is the default for 8 heads in training; the
+    # recompute-everything sweeps of rounds 2 - 4 remain the fallback - vu_set_flash_pcache(0) - and stay held to the oracle)
+    pcache = -1
+    if ks == -1:
+        if H != 8 or mode == "eval" or cross or N not in (784, 1024):
+            pytest.skip("recompute-everything fallback: 8 heads, training modes, the Base and 512 x 512 shapes")
+        ks, pcache = 1, 0
     if ks == 2 and (H != 8 or N == 4096 or (N != 784 and mode != "train_drop")):
         pytest.skip("split form: Base shape in every mode, the other 8-head shapes in train_drop")
     if ks == 3 and (N != 784 or H != 8 or mode == "eval"):
         pytest.skip("split form with eight waves per workgroup: the Base level-2 shape, training modes (the default at <= 19 images per GPU)")
-    attn_form(flash=1, key_split=ks)
+    attn_form(flash=1, key_split=ks, pcache=pcache)
     if cross and N != 784:
         pytest.skip("cross inputs: one shape")
     if N == 4096 and mode != "eval":
@@ -635,3 +642,48 @@ def test_flash_backward_tail_overlap_is_bit_identical_to_the_serial_order(N, Cn,
     assert L.vu_model_prefers_eager(C.byref(lite._cfg), 64) == 1
     assert L.vu_model_prefers_eager(C.byref(lite._cfg), 32) == 1
     assert L.vu_model_prefers_eager(C.byref(lite._cfg), 8) == 0
+
+
+@pytest.mark.parametrize("N,Cn,s,B,ks,cross", [(784, 3, 8, 6, 1, False), (784, 3, 8, 5, 2, True), (784, 3, 8, 3, 3, False),
+                                               (1024, 1, 16, 2, 1, False), (1024, 1, 8, 2, 2, False), (272, 3, 8, 3, 1, True)])
+def test_flash_probability_cache_is_bit_identical_to_recompute(N, Cn, s, B, ks, cross, attn_form):
+    """Round 5: with the probability cache (csrc/vu_flash.hip; vu_set_flash_pcache) the moments sweep stores the packed sign-tagged
+    bf16 probabilities of every 16 x 16 tile and the apply / dq + delta / dk / dv sweeps stream them (LDS-DMA ring in apply and dv)
+    instead of rebuilding logits -> exp2 -> mask -> pack.  Same bits go into the same products in the same order: the output, the
+    input gradients, the head-mix / BatchNorm gradients and the running statistics must be IDENTICAL with the cache off and on, for
+    every instantiation (d = 24 / 32 / 8, unsplit and both split forms, an odd tile count, cross inputs), on a workspace that is
+    filled with a NaN pattern first (nothing of the cache may be read before the moments sweep wrote it).  The convolution and
+    projection weight gradients of the stand-alone op end in float atomics: 1e-5."""
+    dt, H = torch.bfloat16, 8
+    p, xq, xkv, dy, D = _attn_case(N, Cn, s, H, B=B)
+    L = lib()
+    d = {k: dev(v) for k, v in p.items()}
+    pw = dev(p["proj.weight"], dt)
+    xd, dyd = dev(xq, dt), dev(dy, dt)
+    xkd = dev(xkv, dt) if cross else xd
+
+    def run(pcache):
+        attn_form(flash=1, key_split=ks, pcache=pcache)
+        rm, rv = d["var_norm.running_mean"].clone(), d["var_norm.running_var"].clone()
+        prm = _lib.vu_attn_params(*[d[k].data_ptr() for k in GRAD_KEYS[:7]], pw.data_ptr(), d["proj.bias"].data_ptr(), rm.data_ptr(), rv.data_ptr(), 0)
+        nbytes = L.vu_attn_workspace_bytes(1, B, N, D, H)
+        ws = torch.full((nbytes,), 0xFF, dtype=torch.uint8, device=DEV)
+        y, dx, dxk = torch.empty_like(xd), torch.empty_like(xd), torch.empty_like(xd)
+        grads = [torch.zeros_like(d[k]) for k in GRAD_KEYS]
+        gs = _lib.vu_attn_grads(*[g.data_ptr() for g in grads])
+        check(L.vu_attn_forward(1, C.byref(prm), ptr(xd), ptr(xkd), ptr(y), None, ptr(ws), nbytes, B, N, D, H, Cn, 0.2, 0.2, 1, 99, 3, st()))
+        check(L.vu_attn_backward(1, C.byref(prm), C.byref(gs), ptr(xd), ptr(xkd), ptr(dyd), ptr(dx), ptr(dxk) if cross else None, ptr(ws), nbytes,
+                                 B, N, D, H, Cn, 0.2, 0.2, 1, 99, 3, st()))
+        torch.cuda.synchronize()
+        return nbytes, [y, dx] + ([dxk] if cross else []) + grads + [rm, rv]
+
+    n0, off = run(0)
+    n1, on = run(1)
+    assert n1 - n0 >= B * (N // 16) ** 2 * 4096 and n1 - n0 < B * (N // 16) ** 2 * 4096 + 4096      # one 4 KB tile per (sample, query tile, key tile)
+    names = ["y", "dx"] + (["dxkv"] if cross else []) + GRAD_KEYS + ["running_mean", "running_var"]
+    for a_, b_, name in zip(off, on, names):
+        assert torch.isfinite(b_.float()).all(), name
+        if "conv2d" in name or name.startswith("proj."):
+            assert serr(a_, b_) < 1e-5, name
+        else:
+            assert torch.equal(a_, b_), name

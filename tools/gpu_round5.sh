@@ -1,0 +1,24 @@
+# Round-5 record run (on the GPU box: bash tools/gpu_round4.sh [part]): bench lines of every BASELINE configuration, a kernel
+# trace, the HBM counters, MFMA busy and the SQ counters of the recompute sweeps.  Everything lands in gpurun_out/r05_*;
+# tools/record_round5.py copies the summaries into profiles/.  Parts: bench | trace | pmc | all (default).
+set -x
+PART=${1:-all}
+cd $GRAFT_REPO_ROOT
+if [ "$PART" = bench ] || [ "$PART" = all ]; then
+  python bench.py > gpurun_out/r05_bench_base.log 2>&1; tail -1 gpurun_out/r05_bench_base.log > gpurun_out/r05_bench_base.json; cut -c1-300 gpurun_out/r05_bench_base.json
+  for cfg in "lite 32" "large 16" "seg512 32" "seg512 8" "base 16" "base 32" "base 128"; do
+    set -- $cfg
+    timeout 600 python bench.py --model $1 --batch $2 --no-cpu-baseline --no-host-input > gpurun_out/r05_bench_$1_$2.log 2>&1
+    tail -1 gpurun_out/r05_bench_$1_$2.log > gpurun_out/r05_bench_$1_$2.json; cut -c1-200 gpurun_out/r05_bench_$1_$2.json; echo
+  done
+  timeout 600 python bench.py --model seg512 --batch 32 --attn-operands storage --no-cpu-baseline --no-host-input > gpurun_out/r05_bench_seg512_32_storage.log 2>&1
+  tail -1 gpurun_out/r05_bench_seg512_32_storage.log > gpurun_out/r05_bench_seg512_32_storage.json; cut -c1-200 gpurun_out/r05_bench_seg512_32_storage.json; echo
+fi
+if [ "$PART" = trace ] || [ "$PART" = all ]; then
+  bash tools/gpu_trace.sh r05 > gpurun_out/r05_trace.log 2>&1; tail -3 gpurun_out/r05_trace.log
+fi
+if [ "$PART" = pmc ] || [ "$PART" = all ]; then
+  bash tools/gpu_pmc.sh > gpurun_out/r05_pmc.log 2>&1; tail -12 gpurun_out/r05_pmc.log
+  bash tools/gpu_pmc_mfma.sh > gpurun_out/r05_pmc_mfma.log 2>&1; tail -12 gpurun_out/r05_pmc_mfma.log
+  bash tools/gpu_pmc_flash.sh r05_flash > gpurun_out/r05_pmc_flash.log 2>&1; tail -5 gpurun_out/r05_pmc_flash.log
+fi

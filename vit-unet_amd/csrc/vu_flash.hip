@@ -1510,6 +1510,22 @@ __device__ __forceinline__ void pc_dma4(const void* tile, unsigned v0, unsigned 
                "s_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %1 nt\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "s"(tile), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(lds_dst) : "memory", "scc");
 }
+// Instruction-group scheduling hint at the head of a tile body (__builtin_amdgcn_iglp_opt(0): hipcc interleaves the LDS reads with the
+// matrix instructions of the region instead of its default order - a burst of ~260 vector instructions, then the MFMAs behind
+// ~60 waits).  Measured at 64 images (round 5, two runs each on one box): cached dq sweep 339 - 342 -> 319 - 320 us (iglp_opt(1): 329);
+// cached dk sweep 302 -> 299; moments 201 -> 205, apply / dv unchanged; -amdgpu-sched-strategy=max-ilp / max-memory-clause for the
+// whole file: slower.  The other instantiations of the dq sweep (d = 8 / 32, the split forms) and the dk sweep at those shapes measured
+// 3 - 10 % SLOWER with the hint, so it is on for the unsplit d = 24 dq sweep only (-DVU_IGLP_DQ=-1 turns it off).
+#ifndef VU_IGLP_DQ
+#define VU_IGLP_DQ 0
+#endif
+#ifndef VU_IGLP_DK
+#define VU_IGLP_DK -1
+#endif
+#ifndef VU_IGLP_FW
+#define VU_IGLP_FW -1
+#endif
+#define VU_IGLP_HINT(which) do { if constexpr ((which) >= 0) __builtin_amdgcn_iglp_opt((which) >= 0 ? (which) : 0); } while (0)
 #ifndef VU_DQX_ABLATE
 #define VU_DQX_ABLATE 0         // measurement builds of the cached dq sweep: 1 no head-mix-gradient images, 2 no dq product, 4 no transposed mix, 8 no chunk staging / barriers after the first chunk, 16 no dA^ product / mix
 #endif
@@ -1650,6 +1666,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_moments_kernel(const bf16_
     }
     if (active)
       for (int kc = (KS == 1 ? 0 : ((ch * CK) & 1) ^ ksh); kc < nt; kc += KS) {
+        if constexpr (PC) VU_IGLP_HINT(VU_IGLP_FW);
         f32x4 S[H];
         tile_logits<H, DH>(S, Kc, kc, qf, l15, g4);
         tag_probs<H>(S, lse, c, rng, wlane + 4u * (uint32_t)(ch * CK + kc), hstride);
@@ -1825,6 +1842,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_apply_kernel(
         bf16x8 pk[4];
         int slot = 0;
         if constexpr (PC) {
+          VU_IGLP_HINT(VU_IGLP_FW);
           slot = ring.take(pk, lane);
 #pragma unroll
           for (int r = 0; r < 4; ++r) pk[r] = relu_packed(pk[r]);         // P~ (dropped = 0)
@@ -2206,8 +2224,12 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_bwd_dqx_kernel(
   bf16_t* dOs = PC ? Qs : Qs + 16 * C::PITCH;
   // [32 positions][16: e_0..7 | P^_0..7], 8-byte column blocks XOR-swizzled with (row >> 2) & 3 (pitch 32 B: unswizzled,
   // rows 4 apart would meet on the same banks in the stores)
-  bf16_t* img = Vc + CK * 16 * C::PITCH + WPB * SR * C::PITCH + (threadIdx.x >> 6) * (32 * IMP);
-  bf16_t* Zr = Vc + CK * 16 * C::PITCH + WPB * SR * C::PITCH + WPB * (32 * IMP);
+  // (round 5, measured and not kept: eight images per wave in the cached form - the e_hi | P~ and e_lo | P~ images of four (half, r)
+  // groups at a time, so that a tile's sixteen store -> transposing read -> product round trips become two batches: 341 - 348 us
+  // against 339 - 342 at 64 images, 347 against 319 under the scheduling hint; the section is not bound by its LDS round trips)
+  constexpr int NIM = 1;
+  bf16_t* img = Vc + CK * 16 * C::PITCH + WPB * SR * C::PITCH + (threadIdx.x >> 6) * (32 * IMP * NIM);
+  bf16_t* Zr = Vc + CK * 16 * C::PITCH + WPB * SR * C::PITCH + WPB * (32 * IMP * NIM);
   float* red = reinterpret_cast<float*>(Kc);                              // [WPB][NT], after the last tile (aliases the K chunk)
   const vu_rng rng = vu_rng_resolve(rng_in);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
@@ -2274,6 +2296,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash2_bwd_dqx_kernel(
       for (int kc = (KS == 1 ? 0 : ((ch * CK) & 1) ^ ksh); kc < nt; kc += KS) {
         f32x4 T[2][4], E[2][4];
         if constexpr (PC) {
+          if constexpr (DH == 24 && KS == 1 && WPB == 4) VU_IGLP_HINT(VU_IGLP_DQ);      // (the other instantiations measured slower with it)
           bf16x8 pk[4];
           pc_take(pk, nx);
 #pragma unroll
@@ -2524,6 +2547,7 @@ __global__ __launch_bounds__(WPB * 64, DV ? (PC ? VU_PC_DV_WAVES : 3) : 2) void 
     if (active)
       for (int qc = (KS == 1 ? 0 : ((ch * CK) & 1) ^ ksh); qc < nt; qc += KS) {
         // row constants of the tile's queries (log-sum-exp of all heads, delta of the lane's 4 heads): L2-resident
+        if constexpr (PC && !DV) VU_IGLP_HINT(VU_IGLP_DK);
         const long long qg = (long long)(ch * CK + qc) * 16 + l15;
         float lse[H];
         if constexpr (!PC) {
