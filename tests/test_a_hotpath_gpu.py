@@ -41,9 +41,9 @@ def test_one_teacher_forced_block_per_level_bf16(name, attn_form, monkeypatch):
     teacher_forced_blocks(name, torch.bfloat16, 1, attn_form, monkeypatch, one_per_level=True)
 
 
-def _base_step(B, seed_model=0):
+def _base_step(B, seed_model=0, name="base"):
     torch.manual_seed(seed_model)
-    m = M.get_vit_unet("base", dtype=torch.bfloat16).to(DEV).train()
+    m = M.get_vit_unet(name, dtype=torch.bfloat16).to(DEV).train()
     ts = TrainStep(m, lr=1e-4, seed=7)
     return m, ts
 
@@ -57,25 +57,28 @@ def _run_step(m, ts, x, y):
     return out, m._garena.detach().clone()
 
 
-@pytest.mark.parametrize("B", [20, 64])
-def test_base_bf16_step_is_bit_reproducible_on_poisoned_memory(B):
-    """Forward + loss + backward of the Base bf16 step twice - the second time on a freshly built model whose every allocation
+@pytest.mark.parametrize("name,B", [("base", 20), ("base", 64), ("lite", 32), ("large", 16)])
+def test_base_bf16_step_is_bit_reproducible_on_poisoned_memory(name, B):
+    """Forward + loss + backward of a bf16 step twice - the second time on a freshly built model whose every allocation
     (arenas, workspace, outputs) comes out of memory filled with a non-zero pattern - must agree bit for bit: the step may read
-    nothing it did not write.  B = 20: the per-rank batch of the two-rank rehearsal (tests/test_zz_dp_gpu.py); B = 64: the bench
-    line's batch (tail-overlapped dv sweep, library-free GEMM route)."""
-    cfg = O.Config(**O.PRESETS["base"])
+    nothing it did not write.  Base at B = 20: the per-rank batch of the two-rank rehearsal (tests/test_zz_dp_gpu.py); Base at
+    B = 64: the bench line's batch (tail-overlapped dv sweep, library-free GEMM route, probability cache).  Round 5: the whole
+    steps of BASELINE configs 2 and 4 at their own batches - Lite at 32 images (4-head recompute form at two levels, d = 12 padded
+    to 16) and Large at 16 (the eight-wave split form with the probability cache) - which round 4 only checked with tools."""
+    cfg = O.Config(**O.PRESETS[name])
     x, y = O.make_batch(cfg, B=B, seed=5)
     x, y = x.to(DEV), y.to(DEV)
-    m, ts = _base_step(B)
+    m, ts = _base_step(B, name=name)
     out0, g0 = _run_step(m, ts, x, y)
     assert torch.isfinite(out0).all() and torch.isfinite(g0).all()
+    junk_bytes = max(12 * 2 ** 30, int(1.5 * m._workspace(B).numel()) + 4 * 2 ** 30)      # larger than everything the step allocates
     for pattern in (0x7F, 0xCB):
         del m, ts
         torch.cuda.synchronize()
-        junk = torch.empty(12 * 2 ** 30, dtype=torch.uint8, device=DEV)      # larger than everything a Base step at B = 64 allocates
+        junk = torch.empty(junk_bytes, dtype=torch.uint8, device=DEV)
         junk.fill_(pattern)
         del junk                                                              # back to the caching allocator, poisoned
-        m, ts = _base_step(B)
+        m, ts = _base_step(B, name=name)
         m._workspace(B).fill_(pattern)
         out1, g1 = _run_step(m, ts, x, y)
         nout, ng = int((out1 != out0).sum()), int((g1 != g0).sum())

@@ -2674,6 +2674,184 @@ __global__ __launch_bounds__(WPB * 64, DV ? (PC ? VU_PC_DV_WAVES : 3) : 2) void 
   }
 }
 
+// ---- cached dk sweep with LDS-DMA operand staging (round 5): Base / Large level 2 (d = 24), unsplit --------------------------------
+// flash2_bwd_dkv_kernel<.., DV = false, PC> stages its q / dO chunks synchronously (load -> LDS between two barriers: at 256 registers
+// it has none to prefetch into), so every second tile pays the L2 latency of a chunk.  Here the two streamed operands arrive by
+// LDS-DMA into double-buffered 16-row images: the tile after the current one is in flight during the whole tile body, one barrier per
+// tile, no staging registers.  An image [16][PITCH] is 6400 bytes; a DMA instruction writes 64 lanes x 16 bytes LINEARLY, so the
+// padded image is filled by 8 pieces of 1 KiB whose per-lane SOURCE addresses skip nothing and clamp the pad vector of a row to its
+// last data vector (the pads and the slack behind row 15 are never read as operands: the dA^ product re-reads a valid k-slot, the dk
+// product's spare feature rows are not stored).  Same arithmetic in the same order as the flash2 kernel: bit-identical results.
+__device__ __forceinline__ void pc_dma2(const void* tile, unsigned v0, unsigned v1, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\t"
+               "s_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "s"(tile), "v"(v0), "v"(v1), "s"(lds_dst) : "memory", "scc");
+}
+template <int DH>
+__global__ __launch_bounds__(256, 2) void flash3_dk_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ v, const bf16_t* __restrict__ dO,
+                                                           const float* __restrict__ delta, const float* __restrict__ stats,
+                                                           bf16_t* __restrict__ out, int B, int N, float scale, const void* __restrict__ pcache) {
+  constexpr int H = 8, WPB = 4, IMP = 20, IMS = 16 * IMP, SLOT = 8192;
+  typedef FC<H, DH> C;
+  static_assert(16 * C::PITCH * 2 <= SLOT - 0 && (16 * C::PITCH * 2 + 1023) / 1024 <= 8, "a 16-row image must fit eight 1 KiB pieces");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned char* Qb = smem_raw;                                   // [2][SLOT]
+  unsigned char* Db = smem_raw + 2 * SLOT;                        // [2][SLOT]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
+  bf16_t* Vs = reinterpret_cast<bf16_t*>(smem_raw + 4 * SLOT) + wave * 16 * C::PITCH;
+  bf16_t* img = reinterpret_cast<bf16_t*>(smem_raw + 4 * SLOT + WPB * 16 * C::PITCH * 2) + wave * (640 * 4);
+  const int ntiles = N >> 4, per = (ntiles + WPB - 1) / WPB;
+  int b, grp;
+  work_item(blockIdx.x, B, per, b, grp);
+  const int t = grp * WPB + wave;
+  const bool active = t < ntiles;
+  const int tk = active ? t : ntiles - 1;
+  stage_own_rows<H, DH>(Vs, v + ((long long)b * N + tk * 16) * C::D, lane);
+  for (int r = lane; r < 16; r += 64) *reinterpret_cast<uint4*>(Vs + r * C::PITCH + C::D) = make_uint4(0, 0, 0, 0);      // (tile_prod reads the stationary image's pads as zeros)
+  // the wave's two pieces (2 wave, 2 wave + 1) of an image: per-lane byte offset of its source vector inside a 16-row tile
+  constexpr int VPRP = C::PITCH / 8;                              // 16-byte vectors per image row, the pad vector included
+  unsigned voff[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int i = (2 * wave + j) * 64 + lane;
+    int row = i / VPRP, col = i - row * VPRP;
+    if (row > 15) row = 15;
+    if (col > C::VPR - 1) col = C::VPR - 1;
+    voff[j] = (unsigned)(row * C::D * 2 + col * 16);
+  }
+  const unsigned ldsq = (unsigned)(size_t)Qb + (unsigned)(2 * wave) * 1024u, ldsd = (unsigned)(size_t)Db + (unsigned)(2 * wave) * 1024u;
+  const char* qb = reinterpret_cast<const char*>(q + (long long)b * N * C::D);
+  const char* dob = reinterpret_cast<const char*>(dO + (long long)b * N * C::D);
+  auto issue = [&](int qt, int buf) {
+    const unsigned long long aq = (unsigned long long)(qb + (long long)qt * 16 * C::D * 2), ad = (unsigned long long)(dob + (long long)qt * 16 * C::D * 2);
+    // (readfirstlane returns a SIGNED int: each half goes through an unsigned before the halves are joined)
+    const unsigned qlo = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)aq), qhi = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(aq >> 32));
+    const unsigned dlo = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)ad), dhi = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(ad >> 32));
+    const void* pq = reinterpret_cast<const void*>(((unsigned long long)qhi << 32) | (unsigned long long)qlo);
+    const void* pd = reinterpret_cast<const void*>(((unsigned long long)dhi << 32) | (unsigned long long)dlo);
+    pc_dma2(pq, voff[0], voff[1], __builtin_amdgcn_readfirstlane(ldsq + (unsigned)buf * SLOT));
+    pc_dma2(pd, voff[0], voff[1], __builtin_amdgcn_readfirstlane(ldsd + (unsigned)buf * SLOT));
+  };
+  issue(0, 0);
+  PTile nx;
+  pc_load(nx, pc_tile(pcache, b, ntiles, 0, tk, lane));
+  Bwd2Ops ops;
+  make_bwd2_ops(ops, stats, l15, g4);
+  f32x4 oa[H][C::DT];
+#pragma unroll
+  for (int h = 0; h < H; ++h)
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt) oa[h][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int hh = g4 & 1, a2 = g4 >> 1;
+  for (int qt = 0; qt < ntiles; ++qt) {
+    const int buf = qt & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's pieces of tile qt (and its cache tile) have landed
+    __syncthreads();                                            // ... everybody's; and every wave has finished with the other buffer
+    if (qt + 1 < ntiles) issue(qt + 1, buf ^ 1);
+    if (!active) continue;
+    VU_IGLP_HINT(VU_IGLP_DK);
+    const bf16_t* Qc = reinterpret_cast<const bf16_t*>(Qb + buf * SLOT);
+    const bf16_t* Dc = reinterpret_cast<const bf16_t*>(Db + buf * SLOT);
+    const long long qg = (long long)qt * 16 + l15;
+    f32x4 dlt;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dlt[j] = delta[((long long)b * H + 4 * hh + j) * N + qg];
+    f32x4 T[2][4], E[2][4];
+    {
+      bf16x8 pk[4];
+      pc_take(pk, nx);
+      bwd2_head_pk<false>(pk, ops, T);           // T: the signed tags; pk: P~
+      pc_load(nx, pc_tile(pcache, b, ntiles, min(qt + 1, ntiles - 1), tk, lane));
+      bwd2_tail_pk<H, DH, false>(pk, Dc, 0, Vs, ops, E, l15, g4);
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const f32x4 dp = bwd2_dp(E[half][r], ops.back);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) T[half][r][j] = fmaf(fmaxf(T[half][r][j], 0.f), dp[j], -fabsf(T[half][r][j]) * dlt[j]);   // dS
+      }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      bf16_t* im = img + j * 640 + hh * IMS;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const f32x4 x4 = {T[half][0][j], T[half][1][j], T[half][2][j], T[half][3][j]};
+        *reinterpret_cast<s16x4*>(im + l15 * IMP + 8 * half + 4 * a2) = pack4s(x4);
+      }
+    }
+    s16x4 bop[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) bop[j][h2] = tr_operand<IMP>(img + j * 640 + h2 * IMS, 0, 0, l15, g4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const int h = 4 * h2 + j;
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) oa[h][dt] = mfma16(tr_operand<C::PITCH>(Qc, 0, h * DH + 16 * dt, l15, g4), bop[j][h2], oa[h][dt]);
+      }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (active) {
+    bf16_t* orow = out + ((long long)b * N + tk * 16 + l15) * C::D;
+#pragma unroll
+    for (int h = 0; h < H; ++h)
+#pragma unroll
+      for (int dt = 0; dt < C::DT; ++dt) {
+        const int f = 16 * dt + 4 * g4;
+        if (f < DH) {
+          f32x4 o = oa[h][dt];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] *= scale;
+          *reinterpret_cast<bf16x4*>(orow + h * DH + f) = pack4(o);
+        }
+      }
+  }
+}
+
+// ---- LDS-DMA staging of a streamed 16-row operand tile (flash3_* kernels) -----------------------------------------------------------
+// (Round 5, measured and NOT kept: the cached apply and dv sweeps in this form - V / dO tiles double-buffered by DMA, one barrier per
+// tile, every wait explicit.  Bit-identical, but at 64 images apply 141 -> 174 us and dv 137 -> 154: their tile body is ~0.5 us, so a
+// barrier per tile puts the four waves of a workgroup in lock step with the slowest cache load, where the register-staged 4-tile
+// chunks of the flash2 form need a barrier pair per FOUR tiles.  The dk sweep - 3 us per tile, and no registers to prefetch a chunk
+// into - is where the DMA staging pays: 296 -> 254 us.)
+template <int H, int DH>
+struct TileDma {                 // the wave's two 1 KiB pieces of a [16][PITCH] image (see flash3_dk_kernel)
+  unsigned v0, v1, lds;          // per-lane source offsets inside a 16-row tile; LDS byte address of the wave's first piece in buffer 0
+  __device__ __forceinline__ void init(const unsigned char* buf0, int wave, int lane) {
+    typedef FC<H, DH> C;
+    constexpr int VPRP = C::PITCH / 8;
+    unsigned vv[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int i = (2 * wave + j) * 64 + lane;
+      int row = i / VPRP, col = i - row * VPRP;
+      if (row > 15) row = 15;
+      if (col > C::VPR - 1) col = C::VPR - 1;
+      vv[j] = (unsigned)(row * C::D * 2 + col * 16);
+    }
+    v0 = vv[0]; v1 = vv[1];
+    lds = (unsigned)(size_t)buf0 + (unsigned)(2 * wave) * 1024u;
+  }
+  // rows [16 tile, 16 tile + 16) of the sample's (N x D) matrix at `base` -> buffer `buf` (8 KB apart)
+  __device__ __forceinline__ void issue(const char* base, int tile, int buf) const {
+    typedef FC<H, DH> C;
+    const unsigned long long a = (unsigned long long)(base + (long long)tile * 16 * C::D * 2);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)a), hi = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    pc_dma2(reinterpret_cast<const void*>(((unsigned long long)hi << 32) | (unsigned long long)lo), v0, v1,
+            (unsigned)__builtin_amdgcn_readfirstlane(lds + (unsigned)buf * 8192u));
+  }
+};
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+// (Round 5, measured and not kept: the cached dq + delta sweep with its K and V tiles staged the same way - double-buffered DMA, one
+// barrier per tile, no staging registers, no spills: 317 us against 316 for the flash2 form at 64 images.  That sweep already
+// prefetches its one-tile chunks through registers; it is bound by the chain of its tile body, not by staging.)
 // dk <- dk - mean over the keys of dk, per (sample, feature).  The softmax is invariant to a common shift of all keys, so
 // the exact gradient satisfies sum_k dk[k,:] = 0; the sweeps' dk violates it by the rounding of the dS operand (row sums
 // of bf16(dS) are not 0), a component that is pure error - and the one the k convolution's weight gradient, a sum of
@@ -3058,6 +3236,14 @@ int launch_backward_v2(const vu_flash_args& a, hipStream_t st) {
     if (vu_prof_on()) vu_prof_note("flash2_bwd_dq_kernel", 6.0 * E * DH + 4.0 * E * H, 5.0 * act);
     VU_TRY(vu_check_launch("flash2_bwd_dq"));
   }
+  // (VU_FLASH_DK3=0, read once: the flash2 kernel with synchronous chunk staging, for the A/B record)
+  static const bool dk3_off = [] { const char* e = getenv("VU_FLASH_DK3"); return e && e[0] == '0'; }();
+  if (pc && KS == 1 && WPB == 4 && DH == 24 && !dk3_off) {
+    auto k3d = flash3_dk_kernel<24>;
+    constexpr size_t lds3d = 4 * 8192 + (size_t)WPB * 16 * FC<8, 24>::PITCH * 2 + (size_t)WPB * 5120;
+    VU_TRY(reserve_lds(k3d, lds3d));
+    hipLaunchKernelGGL(k3d, dim3(nblk), dim3(256), lds3d, s_dk, q, v, dO, a.delta, a.stats, (bf16_t*)a.dk, a.B, a.N, a.scale, (const void*)a.pcache);
+  } else
   hipLaunchKernelGGL(k3, dim3(nblk), dim3(WPB * 64), lds3, s_dk, q, k, v, dO, a.lse2, a.delta, a.stats, (bf16_t*)a.dk, a.B, a.N, c, a.scale, a.rng, (const void*)a.pcache);
   if (vu_prof_on()) vu_prof_note("flash2_bwd_dk_kernel", (pc ? 4.0 : 6.0) * E * DH + 4.0 * E * H, pc ? 4.0 * act + 2.0 * E : 5.0 * act);
   if (vu_prof_on()) vu_prof_note_strict(2.0 * E * DH);
