@@ -361,8 +361,7 @@ def main():
             traffic, tsrc = None, None
             try:      # HBM bytes per launch from the committed rocprofv3 --pmc passes (not collectable in-process)
                 import glob
-                for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{a.model}_pmc_traffic.json")) or
-                                glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))[::-1]:
+                for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))[::-1]:      # newest round first
                     pj = json.load(open(f))
                     wl = pj.get("workload", {"model": "base", "batch": 64})      # (the PMC passes run the default bench.py workload)
                     if wl.get("model") != a.model or wl.get("batch") != a.batch:

@@ -5,12 +5,15 @@ python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
 cd /tmp && export TMPDIR=/tmp
 # (round 3: one pass per kernel family - with the counters armed on every dispatch of a step this image's rocprofv3 dies with
 # a SIGSEGV in its own dispatch callback; each family alone, 300 - 900 dispatches, runs through)
+# BENCH_ARGS: extra bench.py arguments (e.g. "--model lite --batch 32": the PMC passes of another BASELINE configuration);
+# PMC_FAMILIES="flash": only these kernel families (the other configurations only need their dominant kernels)
 FAMILIES=('flash' 'gemm' 'ln_|layernorm' 'map_|scores|mix_' 'conv' 'adamw|retile|bn_|colsum|cast|mse|tsgemm')
+if [ -n "$PMC_FAMILIES" ]; then IFS=' ' read -r -a FAMILIES <<< "$PMC_FAMILIES"; fi
 for C in FETCH_SIZE WRITE_SIZE; do
   i=0
   for RX in "${FAMILIES[@]}"; do
     i=$((i+1))
-    timeout 600 rocprofv3 --pmc $C --kernel-trace --kernel-include-regex "$RX" --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$C/f$i -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-host-input --no-graph --no-roofline --no-sustained > $GRAFT_REPO_ROOT/gpurun_out/pmc_${C}_f$i.log 2>&1
+    timeout 600 rocprofv3 --pmc $C --kernel-trace --kernel-include-regex "$RX" --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$C/f$i -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-host-input --no-graph --no-roofline --no-sustained $BENCH_ARGS > $GRAFT_REPO_ROOT/gpurun_out/pmc_${C}_f$i.log 2>&1
     echo "$C / $RX: rc=$?"
   done
 done

@@ -22,3 +22,13 @@ if [ "$PART" = pmc ] || [ "$PART" = all ]; then
   bash tools/gpu_pmc_mfma.sh > gpurun_out/r05_pmc_mfma.log 2>&1; tail -12 gpurun_out/r05_pmc_mfma.log
   bash tools/gpu_pmc_flash.sh r05_flash > gpurun_out/r05_pmc_flash.log 2>&1; tail -5 gpurun_out/r05_pmc_flash.log
 fi
+# HBM counters of the dominant kernels of the other BASELINE configurations (round-4 review: `traffic` was null for them): the flash
+# family only, summaries kept per workload for tools/record_round5.py
+if [ "$PART" = pmc2 ] || [ "$PART" = all ]; then
+  for cfg in "lite 32" "base 16" "large 16"; do
+    set -- $cfg
+    BENCH_ARGS="--model $1 --batch $2" PMC_FAMILIES="flash" bash tools/gpu_pmc.sh > gpurun_out/r05_pmc_$1_$2.log 2>&1
+    for C in FETCH_SIZE WRITE_SIZE; do cp gpurun_out/pmc_${C}_summary.csv gpurun_out/r05_$1_$2_pmc_${C}_summary.csv; done
+    tail -4 gpurun_out/r05_pmc_$1_$2.log
+  done
+fi

@@ -18,18 +18,28 @@ for f in glob.glob(root + "/**/*kernel_stats.csv", recursive=True):
     shutil.copy(f, f"gpurun_out/{tag}_kernel_stats.csv")
 agg = collections.defaultdict(lambda: [0, 0.0])
 steps = 6
+# the queue a kernel ran on: the main compute stream is the queue with most launches; every other queue is a forked stream - the
+# low-priority stream of the recompute backward's dv sweep (csrc/vu_flash.hip "Tail overlap"), whose WALL time in this table
+# includes the time its workgroups waited for slots the dq / dk sweeps held (the same kernel alone: profiles/*_flash_alone.txt)
+qcount = collections.Counter()
+recs = []
 for f in glob.glob(root + "/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        k = (r["Kernel_Name"][:110], r.get("Grid_Size_X", r.get("Grid_Size", "")), r.get("Grid_Size_Y", ""), r.get("Grid_Size_Z", ""))
-        a = agg[k]
-        a[0] += 1
-        a[1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
+        qid = r.get("Queue_Id", r.get("Stream_Id", ""))
+        qcount[qid] += 1
+        recs.append((r, qid))
+main_q = qcount.most_common(1)[0][0] if qcount else ""
+for r, qid in recs:
+    k = (r["Kernel_Name"][:110], r.get("Grid_Size_X", r.get("Grid_Size", "")), r.get("Grid_Size_Y", ""), r.get("Grid_Size_Z", ""), "main" if qid == main_q else "side (low priority)")
+    a = agg[k]
+    a[0] += 1
+    a[1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+rows = sorted(agg.items(), key=lambda kv: (kv[0][4] != "main", -kv[1][1]))      # the main stream first: its top row is the dominant kernel
 tot = sum(v[1] for _, v in rows)
 with open(f"gpurun_out/{tag}_by_grid.csv", "w") as o:
-    o.write("kernel,grid_x,grid_y,grid_z,launches_per_step,avg_us,us_per_step,share\n")
-    for (k, gx, gy, gz), (n, us) in rows[:120]:
-        o.write('"%s",%s,%s,%s,%.1f,%.1f,%.1f,%.4f\n' % (k, gx, gy, gz, n / steps, us / n, us / steps, us / tot))
+    o.write("kernel,grid_x,grid_y,grid_z,stream,launches_per_step,avg_us,us_per_step,share\n")
+    for (k, gx, gy, gz, q), (n, us) in rows[:140]:
+        o.write('"%s",%s,%s,%s,%s,%.1f,%.1f,%.1f,%.4f\n' % (k, gx, gy, gz, q, n / steps, us / n, us / steps, us / tot))
 print("total us per step (all launches / %d steps): %.1f" % (steps, tot / steps))
 # idle time between consecutive kernels of the compute stream (end of one -> start of the next), second half of the trace
 ev = []

@@ -1,11 +1,14 @@
 """profiles/<tag>_pmc_traffic.json from the FETCH_SIZE / WRITE_SIZE summaries tools/gpu_pmc.sh leaves in
-gpurun_out/ (usage: python tools/pmc_traffic_json.py r01k)."""
+gpurun_out/ (usage: python tools/pmc_traffic_json.py r05 [model batch]; for another workload use a tag that ends in the model
+name, e.g. r05_lite: bench.py looks for profiles/*_<model>_pmc_traffic.json first and checks the workload field)."""
 import csv
 import json
 import shutil
 import sys
 
 tag = sys.argv[1]
+model = sys.argv[2] if len(sys.argv) > 2 else "base"         # the workload the PMC passes ran (BENCH_ARGS of tools/gpu_pmc.sh)
+batch = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 k = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     shutil.copy(f"gpurun_out/pmc_{c}_summary.csv", f"profiles/{tag}_pmc_{c}_summary.csv")
@@ -15,7 +18,7 @@ out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/
                "all launches of the symbol (a symbol that runs at several token levels averages over them); "
                "traffic_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: on gfx950 FETCH_SIZE counts half the bytes of wide "
                "coalesced reads (MI355X_MICROARCH.md, HBM)",
-       "workload": {"model": "base", "batch": 64},      # tools/gpu_pmc.sh profiles the default bench.py run
+       "workload": {"model": model, "batch": batch},
        "kernels": {}}
 missing = []
 for name, v in sorted(k.items()):

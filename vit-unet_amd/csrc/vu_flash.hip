@@ -3245,7 +3245,8 @@ int launch_backward_v2(const vu_flash_args& a, hipStream_t st) {
     hipLaunchKernelGGL(k3d, dim3(nblk), dim3(256), lds3d, s_dk, q, v, dO, a.delta, a.stats, (bf16_t*)a.dk, a.B, a.N, a.scale, (const void*)a.pcache);
   } else
   hipLaunchKernelGGL(k3, dim3(nblk), dim3(WPB * 64), lds3, s_dk, q, k, v, dO, a.lse2, a.delta, a.stats, (bf16_t*)a.dk, a.B, a.N, c, a.scale, a.rng, (const void*)a.pcache);
-  if (vu_prof_on()) vu_prof_note("flash2_bwd_dk_kernel", (pc ? 4.0 : 6.0) * E * DH + 4.0 * E * H, pc ? 4.0 * act + 2.0 * E : 5.0 * act);
+  if (vu_prof_on()) vu_prof_note((pc && KS == 1 && WPB == 4 && DH == 24 && !dk3_off) ? "flash3_dk_kernel" : "flash2_bwd_dk_kernel",
+                                 (pc ? 4.0 : 6.0) * E * DH + 4.0 * E * H, pc ? 4.0 * act + 2.0 * E : 5.0 * act);
   if (vu_prof_on()) vu_prof_note_strict(2.0 * E * DH);
   VU_TRY(vu_check_launch("flash2_bwd_dk"));
   VU_TRY(launch_center_dk(a, s_dk));
