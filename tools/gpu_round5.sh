@@ -17,8 +17,13 @@ fi
 if [ "$PART" = trace ] || [ "$PART" = all ]; then
   bash tools/gpu_trace.sh r05 > gpurun_out/r05_trace.log 2>&1; tail -3 gpurun_out/r05_trace.log
 fi
+if [ "$PART" = pmc0 ]; then      # only the HBM counters of the default workload
+  bash tools/gpu_pmc.sh > gpurun_out/r05_pmc.log 2>&1; tail -12 gpurun_out/r05_pmc.log
+  for C in FETCH_SIZE WRITE_SIZE; do cp gpurun_out/pmc_${C}_summary.csv gpurun_out/r05_base_64_pmc_${C}_summary.csv; done
+fi
 if [ "$PART" = pmc ] || [ "$PART" = all ]; then
   bash tools/gpu_pmc.sh > gpurun_out/r05_pmc.log 2>&1; tail -12 gpurun_out/r05_pmc.log
+  for C in FETCH_SIZE WRITE_SIZE; do cp gpurun_out/pmc_${C}_summary.csv gpurun_out/r05_base_64_pmc_${C}_summary.csv; done      # (pmc2 below reuses the file names)
   bash tools/gpu_pmc_mfma.sh > gpurun_out/r05_pmc_mfma.log 2>&1; tail -12 gpurun_out/r05_pmc_mfma.log
   bash tools/gpu_pmc_flash.sh r05_flash > gpurun_out/r05_pmc_flash.log 2>&1; tail -5 gpurun_out/r05_pmc_flash.log
 fi

@@ -16,7 +16,9 @@ for src, dst in [("r05_kernel_stats.csv", "r05_kernel_stats.csv"), ("r05_by_grid
         shutil.copy(os.path.join(G, src), os.path.join(P, dst))
     else:
         print("missing", src)
-if os.path.exists(os.path.join(G, "pmc_FETCH_SIZE_summary.csv")):
+if os.path.exists(os.path.join(G, "r05_base_64_pmc_FETCH_SIZE_summary.csv")):
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        shutil.copy(os.path.join(G, f"r05_base_64_pmc_{c}_summary.csv"), os.path.join(G, f"pmc_{c}_summary.csv"))
     subprocess.check_call([sys.executable, os.path.join(R, "tools", "pmc_traffic_json.py"), "r05"], cwd=R)
 # the flash-family PMC passes of the other BASELINE configurations (tools/gpu_round5.sh pmc2)
 for model, batch in (("lite", 32), ("base", 16), ("large", 16)):
