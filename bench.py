@@ -367,8 +367,10 @@ def main():
                     if wl.get("model") != a.model or wl.get("batch") != a.batch:
                         continue          # counters of another workload say nothing about this launch: traffic stays null
                     # several template instances can share the name: the dominant launch is the one with most traffic
+                    # (profiler tag -> kernel symbol: the fused delta + dq sweep of the 4-head form is an instantiation of flash_bwd_delta_kernel)
+                    stem = name.split("<")[0].replace("flash_bwd_delta_dq_kernel", "flash_bwd_delta_kernel")
                     for sym, rec in pj["kernels"].items():
-                        if name.split("<")[0] in sym and rec.get("traffic_bytes") and rec["traffic_bytes"] > (traffic or 0):
+                        if stem in sym and rec.get("traffic_bytes") and rec["traffic_bytes"] > (traffic or 0):
                             traffic, tsrc = rec["traffic_bytes"], os.path.basename(f)
                     if traffic:
                         break
