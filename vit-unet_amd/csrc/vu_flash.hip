@@ -45,7 +45,11 @@ typedef __attribute__((ext_vector_type(8))) short s16x8;
 #define VU_FLASH_V1_WAVES(H, DH) (((H) == 4 && (DH) <= 32) ? VU_FLASH_V1_W4 : 2)      // (d = 48: LDS allows two workgroups per CU anyway)
 template <int H, int DH> struct FC {
   static constexpr int D = H * DH;
-  static constexpr int PITCH = D + 8;            // LDS row pitch of a (token x feature) chunk, elements: 16 B of (zeroed) pad
+  // LDS row pitch of a (token x feature) chunk, elements: 16 B of (zeroed) pad.  (Rows 400 B apart at d = 24 start 4 banks apart, so
+  // the four rows x 32 B a 16-lane group of a transposing read touches overlap pairwise - SQ_LDS_BANK_CONFLICT is 31 - 39 % of the
+  // sweeps' LDS cycles; a 32-byte pad puts them 8 banks apart and changed NOTHING measurable at 64 images (round 5: dk 255 -> 250 us,
+  // every other sweep within 1 %): the sweeps do not wait for LDS bandwidth.)
+  static constexpr int PITCH = D + 8;
   static constexpr int KS = DH / 8;              // valid 8-feature k-slots of the QK^T product (NK MFMAs of k = 32 each)
   static constexpr int NK = (DH + 31) / 32;      // k-steps of a logits-shaped product (1 for d <= 32; d = 48: 32 + 16)
   static constexpr int DT = (DH + 15) / 16;      // 16-row tiles of the head dim in the transposed products
