@@ -170,7 +170,8 @@ def test_gemm_forms(dt, M, N, K):
                                    (980, 3072, 3072),       # 20 images: M % 8 != 0 (k-contiguous A: any M)
                                    (784, 3072, 3072),       # 16 images: 112 x 128 tiles (168 workgroups; 112 x 192 would be 112)
                                    (1568, 2048, 2048),      # 32 images: the weight gradient's K = 1568 = 24.5 k-steps (zeroed tail k-slots)
-                                   (2104, 1544, 1368)])     # ragged everything: N = 8 tiles + 8 columns, K % 64 = 24 forward, 8 in the data gradient
+                                   (2104, 1544, 1368),      # ragged everything: N = 8 tiles + 8 columns, K % 64 = 24 forward, 8 in the data gradient
+                                   (12544, 192, 192)])      # round 5: the 192-class Linear layers of level 2 (16 images): one column tile, three k-steps
 def test_gemm_big_tile_kernel_for_plain_big_products(M, N, K):
     """Plain big bf16 products (no fused GELU; both output extents and K >= 512, M N K >= 2^32 or a >= 2048 x 2048 fp32 output) run
     on csrc/vu_bgemm.hip (one 512-thread workgroup per CU, 224 x 192 tile, LDS-DMA ring): the three layouts the Linear layers
@@ -185,7 +186,7 @@ def test_gemm_big_tile_kernel_for_plain_big_products(M, N, K):
     bias = torch.randn(N, generator=g)
     L = lib()
     L.vu_prof_enable(C.c_void_p(torch.cuda.current_stream().cuda_stream))
-    big = M * N * K >= 2 ** 32
+    big = M * N * K >= 2 ** 32 or (N == 192 and K == 192 and M >= 4096)
     y = _gemm(dt, dev(x), dev(w), M, N, K, K, 1, 1, K, bias=dev(bias))                      # B stored (N, K)
     assert serr(y.view(M, N), x.double() @ w.double().t() + bias.double()) < 8e-3
     dx = _gemm(dt, dev(dy), dev(w), M, K, N, N, 1, K, 1)                                      # B stored (K', N') = (N, K) row-major

@@ -458,8 +458,17 @@ int vu_bgemm_try(const vu_gemm_args& g, int c_float, hipStream_t st) {
   if (g.Z1 * g.Z2 != 1 || g.act != VU_ACT_NONE || g.aux || g.alpha != 1.f) return 0;
   if (!c_float && g.accumulate) return 0;
   if (c_float && (g.bias || g.dropout || g.addend)) return 0;
-  if (g.K % 8 != 0 || g.K < 512 || g.N < 512 || g.M < 512 || g.N % 8 != 0 || g.ldc % 8 != 0) return 0;
-  if (c_float ? ((long long)g.M * g.N < (4ll << 20)) : ((long long)g.M * g.N * g.K < (1ll << 32))) return 0;
+  // Round 5: also the 192-class Linear layers of level 2 (attention projection and its data gradient: N = K = 192, M = B * 784 rows).
+  // As 128 x 128 tiles of vu_gemm.h they were 784 workgroups on 768 slots (a second, nearly empty round) with half of the second
+  // column tile idle: 20.5 us stand-alone at 64 images; here 224 workgroups of one 224 x 192 tile, the three k-steps of the ring in
+  // flight at once: 12.0 us (Base step at 64 images 11.78 -> 11.65 ms).  VU_BGEMM_SMALL=0 (read once) restores the tiled route.
+  static const bool small_ok = [] { const char* e = getenv("VU_BGEMM_SMALL"); return !(e && e[0] == '0'); }();
+  const bool small = small_ok && !c_float && g.K == 192 && g.N == 192 && g.M >= 4096;
+  if (g.K % 8 != 0 || g.N % 8 != 0 || g.ldc % 8 != 0) return 0;
+  if (!small) {
+    if (g.K < 512 || g.N < 512 || g.M < 512) return 0;
+    if (c_float ? ((long long)g.M * g.N < (4ll << 20)) : ((long long)g.M * g.N * g.K < (1ll << 32))) return 0;
+  }
   if (!((g.sAk == 1) != (g.sAm == 1)) || !((g.sBn == 1) != (g.sBk == 1))) return 0;
   const bool TA = g.sAm == 1, TB = g.sBn == 1;
   if (TA && !TB) return 0;                                 // (no caller has this form)

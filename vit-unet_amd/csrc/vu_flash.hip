@@ -43,6 +43,9 @@ typedef __attribute__((ext_vector_type(8))) short s16x8;
 #define VU_FLASH_V1_W4 4
 #endif
 #define VU_FLASH_V1_WAVES(H, DH) (((H) == 4 && (DH) <= 32) ? VU_FLASH_V1_W4 : 2)      // (d = 48: LDS allows two workgroups per CU anyway)
+#ifndef VU_V1_NOSTAGE
+#define VU_V1_NOSTAGE 0          // measurement builds (results wrong): the 4-head sweeps stage only their first chunk
+#endif
 template <int H, int DH> struct FC {
   static constexpr int D = H * DH;
   // LDS row pitch of a (token x feature) chunk, elements: 16 B of (zeroed) pad.  (Rows 400 B apart at d = 24 start 4 banks apart, so
@@ -331,9 +334,11 @@ __global__ __launch_bounds__(WPB * 64) void flash_stats_kernel(const bf16_t* __r
   // the four lane groups of a query are merged at the end (every lane ends up with the row's pair)
   for (int ch = 0; ch < nchunks; ++ch) {
     const int nt = min(CK, ntiles - ch * CK);
+    if (!(VU_V1_NOSTAGE && ch > 0)) {
     __syncthreads();
     load_chunk<H, DH>(Kc, kb + (long long)ch * CK * 16 * C::D, nt * 16, tid, WPB * 64);
     __syncthreads();
+    }
     if (active)
       for (int kc = 0; kc < nt; ++kc) {
         f32x4 acc[H];
@@ -391,9 +396,11 @@ __global__ __launch_bounds__(WPB * 64) void flash_stats_kernel(const bf16_t* __r
   const uint32_t wlane = (uint32_t)((((unsigned long long)b * N + qrow) * (unsigned long long)N) >> 2) + (uint32_t)g4;
   for (int ch = 0; ch < nchunks; ++ch) {
     const int nt = min(CK, ntiles - ch * CK);
+    if (!(VU_V1_NOSTAGE && ch > 0)) {
     __syncthreads();
     load_chunk<H, DH>(Kc, kb + (long long)ch * CK * 16 * C::D, nt * 16, tid, WPB * 64);
     __syncthreads();
+    }
     if (active)
       for (int kc = 0; kc < nt; ++kc) {
         f32x4 acc[H];
@@ -715,10 +722,12 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash_apply_kernel(
 
   for (int ch = 0; ch < nchunks; ++ch) {
     const int nt = min(CK, ntiles - ch * CK);
+    if (!(VU_V1_NOSTAGE && ch > 0)) {
     __syncthreads();
     load_chunk<H, DH>(Kc, kb + (long long)ch * CK * 16 * C::D, nt * 16, tid, WPB * 64);
     load_chunk<H, DH>(Vc, vb + (long long)ch * CK * 16 * C::D, nt * 16, tid, WPB * 64);
     __syncthreads();
+    }
     if (active)
       for (int kc = 0; kc < nt; ++kc) {
         f32x4 acc[H];
@@ -974,10 +983,12 @@ __global__ __launch_bounds__(WPB * 64, VU_FLASH_V1_WAVES(H, DH)) void flash_bwd_
   const int nchunks = (ntiles + CK - 1) / CK;
   for (int ch = 0; ch < nchunks; ++ch) {
     const int nt = min(CK, ntiles - ch * CK);
+    if (!(VU_V1_NOSTAGE && ch > 0)) {
     __syncthreads();
     load_chunk<H, DH>(Kc, kb + (long long)ch * CK * 16 * C::D, nt * 16, tid, WPB * 64);
     load_chunk<H, DH>(Vc, vb + (long long)ch * CK * 16 * C::D, nt * 16, tid, WPB * 64);
     __syncthreads();
+    }
     if (active)
       for (int kc = 0; kc < nt; ++kc) {
         f32x4 S[H], E[H];
@@ -1129,10 +1140,12 @@ __global__ __launch_bounds__(WPB * 64, 2) void flash_bwd_dq_kernel(
   const int nchunks = (ntiles + CK - 1) / CK;
   for (int ch = 0; ch < nchunks; ++ch) {
     const int nt = min(CK, ntiles - ch * CK);
+    if (!(VU_V1_NOSTAGE && ch > 0)) {
     __syncthreads();
     load_chunk<H, DH>(Kc, kb + (long long)ch * CK * 16 * C::D, nt * 16, tid, WPB * 64);
     load_chunk<H, DH>(Vc, vb + (long long)ch * CK * 16 * C::D, nt * 16, tid, WPB * 64);
     __syncthreads();
+    }
     if (active)
       for (int kc = 0; kc < nt; ++kc) {
         f32x4 S[H], E[H];
