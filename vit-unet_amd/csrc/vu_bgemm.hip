@@ -463,7 +463,12 @@ int vu_bgemm_try(const vu_gemm_args& g, int c_float, hipStream_t st) {
   // column tile idle: 20.5 us stand-alone at 64 images; here 224 workgroups of one 224 x 192 tile, the three k-steps of the ring in
   // flight at once: 12.0 us (Base step at 64 images 11.78 -> 11.65 ms).  VU_BGEMM_SMALL=0 (read once) restores the tiled route.
   static const bool small_ok = [] { const char* e = getenv("VU_BGEMM_SMALL"); return !(e && e[0] == '0'); }();
-  const bool small = small_ok && !c_float && g.K == 192 && g.N == 192 && g.M >= 4096;
+  // ... and the short-K products with a wide output: the second feed-forward layer and the data gradient of the first at levels
+  // 1 / 0 (K = 64 / 128, N = 768 / 3072; 21 - 23 us as vu_gemm.h tiles in the step, 9.5 - 10.6 stand-alone here: 11.595 -> 11.55 ms).
+  // VU_BGEMM_SMALL=1 keeps them on the tiled route.
+  static const bool shortk_ok = [] { const char* e = getenv("VU_BGEMM_SMALL"); return !(e && (e[0] == '0' || e[0] == '1')); }();
+  const bool small = small_ok && !c_float && ((g.K == 192 && g.N == 192 && g.M >= 4096) ||
+                                              (shortk_ok && g.K >= 64 && g.K < 512 && g.N >= 512 && g.M >= 2048 && (long long)g.M * g.N >= (1ll << 22)));
   if (g.K % 8 != 0 || g.N % 8 != 0 || g.ldc % 8 != 0) return 0;
   if (!small) {
     if (g.K < 512 || g.N < 512 || g.M < 512) return 0;
