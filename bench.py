@@ -55,7 +55,7 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-host-input", action="store_true", help="skip the PCIe-inclusive legs (N=1 only)")
     ap.add_argument("--grad-wire", default="fp32", choices=["fp32", "bf16"], help="N > 1: dtype of the gradient buckets on the links")
-    ap.add_argument("--collective", default="all_reduce", choices=["all_reduce", "rs_ag"],
+    ap.add_argument("--collective", default="all_reduce", choices=["all_reduce", "rs_ag", "c_abi"],
                     help="N > 1: one all-reduce per gradient bucket, or reduce-scatter + all-gather (engine._sum_over_ranks)")
     ap.add_argument("--no-sustained", action="store_true", help="skip the second, longer timed region (profiler runs)")
     ap.add_argument("--profile-steps", type=int, default=2)
@@ -217,6 +217,9 @@ def main():
         y = torch.rand(a.batch, 3, 224, 224, generator=g)
         x = (y + 0.1 * torch.randn(y.shape, generator=g)).clamp(0, 1)
     x, y = x.to(dev), y.to(dev)
+    if dp and a.collective == "c_abi":       # the library's own RCCL communicator (vu_dp_init) beside torch's process group
+        from vit_unet.torch.engine import dp_c_abi_init
+        dp_c_abi_init()
     ts = TrainStep(model, lr=1e-4, seed=1234 + rank, loss="dice" if seg else "mse",
                    grad_wire_dtype=torch.bfloat16 if a.grad_wire == "bf16" else None, collective=a.collective)
     # what the collective library itself reports, so that the driver can check "RCCL formed N ranks" against n_gpus

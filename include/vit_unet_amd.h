@@ -296,6 +296,23 @@ int vu_set_flash_key_split(int ks);
  * Initial value: VU_FLASH_PCACHE (0 / 1), read once. */
 int vu_set_flash_pcache(int on);
 
+/* Data-parallel gradient exchange over RCCL (csrc/vu_dp.cpp).  The reference has no collective
+ * (/root/reference/run_denoising.py:79,87: one 'cuda' device); the default exchange of this build is torch.distributed (backend
+ * "nccl" = RCCL) and these are the same sums for a host without torch.  One communicator per process (one process per GPU), created
+ * on the current HIP device.  RCCL is opened with dlopen at vu_dp_unique_id / vu_dp_init (the copy the process already holds, or
+ * librccl.so.1 of the ROCm installation): the library has no link-time dependency on it.
+ *   vu_dp_unique_id         rank 0 fills 128 bytes (an ncclUniqueId) and hands them to every rank by any channel
+ *   vu_dp_init              collective over all `world` ranks; one communicator per process (vu_dp_finalize before another)
+ *   vu_dp_allreduce_bucket  in-place SUM over the ranks of ptr[0 .. count), dtype 0 = fp32 / 1 = bf16, enqueued on `stream`; the
+ *                           1 / world average is applied by vu_adamw's grad_scale
+ *   vu_dp_world             ranks of the communicator (0: none)
+ * PROCESS-GLOBAL state (the communicator); not thread-safe against itself. */
+int vu_dp_unique_id(void* out128);
+int vu_dp_init(int rank, int world, const void* unique_id_128);
+int vu_dp_allreduce_bucket(void* ptr, long long count, int dtype, void* stream);
+int vu_dp_world(void);
+int vu_dp_finalize(void);
+
 /* In-process launch profiler (bench.py's roofline leg): PROCESS-GLOBAL state, meant for one
  * instrumented stream at a time.  After vu_prof_enable(stream) an event is
  * recorded behind every launch; vu_prof_report() stops, waits, and returns a JSON object

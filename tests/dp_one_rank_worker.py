@@ -91,6 +91,35 @@ def main(golden_dir):
     for (k, pe), (_, pf) in zip(me.named_parameters(), mf.named_parameters()):
         if not k.endswith("reatten_matrix.bias"):
             assert serr(pe, pf) < 1e-4, k
+    # the library's own RCCL communicator behind the C ABI (include/vit_unet_amd.h: vu_dp_init / vu_dp_allreduce_bucket):
+    # created from the process group (the unique id travels through it), one rank: a bucket summed over one rank is unchanged, in
+    # fp32 and in bf16, and the step with collective="c_abi" is the single-GPU step
+    from vit_unet.torch import _lib
+    from vit_unet.torch.engine import dp_c_abi_init
+    L = _lib.lib()
+    assert L.vu_dp_world() == 0
+    assert L.vu_dp_allreduce_bucket(None, 4, 0, None) < 0 and b"vu_dp_init" in L.vu_last_error()      # refuses before vu_dp_init
+    assert dp_c_abi_init() == 1 and L.vu_dp_world() == 1 and dp_c_abi_init() == 1
+    for dt, code in ((torch.float32, 0), (torch.bfloat16, 1)):
+        t = torch.randn(100003, device=DEV).to(dt)
+        ref = t.clone()
+        _lib.check(L.vu_dp_allreduce_bucket(_lib.ptr(t), t.numel(), code, _lib.stream_ptr(t.device)), "vu_dp_allreduce_bucket")
+        torch.cuda.synchronize()
+        assert torch.equal(t, ref), dt
+    mg, mh = build(kw, w).train(), build(kw, w).train()
+    tg = TrainStep(mg, lr=1e-3, seed=5, bucket_mb=0, collective="c_abi")
+    assert tg.dp and tg.collective == "c_abi"
+    os.environ.pop("VU_DP_FORCE", None)
+    th = TrainStep(mh, lr=1e-3, seed=5)
+    os.environ["VU_DP_FORCE"] = "1"
+    for _ in range(2):
+        lg, lh = tg.step(x, y).item(), th.step(x, y).item()
+        assert abs(lg - lh) < 1e-4 * abs(lh), (lg, lh)
+    torch.cuda.synchronize()
+    for (k, pg), (_, ph) in zip(mg.named_parameters(), mh.named_parameters()):
+        if not k.endswith("reatten_matrix.bias"):
+            assert serr(pg, ph) < 1e-4, k
+    assert L.vu_dp_finalize() == 0 and L.vu_dp_world() == 0
     print("DP_ONE_RANK_OK", flush=True)
 
 

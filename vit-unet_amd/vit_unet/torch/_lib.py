@@ -118,6 +118,11 @@ SIGNATURES = {
     "vu_prof_enable": (_i, [_vp]),
     "vu_prof_report": (C.c_char_p, []),
     "vu_prof_gate": (_i, [_i]),
+    "vu_dp_unique_id": (_i, [_vp]),
+    "vu_dp_init": (_i, [_i, _i, _vp]),
+    "vu_dp_allreduce_bucket": (_i, [_vp, _ll, _i, _vp]),
+    "vu_dp_world": (_i, []),
+    "vu_dp_finalize": (_i, []),
 }
 
 _lib: Optional[C.CDLL] = None

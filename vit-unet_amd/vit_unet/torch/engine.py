@@ -79,6 +79,10 @@ def _sum_over_ranks(t: torch.Tensor, group, collective: str):
     if collective == "all_reduce":
         torch.distributed.all_reduce(t, group=group)
         return
+    if collective == "c_abi":       # the library's own RCCL communicator (include/vit_unet_amd.h: vu_dp_allreduce_bucket), on the current stream
+        check(lib().vu_dp_allreduce_bucket(ptr(t), t.numel(), 0 if t.dtype == torch.float32 else 1, stream_ptr(t.device)),
+              "vu_dp_allreduce_bucket")
+        return
     w = torch.distributed.get_world_size(group)
     n = t.numel()
     main = n - n % w
@@ -107,6 +111,23 @@ def allreduce_bucket(flat: torch.Tensor, lo: int, hi: int, group=None, wire_dtyp
         flat[lo:hi].copy_(wire)
 
 
+def dp_c_abi_init(group=None) -> int:
+    """Create the library's RCCL communicator (vu_dp_init) for the ranks of a torch process group: rank 0 draws the unique id
+    (vu_dp_unique_id) and the group broadcasts its 128 bytes.  Returns the world size.  Idempotent."""
+    L = lib()
+    if L.vu_dp_world():
+        return L.vu_dp_world()
+    rank, world = torch.distributed.get_rank(group), torch.distributed.get_world_size(group)
+    buf = (C.c_ubyte * 128)()
+    if rank == 0:
+        check(L.vu_dp_unique_id(buf), "vu_dp_unique_id")
+    box = [bytes(buf)]
+    torch.distributed.broadcast_object_list(box, src=0, group=group)
+    raw = (C.c_ubyte * 128).from_buffer_copy(box[0])
+    check(L.vu_dp_init(rank, world, raw), "vu_dp_init")
+    return world
+
+
 class TrainStep:
     def __init__(self, model, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
                  process_group=None, seed: int = 0, overlap: bool = True, loss: str = "mse", bucket_mb: Optional[int] = None,
@@ -114,11 +135,13 @@ class TrainStep:
         """`loss`: "mse" (run_denoising.py:80) or "dice" (README.md:91-101 on sigmoid(model output),
         the segmentation configuration of BASELINE config 5).  `grad_wire_dtype=torch.bfloat16`: data-parallel gradient
         buckets are all-reduced in bf16 (allreduce_bucket); default: fp32, as the reference's DDP would.
-        `collective="rs_ag"`: every bucket as reduce-scatter + all-gather instead of one all-reduce (`_sum_over_ranks`)."""
+        `collective="rs_ag"`: every bucket as reduce-scatter + all-gather instead of one all-reduce (`_sum_over_ranks`);
+        `collective="c_abi"`: every bucket through the library's own RCCL communicator (`vu_dp_allreduce_bucket`; `dp_c_abi_init`
+        creates it from the torch process group: the unique id travels through the group's store)."""
         if grad_wire_dtype not in (None, torch.float32, torch.bfloat16):
             raise ValueError("grad_wire_dtype must be None, torch.float32 or torch.bfloat16")
-        if collective not in ("all_reduce", "rs_ag"):
-            raise ValueError("collective must be 'all_reduce' or 'rs_ag' (reduce-scatter + all-gather per bucket)")
+        if collective not in ("all_reduce", "rs_ag", "c_abi"):
+            raise ValueError("collective must be 'all_reduce', 'rs_ag' (reduce-scatter + all-gather per bucket) or 'c_abi' (vu_dp_allreduce_bucket)")
         self.collective = collective
         self.grad_wire_dtype = None if grad_wire_dtype == torch.float32 else grad_wire_dtype
         if loss not in ("mse", "dice"):
