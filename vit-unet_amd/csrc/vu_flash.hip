@@ -43,6 +43,13 @@ typedef __attribute__((ext_vector_type(8))) short s16x8;
 #define VU_FLASH_V1_W4 4
 #endif
 #define VU_FLASH_V1_WAVES(H, DH) (((H) == 4 && (DH) <= 32) ? VU_FLASH_V1_W4 : 2)      // (d = 48: LDS allows two workgroups per CU anyway)
+// Round 5, the 4-head sweeps' synchronous chunk staging (load_chunk between two barriers; at four waves per SIMD they have no
+// registers to prefetch into).  Ablated (VU_V1_NOSTAGE=1, results wrong) Lite at 32 images goes 15.70 -> 14.85 ms: delta + dq -16 %,
+// row statistics + moments -10 %, apply -16 %.  Built and measured: double-buffered LDS-DMA staging as in flash3_dk_kernel (generic
+// padded-image DMA for any (H, d), row constants of the key-major sweep by 4-byte DMA), HALF the tiles per buffer so that the LDS
+// and the four workgroups per CU stay: correct (the 4-head parity tests pass) and NO faster - 15.70 ms; delta + dq -2 %, apply -3 %,
+// dk +5 % - because what the ablation removed was the barrier pair per chunk (twice as frequent with half-size buffers), not the
+// load latency, which four to five waves per SIMD already hide.  Not kept.
 #ifndef VU_V1_NOSTAGE
 #define VU_V1_NOSTAGE 0          // measurement builds (results wrong): the 4-head sweeps stage only their first chunk
 #endif
