@@ -493,6 +493,41 @@ def test_feedforward_linear_drop_vs_oracle(dt):
         assert serr(q.grad, p["net." + k].grad) < bt, k
 
 
+@pytest.mark.parametrize("B,N", [(8, 196), (3, 347), (64, 196)])
+def test_feedforward_fused_level2_vs_oracle(B, N):
+    """The level-2 shape (D = 192, hidden = 32, bf16, no linear dropout) takes the ONE-kernel-per-direction route of
+    csrc/vu_ff2.hip (the launch profiler names it); forward and every gradient against the oracle's bf16-storage replay, on row
+    counts that are and are not a multiple of the 16-token tile (3 * 347 = 1041).  (The residual form is the block's: the
+    teacher-forced block tests and the whole-model parity tests run it.)"""
+    import ctypes as C
+    from vit_unet.torch._lib import lib
+    D, hid, dt = 192, 32, torch.bfloat16
+    gen = torch.Generator().manual_seed(21)
+    ff = M.FeedForward(D, hid, 0.0).to(DEV).train()
+    x = torch.randn(B, N, D, generator=gen)
+    dy = torch.randn(B, N, D, generator=gen).to(dt)
+    xd = x.to(dt).to(DEV).requires_grad_(True)
+    L = lib()
+    torch.cuda.synchronize()
+    L.vu_prof_enable(C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    out = ff(xd, seed=5, stream_id=2)
+    out.backward(dy.to(DEV))
+    torch.cuda.synchronize()
+    rep = json.loads(L.vu_prof_report().decode())
+    assert "vu_ff2_fwd_kernel" in rep and "vu_ff2_bwd_kernel" in rep, rep.keys()
+    p = {"net.0.weight": ff.net[0].weight.detach().cpu().to(dt).float().requires_grad_(True),
+         "net.0.bias": ff.net[0].bias.detach().cpu().clone().requires_grad_(True),
+         "net.3.weight": ff.net[3].weight.detach().cpu().to(dt).float().requires_grad_(True),
+         "net.3.bias": ff.net[3].bias.detach().cpu().clone().requires_grad_(True)}
+    xr = x.to(dt).float().requires_grad_(True)
+    ref = O.feed_forward(xr, p, "", training=True, linear_drop=0.0, seed=5, stream=2, storage=dt)
+    ref.backward(dy.float())
+    assert serr(out.float(), ref) < 1e-2                               # one bf16 rounding of the output
+    assert serr(xd.grad.float(), xr.grad) < 2e-2
+    for (k, q) in ff.net.named_parameters():
+        assert serr(q.grad, p["net." + k].grad) < 2e-2, k
+
+
 def test_model_linear_drop_vs_oracle(golden_dir):
     """A whole (tiny) model with all three dropouts on: element-for-element against the oracle's replay."""
     with open(os.path.join(golden_dir, "manifest.json")) as f:

@@ -1,0 +1,201 @@
+// FeedForward of level 2 as ONE kernel per direction (model.py:95-110): D = 192, hidden = 32, bf16 storage, no
+// linear dropout (every preset has linear_drop = 0; any other value keeps the two-launch route of vu_model.hip).
+//   forward   hpre = x W1^T + b1,  hact = gelu(hpre),  y = hact W2^T + b2 (+ resid)
+//   backward  dh = (dy W2) gelu'(hpre),  dx = dh W1 (+ addend)           (the weight gradients stay on vu_tsgemm: they read hact / dh)
+// The hidden activation of a token never leaves the wave that made it: both products are computed TRANSPOSED (rows = output units,
+// columns = the wave's 16 tokens), so the accumulator of the first - lane (token l15, hidden units 4 g4 + r of tile 0 and 16 + 4 g4 + r
+// of tile 1) - IS the B operand of the second once packed to bf16: an MFMA contracts over its k-slots in any order as long as both
+// operands agree, so the second product's weight fragments are built with exactly that order of hidden units (no transpose, no LDS
+// round trip for the activation).  The weights (2 x 12 KB) become 24 fragment images of 1 KiB in LDS once per workgroup; a wave reads
+// a fragment (ds_read_b128, lane-contiguous) right before the MFMA that uses it, so it holds almost no registers between tiles and
+// many waves per SIMD hide the direct global loads of the 16 x 192 token rows.  hpre / hact / dh are still written (3 MB each): the
+// backward and the weight-gradient kernels read them.  As two vu_pgemm launches the pair took 32.6 us forward / 35.2 us backward per
+// block at 64 images.
+#include <stdio.h>
+#include <stdlib.h>
+#include "vu_gemm.h"
+
+namespace {
+
+constexpr int D = 192, HID = 32, NF1 = 12, NF2 = 12;      // fragments: first product 2 tiles x 6 k-steps, second 12 tiles x 1 k-step
+
+struct ff2_args {
+  const bf16_t *x, *w1, *w2;       // forward: x; backward: dy.  w1 [32][192], w2 [192][32] row-major (torch Linear layout)
+  const float *b1, *b2;
+  const bf16_t* addend;            // forward: resid; backward: addend of dx (may be null)
+  bf16_t *hpre, *hact, *y;         // forward outputs; backward: hpre is an INPUT, hact = dh (output), y = dx (output)
+  long long rows;
+};
+
+__device__ __forceinline__ f32x4 mf(const bf16x8& a, const bf16x8& b, const f32x4& c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+typedef __attribute__((ext_vector_type(2))) __bf16 b2_t;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+typedef __attribute__((ext_vector_type(2))) float f2_t;
+__device__ __forceinline__ unsigned pk2f(float a, float b) { const f2_t v = {a, b}; return __builtin_bit_cast(unsigned, __builtin_convertvector(v, b2_t)); }
+__device__ __forceinline__ float lo16(unsigned w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float hi16(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+
+// hidden unit that k-slot (g4, j) of the second product carries: the first product's accumulator order
+__device__ __forceinline__ int perm_hid(int g4, int j) { return j < 4 ? 4 * g4 + j : 16 + 4 * g4 + (j - 4); }
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void ff2_kernel(const ff2_args a) {
+  // fragment images [frag][lane] of 16 bytes; backward: the plain weights first (the transposed fragments are gathered from LDS)
+  __shared__ __attribute__((aligned(16))) bf16_t frag[(NF1 + NF2) * 64 * 8];
+  __shared__ __attribute__((aligned(16))) bf16_t plain[BWD ? 2 * D * HID : 8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
+  // the first tile's token rows are requested before the weights: they fly under the whole fragment build
+  const long long ntile = (a.rows + 15) >> 4;
+  long long t = (long long)blockIdx.x * 4 + wave;
+  bf16x8 xf[6];
+  {
+    long long row = (t < ntile ? t : ntile - 1) * 16 + l15;
+    if (row >= a.rows) row = a.rows - 1;
+    const bf16_t* xr = a.x + row * D + 8 * g4;
+#pragma unroll
+    for (int kk = 0; kk < 6; ++kk) xf[kk] = *reinterpret_cast<const bf16x8*>(xr + 32 * kk);
+  }
+  // Fragment f = wave + 4 it of image entry e = tid + 256 it (it = 0..5): it < 3 are the first product's, the rest the second's -
+  // two straight-line groups of three independent loads each, no per-entry branch.
+  const int r = l15, q = g4;
+  if constexpr (!BWD) {
+    bf16x8 o1[3];
+    bf16x4 p0[3], p1[3];
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {       // first product: A = W1, fragment (t1, kk): row 16 t1 + r, k = 32 kk + 8 q + j
+      const int f = wave + 4 * it, t1 = f / 6, kk = f % 6;
+      o1[it] = *reinterpret_cast<const bf16x8*>(a.w1 + (16 * t1 + r) * D + 32 * kk + 8 * q);
+    }
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {       // second product: A = W2, fragment t2: row 16 t2 + r, k-slot j = hidden perm_hid(q, j)
+      const int t2 = wave + 4 * it;
+      p0[it] = *reinterpret_cast<const bf16x4*>(a.w2 + (16 * t2 + r) * HID + 4 * q);
+      p1[it] = *reinterpret_cast<const bf16x4*>(a.w2 + (16 * t2 + r) * HID + 16 + 4 * q);
+    }
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+      *reinterpret_cast<bf16x8*>(frag + ((wave + 4 * it) * 64 + lane) * 8) = o1[it];
+      *reinterpret_cast<bf16x8*>(frag + ((NF1 + wave + 4 * it) * 64 + lane) * 8) =
+          bf16x8{p0[it][0], p0[it][1], p0[it][2], p0[it][3], p1[it][0], p1[it][1], p1[it][2], p1[it][3]};
+    }
+  } else {
+    uint4 st[6];
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {       // the plain weights (w1 then w2), 16 bytes per thread per trip
+      const int v = tid + 256 * it;
+      const bf16_t* src = v < D * HID / 8 ? a.w1 + v * 8 : a.w2 + (v - D * HID / 8) * 8;
+      st[it] = *reinterpret_cast<const uint4*>(src);
+    }
+#pragma unroll
+    for (int it = 0; it < 6; ++it) *reinterpret_cast<uint4*>(plain + (tid + 256 * it) * 8) = st[it];
+    __syncthreads();
+    const bf16_t* W1 = plain;
+    const bf16_t* W2 = plain + D * HID;
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {       // dh^T = W2^T dy^T: fragment (t1, kk): row = hidden 16 t1 + r, k = feature 32 kk + 8 q + j
+      const int f = wave + 4 * it, t1 = f / 6, kk = f % 6;
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = W2[(32 * kk + 8 * q + j) * HID + 16 * t1 + r];
+      *reinterpret_cast<bf16x8*>(frag + (f * 64 + lane) * 8) = o;
+    }
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {       // dx^T = W1^T dh^T: fragment t2: row = feature 16 t2 + r, k-slot j = hidden perm_hid(q, j)
+      const int t2 = wave + 4 * it;
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = W1[perm_hid(q, j) * D + 16 * t2 + r];
+      *reinterpret_cast<bf16x8*>(frag + ((NF1 + t2) * 64 + lane) * 8) = o;
+    }
+  }
+  __syncthreads();
+  for (bool first = true; t < ntile; t += (long long)gridDim.x * 4, first = false) {
+    long long row = t * 16 + l15;
+    const bool rok = row < a.rows;
+    if (!rok) row = a.rows - 1;                       // clamped loads; nothing is stored for rows past the end
+    // ---- first product: 2 tiles of hidden units x 16 tokens, K = 192 ----
+    if (!first) {
+      const bf16_t* xr = a.x + row * D + 8 * g4;
+#pragma unroll
+      for (int kk = 0; kk < 6; ++kk) xf[kk] = *reinterpret_cast<const bf16x8*>(xr + 32 * kk);
+    }
+    f32x4 h[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int kk = 0; kk < 6; ++kk)
+#pragma unroll
+      for (int t1 = 0; t1 < 2; ++t1) h[t1] = mf(*reinterpret_cast<const bf16x8*>(frag + ((t1 * 6 + kk) * 64 + lane) * 8), xf[kk], h[t1]);
+    // lane: token l15, hidden units 16 t1 + 4 g4 + r
+    unsigned hp[2][2];                                // packed bf16 pairs of the second product's B operand
+#pragma unroll
+    for (int t1 = 0; t1 < 2; ++t1) {
+      const long long ho = row * HID + 16 * t1 + 4 * g4;
+      if constexpr (!BWD) {
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(a.b1 + 16 * t1 + 4 * g4);
+        f32x4 v = h[t1] + bb;
+        const u32x2_t pre = {pk2f(v[0], v[1]), pk2f(v[2], v[3])};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = vu_gelu(v[r]);
+        hp[t1][0] = pk2f(v[0], v[1]); hp[t1][1] = pk2f(v[2], v[3]);
+        if (rok) {
+          *reinterpret_cast<u32x2_t*>(a.hpre + ho) = pre;
+          *reinterpret_cast<u32x2_t*>(a.hact + ho) = u32x2_t{hp[t1][0], hp[t1][1]};
+        }
+      } else {
+        const u32x2_t pre = *reinterpret_cast<const u32x2_t*>(a.hpre + ho);
+        f32x4 v = h[t1];
+        v[0] *= vu_gelu_grad(lo16(pre[0])); v[1] *= vu_gelu_grad(hi16(pre[0]));
+        v[2] *= vu_gelu_grad(lo16(pre[1])); v[3] *= vu_gelu_grad(hi16(pre[1]));
+        hp[t1][0] = pk2f(v[0], v[1]); hp[t1][1] = pk2f(v[2], v[3]);
+        if (rok) *reinterpret_cast<u32x2_t*>(a.hact + ho) = u32x2_t{hp[t1][0], hp[t1][1]};      // dh
+      }
+    }
+    const u32x4_t bw = {hp[0][0], hp[0][1], hp[1][0], hp[1][1]};      // k-slots j = 0..3: tile 0, 4..7: tile 1 (perm_hid)
+    const bf16x8 bop = __builtin_bit_cast(bf16x8, bw);
+    // ---- second product: 12 tiles of output features x 16 tokens, K = 32 ----
+#pragma unroll
+    for (int t2 = 0; t2 < 12; ++t2) {
+      f32x4 o = mf(*reinterpret_cast<const bf16x8*>(frag + ((NF1 + t2) * 64 + lane) * 8), bop, f32x4{0.f, 0.f, 0.f, 0.f});
+      const long long oo = row * D + 16 * t2 + 4 * g4;
+      if constexpr (!BWD) o += *reinterpret_cast<const f32x4*>(a.b2 + 16 * t2 + 4 * g4);
+      if (a.addend) {
+        const u32x2_t ad = *reinterpret_cast<const u32x2_t*>(a.addend + oo);
+        o[0] += lo16(ad[0]); o[1] += hi16(ad[0]); o[2] += lo16(ad[1]); o[3] += hi16(ad[1]);
+      }
+      if (rok) *reinterpret_cast<u32x2_t*>(a.y + oo) = u32x2_t{pk2f(o[0], o[1]), pk2f(o[2], o[3])};
+    }
+  }
+}
+
+bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+}  // namespace
+
+// 1 = launched, 0 = shape / options not covered (the caller takes the two-launch route), < 0 = error
+int vu_ff2_forward_try(int dtype, const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* hpre, void* hact,
+                       void* y, const void* resid, long long rows, int Din, int hid, hipStream_t st) {
+  static const bool off = [] { const char* e = getenv("VU_FF2"); return e && e[0] == '0'; }();      // A/B switch, read once
+  if (off || dtype != 1 || Din != D || hid != HID || rows < 1024) return 0;
+  if (!aligned16(x) || !aligned16(w1) || !aligned16(w2) || !aligned16(b1) || !aligned16(b2) || !aligned16(hpre) || !aligned16(hact) || !aligned16(y) ||
+      (resid && !aligned16(resid))) return 0;
+  ff2_args a{(const bf16_t*)x, (const bf16_t*)w1, (const bf16_t*)w2, b1, b2, (const bf16_t*)resid, (bf16_t*)hpre, (bf16_t*)hact, (bf16_t*)y, rows};
+  const long long groups = (rows + 63) / 64;
+  const int grid = (int)(groups < 2048 ? groups : 2048);
+  hipLaunchKernelGGL(ff2_kernel<false>, dim3(grid), dim3(256), 0, st, a);
+  if (vu_prof_on()) vu_prof_note("vu_ff2_fwd_kernel", 4.0 * rows * (double)D * HID, 2.0 * rows * (D * (resid ? 3.0 : 2.0) + 2.0 * HID));
+  const int rc = vu_check_launch("vu_ff2_forward");
+  return rc ? rc : 1;
+}
+int vu_ff2_backward_try(int dtype, const void* dy, const void* w1, const void* w2, const void* hpre, void* gh, void* dx, const void* addend,
+                        long long rows, int Din, int hid, hipStream_t st) {
+  static const bool off = [] { const char* e = getenv("VU_FF2"); return e && e[0] == '0'; }();
+  if (off || dtype != 1 || Din != D || hid != HID || rows < 1024) return 0;
+  if (!aligned16(dy) || !aligned16(w1) || !aligned16(w2) || !aligned16(hpre) || !aligned16(gh) || !aligned16(dx) || (addend && !aligned16(addend))) return 0;
+  ff2_args a{(const bf16_t*)dy, (const bf16_t*)w1, (const bf16_t*)w2, nullptr, nullptr, (const bf16_t*)addend, (bf16_t*)const_cast<void*>(hpre), (bf16_t*)gh, (bf16_t*)dx, rows};
+  const long long groups = (rows + 63) / 64;
+  const int grid = (int)(groups < 2048 ? groups : 2048);
+  hipLaunchKernelGGL(ff2_kernel<true>, dim3(grid), dim3(256), 0, st, a);
+  if (vu_prof_on()) vu_prof_note("vu_ff2_bwd_kernel", 4.0 * rows * (double)D * HID, 2.0 * rows * (D * (addend ? 3.0 : 2.0) + 2.0 * HID));
+  const int rc = vu_check_launch("vu_ff2_backward");
+  return rc ? rc : 1;
+}

@@ -23,6 +23,12 @@ const char* vu_get_error();
     if (_rc != VU_OK) return _rc; \
   } while (0)
 
+// vu_ff2.hip: the pair as ONE kernel per direction where the shape is covered (level 2: D = 192, hidden = 32, no linear dropout)
+int vu_ff2_forward_try(int dtype, const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* hpre, void* hact,
+                       void* y, const void* resid, long long rows, int Din, int hid, hipStream_t st);
+int vu_ff2_backward_try(int dtype, const void* dy, const void* w1, const void* w2, const void* hpre, void* gh, void* dx, const void* addend,
+                        long long rows, int Din, int hid, hipStream_t st);
+
 namespace {
 
 inline size_t esize(int dtype) { return dtype == 0 ? 4 : 2; }
@@ -578,6 +584,11 @@ struct FFDims { int dtype; long long rows; int D, hid; };
 int ff_forward(const FFDims& f, const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* hpre,
                void* hact, void* y, const void* resid, float linear_drop, int training, uint64_t seed, uint64_t stream_id,
                const uint32_t* salt, hipStream_t st) {
+  if (!(training && linear_drop > 0.f)) {      // no dropout to draw: the fused pair where the shape is covered
+    const int rc = vu_ff2_forward_try(f.dtype, x, w1, b1, w2, b2, hpre, hact, y, resid, f.rows, f.D, f.hid, st);
+    if (rc < 0) return rc;
+    if (rc > 0) return VU_OK;
+  }
   {  // hact = dropout(gelu(x W1^T + b1))  (model.py:102-105)
     vu_gemm_args g;
     memset(&g, 0, sizeof(g));
@@ -619,7 +630,12 @@ int ff_backward(const FFDims& f, const void* x, const void* w1, const void* w2, 
     g.colsum = db2; g.colsum_side = 1;
     VU_TRY(vu_gemm_launch(f.dtype, 1, g, sw));
   }
-  {  // dh = dropout-mask * (dym W2) * gelu'(hpre)
+  int fused = 0;                                        // dh and dx in one kernel (vu_ff2.hip) where covered
+  if (!(training && linear_drop > 0.f)) {
+    fused = vu_ff2_backward_try(f.dtype, dym, w1, w2, hpre, gh, dx, addend, f.rows, f.D, f.hid, st);
+    if (fused < 0) return fused;
+  }
+  if (!fused) {  // dh = dropout-mask * (dym W2) * gelu'(hpre)
     vu_gemm_args g;
     memset(&g, 0, sizeof(g));
     g.A = dym; g.B = w2; g.C = gh; g.aux = (void*)hpre;
@@ -639,7 +655,7 @@ int ff_backward(const FFDims& f, const void* x, const void* w1, const void* w2, 
     if (sl) VU_TRY(lane_wait(sl, 1, st, sw));           // dh is ready
     VU_TRY(vu_gemm_launch(f.dtype, 1, g, sw));
   }
-  {  // dx = dh W1 (+ addend)
+  if (!fused) {  // dx = dh W1 (+ addend)
     vu_gemm_args g;
     memset(&g, 0, sizeof(g));
     g.A = gh; g.B = w1; g.C = dx; g.addend = addend;
