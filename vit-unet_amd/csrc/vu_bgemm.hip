@@ -472,7 +472,8 @@ int vu_bgemm_try(const vu_gemm_args& g, int c_float, hipStream_t st) {
   if (g.K % 8 != 0 || g.N % 8 != 0 || g.ldc % 8 != 0) return 0;
   if (!small) {
     if (g.K < 512 || g.N < 512 || g.M < 512) return 0;
-    if (c_float ? ((long long)g.M * g.N < (4ll << 20)) : ((long long)g.M * g.N * g.K < (1ll << 32))) return 0;
+    static const int min_work = [] { const char* e = getenv("VU_BGEMM_MINWORK"); return e ? atoi(e) : 30; }();      // log2 of M N K below which the tiled route keeps the product (round 5: 32 -> 30, the 768-class layers at 16 - 32 images: Base 16 / GPU 2699 -> 2728, Large 16 1445 -> 1467, Base 32 4160 -> 4194 images/s)
+    if (c_float ? ((long long)g.M * g.N < (4ll << 20)) : ((long long)g.M * g.N * g.K < (1ll << min_work))) return 0;
   }
   if (!((g.sAk == 1) != (g.sAm == 1)) || !((g.sBn == 1) != (g.sBk == 1))) return 0;
   const bool TA = g.sAm == 1, TB = g.sBn == 1;

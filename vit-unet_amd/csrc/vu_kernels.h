@@ -92,7 +92,10 @@ int vu_k_map_bwd_2sweep(int dtype, const void* Ps, void* dAhat_dS, const float* 
                         int ld, float inv_keep, float scale, hipStream_t st);
 
 // K13: residual add + LayerNorm over all P elements of a sample.
-#define VU_LN_CHUNK 4096
+#ifndef VU_LN_ITS
+#define VU_LN_ITS 2          /* 16-byte (8 x bf16) accesses per thread and chunk; the 4-element kernels make twice as many */
+#endif
+#define VU_LN_CHUNK (2048 * VU_LN_ITS)
 #define VU_LN_BCHUNK 256
 static inline int vu_ln_nchunks(long long P) { return (int)((P + VU_LN_CHUNK - 1) / VU_LN_CHUNK); }
 static inline int vu_ln_nbchunks(long long P) { return (int)((P + VU_LN_BCHUNK - 1) / VU_LN_BCHUNK); }

@@ -663,11 +663,11 @@ __global__ __launch_bounds__(256) void add_ln_stats_kernel(const T* a, const T* 
   const int c = blockIdx.x, b = blockIdx.y, nch = gridDim.x;
   const long long base = (long long)c * VU_LN_CHUNK;
   const long long sb = (long long)b * P;
-  float v[16];
+  float v[8 * VU_LN_ITS];
   int cnt = 0;
   float sum = 0.f;
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
+  for (int it = 0; it < 2 * VU_LN_ITS; ++it) {
     const long long e = base + (it * 256 + threadIdx.x) * 4;
     if (e < P) {
       vu_f4 t = vu_ld4(a + sb + e);
@@ -690,7 +690,7 @@ __global__ __launch_bounds__(256) void add_ln_stats_kernel(const T* a, const T* 
   const float mean = tot / (float)n;
   float m2 = 0.f;
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
+  for (int it = 0; it < 2 * VU_LN_ITS; ++it) {
     const long long e = base + (it * 256 + threadIdx.x) * 4;
     if (e < P) {
 #pragma unroll
@@ -738,9 +738,9 @@ __global__ __launch_bounds__(256) void ln_apply_kernel(const T* __restrict__ z, 
   __shared__ float sm2[2];
   const int c = blockIdx.x, b = blockIdx.y, nch = gridDim.x;
   const long long base = (long long)c * VU_LN_CHUNK, sb = (long long)b * P;
-  vu_f4 tz[4];       // the chunk's values are in flight while the statistics are merged
+  vu_f4 tz[2 * VU_LN_ITS];       // the chunk's values are in flight while the statistics are merged
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
+  for (int it = 0; it < 2 * VU_LN_ITS; ++it) {
     const long long e = base + (it * 256 + threadIdx.x) * 4;
     if (e < P) tz[it] = vu_ld4(z + sb + e);
   }
@@ -748,7 +748,7 @@ __global__ __launch_bounds__(256) void ln_apply_kernel(const T* __restrict__ z, 
   ln_merge_stats(partials, b, nch, eps, sm2, mean, rstd);
   if (c == 0 && threadIdx.x == 0) { stats[2 * b] = mean; stats[2 * b + 1] = rstd; }
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
+  for (int it = 0; it < 2 * VU_LN_ITS; ++it) {
     const long long e = base + (it * 256 + threadIdx.x) * 4;
     if (e < P) {
       vu_f4 t = tz[it];
@@ -780,11 +780,11 @@ __global__ __launch_bounds__(256) void add_ln_stats8_kernel(const bf16_t* a, con
   __shared__ float sm[16];
   const int c = blockIdx.x, b = blockIdx.y, nch = gridDim.x;
   const long long base = (long long)c * VU_LN_CHUNK, sb = (long long)b * P;
-  float v[2][8];
+  float v[VU_LN_ITS][8];
   float sum = 0.f;
   const bool writes = x || z != a;      // (z == a, no x: the sum was already formed by the producing GEMM's epilogue)
 #pragma unroll
-  for (int it = 0; it < 2; ++it) {
+  for (int it = 0; it < VU_LN_ITS; ++it) {
     const long long e = base + (it * 256 + threadIdx.x) * 8;
     if (e < P) {
       vu_unpack8(*reinterpret_cast<const uint4*>(a + sb + e), v[it]);
@@ -811,7 +811,7 @@ __global__ __launch_bounds__(256) void add_ln_stats8_kernel(const bf16_t* a, con
   const float mean = tot / (float)n;
   float m2 = 0.f;
 #pragma unroll
-  for (int it = 0; it < 2; ++it) {
+  for (int it = 0; it < VU_LN_ITS; ++it) {
     const long long e = base + (it * 256 + threadIdx.x) * 8;
     if (e < P) {
 #pragma unroll
@@ -829,9 +829,9 @@ __global__ __launch_bounds__(256) void ln_apply8_kernel(const bf16_t* __restrict
   __shared__ float sm2[2];
   const int c = blockIdx.x, b = blockIdx.y, nch = gridDim.x;
   const long long base = (long long)c * VU_LN_CHUNK, sb = (long long)b * P;
-  uint4 tz[2];       // the chunk's values are in flight while the statistics are merged
+  uint4 tz[VU_LN_ITS];       // the chunk's values are in flight while the statistics are merged
 #pragma unroll
-  for (int it = 0; it < 2; ++it) {
+  for (int it = 0; it < VU_LN_ITS; ++it) {
     const long long e = base + (it * 256 + threadIdx.x) * 8;
     tz[it] = e < P ? *reinterpret_cast<const uint4*>(z + sb + e) : make_uint4(0, 0, 0, 0);
   }
@@ -839,7 +839,7 @@ __global__ __launch_bounds__(256) void ln_apply8_kernel(const bf16_t* __restrict
   ln_merge_stats(partials, b, nch, eps, sm2, mean, rstd);
   if (c == 0 && threadIdx.x == 0) { stats[2 * b] = mean; stats[2 * b + 1] = rstd; }
 #pragma unroll
-  for (int it = 0; it < 2; ++it) {
+  for (int it = 0; it < VU_LN_ITS; ++it) {
     const long long e = base + (it * 256 + threadIdx.x) * 8;
     if (e < P) {
       float t[8];
@@ -949,9 +949,9 @@ __global__ __launch_bounds__(256) void ln_bwd_apply_kernel(const T* __restrict__
   __shared__ float sm[16];
   const int c = blockIdx.x, b = blockIdx.y;
   const long long base = (long long)c * VU_LN_CHUNK, sb = (long long)b * P;
-  vu_f4 td[4], tz[4];      // in flight while the sample's partial sums are reduced
+  vu_f4 td[2 * VU_LN_ITS], tz[2 * VU_LN_ITS];      // in flight while the sample's partial sums are reduced
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
+  for (int it = 0; it < 2 * VU_LN_ITS; ++it) {
     const long long e = base + (it * 256 + threadIdx.x) * 4;
     if (e < P) { td[it] = vu_ld4(dy + sb + e); tz[it] = vu_ld4(z + sb + e); }
   }
@@ -964,7 +964,7 @@ __global__ __launch_bounds__(256) void ln_bwd_apply_kernel(const T* __restrict__
   const float c2 = vu_block_sum(a2, sm) / (float)P;
   const float mean = stats[2 * b], rstd = stats[2 * b + 1];
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
+  for (int it = 0; it < 2 * VU_LN_ITS; ++it) {
     const long long e = base + (it * 256 + threadIdx.x) * 4;
     if (e < P) {
       const vu_f4 d = td[it], zz = tz[it];
@@ -995,9 +995,9 @@ __global__ __launch_bounds__(256) void ln_bwd_apply8_kernel(const bf16_t* __rest
   __shared__ float sm[16];
   const int c = blockIdx.x, b = blockIdx.y;
   const long long base = (long long)c * VU_LN_CHUNK, sb = (long long)b * P;
-  uint4 td[2], tz[2];      // in flight while the sample's partial sums are reduced
+  uint4 td[VU_LN_ITS], tz[VU_LN_ITS];      // in flight while the sample's partial sums are reduced
 #pragma unroll
-  for (int it = 0; it < 2; ++it) {
+  for (int it = 0; it < VU_LN_ITS; ++it) {
     const long long e = base + (it * 256 + threadIdx.x) * 8;
     const bool ok = e < P;
     td[it] = ok ? *reinterpret_cast<const uint4*>(dy + sb + e) : make_uint4(0, 0, 0, 0);
@@ -1012,7 +1012,7 @@ __global__ __launch_bounds__(256) void ln_bwd_apply8_kernel(const bf16_t* __rest
   const float c2 = vu_block_sum(a2, sm) / (float)P;
   const float mean = stats[2 * b], rstd = stats[2 * b + 1];
 #pragma unroll
-  for (int it = 0; it < 2; ++it) {
+  for (int it = 0; it < VU_LN_ITS; ++it) {
     const long long e = base + (it * 256 + threadIdx.x) * 8;
     if (e < P) {
       float d[8], zz[8], o[8];
