@@ -776,15 +776,16 @@ __device__ __forceinline__ void vu_unpack8(const uint4& u, float (&v)[8]) {
   v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xffff0000u);
   v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xffff0000u);
 }
+template <int ITS>
 __global__ __launch_bounds__(256) void add_ln_stats8_kernel(const bf16_t* a, const bf16_t* __restrict__ x, bf16_t* z, float* partials, long long P) {
   __shared__ float sm[16];
   const int c = blockIdx.x, b = blockIdx.y, nch = gridDim.x;
-  const long long base = (long long)c * VU_LN_CHUNK, sb = (long long)b * P;
-  float v[VU_LN_ITS][8];
+  const long long base = (long long)c * (2048 * ITS), sb = (long long)b * P;
+  float v[ITS][8];
   float sum = 0.f;
   const bool writes = x || z != a;      // (z == a, no x: the sum was already formed by the producing GEMM's epilogue)
 #pragma unroll
-  for (int it = 0; it < VU_LN_ITS; ++it) {
+  for (int it = 0; it < ITS; ++it) {
     const long long e = base + (it * 256 + threadIdx.x) * 8;
     if (e < P) {
       vu_unpack8(*reinterpret_cast<const uint4*>(a + sb + e), v[it]);
@@ -807,11 +808,11 @@ __global__ __launch_bounds__(256) void add_ln_stats8_kernel(const bf16_t* a, con
     }
   }
   const float tot = vu_block_sum(sum, sm);
-  long long n = P - base; if (n > VU_LN_CHUNK) n = VU_LN_CHUNK;
+  long long n = P - base; if (n > (2048 * ITS)) n = (2048 * ITS);
   const float mean = tot / (float)n;
   float m2 = 0.f;
 #pragma unroll
-  for (int it = 0; it < VU_LN_ITS; ++it) {
+  for (int it = 0; it < ITS; ++it) {
     const long long e = base + (it * 256 + threadIdx.x) * 8;
     if (e < P) {
 #pragma unroll
@@ -824,14 +825,15 @@ __global__ __launch_bounds__(256) void add_ln_stats8_kernel(const bf16_t* a, con
     o[0] = (float)n; o[1] = mean; o[2] = M2;
   }
 }
+template <int ITS>
 __global__ __launch_bounds__(256) void ln_apply8_kernel(const bf16_t* __restrict__ z, const float* __restrict__ w, const float* __restrict__ bias,
                                                         bf16_t* __restrict__ y, const float* partials, float* stats, long long P, float eps) {
   __shared__ float sm2[2];
   const int c = blockIdx.x, b = blockIdx.y, nch = gridDim.x;
-  const long long base = (long long)c * VU_LN_CHUNK, sb = (long long)b * P;
-  uint4 tz[VU_LN_ITS];       // the chunk's values are in flight while the statistics are merged
+  const long long base = (long long)c * (2048 * ITS), sb = (long long)b * P;
+  uint4 tz[ITS];       // the chunk's values are in flight while the statistics are merged
 #pragma unroll
-  for (int it = 0; it < VU_LN_ITS; ++it) {
+  for (int it = 0; it < ITS; ++it) {
     const long long e = base + (it * 256 + threadIdx.x) * 8;
     tz[it] = e < P ? *reinterpret_cast<const uint4*>(z + sb + e) : make_uint4(0, 0, 0, 0);
   }
@@ -839,7 +841,7 @@ __global__ __launch_bounds__(256) void ln_apply8_kernel(const bf16_t* __restrict
   ln_merge_stats(partials, b, nch, eps, sm2, mean, rstd);
   if (c == 0 && threadIdx.x == 0) { stats[2 * b] = mean; stats[2 * b + 1] = rstd; }
 #pragma unroll
-  for (int it = 0; it < VU_LN_ITS; ++it) {
+  for (int it = 0; it < ITS; ++it) {
     const long long e = base + (it * 256 + threadIdx.x) * 8;
     if (e < P) {
       float t[8];
@@ -853,6 +855,11 @@ __global__ __launch_bounds__(256) void ln_apply8_kernel(const bf16_t* __restrict
     }
   }
 }
+inline bool ln_big_chunk(int B, long long P) {
+  static const int force = [] { const char* e = getenv("VU_LN_CHUNK8K"); return e ? atoi(e) : -1; }();      // A/B switch: 0 / 1
+  if (force >= 0) return force != 0;
+  return (long long)B * ((P + 4095) / 4096) > 2048;
+}
 inline bool ln_wide_ok(int dtype, long long P, const void* p0, const void* p1, const void* p2, const void* p3) {
   static const bool off = [] { const char* e = getenv("VU_LN_WIDE"); return e && e[0] == '0'; }();      // A/B switch
   return !off && dtype == 1 && P % 8 == 0 && !(((uintptr_t)p0 | (uintptr_t)p1 | (uintptr_t)p2 | (uintptr_t)p3) & 15);
@@ -863,8 +870,17 @@ int vu_k_add_ln_fwd(int dtype, const void* a, const void* x, void* z, const floa
   VU_REQUIRE(P % 4 == 0, "layernorm: P %% 4");
   const int nch = vu_ln_nchunks(P);
   if (ln_wide_ok(dtype, P, a, x, z, y) && !(((uintptr_t)w | (uintptr_t)bias) & 15)) {
-    hipLaunchKernelGGL(add_ln_stats8_kernel, dim3(nch, B), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)x, (bf16_t*)z, partials, P);
-    hipLaunchKernelGGL(ln_apply8_kernel, dim3(nch, B), dim3(256), 0, st, (const bf16_t*)z, w, bias, (bf16_t*)y, partials, stats, P, eps);
+    // chunk of 4096 elements per workgroup; 8192 once the 4096-element grid would not be resident at once (8 workgroups per CU:
+    // 2368 workgroups at 64 images leave a second, nearly empty round): 19.4 -> 17.4 us forward, 29.7 -> 28.3 backward at 64 images
+    // (tools/ln_time.py; at 16 images the larger chunk is 0.3 us slower)
+    if (ln_big_chunk(B, P)) {
+      const int nc = (int)((P + 8191) / 8192);
+      hipLaunchKernelGGL(add_ln_stats8_kernel<4>, dim3(nc, B), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)x, (bf16_t*)z, partials, P);
+      hipLaunchKernelGGL(ln_apply8_kernel<4>, dim3(nc, B), dim3(256), 0, st, (const bf16_t*)z, w, bias, (bf16_t*)y, partials, stats, P, eps);
+    } else {
+      hipLaunchKernelGGL(add_ln_stats8_kernel<2>, dim3(nch, B), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)x, (bf16_t*)z, partials, P);
+      hipLaunchKernelGGL(ln_apply8_kernel<2>, dim3(nch, B), dim3(256), 0, st, (const bf16_t*)z, w, bias, (bf16_t*)y, partials, stats, P, eps);
+    }
     if (vu_prof_on()) vu_prof_note("add_ln_fwd(2 kernels)", 0.0, (double)B * P * 5 * 2.0 + (double)P * 8);
     return vu_check_launch("vu_add_ln_fwd");
   }
@@ -988,16 +1004,17 @@ __global__ __launch_bounds__(256) void ln_bwd_apply_kernel(const T* __restrict__
   }
 }
 
+template <int ITS>
 __global__ __launch_bounds__(256) void ln_bwd_apply8_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ z, const float* __restrict__ w,
                                                             const float* __restrict__ stats, const float* partials2, int nbch, bf16_t* __restrict__ dz,
                                                             bf16_t* __restrict__ dzd, vu_rng rng_in, long long P) {
   const vu_rng rng = vu_rng_resolve(rng_in);
   __shared__ float sm[16];
   const int c = blockIdx.x, b = blockIdx.y;
-  const long long base = (long long)c * VU_LN_CHUNK, sb = (long long)b * P;
-  uint4 td[VU_LN_ITS], tz[VU_LN_ITS];      // in flight while the sample's partial sums are reduced
+  const long long base = (long long)c * (2048 * ITS), sb = (long long)b * P;
+  uint4 td[ITS], tz[ITS];      // in flight while the sample's partial sums are reduced
 #pragma unroll
-  for (int it = 0; it < VU_LN_ITS; ++it) {
+  for (int it = 0; it < ITS; ++it) {
     const long long e = base + (it * 256 + threadIdx.x) * 8;
     const bool ok = e < P;
     td[it] = ok ? *reinterpret_cast<const uint4*>(dy + sb + e) : make_uint4(0, 0, 0, 0);
@@ -1012,7 +1029,7 @@ __global__ __launch_bounds__(256) void ln_bwd_apply8_kernel(const bf16_t* __rest
   const float c2 = vu_block_sum(a2, sm) / (float)P;
   const float mean = stats[2 * b], rstd = stats[2 * b + 1];
 #pragma unroll
-  for (int it = 0; it < VU_LN_ITS; ++it) {
+  for (int it = 0; it < ITS; ++it) {
     const long long e = base + (it * 256 + threadIdx.x) * 8;
     if (e < P) {
       float d[8], zz[8], o[8];
@@ -1045,7 +1062,10 @@ int vu_k_ln_bwd(int dtype, const void* dy, const void* z, const float* w, const 
   const int nbch = vu_ln_nbchunks(P), nch = vu_ln_nchunks(P);
   if (ln_wide_ok(dtype, P, dy, z, dz, dz_drop) && !((uintptr_t)w & 15)) {
     hipLaunchKernelGGL((ln_bwd_stats_kernel<bf16_t>), dim3(nbch), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)z, w, stats, dw, db, partials2, B, P);
-    hipLaunchKernelGGL(ln_bwd_apply8_kernel, dim3(nch, B), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)z, w, stats, partials2, nbch, (bf16_t*)dz, (bf16_t*)dz_drop, rng, P);
+    if (ln_big_chunk(B, P))
+      hipLaunchKernelGGL(ln_bwd_apply8_kernel<4>, dim3((unsigned)((P + 8191) / 8192), B), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)z, w, stats, partials2, nbch, (bf16_t*)dz, (bf16_t*)dz_drop, rng, P);
+    else
+      hipLaunchKernelGGL(ln_bwd_apply8_kernel<2>, dim3(nch, B), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)z, w, stats, partials2, nbch, (bf16_t*)dz, (bf16_t*)dz_drop, rng, P);
     if (vu_prof_on()) vu_prof_note("ln_bwd(2 kernels)", 0.0, (double)B * P * 5 * 2.0 + (double)P * 24);
     return vu_check_launch("vu_ln_bwd");
   }
