@@ -476,8 +476,10 @@ def test_e4m3_operands_change_the_result():
 
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("B,P", [(3, 49 * 192), (2, 150528), (1, 4096), (5, 1028)])
+@pytest.mark.parametrize("B,P", [(3, 49 * 192), (2, 150528), (1, 4096), (5, 1028), (60, 150528), (70, 131080)])
 def test_add_layernorm_fwd_bwd(dt, B, P):
+    """(the last two cases put more than 2048 chunks of 4096 elements on the chip: the bf16 kernels then take 8192-element chunks,
+    csrc/vu_kernels.hip ln_big_chunk; 131080 leaves a ragged last chunk)"""
     g = torch.Generator().manual_seed(P)
     a = torch.randn(B, P, generator=g).to(dt)
     x = (3 + torch.randn(B, P, generator=g)).to(dt)

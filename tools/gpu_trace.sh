@@ -54,6 +54,18 @@ busy = sum((e[1] - e[0]) for e in ev) / 1e3
 with open(f"gpurun_out/{tag}_gaps.txt", "w") as o:
     o.write("launches %d  busy %.1f us  gaps(<200us) %.1f us  = %.1f %% of busy+gaps\n" % (len(ev), busy, sum(small), 100.0 * sum(small) / (busy + sum(small))))
     o.write("gap us: p10 %.2f  median %.2f  p90 %.2f  max(<200) %.2f  overlapping (<0): %d\n" % (gaps[len(gaps) // 10], gaps[len(gaps) // 2], gaps[9 * len(gaps) // 10], max(small), sum(1 for g in gaps if g < 0)))
+# the same for the MAIN stream alone: time its queue sat idle between two of its own kernels (waiting for a forked stream to join,
+# or for the host), second half of the trace
+mev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"][:70]) for r, qid in recs if qid == main_q)
+mev = mev[len(mev) // 2:]
+idle = [((b[0] - a[1]) / 1e3, a[2], b[2]) for a, b in zip(mev, mev[1:])]
+small = [g for g in idle if 0.0 < g[0] < 2000.0]
+span = (mev[-1][1] - mev[0][0]) / 1e3
+with open(f"gpurun_out/{tag}_gaps.txt", "a") as o:
+    o.write("main stream alone: %d launches over %.1f us; idle between its kernels %.1f us = %.1f %% (gaps > 3 us: %d, sum %.1f us)\n" % (
+        len(mev), span, sum(g[0] for g in small), 100.0 * sum(g[0] for g in small) / span, sum(1 for g in small if g[0] > 3.0), sum(g[0] for g in small if g[0] > 3.0)))
+    for g in sorted(small, reverse=True)[:12]:
+        o.write("  %.1f us idle after %s before %s\n" % g)
 print(open(f"gpurun_out/{tag}_gaps.txt").read())
 shutil.rmtree(root, ignore_errors=True)
 PY
