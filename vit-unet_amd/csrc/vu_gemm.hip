@@ -82,7 +82,16 @@ static int launch_tiles(const vu_gemm_args& g, hipStream_t st) {
       if (!eighth_off && (long long)vu_cdiv(g.M, 64) * vu_cdiv(g.N, 64) * g.Z1 * g.Z2 < 128) {
         static const bool t3232_off = [] { const char* e = getenv("VU_GEMM_3232"); return e && e[0] == '0'; }();      // A/B switch
         // (98 tiles of 64 x 64: 32 x 32 tiles put 392 workgroups on the chip: 31 -> 26 (32 x 64) -> 23 us)
-        if (!t3232_off && (long long)vu_cdiv(g.M, 32) * vu_cdiv(g.N, 64) * g.Z1 * g.Z2 < 256) return launch_bk<T, TC, TA, TB, 32, 32, 64, 4>(g, st);
+        if (!t3232_off && (long long)vu_cdiv(g.M, 32) * vu_cdiv(g.N, 64) * g.Z1 * g.Z2 < 256) {
+          // 48 k-steps of 64 are 48 barrier pairs on a 4 KB + 4 KB tile: k-steps of 256 with one tile in flight (the same 32 KB per
+          // workgroup as the ring of four 64-steps, a quarter of the barriers): 33.1 -> 26.6 us at 16 images, 30.6 -> 26.0 at 64
+          // (tools/step_tags.py; 128 x 2: 30.4 / 27.4, 256 x 2: 28.3 / 28.1).  VU_GEMM_3232_BK = 64 / 128 / 257 select the others.
+          static const int bk3232 = [] { const char* e = getenv("VU_GEMM_3232_BK"); return e ? atoi(e) : 256; }();
+          if (bk3232 == 128 && g.K % 128 == 0) return launch_bk<T, TC, TA, TB, 32, 32, 128, 2>(g, st);
+          if (bk3232 == 256 && g.K % 256 == 0) return launch_bk<T, TC, TA, TB, 32, 32, 256, 1>(g, st);
+          if (bk3232 == 257 && g.K % 256 == 0) return launch_bk<T, TC, TA, TB, 32, 32, 256, 2>(g, st);
+          return launch_bk<T, TC, TA, TB, 32, 32, 64, 4>(g, st);
+        }
         return launch_bk<T, TC, TA, TB, 32, 64, 64, 4>(g, st);
       }
     }
