@@ -467,8 +467,10 @@ int vu_bgemm_try(const vu_gemm_args& g, int c_float, hipStream_t st) {
   // 1 / 0 (K = 64 / 128, N = 768 / 3072; 21 - 23 us as vu_gemm.h tiles in the step, 9.5 - 10.6 stand-alone here: 11.595 -> 11.55 ms).
   // VU_BGEMM_SMALL=1 keeps them on the tiled route.
   static const bool shortk_ok = [] { const char* e = getenv("VU_BGEMM_SMALL"); return !(e && (e[0] == '0' || e[0] == '1')); }();
+  static const int shortk_m = [] { const char* e = getenv("VU_BGEMM_SHORTK_M"); return e ? atoi(e) : 512; }();         // the smallest M and
+  static const int shortk_mn = [] { const char* e = getenv("VU_BGEMM_SHORTK_MN"); return e ? atoi(e) : 21; }();      // log2(M N) of the short-K route (2048 / 22 until the 16-image batches were measured: Base 16 / GPU 2743 -> 2779, Large 16 / GPU 1476 -> 1486 images/s)
   const bool small = small_ok && !c_float && ((g.K == 192 && g.N == 192 && g.M >= 4096) ||
-                                              (shortk_ok && g.K >= 64 && g.K < 512 && g.N >= 512 && g.M >= 2048 && (long long)g.M * g.N >= (1ll << 22)));
+                                              (shortk_ok && g.K >= 64 && g.K < 512 && g.N >= 512 && g.M >= shortk_m && (long long)g.M * g.N >= (1ll << shortk_mn)));
   if (g.K % 8 != 0 || g.N % 8 != 0 || g.ldc % 8 != 0) return 0;
   if (!small) {
     if (g.K < 512 || g.N < 512 || g.M < 512) return 0;
