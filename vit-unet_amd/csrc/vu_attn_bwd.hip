@@ -1088,11 +1088,14 @@ int vu_k_mix_stats_mm(int dtype, const void* Ps, const float* W, float* partials
 namespace {
 
 // one block per (sample, head): feature columns side by side, row lanes stacked, LDS combine
-template <typename T>
-__global__ __launch_bounds__(256) void bn_bwd_small_kernel(const T* __restrict__ dO, const T* __restrict__ O,
+// NT threads per workgroup: 256; 1024 (bf16 16-byte path only, VU_BN_BWD_WIDE=1: every thread makes ONE batch of 4 row loads) is a
+// measurement variant.  Round 5: the row lanes of a feature octet are combined by wave shuffles and a parallel LDS sum instead of a
+// serial loop of TV threads over RL LDS rows: 22.7 -> 17.5 us per call at 16 images, 28.2 -> 24.1 at 64 (tools/step_tags.py).
+template <typename T, int NT>
+__global__ __launch_bounds__(NT) void bn_bwd_small_kernel(const T* __restrict__ dO, const T* __restrict__ O,
                                                            const T* __restrict__ v, float* partials, int N, int D, int H) {
   __shared__ float sm[16];
-  __shared__ float sdo[4 * 256], sv[4 * 256];
+  __shared__ float sdo[4 * NT], sv[4 * NT];
   const int b = blockIdx.x, g = blockIdx.y, d = D / H;
   const long long base = (long long)b * N * D + g * d;
   float s1 = 0.f, r = 0.f;
@@ -1100,10 +1103,14 @@ __global__ __launch_bounds__(256) void bn_bwd_small_kernel(const T* __restrict__
     // bf16, 16-byte loads: a thread owns 8 consecutive features of the rows i = rl, rl + RL, ... with 4 rows (12 loads,
     // 192 bytes) in flight - the rate of this kernel is bytes in flight per CU over the memory latency
     const int nv = d >> 3;
-    int TV = 256;                       // feature octets side by side (power of two >= min(nv, 256))
+    int TV = NT;                        // feature octets side by side (power of two >= min(nv, NT))
     while (TV / 2 >= nv) TV /= 2;
-    const int RL = 256 / TV;
-    const int tc = threadIdx.x % TV, rl = threadIdx.x / TV;
+    const int RL = NT / TV;
+    const int tc = threadIdx.x % TV, rl = threadIdx.x / TV, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the row lanes of a feature octet meet in two steps: inside a wave by shuffles (TV < 64: lanes tc, tc + TV, ...), then one
+    // value per wave (or per row lane when an octet row spans whole waves) through LDS, summed by 8 TV threads in parallel
+    const bool leader = TV >= 64 || lane < TV;
+    const int slot = TV >= 64 ? rl : wave, nslot = TV >= 64 ? RL : NT / 64;
     for (int v0 = 0; v0 < nv; v0 += TV) {
       const int vq = v0 + tc;
       float cdo[8], cv[8];
@@ -1117,7 +1124,7 @@ __global__ __launch_bounds__(256) void bn_bwd_small_kernel(const T* __restrict__
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const int i = i0 + k * RL;
-            const long long off = cb + (long long)(i < N ? i : rl) * D;
+            const long long off = cb + (long long)(i < N ? i : i0) * D;
             a[k].u = *reinterpret_cast<const uint4*>((const bf16_t*)dO + off);
             vv[k].u = *reinterpret_cast<const uint4*>((const bf16_t*)v + off);
             o[k].u = *reinterpret_cast<const uint4*>((const bf16_t*)O + off);
@@ -1135,17 +1142,22 @@ __global__ __launch_bounds__(256) void bn_bwd_small_kernel(const T* __restrict__
         }
       }
       // column sums over the row lanes, then sum_t cdo[t] * cv[t]
-      for (int e0 = 0; e0 < 8; e0 += 4) {
+      for (int m = TV; m < 64; m <<= 1) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { sdo[e * 256 + threadIdx.x] = cdo[e0 + e]; sv[e * 256 + threadIdx.x] = cv[e0 + e]; }
+        for (int e = 0; e < 8; ++e) { cdo[e] += __shfl_xor(cdo[e], m, 64); cv[e] += __shfl_xor(cv[e], m, 64); }
+      }
+#pragma unroll
+      for (int e0 = 0; e0 < 8; e0 += 4) {              // (two halves: 4 NT floats per array)
+        if (leader) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { sdo[(slot * 4 + e) * TV + tc] = cdo[e0 + e]; sv[(slot * 4 + e) * TV + tc] = cv[e0 + e]; }
+        }
         __syncthreads();
-        if (rl == 0 && vq < nv) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float a2 = 0.f, c2 = 0.f;
-            for (int q = 0; q < RL; ++q) { a2 += sdo[e * 256 + q * TV + tc]; c2 += sv[e * 256 + q * TV + tc]; }
-            s1 = fmaf(a2, c2, s1);
-          }
+        for (int idx = threadIdx.x; idx < 4 * TV; idx += NT) {
+          const int e = idx / TV, t = idx - e * TV;
+          float a2 = 0.f, c2 = 0.f;
+          for (int q = 0; q < nslot; ++q) { a2 += sdo[(q * 4 + e) * TV + t]; c2 += sv[(q * 4 + e) * TV + t]; }
+          s1 = fmaf(a2, c2, s1);
         }
         __syncthreads();
       }
@@ -1249,8 +1261,12 @@ __global__ void bn_bwd_small_finalize_kernel(const float* partials, int nb, cons
 int vu_k_bn_bwd_small(int dtype, const void* dO, const void* O, const void* v, const float* gamma, const float* beta,
                       const float* W, const float* c, float* stats, float* dgamma, float* dbeta, float* partials, int B, int N, int D, int H,
                       int training, hipStream_t st) {
-  if (dtype == 0) hipLaunchKernelGGL((bn_bwd_small_kernel<float>), dim3(B, H), dim3(256), 0, st, (const float*)dO, (const float*)O, (const float*)v, partials, N, D, H);
-  else hipLaunchKernelGGL((bn_bwd_small_kernel<bf16_t>), dim3(B, H), dim3(256), 0, st, (const bf16_t*)dO, (const bf16_t*)O, (const bf16_t*)v, partials, N, D, H);
+  static const int wide_force = [] { const char* e = getenv("VU_BN_BWD_WIDE"); return e ? atoi(e) : -1; }();      // A/B switch: 0 / 1
+  const int dh = D / H;
+  const bool wide = dtype == 1 && dh % 8 == 0 && dh <= 2048 && wide_force > 0;      // (1024 threads: one batch of row loads per thread; measured level at 16 images - 17.9 against 17.5 us - and slower at 64)
+  if (dtype == 0) hipLaunchKernelGGL((bn_bwd_small_kernel<float, 256>), dim3(B, H), dim3(256), 0, st, (const float*)dO, (const float*)O, (const float*)v, partials, N, D, H);
+  else if (wide) hipLaunchKernelGGL((bn_bwd_small_kernel<bf16_t, 1024>), dim3(B, H), dim3(1024), 0, st, (const bf16_t*)dO, (const bf16_t*)O, (const bf16_t*)v, partials, N, D, H);
+  else hipLaunchKernelGGL((bn_bwd_small_kernel<bf16_t, 256>), dim3(B, H), dim3(256), 0, st, (const bf16_t*)dO, (const bf16_t*)O, (const bf16_t*)v, partials, N, D, H);
   hipLaunchKernelGGL(bn_bwd_small_finalize_kernel, dim3(1), dim3(32 * H), 0, st, partials, B, gamma, beta, W, c, stats, dgamma, dbeta, H,
                      (double)B * N * N, training);
   if (vu_prof_on()) vu_prof_note("bn_bwd_small(2 kernels)", 0.0, 3.0 * B * N * D * (dtype == 0 ? 4.0 : 2.0));
