@@ -2884,42 +2884,88 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 // dk x over ALL pixels, picks up coherently when its input has a non-zero mean (un-normalised skip outputs; measured on
 // the 512 x 512 configuration's level-1 decoder block: weight-gradient error 0.6 -> 2e-3 of its range).  One workgroup per
 // (sample, 64-feature slab): column sums in registers -> LDS -> subtract on a second pass (L2-resident).
-__global__ __launch_bounds__(256) void flash_center_dk_kernel(bf16_t* __restrict__ dk, int N, int D) {
-  __shared__ float red[32][65];
+// (round 5: 1024 threads = 128 row lanes, the 6 - 7 rows of a thread all in flight, the lanes' sums met by a two-level LDS sum: the
+// 256-thread form walked 25 dependent row loads per thread - 18 us at 16 AND at 64 images)
+template <int NT>
+__global__ __launch_bounds__(NT) void flash_center_dk_kernel(bf16_t* __restrict__ dk, int N, int D) {
+  constexpr int RLN = NT / 8, MAXR = 8;
+  __shared__ float red[RLN][65];
+  __shared__ float red2[8][65];
   const int b = blockIdx.x, slab = blockIdx.y, v = threadIdx.x & 7, rl = threadIdx.x >> 3;
   const int f0 = slab * 64 + v * 8;
-  if (f0 >= D) { /* (D is a multiple of 8; slabs past D do not exist) */ }
   bf16_t* base = dk + (long long)b * N * D + f0;
   float a[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) a[i] = 0.f;
-  const bool live = f0 < D;
-  if (live)
-    for (int r = rl; r < N; r += 32) {
-      const bf16x8 x = *reinterpret_cast<const bf16x8*>(base + (long long)r * D);
+  const bool live = f0 < D;                       // (D is a multiple of 8; slabs past D do not exist)
+  const bool held = N <= MAXR * RLN;              // every row of the thread stays in registers between the two passes
+  bf16x8 x[MAXR];
+  if (live) {
+    if (held) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) a[i] += (float)x[i];
+      for (int k = 0; k < MAXR; ++k) {
+        const int r = rl + k * RLN;
+        x[k] = *reinterpret_cast<const bf16x8*>(base + (long long)(r < N ? r : rl) * D);
+      }
+#pragma unroll
+      for (int k = 0; k < MAXR; ++k)
+        if (rl + k * RLN < N) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) a[i] += (float)x[k][i];
+        }
+    } else {
+      for (int r = rl; r < N; r += RLN) {
+        const bf16x8 y = *reinterpret_cast<const bf16x8*>(base + (long long)r * D);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] += (float)y[i];
+      }
     }
+  }
 #pragma unroll
   for (int i = 0; i < 8; ++i) red[rl][v * 8 + i] = a[i];
+  __syncthreads();
+  if (threadIdx.x < 512 && threadIdx.x < 8 * 64) {      // 8 groups of 64 columns: group g sums the row lanes g, g + 8, ...
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    if (g < 8 && (NT >= 512 || g < NT / 64)) {
+      float t = 0.f;
+      for (int r = g; r < RLN; r += (NT >= 512 ? 8 : NT / 64)) t += red[r][c];
+      red2[g][c] = t;
+    }
+  }
   __syncthreads();
   if (threadIdx.x < 64) {
     float t = 0.f;
 #pragma unroll
-    for (int r = 0; r < 32; ++r) t += red[r][threadIdx.x];
+    for (int g = 0; g < (NT >= 512 ? 8 : NT / 64); ++g) t += red2[g][threadIdx.x];
     red[0][threadIdx.x] = t / (float)N;
   }
   __syncthreads();
-  if (live)
-    for (int r = rl; r < N; r += 32) {
-      bf16x8 x = *reinterpret_cast<const bf16x8*>(base + (long long)r * D);
+  if (live) {
+    if (held) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) x[i] = (bf16_t)((float)x[i] - red[0][v * 8 + i]);
-      *reinterpret_cast<bf16x8*>(base + (long long)r * D) = x;
+      for (int k = 0; k < MAXR; ++k) {
+        const int r = rl + k * RLN;
+        if (r < N) {
+          bf16x8 y = x[k];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) y[i] = (bf16_t)((float)y[i] - red[0][v * 8 + i]);
+          *reinterpret_cast<bf16x8*>(base + (long long)r * D) = y;
+        }
+      }
+    } else {
+      for (int r = rl; r < N; r += RLN) {
+        bf16x8 y = *reinterpret_cast<const bf16x8*>(base + (long long)r * D);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) y[i] = (bf16_t)((float)y[i] - red[0][v * 8 + i]);
+        *reinterpret_cast<bf16x8*>(base + (long long)r * D) = y;
+      }
     }
+  }
 }
 int launch_center_dk(const vu_flash_args& a, hipStream_t st) {
-  hipLaunchKernelGGL(flash_center_dk_kernel, dim3(a.B, (a.D + 63) / 64), dim3(256), 0, st, (bf16_t*)a.dk, a.N, a.D);
+  static const bool narrow = [] { const char* e = getenv("VU_CENTER_DK_WIDE"); return e && e[0] == '0'; }();      // A/B switch
+  if (narrow) hipLaunchKernelGGL(flash_center_dk_kernel<256>, dim3(a.B, (a.D + 63) / 64), dim3(256), 0, st, (bf16_t*)a.dk, a.N, a.D);
+  else hipLaunchKernelGGL(flash_center_dk_kernel<1024>, dim3(a.B, (a.D + 63) / 64), dim3(1024), 0, st, (bf16_t*)a.dk, a.N, a.D);
   if (vu_prof_on()) vu_prof_note("flash_center_dk_kernel", 0.0, 4.0 * (double)a.B * a.N * a.D * 2.0);
   return vu_check_launch("flash_center_dk");
 }
