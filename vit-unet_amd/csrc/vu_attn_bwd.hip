@@ -134,8 +134,17 @@ __global__ __launch_bounds__(1024) void map_bwd_partials_reduce_kernel(const flo
                                                                        float* dW, float* dc) {
   const int i = blockIdx.x * 16 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (i >= n) return;          // wave-uniform
-  float a = 0.f;
-  for (int b = lane; b < nblocks; b += 64) a += part[(long long)b * n + i];
+  float s[4] = {0.f, 0.f, 0.f, 0.f};      // four independent chains over loads issued together (fixed order all the same)
+  int b = lane;
+  for (; b + 3 * 64 < nblocks; b += 4 * 64) {
+    float x[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) x[u] = part[(long long)(b + 64 * u) * n + i];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s[u] += x[u];
+  }
+  for (; b < nblocks; b += 64) s[0] += part[(long long)b * n + i];
+  float a = (s[0] + s[1]) + (s[2] + s[3]);
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m, 64);
   if (lane == 0) { if (i < hh) dW[i] += a; else dc[i - hh] += a; }

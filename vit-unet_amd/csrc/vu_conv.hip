@@ -495,8 +495,17 @@ __global__ __launch_bounds__(1024) void conv_wgrad_mm_reduce_kernel(const float*
   const int which = i >> 9, tt = (i >> 8) & 1, e = i & 255;
   const int n = e >> 4, t = tt * 16 + (e & 15);
   if (i >= 1024 || t >= NW || n >= (which == 0 ? 3 : 6)) return;          // wave-uniform
-  float a = 0.f;
-  for (int b = lane; b < nblocks; b += 64) a += part[(long long)b * 1024 + i];
+  float s[4] = {0.f, 0.f, 0.f, 0.f};      // four independent chains over loads issued together (256 blocks: one trip)
+  int b = lane;
+  for (; b + 3 * 64 < nblocks; b += 4 * 64) {
+    float x[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) x[u] = part[(long long)(b + 64 * u) * 1024 + i];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s[u] += x[u];
+  }
+  for (; b < nblocks; b += 64) s[0] += part[(long long)b * 1024 + i];
+  float a = (s[0] + s[1]) + (s[2] + s[3]);
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m, 64);
   if (lane == 0) {
