@@ -165,10 +165,13 @@ __global__ __launch_bounds__(64 * WM * WN) void vu_tsgemm_kernel(const bf16_t* _
   }
 }
 
-// C[m][n] += sum over the K slices of slab[s][m][n], and the same for the column sums, in a fixed order (deterministic):
-// a workgroup takes 16 float4 items x 16 slice lanes (lane sl adds slices sl, sl + 16, ...), then one thread per item adds
-// the 16 lane sums in order.  `tile`: floats between two slices' tiles (padded so that the slices do not all start on the
-// same memory channels).
+// C[m][n] += sum over the K slices of slab[s][m][n], and the same for the column sums, in a fixed order (deterministic): one
+// float4 item per thread, the slices added in order (interleaved chains, then a fixed tree).  `tile`: floats between two
+// slices' tiles (padded so that the slices do not all start on the same memory channels).
+#define VU_TS_RED_ITEMS 256      /* float4 items per reduce workgroup: one per thread */
+#ifndef VU_TS_RED_CHAINS
+#define VU_TS_RED_CHAINS 8
+#endif
 struct RedDesc {
   const float* slab; const float* slab_cs; float* C; float* colsum;
   int M, N, Mp, Np, ldc, nsplit, nitems, blk0;       // blk0: first workgroup of this reduction inside a batched launch
@@ -177,44 +180,48 @@ struct RedDesc {
 __device__ __forceinline__ void tsgemm_reduce_body(const float* __restrict__ slab, const float* __restrict__ slab_cs, float* __restrict__ C,
                                                    float* __restrict__ colsum, int M, int N, int Mp, int Np, int ldc, int nsplit, long long tile,
                                                    int nitems, int blk) {
-  __shared__ float4 part[16][16];
-  const int it = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  const int id = blk * 16 + it;
+  // (round 5: one float4 item per thread, the slices of an item added in order by four independent chains over loads issued
+  // together - 256 consecutive items of a slice are one 4 KB run.  The 16 items x 16 slice lanes form with its LDS exchange ran
+  // at 1.3 TB/s: 87 us for the one batched launch of a Base backward at 16 images.)
+  const int id = blk * VU_TS_RED_ITEMS + threadIdx.x;
   const int nq = N >> 2;                                    // N % 8 == 0 (checked by the launcher)
-  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
   const bool is_c = id < nitems;
   const int ncs = (M + 3) >> 2;                             // column-sum items (float4 of 4 rows' sums; Mp % 4 == 0)
   const bool is_cs = !is_c && colsum && id - nitems < ncs;
-  int m = 0, n = 0;
-  if (is_c) {
-    m = id / nq; n = (id - m * nq) * 4;
-    const float* p = slab + (long long)m * Np + n;
-    for (int s_ = sl; s_ < nsplit; s_ += 16) {
-      const float4 x = *reinterpret_cast<const float4*>(p + (long long)s_ * tile);
-      a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
-    }
-  } else if (is_cs) {
-    m = (id - nitems) * 4;
-    for (int s_ = sl; s_ < nsplit; s_ += 16) {
-      const float4 x = *reinterpret_cast<const float4*>(slab_cs + (long long)s_ * Mp + m);
-      a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
-    }
-  }
-  part[sl][it] = a;
-  __syncthreads();
-  if (sl == 0 && (is_c || is_cs)) {
-    float4 t = part[0][it];
+  if (!is_c && !is_cs) return;
+  int m, n = 0;
+  const float* p;
+  long long stride;
+  if (is_c) { m = id / nq; n = (id - m * nq) * 4; p = slab + (long long)m * Np + n; stride = tile; }
+  else { m = (id - nitems) * 4; p = slab_cs + m; stride = Mp; }
+  typedef __attribute__((ext_vector_type(4))) float f4v;
+  constexpr int CH = VU_TS_RED_CHAINS;
+  f4v acc[CH];
 #pragma unroll
-    for (int k = 1; k < 16; ++k) { const float4 x = part[k][it]; t.x += x.x; t.y += x.y; t.z += x.z; t.w += x.w; }
-    if (is_c) {
-      float4* cp = reinterpret_cast<float4*>(C + (long long)m * ldc + n);
-      float4 c4 = *cp;
-      c4.x += t.x; c4.y += t.y; c4.z += t.z; c4.w += t.w;
-      *cp = c4;
-    } else {
-      const float tv[4] = {t.x, t.y, t.z, t.w};
-      for (int r = 0; r < 4; ++r) if (m + r < M) colsum[m + r] += tv[r];
-    }
+  for (int u = 0; u < CH; ++u) acc[u] = f4v{0.f, 0.f, 0.f, 0.f};
+  int s_ = 0;
+  for (; s_ + CH - 1 < nsplit; s_ += CH) {
+    f4v x[CH];
+#pragma unroll
+    for (int u = 0; u < CH; ++u) x[u] = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p + (long long)(s_ + u) * stride));      // (read once)
+#pragma unroll
+    for (int u = 0; u < CH; ++u) acc[u] += x[u];
+  }
+  for (; s_ < nsplit; ++s_) acc[0] += __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p + (long long)s_ * stride));
+#pragma unroll
+  for (int w = CH / 2; w >= 1; w >>= 1)
+#pragma unroll
+    for (int u = 0; u < w; ++u) acc[u] += acc[u + w];
+  float4 t;
+  t.x = acc[0][0]; t.y = acc[0][1]; t.z = acc[0][2]; t.w = acc[0][3];
+  if (is_c) {
+    float4* cp = reinterpret_cast<float4*>(C + (long long)m * ldc + n);
+    float4 c4 = *cp;
+    c4.x += t.x; c4.y += t.y; c4.z += t.z; c4.w += t.w;
+    *cp = c4;
+  } else {
+    const float tv[4] = {t.x, t.y, t.z, t.w};
+    for (int r = 0; r < 4; ++r) if (m + r < M) colsum[m + r] += tv[r];
   }
 }
 
@@ -312,13 +319,13 @@ int launch_ts(const vu_gemm_args& g, hipStream_t st) {
     RedDesc& d = ar.batch.d[ar.batch.n++];
     d.slab = sl; d.slab_cs = slcs; d.C = (float*)g.C; d.colsum = g.colsum; d.M = g.M; d.N = g.N; d.Mp = mt * MT; d.Np = nt * NT;
     d.ldc = (int)g.ldc; d.nsplit = nsplit; d.nitems = nitems; d.blk0 = ar.blocks; d.tile = slab_tile;
-    ar.blocks += (int)((items + 15) / 16);
+    ar.blocks += (int)((items + VU_TS_RED_ITEMS - 1) / VU_TS_RED_ITEMS);
     return VU_OK;
   }
   if (slab) {
     const int nitems = g.M * (g.N / 4);
     const long long items = (long long)nitems + (g.colsum ? (g.M + 3) / 4 : 0);
-    hipLaunchKernelGGL(tsgemm_reduce_kernel, dim3((unsigned)((items + 15) / 16)), dim3(256), 0, st, sl, slcs, (float*)g.C, g.colsum, g.M,
+    hipLaunchKernelGGL(tsgemm_reduce_kernel, dim3((unsigned)((items + VU_TS_RED_ITEMS - 1) / VU_TS_RED_ITEMS)), dim3(256), 0, st, sl, slcs, (float*)g.C, g.colsum, g.M,
                        g.N, mt * MT, nt * NT, (int)g.ldc, nsplit, slab_tile, nitems);
     if (vu_prof_on()) vu_prof_note("tsgemm_reduce_kernel", 0.0, (double)nsplit * out_bytes + 2.0 * out_bytes);
     return vu_check_launch("vu_tsgemm_reduce");
