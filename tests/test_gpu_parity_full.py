@@ -493,15 +493,15 @@ def test_feedforward_linear_drop_vs_oracle(dt):
         assert serr(q.grad, p["net." + k].grad) < bt, k
 
 
-@pytest.mark.parametrize("B,N", [(8, 196), (3, 347), (64, 196)])
-def test_feedforward_fused_level2_vs_oracle(B, N):
+@pytest.mark.parametrize("B,N,D,hid", [(8, 196, 192, 32), (3, 347, 192, 32), (64, 196, 192, 32), (4, 3136, 48, 16), (3, 347, 48, 16)])
+def test_feedforward_fused_level2_vs_oracle(B, N, D, hid):
     """The level-2 shape (D = 192, hidden = 32, bf16, no linear dropout) takes the ONE-kernel-per-direction route of
     csrc/vu_ff2.hip (the launch profiler names it); forward and every gradient against the oracle's bf16-storage replay, on row
     counts that are and are not a multiple of the 16-token tile (3 * 347 = 1041).  (The residual form is the block's: the
     teacher-forced block tests and the whole-model parity tests run it.)"""
     import ctypes as C
     from vit_unet.torch._lib import lib
-    D, hid, dt = 192, 32, torch.bfloat16
+    dt = torch.bfloat16                                # (48, 16: Lite's 3136-token level, the generic form of the same kernel)
     gen = torch.Generator().manual_seed(21)
     ff = M.FeedForward(D, hid, 0.0).to(DEV).train()
     x = torch.randn(B, N, D, generator=gen)

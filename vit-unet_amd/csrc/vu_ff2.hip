@@ -167,6 +167,112 @@ __global__ __launch_bounds__(256) void ff2_kernel(const ff2_args a) {
   }
 }
 
+// The same kernel for other small (D, hidden) pairs (Lite's level of 3136 tokens: D = 48, hidden = 16), written for any D % 16 == 0,
+// HID in {16, 32}: the k-steps past D and the k-slots past HID are zero in BOTH operands; the fragment build is a plain loop (the
+// weights are 1.5 KB each).  One workgroup = 4 waves = 64 token rows, as above.
+template <int DG, int HG, bool BWD>
+__global__ __launch_bounds__(256) void ffg_kernel(const ff2_args a) {
+  constexpr int NT1 = HG / 16, K1 = (DG + 31) / 32, NF1g = NT1 * K1, NT2 = DG / 16, NF2g = NT2;
+  __shared__ __attribute__((aligned(16))) bf16_t frag[(NF1g + NF2g) * 64 * 8];
+  __shared__ __attribute__((aligned(16))) bf16_t plain[BWD ? 2 * DG * HG : 8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
+  const bf16x8 zero8 = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+  const long long ntile = (a.rows + 15) >> 4;
+  long long t = (long long)blockIdx.x * 4 + wave;
+  bf16x8 xf[K1];
+  {
+    long long row = (t < ntile ? t : ntile - 1) * 16 + l15;
+    if (row >= a.rows) row = a.rows - 1;
+    const bf16_t* xr = a.x + row * DG + 8 * g4;
+#pragma unroll
+    for (int kk = 0; kk < K1; ++kk) xf[kk] = (32 * kk + 8 * g4 < DG) ? *reinterpret_cast<const bf16x8*>(xr + 32 * kk) : zero8;
+  }
+  if constexpr (BWD) {
+    for (int v = tid; v < 2 * DG * HG / 8; v += 256) {
+      const bf16_t* src = v < DG * HG / 8 ? a.w1 + v * 8 : a.w2 + (v - DG * HG / 8) * 8;
+      *reinterpret_cast<uint4*>(plain + v * 8) = *reinterpret_cast<const uint4*>(src);
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < (NF1g + NF2g) * 64; e += 256) {
+    const int f = e >> 6, ln = e & 63, r = ln & 15, q = ln >> 4;
+    bf16x8 o = zero8;
+    if (f < NF1g) {              // first product's A operand: row = hidden 16 t1 + r, k = feature 32 kk + 8 q + j
+      const int t1 = f / K1, kk = f % K1, k0 = 32 * kk + 8 * q;
+      if (k0 < DG) {
+        if constexpr (!BWD) o = *reinterpret_cast<const bf16x8*>(a.w1 + (16 * t1 + r) * DG + k0);
+        else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] = plain[DG * HG + (k0 + j) * HG + 16 * t1 + r];        // W2[k0 + j][16 t1 + r]
+        }
+      }
+    } else {                     // second product's A operand: row = feature 16 t2 + r, k-slot j = hidden perm_hid(q, j)
+      const int t2 = f - NF1g;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int hu = perm_hid(q, j);
+        if (hu < HG) o[j] = BWD ? plain[hu * DG + 16 * t2 + r] : a.w2[(16 * t2 + r) * HG + hu];      // bwd: W1[hu][16 t2 + r]; fwd: W2[16 t2 + r][hu]
+      }
+    }
+    *reinterpret_cast<bf16x8*>(frag + e * 8) = o;
+  }
+  __syncthreads();
+  for (bool first = true; t < ntile; t += (long long)gridDim.x * 4, first = false) {
+    long long row = t * 16 + l15;
+    const bool rok = row < a.rows;
+    if (!rok) row = a.rows - 1;
+    if (!first) {
+      const bf16_t* xr = a.x + row * DG + 8 * g4;
+#pragma unroll
+      for (int kk = 0; kk < K1; ++kk) xf[kk] = (32 * kk + 8 * g4 < DG) ? *reinterpret_cast<const bf16x8*>(xr + 32 * kk) : zero8;
+    }
+    f32x4 h[NT1];
+#pragma unroll
+    for (int t1 = 0; t1 < NT1; ++t1) h[t1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < K1; ++kk)
+#pragma unroll
+      for (int t1 = 0; t1 < NT1; ++t1) h[t1] = mf(*reinterpret_cast<const bf16x8*>(frag + ((t1 * K1 + kk) * 64 + lane) * 8), xf[kk], h[t1]);
+    unsigned hp[2][2] = {{0u, 0u}, {0u, 0u}};
+#pragma unroll
+    for (int t1 = 0; t1 < NT1; ++t1) {
+      const long long ho = row * HG + 16 * t1 + 4 * g4;
+      if constexpr (!BWD) {
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(a.b1 + 16 * t1 + 4 * g4);
+        f32x4 v = h[t1] + bb;
+        const u32x2_t pre = {pk2f(v[0], v[1]), pk2f(v[2], v[3])};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = vu_gelu(v[r]);
+        hp[t1][0] = pk2f(v[0], v[1]); hp[t1][1] = pk2f(v[2], v[3]);
+        if (rok) {
+          *reinterpret_cast<u32x2_t*>(a.hpre + ho) = pre;
+          *reinterpret_cast<u32x2_t*>(a.hact + ho) = u32x2_t{hp[t1][0], hp[t1][1]};
+        }
+      } else {
+        const u32x2_t pre = *reinterpret_cast<const u32x2_t*>(a.hpre + ho);
+        f32x4 v = h[t1];
+        v[0] *= vu_gelu_grad(lo16(pre[0])); v[1] *= vu_gelu_grad(hi16(pre[0]));
+        v[2] *= vu_gelu_grad(lo16(pre[1])); v[3] *= vu_gelu_grad(hi16(pre[1]));
+        hp[t1][0] = pk2f(v[0], v[1]); hp[t1][1] = pk2f(v[2], v[3]);
+        if (rok) *reinterpret_cast<u32x2_t*>(a.hact + ho) = u32x2_t{hp[t1][0], hp[t1][1]};      // dh
+      }
+    }
+    const u32x4_t bw = {hp[0][0], hp[0][1], hp[1][0], hp[1][1]};      // (k-slots 4..7 stay zero when there is one hidden tile)
+    const bf16x8 bop = __builtin_bit_cast(bf16x8, bw);
+#pragma unroll
+    for (int t2 = 0; t2 < NT2; ++t2) {
+      f32x4 o = mf(*reinterpret_cast<const bf16x8*>(frag + ((NF1g + t2) * 64 + lane) * 8), bop, f32x4{0.f, 0.f, 0.f, 0.f});
+      const long long oo = row * DG + 16 * t2 + 4 * g4;
+      if constexpr (!BWD) o += *reinterpret_cast<const f32x4*>(a.b2 + 16 * t2 + 4 * g4);
+      if (a.addend) {
+        const u32x2_t ad = *reinterpret_cast<const u32x2_t*>(a.addend + oo);
+        o[0] += lo16(ad[0]); o[1] += hi16(ad[0]); o[2] += lo16(ad[1]); o[3] += hi16(ad[1]);
+      }
+      if (rok) *reinterpret_cast<u32x2_t*>(a.y + oo) = u32x2_t{pk2f(o[0], o[1]), pk2f(o[2], o[3])};
+    }
+  }
+}
+
 bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 }  // namespace
@@ -175,27 +281,31 @@ bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 int vu_ff2_forward_try(int dtype, const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* hpre, void* hact,
                        void* y, const void* resid, long long rows, int Din, int hid, hipStream_t st) {
   static const bool off = [] { const char* e = getenv("VU_FF2"); return e && e[0] == '0'; }();      // A/B switch, read once
-  if (off || dtype != 1 || Din != D || hid != HID || rows < 1024) return 0;
+  const bool small48 = Din == 48 && hid == 16;          // Lite's 3136-token level
+  if (off || dtype != 1 || !((Din == D && hid == HID) || small48) || rows < 1024) return 0;
   if (!aligned16(x) || !aligned16(w1) || !aligned16(w2) || !aligned16(b1) || !aligned16(b2) || !aligned16(hpre) || !aligned16(hact) || !aligned16(y) ||
       (resid && !aligned16(resid))) return 0;
   ff2_args a{(const bf16_t*)x, (const bf16_t*)w1, (const bf16_t*)w2, b1, b2, (const bf16_t*)resid, (bf16_t*)hpre, (bf16_t*)hact, (bf16_t*)y, rows};
   const long long groups = (rows + 63) / 64;
   const int grid = (int)(groups < 2048 ? groups : 2048);
-  hipLaunchKernelGGL(ff2_kernel<false>, dim3(grid), dim3(256), 0, st, a);
-  if (vu_prof_on()) vu_prof_note("vu_ff2_fwd_kernel", 4.0 * rows * (double)D * HID, 2.0 * rows * (D * (resid ? 3.0 : 2.0) + 2.0 * HID));
+  if (small48) hipLaunchKernelGGL((ffg_kernel<48, 16, false>), dim3(grid), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(ff2_kernel<false>, dim3(grid), dim3(256), 0, st, a);
+  if (vu_prof_on()) vu_prof_note("vu_ff2_fwd_kernel", 4.0 * rows * (double)Din * hid, 2.0 * rows * (Din * (resid ? 3.0 : 2.0) + 2.0 * hid));
   const int rc = vu_check_launch("vu_ff2_forward");
   return rc ? rc : 1;
 }
 int vu_ff2_backward_try(int dtype, const void* dy, const void* w1, const void* w2, const void* hpre, void* gh, void* dx, const void* addend,
                         long long rows, int Din, int hid, hipStream_t st) {
   static const bool off = [] { const char* e = getenv("VU_FF2"); return e && e[0] == '0'; }();
-  if (off || dtype != 1 || Din != D || hid != HID || rows < 1024) return 0;
+  const bool small48 = Din == 48 && hid == 16;
+  if (off || dtype != 1 || !((Din == D && hid == HID) || small48) || rows < 1024) return 0;
   if (!aligned16(dy) || !aligned16(w1) || !aligned16(w2) || !aligned16(hpre) || !aligned16(gh) || !aligned16(dx) || (addend && !aligned16(addend))) return 0;
   ff2_args a{(const bf16_t*)dy, (const bf16_t*)w1, (const bf16_t*)w2, nullptr, nullptr, (const bf16_t*)addend, (bf16_t*)const_cast<void*>(hpre), (bf16_t*)gh, (bf16_t*)dx, rows};
   const long long groups = (rows + 63) / 64;
   const int grid = (int)(groups < 2048 ? groups : 2048);
-  hipLaunchKernelGGL(ff2_kernel<true>, dim3(grid), dim3(256), 0, st, a);
-  if (vu_prof_on()) vu_prof_note("vu_ff2_bwd_kernel", 4.0 * rows * (double)D * HID, 2.0 * rows * (D * (addend ? 3.0 : 2.0) + 2.0 * HID));
+  if (small48) hipLaunchKernelGGL((ffg_kernel<48, 16, true>), dim3(grid), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(ff2_kernel<true>, dim3(grid), dim3(256), 0, st, a);
+  if (vu_prof_on()) vu_prof_note("vu_ff2_bwd_kernel", 4.0 * rows * (double)Din * hid, 2.0 * rows * (Din * (addend ? 3.0 : 2.0) + 2.0 * hid));
   const int rc = vu_check_launch("vu_ff2_backward");
   return rc ? rc : 1;
 }
