@@ -63,7 +63,7 @@ def test_ops_are_bit_reproducible_while_another_process_uses_the_gpu():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "contention_ops.py"), "--load", "45", "--iters", "120"],
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "contention_ops.py"), "--load", "35", "--iters", "90"],
                        capture_output=True, text=True, timeout=420, env=env)
     assert "CONTENTION_OPS CLEAN" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
     assert r.returncode == 0
@@ -79,7 +79,7 @@ def test_four_head_recompute_attention_under_gpu_sharing():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CONTENTION_ATTN_ONLY="1")
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "contention_ops.py"), "--load", "60", "--iters", "30", "--B", "16", "--attn", "all"],
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "contention_ops.py"), "--load", "45", "--iters", "20", "--B", "16", "--attn", "all"],
                        capture_output=True, text=True, timeout=420, env=env)
     assert "CONTENTION_OPS CLEAN" in r.stdout, r.stdout[-2000:]
 
