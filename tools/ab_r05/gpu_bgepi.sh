@@ -1,0 +1,4 @@
+cd $GRAFT_REPO_ROOT
+timeout -k 10 400 python -m pytest tests/test_gpu_ops.py tests/test_gpu_parity_full.py -x -q -m gpu -k "gemm or big_tile" 2>&1 | tail -2
+for b in 64 16; do VU_PROF_SHAPES=1 timeout -k 10 200 python tools/step_tags.py --batch $b --grep "bgemm" 2>&1 | grep bgemm | cut -c1-170; done
+for b in 64 16; do timeout -k 10 300 python bench.py --batch $b --steps 40 --no-cpu-baseline --no-host-input --no-roofline > gpurun_out/f.log 2>&1 && tail -1 gpurun_out/f.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('BENCH B=$b', round(d['value'],1), round(d['ms_per_step'],4))"; done
