@@ -43,8 +43,13 @@ template <bool BWD>
 __global__ __launch_bounds__(256) void ff2_kernel(const ff2_args a) {
   // fragment images [frag][lane] of 16 bytes; backward: the plain weights first (the transposed fragments are gathered from LDS)
   __shared__ __attribute__((aligned(16))) bf16_t frag[(NF1 + NF2) * 64 * 8];
-  __shared__ __attribute__((aligned(16))) bf16_t plain[BWD ? 2 * D * HID : 8];
+  // 25 600 bytes: the backward's plain weights during the fragment build (24 576), then - both directions - one fp32 tile of
+  // 16 token rows x 96 features (+ 4 pad) per wave, through which the outputs leave as 16-byte row-contiguous stores
+  constexpr int LDC = 100;
+  __shared__ __attribute__((aligned(16))) float pool[4 * 16 * LDC];
+  bf16_t* plain = reinterpret_cast<bf16_t*>(pool);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
+  float* ct = pool + wave * 16 * LDC;
   // the first tile's token rows are requested before the weights: they fly under the whole fragment build
   const long long ntile = (a.rows + 15) >> 4;
   long long t = (long long)blockIdx.x * 4 + wave;
@@ -152,17 +157,44 @@ __global__ __launch_bounds__(256) void ff2_kernel(const ff2_args a) {
     }
     const u32x4_t bw = {hp[0][0], hp[0][1], hp[1][0], hp[1][1]};      // k-slots j = 0..3: tile 0, 4..7: tile 1 (perm_hid)
     const bf16x8 bop = __builtin_bit_cast(bf16x8, bw);
-    // ---- second product: 12 tiles of output features x 16 tokens, K = 32 ----
+    // ---- second product: 12 tiles of output features x 16 tokens, K = 32; the outputs leave in two halves of 96 features through
+    // the wave's fp32 tile (wave-private: the LDS operations of a wave are ordered, no barrier): lane = (row, 16-byte chunk) items,
+    // so the residual / addend is read and y written as whole 192-byte row halves (the accumulator layout - a lane owns 4 features
+    // of ONE token - made them 8-byte pieces of 16 different rows per instruction: 27 us per launch at 64 images for 64 MB)
+    const long long row0 = t * 16;
+    uint4 adv[2][3];
+    if (a.addend) {
 #pragma unroll
-    for (int t2 = 0; t2 < 12; ++t2) {
-      f32x4 o = mf(*reinterpret_cast<const bf16x8*>(frag + ((NF1 + t2) * 64 + lane) * 8), bop, f32x4{0.f, 0.f, 0.f, 0.f});
-      const long long oo = row * D + 16 * t2 + 4 * g4;
-      if constexpr (!BWD) o += *reinterpret_cast<const f32x4*>(a.b2 + 16 * t2 + 4 * g4);
-      if (a.addend) {
-        const u32x2_t ad = *reinterpret_cast<const u32x2_t*>(a.addend + oo);
-        o[0] += lo16(ad[0]); o[1] += hi16(ad[0]); o[2] += lo16(ad[1]); o[3] += hi16(ad[1]);
+      for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const int i = lane + 64 * k, rl = i / 12, c8 = (i - rl * 12) * 8;
+          long long rg = row0 + rl; if (rg >= a.rows) rg = a.rows - 1;
+          adv[hf][k] = *reinterpret_cast<const uint4*>(a.addend + rg * D + 96 * hf + c8);
+        }
+    }
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+      for (int u = 0; u < 6; ++u) {
+        const int t2 = 6 * hf + u;
+        f32x4 o = mf(*reinterpret_cast<const bf16x8*>(frag + ((NF1 + t2) * 64 + lane) * 8), bop, f32x4{0.f, 0.f, 0.f, 0.f});
+        if constexpr (!BWD) o += *reinterpret_cast<const f32x4*>(a.b2 + 16 * t2 + 4 * g4);
+        *reinterpret_cast<f32x4*>(ct + l15 * LDC + 16 * u + 4 * g4) = o;
       }
-      if (rok) *reinterpret_cast<u32x2_t*>(a.y + oo) = u32x2_t{pk2f(o[0], o[1]), pk2f(o[2], o[3])};
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int i = lane + 64 * k, rl = i / 12, c8 = (i - rl * 12) * 8;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(ct + rl * LDC + c8), v1 = *reinterpret_cast<const f32x4*>(ct + rl * LDC + c8 + 4);
+        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        if (a.addend) {
+          const uint4 ad = adv[hf][k];
+          v[0] += lo16(ad.x); v[1] += hi16(ad.x); v[2] += lo16(ad.y); v[3] += hi16(ad.y);
+          v[4] += lo16(ad.z); v[5] += hi16(ad.z); v[6] += lo16(ad.w); v[7] += hi16(ad.w);
+        }
+        if (row0 + rl < a.rows)
+          *reinterpret_cast<u32x4_t*>(a.y + (row0 + rl) * D + 96 * hf + c8) = u32x4_t{pk2f(v[0], v[1]), pk2f(v[2], v[3]), pk2f(v[4], v[5]), pk2f(v[6], v[7])};
+      }
     }
   }
 }
