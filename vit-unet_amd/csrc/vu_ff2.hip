@@ -6,11 +6,13 @@
 // columns = the wave's 16 tokens), so the accumulator of the first - lane (token l15, hidden units 4 g4 + r of tile 0 and 16 + 4 g4 + r
 // of tile 1) - IS the B operand of the second once packed to bf16: an MFMA contracts over its k-slots in any order as long as both
 // operands agree, so the second product's weight fragments are built with exactly that order of hidden units (no transpose, no LDS
-// round trip for the activation).  The weights (2 x 12 KB) become 24 fragment images of 1 KiB in LDS once per workgroup; a wave reads
-// a fragment (ds_read_b128, lane-contiguous) right before the MFMA that uses it, so it holds almost no registers between tiles and
-// many waves per SIMD hide the direct global loads of the 16 x 192 token rows.  hpre / hact / dh are still written (3 MB each): the
-// backward and the weight-gradient kernels read them.  As two vu_pgemm launches the pair took 32.6 us forward / 35.2 us backward per
-// block at 64 images.
+// round trip for the activation).  The weights (2 x 12 KB) become 24 fragment images of 1 KiB in LDS once per workgroup (ds_read_b128,
+// lane-contiguous).  The OUTPUT rows (y / dx, with the residual / addend) do take a trip through LDS: the accumulator layout - a lane
+// owns 4 features of one token - would store 8-byte pieces of 16 different rows per instruction, so each wave hands its 16 x 96 fp32
+// half tiles over through a private tile and lanes store 16-byte items of whole row halves (27.5 -> 21.5 us forward, 23.9 -> 18.2
+// backward per launch at 64 images).  hpre / hact / dh are still written (3 MB each): the backward and the weight-gradient kernels
+// read them.  As two vu_pgemm launches the pair took 32.6 us forward / 35.2 us backward per block at 64 images.  ffg_kernel below is
+// the same kernel for other small (D, hidden) pairs (Lite: 48, 16).
 #include <stdio.h>
 #include <stdlib.h>
 #include "vu_gemm.h"
