@@ -10,7 +10,7 @@
 // lane-contiguous).  The OUTPUT rows (y / dx, with the residual / addend) do take a trip through LDS: the accumulator layout - a lane
 // owns 4 features of one token - would store 8-byte pieces of 16 different rows per instruction, so each wave hands its 16 x 96 fp32
 // half tiles over through a private tile and lanes store 16-byte items of whole row halves (27.5 -> 21.5 us forward, 23.9 -> 18.2
-// backward per launch at 64 images).  hpre / hact / dh are still written (3 MB each): the backward and the weight-gradient kernels
+// backward per launch at 64 images).  hpre / hact / dh are still written (6.4 MB each at 64 images): the backward and the weight-gradient kernels
 // read them.  As two vu_pgemm launches the pair took 32.6 us forward / 35.2 us backward per block at 64 images.  ffg_kernel below is
 // the same kernel for other small (D, hidden) pairs (Lite: 48, 16).
 #include <stdio.h>
