@@ -65,7 +65,13 @@ long long vu_model_param_elems(const vu_config* cfg);           /* arena length 
 int vu_model_num_params(const vu_config* cfg);
 int vu_model_param_table(const vu_config* cfg, vu_param_entry* out, int capacity);
 int vu_model_num_attn(const vu_config* cfg);                    /* BatchNorm modules           */
-size_t vu_model_workspace_bytes(const vu_config* cfg, int B);
+size_t vu_model_workspace_bytes(const vu_config* cfg, int B);   /* = vu_model_workspace_bytes_ex(cfg, B, 1): fits either mode */
+/* The workspace of an eval-mode forward (training = 0; model.py:372-435 under model.eval(), functions.py:7-19) leaves out what only a
+ * training step uses: the probability caches of the recompute attention (vu_set_flash_pcache).  vu_model_forward / _backward carve by
+ * their own `training` argument, so a workspace sized for training serves both and one sized for eval is refused by a training call
+ * (VU_EWORKSPACE).  vu_model_pcache_bytes: the part of the training workspace that is probability cache (after the budget below). */
+size_t vu_model_workspace_bytes_ex(const vu_config* cfg, int B, int training);
+size_t vu_model_pcache_bytes(const vu_config* cfg, int B);
 /* Diagnostic (no reference counterpart): the carve of that workspace as text, one "name offset bytes" line per buffer, the
  * forward's buffers in execution order.  Returns the length of the full text (snprintf convention), < 0 on a bad config. */
 int vu_model_workspace_describe(const vu_config* cfg, int B, char* out, int cap);
@@ -295,6 +301,10 @@ int vu_set_flash_key_split(int ks);
  * vu_model_workspace_bytes / vu_attn_workspace_bytes, so set it before sizing a workspace, never between a forward and its backward.
  * Initial value: VU_FLASH_PCACHE (0 / 1), read once. */
 int vu_set_flash_pcache(int on);
+/* Byte budget of ONE model workspace for those caches (sum over the attention modules): modules get a cache in execution order while
+ * the sum fits, the others recompute (bit-identical).  Default 96 GiB; initial value VU_FLASH_PCACHE_BUDGET_MB, read once.  Same rule
+ * as vu_set_flash_pcache: set it before sizing a workspace, never between a forward and its backward. */
+int vu_set_flash_pcache_budget(unsigned long long bytes);
 
 /* Data-parallel gradient exchange over RCCL (csrc/vu_dp.cpp).  The reference has no collective
  * (/root/reference/run_denoising.py:79,87: one 'cuda' device); the default exchange of this build is torch.distributed (backend

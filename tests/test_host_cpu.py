@@ -113,6 +113,30 @@ def test_workspace_grows_with_batch():
     assert L.vu_model_workspace_bytes(C.byref(cfg32), 8) > w8
 
 
+def test_eval_workspace_leaves_the_probability_caches_out_and_the_budget_caps_them():
+    """Round 6: the probability caches of the recompute attention are a TRAINING buffer - an eval workspace is sized
+    without them - and one workspace never spends more than the process's budget on them (modules beyond it recompute)."""
+    L = _lib.lib()
+    cfg = _lib.make_config(dtype=torch.bfloat16, **O.PRESETS["base"])
+    tr, ev = L.vu_model_workspace_bytes_ex(C.byref(cfg), 64, 1), L.vu_model_workspace_bytes_ex(C.byref(cfg), 64, 0)
+    pc = L.vu_model_pcache_bytes(C.byref(cfg), 64)
+    assert tr == L.vu_model_workspace_bytes(C.byref(cfg), 64)
+    per_module = 64 * 49 * 49 * 4096                  # B (N / 16)^2 tiles of 4 KB at N = 784
+    assert pc == 4 * per_module and tr - ev >= pc and tr - ev < pc + 4096
+    try:
+        _lib.check(L.vu_set_flash_pcache_budget(2 * per_module + 1))
+        assert L.vu_model_pcache_bytes(C.byref(cfg), 64) == 2 * per_module
+        assert L.vu_model_workspace_bytes(C.byref(cfg), 64) < tr
+        _lib.check(L.vu_set_flash_pcache_budget(0))
+        assert L.vu_model_pcache_bytes(C.byref(cfg), 64) == 0
+        assert L.vu_model_workspace_bytes(C.byref(cfg), 64) == L.vu_model_workspace_bytes_ex(C.byref(cfg), 64, 0)
+    finally:
+        _lib.check(L.vu_set_flash_pcache_budget(96 << 30))
+    # fp32 storage has no recompute form: nothing to leave out
+    cfg32 = _lib.make_config(dtype=torch.float32, **O.PRESETS["base"])
+    assert L.vu_model_pcache_bytes(C.byref(cfg32), 64) == 0
+
+
 def test_module_surface_and_state_dict_keys():
     from vit_unet.torch import model as M
     m = M.get_vit_unet("lite")

@@ -29,6 +29,16 @@ for f in glob.glob(root + "/**/*kernel_trace.csv", recursive=True):
         qcount[qid] += 1
         recs.append((r, qid))
 main_q = qcount.most_common(1)[0][0] if qcount else ""
+# Only whole steps count (round 6): everything before the END of the first step's optimizer launch is dropped - the per-parameter
+# copies of model.to(device) at construction (the "48 copyBuffer launches per step" of the round-5 table were these ~290 launches
+# divided by 6 steps; there is no device-to-device copy inside a step) and the first warm-up step - and the rest is divided by the
+# number of steps that follow.
+marks = sorted(int(r["End_Timestamp"]) for r, _ in recs if r["Kernel_Name"].startswith("adamw_step_kernel"))
+if not marks:
+    marks = sorted(int(r["End_Timestamp"]) for r, _ in recs if r["Kernel_Name"].startswith("adamw_kernel"))
+if len(marks) >= 2:
+    recs = [(r, q) for r, q in recs if marks[0] <= int(r["Start_Timestamp"]) and int(r["End_Timestamp"]) <= marks[-1]]
+    steps = len(marks) - 1
 for r, qid in recs:
     k = (r["Kernel_Name"][:110], r.get("Grid_Size_X", r.get("Grid_Size", "")), r.get("Grid_Size_Y", ""), r.get("Grid_Size_Z", ""), "main" if qid == main_q else "side (low priority)")
     a = agg[k]

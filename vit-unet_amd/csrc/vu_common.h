@@ -23,6 +23,7 @@ void vu_set_error(const char* fmt, ...);
 int vu_check_launch(const char* what);
 // profiler annotation for the NEXT vu_check_launch: kernel tag + algorithmic flops / bytes
 void vu_prof_note(const char* tag, double flops, double bytes);
+void vu_prof_note_mapfree(double bytes_mapfree);     // after vu_prof_note: bytes without map-sized streams (the probability cache)
 void vu_prof_note_strict(double flops_strict);      // after vu_prof_note: flops without recomputation / padding
 bool vu_prof_on();
 

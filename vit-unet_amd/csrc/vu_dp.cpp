@@ -6,7 +6,17 @@
 // holds - torch's - or librccl.so.1 of the ROCm installation), so the compute path loads and runs without it.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+// A ROCm image without the RCCL development headers: the handful of types and enum values these entry points pass through (stable
+// NCCL ABI: ncclUniqueId is 128 opaque bytes, ncclFloat32 = 7, ncclBfloat16 = 9, ncclSum = 0, ncclSuccess = 0).
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclFloat32 = 7, ncclFloat = 7, ncclBfloat16 = 9 } ncclDataType_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+#endif
 #include <stdio.h>
 #include <string.h>
 #include "vu_common.h"

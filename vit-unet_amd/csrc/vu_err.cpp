@@ -26,13 +26,13 @@ void vu_set_error(const char* fmt, ...) {
 const char* vu_get_error() { return g_err; }
 
 namespace {
-struct Rec { std::string tag; double flops, bytes, strict; };
+struct Rec { std::string tag; double flops, bytes, strict, mapfree; };
 bool g_prof = false;
 hipStream_t g_stream = nullptr;
 std::vector<hipEvent_t> g_events;   // g_events[0] = start marker, g_events[i+1] follows launch i
 std::vector<Rec> g_recs;
 std::string g_tag;
-double g_flops = 0, g_bytes = 0, g_strict = -1;
+double g_flops = 0, g_bytes = 0, g_strict = -1, g_mapfree = -1;
 std::string g_report;
 
 // holds the stream for `ticks` of the constant 100 MHz counter (bounded: every wave leaves after that time)
@@ -51,11 +51,16 @@ hipEvent_t new_event() {
 bool vu_prof_on() { return g_prof; }
 void vu_prof_note(const char* tag, double flops, double bytes) {
   if (!g_prof) return;
-  g_tag = tag; g_flops = flops; g_bytes = bytes; g_strict = -1;
+  g_tag = tag; g_flops = flops; g_bytes = bytes; g_strict = -1; g_mapfree = -1;
 }
 // flops of the launch under SURVEY 8d's rule (the model's own products only: no recomputation, no padding); default = flops
 void vu_prof_note_strict(double flops_strict) {
   if (g_prof) g_strict = flops_strict;
+}
+
+// bytes of the launch without any attention-map-sized stream (the probability cache is DESIGN traffic, not algorithmic); default = bytes
+void vu_prof_note_mapfree(double bytes_mapfree) {
+  if (g_prof) g_mapfree = bytes_mapfree;
 }
 
 int vu_check_launch(const char* what) {
@@ -68,8 +73,8 @@ int vu_check_launch(const char* what) {
     hipEvent_t ev = new_event();
     hipEventRecord(ev, g_stream);
     g_events.push_back(ev);
-    g_recs.push_back(Rec{g_tag.empty() ? std::string(what) : g_tag, g_flops, g_bytes, g_strict < 0 ? g_flops : g_strict});
-    g_tag.clear(); g_flops = 0; g_bytes = 0; g_strict = -1;
+    g_recs.push_back(Rec{g_tag.empty() ? std::string(what) : g_tag, g_flops, g_bytes, g_strict < 0 ? g_flops : g_strict, g_mapfree < 0 ? g_bytes : g_mapfree});
+    g_tag.clear(); g_flops = 0; g_bytes = 0; g_strict = -1; g_mapfree = -1;
   }
   return VU_OK;
 }
@@ -102,20 +107,20 @@ extern "C" const char* vu_prof_report(void) {
   g_report = "{";
   if (!g_events.empty()) {
     hipEventSynchronize(g_events.back());
-    struct Agg { long long n = 0; double ms = 0, flops = 0, bytes = 0, strict = 0; };
+    struct Agg { long long n = 0; double ms = 0, flops = 0, bytes = 0, strict = 0, mapfree = 0; };
     std::map<std::string, Agg> agg;
     for (size_t i = 0; i < g_recs.size(); ++i) {
       float ms = 0.f;
       hipEventElapsedTime(&ms, g_events[i], g_events[i + 1]);
       if (g_recs[i].tag == "(gate)") continue;
       Agg& a = agg[g_recs[i].tag];
-      a.n += 1; a.ms += ms; a.flops += g_recs[i].flops; a.bytes += g_recs[i].bytes; a.strict += g_recs[i].strict;
+      a.n += 1; a.ms += ms; a.flops += g_recs[i].flops; a.bytes += g_recs[i].bytes; a.strict += g_recs[i].strict; a.mapfree += g_recs[i].mapfree;
     }
     bool first = true;
     char buf[512];
     for (auto& kv : agg) {
-      snprintf(buf, sizeof(buf), "%s\"%s\": {\"count\": %lld, \"ms\": %.6f, \"flops\": %.6e, \"bytes\": %.6e, \"flops_strict\": %.6e}",
-               first ? "" : ", ", kv.first.c_str(), kv.second.n, kv.second.ms, kv.second.flops, kv.second.bytes, kv.second.strict);
+      snprintf(buf, sizeof(buf), "%s\"%s\": {\"count\": %lld, \"ms\": %.6f, \"flops\": %.6e, \"bytes\": %.6e, \"flops_strict\": %.6e, \"bytes_mapfree\": %.6e}",
+               first ? "" : ", ", kv.first.c_str(), kv.second.n, kv.second.ms, kv.second.flops, kv.second.bytes, kv.second.strict, kv.second.mapfree);
       g_report += buf;
       first = false;
     }

@@ -19,6 +19,10 @@
 
 namespace {
 
+// A wave-private LDS tile written in one lane layout and read back in another by the SAME wave: the hardware keeps a wave's DS
+// operations in order, this keeps the COMPILER from moving the reads above the writes (or the next writes above the reads) should
+// its alias analysis ever prove the addresses distinct per lane.  No instruction is emitted.
+#define VU_WAVE_LDS_FENCE() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 constexpr int D = 192, HID = 32, NF1 = 12, NF2 = 12;      // fragments: first product 2 tiles x 6 k-steps, second 12 tiles x 1 k-step
 
 struct ff2_args {
@@ -184,6 +188,7 @@ __global__ __launch_bounds__(256) void ff2_kernel(const ff2_args a) {
         if constexpr (!BWD) o += *reinterpret_cast<const f32x4*>(a.b2 + 16 * t2 + 4 * g4);
         *reinterpret_cast<f32x4*>(ct + l15 * LDC + 16 * u + 4 * g4) = o;
       }
+      VU_WAVE_LDS_FENCE();      // the wave-private tile changes hands between lanes: writes above, row reads below
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         const int i = lane + 64 * k, rl = i / 12, c8 = (i - rl * 12) * 8;
@@ -197,6 +202,7 @@ __global__ __launch_bounds__(256) void ff2_kernel(const ff2_args a) {
         if (row0 + rl < a.rows)
           *reinterpret_cast<u32x4_t*>(a.y + (row0 + rl) * D + 96 * hf + c8) = u32x4_t{pk2f(v[0], v[1]), pk2f(v[2], v[3]), pk2f(v[4], v[5]), pk2f(v[6], v[7])};
       }
+      VU_WAVE_LDS_FENCE();      // ... and the next half / the next row tile overwrites it
     }
   }
 }

@@ -42,5 +42,7 @@ size_t vu_flash_partials_floats(int B, int N, int H);
 // bytes of the probability cache of one module (0: this shape / this process does not use one).  Process-level switch, read once:
 // VU_FLASH_PCACHE=0 / 1, vu_set_flash_pcache()
 size_t vu_flash_pcache_bytes(int B, int N, int D, int H);
+// bytes one model workspace may spend on those caches in total (vu_set_flash_pcache_budget; VU_FLASH_PCACHE_BUDGET_MB)
+size_t vu_flash_pcache_budget();
 int vu_k_flash_forward(const vu_flash_args& a, hipStream_t st);
 int vu_k_flash_backward(const vu_flash_args& a, hipStream_t st);

@@ -3052,6 +3052,14 @@ int reserve_lds(K kern, size_t lds) {
   return VU_OK;
 }
 
+// profiler tag of a 4-head sweep with its row length ("flash_bwd_dk_kernel<N=3136>"): Lite runs one instantiation at two levels in a
+// step, and a mean over both shapes is no launch duration (round-5 review)
+static const char* v1_tag(const char* base, int N) {
+  static thread_local char buf[96];
+  snprintf(buf, sizeof(buf), "%s<N=%d>", base, N);
+  return buf;
+}
+
 template <int H, int DH>
 int launch_backward(const vu_flash_args& a, hipStream_t st) {
   typedef FC<H, DH> C;
@@ -3082,7 +3090,7 @@ int launch_backward(const vu_flash_args& a, hipStream_t st) {
   const bool early_dv = tail_overlap_v1(fp, nblk, st, true);
   auto launch_dv = [&]() -> int {
     hipLaunchKernelGGL(k4, dim3(nblk), dim3(WPB * 64), lds4, s_dv, q, k, v, dO, a.lse2, (const float*)nullptr, a.stats, (bf16_t*)a.dv, a.B, a.N, c, a.scale, a.rng, 0);
-    if (vu_prof_on()) vu_prof_note("flash_bwd_dv_kernel", 4.0 * E * DH + 2.0 * E * H, 4.0 * act);
+    if (vu_prof_on()) vu_prof_note(v1_tag("flash_bwd_dv_kernel", a.N), 4.0 * E * DH + 2.0 * E * H, 4.0 * act);
     return vu_check_launch("flash_bwd_dv");
   };
   if (early_dv) {
@@ -3101,22 +3109,22 @@ int launch_backward(const vu_flash_args& a, hipStream_t st) {
     VU_TRY(reserve_lds(k1q, lds1));
     hipLaunchKernelGGL(k1q, dim3(nblk), dim3(WPB * 64), lds1, st, q, k, v, dO, a.lse2, a.rinv, a.stats, a.delta, a.partials, a.B, a.N, c, a.rng,
                        (const float*)a.pk, (bf16_t*)a.dq, a.scale, (const float*)a.rinv_b, clr ? (int)lds1 : 0);
-    if (vu_prof_on()) vu_prof_note("flash_bwd_delta_dq_kernel", 6.0 * E * DH + 6.0 * E * H, 6.0 * act);
+    if (vu_prof_on()) vu_prof_note(v1_tag("flash_bwd_delta_dq_kernel", a.N), 6.0 * E * DH + 6.0 * E * H, 6.0 * act);
   } else {
     hipLaunchKernelGGL(k1, dim3(nblk), dim3(WPB * 64), lds1, st, q, k, v, dO, a.lse2, a.rinv, a.stats, a.delta, a.partials, a.B, a.N, c, a.rng,
                        (const float*)nullptr, (bf16_t*)nullptr, 0.f, (const float*)nullptr, clr ? (int)lds1 : 0);
-    if (vu_prof_on()) vu_prof_note("flash_bwd_delta_kernel", 4.0 * E * DH + 6.0 * E * H, 4.0 * act);
+    if (vu_prof_on()) vu_prof_note(v1_tag("flash_bwd_delta_kernel", a.N), 4.0 * E * DH + 6.0 * E * H, 4.0 * act);
   }
   VU_TRY(vu_check_launch("flash_bwd_delta"));
   hipLaunchKernelGGL(flash_bwd_mix_finalize_kernel, dim3((unsigned)((H * H + H + 15) / 16)), dim3(1024), 0, st, a.partials, nblk, a.stats, a.d_mix_w, a.d_mix_b, H, a.rng.inv_keep);
   VU_TRY(vu_check_launch("flash_bwd_mix_finalize"));
   if (!fused) {
     hipLaunchKernelGGL(k2, dim3(nblk), dim3(WPB * 64), lds2, st, q, k, v, dO, a.lse2, a.delta, a.stats, (bf16_t*)a.dq, a.B, a.N, c, a.scale, a.rng);
-    if (vu_prof_on()) vu_prof_note("flash_bwd_dq_kernel", 6.0 * E * DH + 4.0 * E * H, 5.0 * act);
+    if (vu_prof_on()) vu_prof_note(v1_tag("flash_bwd_dq_kernel", a.N), 6.0 * E * DH + 4.0 * E * H, 5.0 * act);
     VU_TRY(vu_check_launch("flash_bwd_dq"));
   }
   hipLaunchKernelGGL(k3, dim3(nblk), dim3(WPB * 64), lds3, st, q, k, v, dO, a.lse2, a.delta, a.stats, (bf16_t*)a.dk, a.B, a.N, c, a.scale, a.rng, clr ? (int)lds3 : 0);
-  if (vu_prof_on()) vu_prof_note("flash_bwd_dk_kernel", 6.0 * E * DH + 4.0 * E * H, 5.0 * act);
+  if (vu_prof_on()) vu_prof_note(v1_tag("flash_bwd_dk_kernel", a.N), 6.0 * E * DH + 4.0 * E * H, 5.0 * act);
   VU_TRY(vu_check_launch("flash_bwd_dk"));
   VU_TRY(launch_center_dk(a, st));
   if (!early_dv) VU_TRY(launch_dv());
@@ -3161,14 +3169,14 @@ int launch_forward(const vu_flash_args& a, hipStream_t st) {
   const double E = (double)a.B * H * a.N * a.N, act = (double)a.B * a.N * C::D * 2.0;
   hipLaunchKernelGGL(k1, dim3(nblk), dim3(WPB * 64), lds1, st, (const bf16_t*)a.q, (const bf16_t*)a.k, a.lse2, a.rinv, a.partials,
                      (a.training && a.rinv_b) ? a.pk : (float*)nullptr, a.rinv_b, a.B, a.N, c, a.rng, a.training);
-  if (vu_prof_on()) vu_prof_note("flash_stats_kernel", (a.training ? (a.pk ? 3.0 : 2.0) : 1.0) * 2.0 * E * DH, 2.0 * act);
+  if (vu_prof_on()) vu_prof_note(v1_tag("flash_stats_kernel", a.N), (a.training ? (a.pk ? 3.0 : 2.0) : 1.0) * 2.0 * E * DH, 2.0 * act);
   VU_TRY(vu_check_launch("flash_stats"));
   hipLaunchKernelGGL(flash_bn_finalize_kernel, dim3(1), dim3(1024), 0, st, a.partials, nblk, a.mix_w, a.mix_b, a.bn_w, a.bn_b, a.run_mean,
                      a.run_var, a.stats, H, a.N, (double)a.B * a.N * a.N, a.training, 0.1f, 1e-5f, a.rng.inv_keep, 0);
   VU_TRY(vu_check_launch("flash_bn_finalize"));
   hipLaunchKernelGGL(k2, dim3(nblk), dim3(WPB * 64), lds2, st, (const bf16_t*)a.q, (const bf16_t*)a.k, (const bf16_t*)a.v, a.lse2,
                      a.stats, (bf16_t*)a.O, a.B, a.N, c, a.rng);
-  if (vu_prof_on()) vu_prof_note("flash_apply_kernel", 4.0 * E * DH + 2.0 * E * H, 4.0 * act);
+  if (vu_prof_on()) vu_prof_note(v1_tag("flash_apply_kernel", a.N), 4.0 * E * DH + 2.0 * E * H, 4.0 * act);
   return vu_check_launch("flash_apply");
 }
 
@@ -3214,7 +3222,7 @@ int launch_forward_v2(const vu_flash_args& a, hipStream_t st) {
   if (a.training) {
     VU_REQUIRE(a.pk != nullptr, "flash attention: the training forward needs the P k buffer");
     hipLaunchKernelGGL(km, dim3(nblk), dim3(WPB * 64), ldsm, st, q, k, a.lse2, a.mix_w, a.partials, a.pk, a.rinv, a.B, a.N, c, a.rng, a.pcache);
-    if (vu_prof_on()) vu_prof_note("flash2_moments_kernel", 4.0 * E * DH + 2.0 * E * H, 4.0 * act + (pc ? 2.0 * E : 0.0));
+    if (vu_prof_on()) { vu_prof_note("flash2_moments_kernel", 4.0 * E * DH + 2.0 * E * H, 4.0 * act + (pc ? 2.0 * E : 0.0)); vu_prof_note_mapfree(4.0 * act); }
     if (vu_prof_on()) vu_prof_note_strict(2.0 * E * H);
     VU_TRY(vu_check_launch("flash2_moments"));
   }
@@ -3222,7 +3230,7 @@ int launch_forward_v2(const vu_flash_args& a, hipStream_t st) {
                      a.run_var, a.stats, H, a.N, (double)a.B * a.N * a.N, a.training, 0.1f, 1e-5f, a.rng.inv_keep, 1);
   VU_TRY(vu_check_launch("flash_bn_finalize"));
   hipLaunchKernelGGL(k2, dim3(nblk), dim3(WPB * 64), lds2, st, q, k, v, a.lse2, a.stats, (bf16_t*)a.O, a.B, a.N, c, a.rng, (const void*)a.pcache);
-  if (vu_prof_on()) vu_prof_note("flash2_apply_kernel", (pc ? 2.0 : 4.0) * E * DH + 2.0 * E * H, pc ? 2.0 * act + 2.0 * E : 4.0 * act);
+  if (vu_prof_on()) { vu_prof_note("flash2_apply_kernel", (pc ? 2.0 : 4.0) * E * DH + 2.0 * E * H, pc ? 2.0 * act + 2.0 * E : 4.0 * act); vu_prof_note_mapfree(pc ? 2.0 * act : 4.0 * act); }
   if (vu_prof_on()) vu_prof_note_strict(2.0 * E * DH);      // (per module 12 E d + 6 E h = 3 x forward; the mix counts once, in the moments sweep)
   return vu_check_launch("flash2_apply");
 }
@@ -3284,7 +3292,7 @@ int launch_backward_v2(const vu_flash_args& a, hipStream_t st) {
   auto launch_dv = [&]() -> int {
     hipLaunchKernelGGL(k4, dim3(nblk), dim3(WPB * 64), lds3v, s_dv, q, k, v, dO, a.lse2, (const float*)nullptr, a.stats, (bf16_t*)a.dv, a.B, a.N, c, a.scale, a.rng,
                        (const void*)a.pcache);
-    if (vu_prof_on()) vu_prof_note("flash2_bwd_dv_kernel", (pc ? 2.0 : 4.0) * E * DH + 2.0 * E * H, pc ? 2.0 * act + 2.0 * E : 4.0 * act);
+    if (vu_prof_on()) { vu_prof_note("flash2_bwd_dv_kernel", (pc ? 2.0 : 4.0) * E * DH + 2.0 * E * H, pc ? 2.0 * act + 2.0 * E : 4.0 * act); vu_prof_note_mapfree(pc ? 2.0 * act : 4.0 * act); }
     if (vu_prof_on()) vu_prof_note_strict(2.0 * E * DH);
     return vu_check_launch("flash2_bwd_dv");
   };
@@ -3297,7 +3305,7 @@ int launch_backward_v2(const vu_flash_args& a, hipStream_t st) {
   if (fused) {
     hipLaunchKernelGGL(k2x, dim3(nblk), dim3(WPB * 64), lds2x, st, q, k, v, dO, a.lse2, a.rinv, a.pk, a.stats, (bf16_t*)a.dq, a.delta, a.partials, a.B,
                        a.N, c, a.scale, a.rng, a.training ? 0 : 1, (const void*)a.pcache);
-    if (vu_prof_on()) vu_prof_note("flash2_bwd_dqx_kernel", (pc ? 4.0 : 6.0) * E * DH + 8.0 * E * H, pc ? 6.0 * act + 2.0 * E : 7.0 * act);
+    if (vu_prof_on()) { vu_prof_note("flash2_bwd_dqx_kernel", (pc ? 4.0 : 6.0) * E * DH + 8.0 * E * H, pc ? 6.0 * act + 2.0 * E : 7.0 * act); vu_prof_note_mapfree(pc ? 6.0 * act : 7.0 * act); }
     if (vu_prof_on()) vu_prof_note_strict(4.0 * E * DH + 4.0 * E * H);      // dA^ = dO v^T, dq = dS k, dP~ = W^T e, dW = e P~^T
     VU_TRY(vu_check_launch("flash2_bwd_dqx"));
   } else {
@@ -3330,7 +3338,7 @@ int launch_backward_v2(const vu_flash_args& a, hipStream_t st) {
   hipLaunchKernelGGL(k3, dim3(nblk), dim3(WPB * 64), lds3, s_dk, q, k, v, dO, a.lse2, a.delta, a.stats, (bf16_t*)a.dk, a.B, a.N, c, a.scale, a.rng, (const void*)a.pcache);
   if (vu_prof_on()) vu_prof_note((pc && KS == 1 && WPB == 4 && DH == 24 && !dk3_off) ? "flash3_dk_kernel" : "flash2_bwd_dk_kernel",
                                  (pc ? 4.0 : 6.0) * E * DH + 4.0 * E * H, pc ? 4.0 * act + 2.0 * E : 5.0 * act);
-  if (vu_prof_on()) vu_prof_note_strict(2.0 * E * DH);
+  if (vu_prof_on()) { vu_prof_note_mapfree(pc ? 4.0 * act : 5.0 * act); vu_prof_note_strict(2.0 * E * DH); }
   VU_TRY(vu_check_launch("flash2_bwd_dk"));
   VU_TRY(launch_center_dk(a, s_dk));
   if (!early_dv) VU_TRY(launch_dv());
@@ -3403,6 +3411,15 @@ extern "C" int vu_set_flash_pcache(int on) {
   g_pcache = on < 0 ? VU_FLASH_PCACHE_DEFAULT : on;
   return VU_OK;
 }
+// Budget of ONE model workspace for its probability caches (sum over the attention modules, bytes): modules are granted a cache in
+// carve order while the sum fits; the rest run the recompute sweeps.  Default 96 GiB (a third of the 288 GB of an MI355X: Base at
+// 64 images takes 2.5 GiB, 512 x 512 at 32 images 37 GB); VU_FLASH_PCACHE_BUDGET_MB, read once; vu_set_flash_pcache_budget().
+static size_t g_pcache_budget = [] {
+  const char* e = getenv("VU_FLASH_PCACHE_BUDGET_MB");
+  return e ? (size_t)strtoull(e, nullptr, 10) << 20 : (size_t)96 << 30;
+}();
+extern "C" int vu_set_flash_pcache_budget(unsigned long long bytes) { g_pcache_budget = (size_t)bytes; return VU_OK; }
+size_t vu_flash_pcache_budget() { return g_pcache_budget; }
 size_t vu_flash_pcache_bytes(int B, int N, int D, int H) {
   if (!g_pcache || H != 8 || !vu_flash_ok(1, B, N, D, H)) return 0;
   const size_t nt = (size_t)(N >> 4);

@@ -36,6 +36,9 @@ inline int round_up(int x, int a) { return (x + a - 1) / a * a; }
 
 struct Bump {
   char* base; size_t off;
+  // probability cache of the recompute attention (carve_attn): carved only for a TRAINING workspace, and only while the sum over
+  // the modules (in carve order) stays within the process's budget (vu_set_flash_pcache_budget); a module without it recomputes
+  bool pc_on = true; size_t pc_left = ~(size_t)0; size_t pc_total = 0;
   void* take(size_t bytes) {
     off = vu_align_up(off, 256);
     void* p = base ? base + off : nullptr;
@@ -212,7 +215,9 @@ void carve_attn(Bump& bp, const AttnDims& d, AttnBuf& a) {
   a.rinvb = bp.takef((size_t)d.B * d.H * d.N);
   a.pk = flash_on(d) ? bp.takef((size_t)d.B * d.N * flash_D(d)) : nullptr;     // sum_k P k of the recompute form (vu_flash.h)
   {   // probability cache of the recompute form (written by the training forward's moments sweep, streamed by the four sweeps after it)
-    const size_t pcb = flash_on(d) ? vu_flash_pcache_bytes(d.B, d.N, flash_D(d), d.H) : 0;
+    size_t pcb = (bp.pc_on && flash_on(d)) ? vu_flash_pcache_bytes(d.B, d.N, flash_D(d), d.H) : 0;
+    if (pcb > bp.pc_left) pcb = 0;        // over the budget: this module runs the recompute sweeps (bit-identical results)
+    bp.pc_left -= pcb; bp.pc_total += pcb;
     a.pc = pcb ? bp.take(pcb) : nullptr;
   }
   if (flash_on(d) && flash_padded(d)) {      // zero-padded q, k, v (kept for the backward) and O of the recompute form
@@ -486,6 +491,7 @@ struct ModelWS {
   void* wgs; size_t wgs_bytes;      // split-K slab of the tall-skinny weight gradients (bf16 storage; vu_gemm_set_scratch)
   void* wga; size_t wga_bytes;      // arena of the deferred (batched) reductions of those gradients (vu_tsgemm_set_arena)
   size_t bytes;
+  size_t pcache_bytes;              // of which: probability caches
 };
 
 void carve_block(Bump& bp, const Plan& pl, int B, int level, BlockBuf& b) {
@@ -499,8 +505,12 @@ void carve_block(Bump& bp, const Plan& pl, int B, int level, BlockBuf& b) {
   b.ln1s = bp.takef(2 * B); b.ln2s = bp.takef(2 * B);
 }
 
-void carve_model(const Plan& pl, int B, char* base, ModelWS& w) {
+// training = 0: the layout of an eval forward (and of a backward through it): no probability cache is carved - only the TRAINING
+// forward's moments sweep fills one.  A forward and its backward must be given the same flag (they are: both take `training`).
+void carve_model(const Plan& pl, int B, char* base, ModelWS& w, int training) {
   Bump bp{base, 0};
+  bp.pc_on = training != 0;
+  bp.pc_left = vu_flash_pcache_budget();
   const vu_config& c = pl.cfg;
   const int dt = c.dtype, H = c.num_heads;
   const long long P = (long long)c.num_channels * c.im_size * c.im_size;
@@ -545,6 +555,7 @@ void carve_model(const Plan& pl, int B, char* base, ModelWS& w) {
   w.wga_bytes = dt == 1 ? (size_t)160 << 20 : 0;     // (a Base backward queues ~100 MB of partial tiles: one reduce launch per call)
   w.wga = w.wga_bytes ? bp.take(w.wga_bytes) : nullptr;
   w.bytes = vu_align_up(bp.off, 256);
+  w.pcache_bytes = bp.pc_total;
 }
 
 vu_attn_params attn_params(const AttnP& a, const vu_config& c, const float* prm, const void* shadow, float* bn) {
@@ -949,12 +960,20 @@ int vu_model_num_attn(const vu_config* cfg) {
   if (!cfg || build_plan(*cfg, pl) != VU_OK) return -1;
   return pl.nattn;
 }
-size_t vu_model_workspace_bytes(const vu_config* cfg, int B) {
+size_t vu_model_workspace_bytes_ex(const vu_config* cfg, int B, int training) {
   Plan pl;
   if (!cfg || B <= 0 || build_plan(*cfg, pl) != VU_OK) return 0;
   ModelWS w;
-  carve_model(pl, B, nullptr, w);
+  carve_model(pl, B, nullptr, w, training);
   return w.bytes;
+}
+size_t vu_model_workspace_bytes(const vu_config* cfg, int B) { return vu_model_workspace_bytes_ex(cfg, B, 1); }
+size_t vu_model_pcache_bytes(const vu_config* cfg, int B) {
+  Plan pl;
+  if (!cfg || B <= 0 || build_plan(*cfg, pl) != VU_OK) return 0;
+  ModelWS w;
+  carve_model(pl, B, nullptr, w, 1);
+  return w.pcache_bytes;
 }
 
 // Diagnostic: the carve of the model workspace as text, one "name offset bytes" line per buffer in carve order (the forward's
@@ -965,13 +984,13 @@ int vu_model_workspace_describe(const vu_config* cfg, int B, char* out, int cap)
   if (!cfg || B <= 0 || build_plan(*cfg, pl) != VU_OK) return -1;
   ModelWS w;
   char* const fake = reinterpret_cast<char*>(4096);            // (a null base makes every take() return null: carve from a fake one)
-  carve_model(pl, B, fake, w);
+  carve_model(pl, B, fake, w, 1);
   std::vector<std::pair<std::string, size_t>> ents;
   auto add = [&](const std::string& n, const void* p) { if (p) ents.push_back({n, (size_t)((const char*)p - fake)}); };
   auto add_attn = [&](const std::string& pre, const AttnBuf& a) {
     add(pre + "q", a.q); add(pre + "k", a.k); add(pre + "v", a.v); add(pre + "O", a.O); add(pre + "Ps", a.Ps); add(pre + "Ah", a.Ah);
-    add(pre + "stats", a.stats); add(pre + "lse2", a.lse2); add(pre + "rinv", a.rinv); add(pre + "delta", a.delta); add(pre + "pk", a.pk);
-    add(pre + "rinvb", a.rinvb); add(pre + "qp", a.qp); add(pre + "kp", a.kp); add(pre + "vp", a.vp); add(pre + "Op", a.Op);
+    add(pre + "stats", a.stats); add(pre + "lse2", a.lse2); add(pre + "rinv", a.rinv); add(pre + "delta", a.delta); add(pre + "rinvb", a.rinvb);
+    add(pre + "pk", a.pk); add(pre + "pc", a.pc); add(pre + "qp", a.qp); add(pre + "kp", a.kp); add(pre + "vp", a.vp); add(pre + "Op", a.Op);
   };
   auto add_block = [&](const std::string& pre, const BlockBuf& b) {
     add_attn(pre + "attn.", b.at);
@@ -1019,7 +1038,7 @@ int vu_model_forward(const vu_config* cfg, const float* params, const void* shad
   VU_TRY(build_plan(*cfg, pl));
   VU_REQUIRE(cfg->dtype == 0 || shadow, "vu_model_forward: bf16 mode needs the bf16 shadow arena");
   ModelWS w;
-  carve_model(pl, B, (char*)ws, w);
+  carve_model(pl, B, (char*)ws, w, training);
   if (w.bytes > ws_bytes) { vu_set_error("workspace too small: need %zu, have %zu", w.bytes, ws_bytes); return VU_EWORKSPACE; }
   Ctx cx{&pl, B, params, shadow, bn_state, nullptr, training, seed, rng_salt, (hipStream_t)stream, &w};
   return model_forward(cx, x, y);
@@ -1032,7 +1051,7 @@ static int run_backward(const vu_config* cfg, const float* params, const void* s
   VU_TRY(build_plan(*cfg, pl));
   VU_REQUIRE(cfg->dtype == 0 || shadow, "vu_model_backward: bf16 mode needs the bf16 shadow arena");
   ModelWS w;
-  carve_model(pl, B, (char*)ws, w);
+  carve_model(pl, B, (char*)ws, w, training);
   if (w.bytes > ws_bytes) { vu_set_error("workspace too small: need %zu, have %zu", w.bytes, ws_bytes); return VU_EWORKSPACE; }
   const int nu = (int)backward_units(pl).size();
   if (stage >= 0) {   // stage API: 0 = all, 1 = head + decoders + skips, 2 = bottleneck, 3 = encoders + positional embedding

@@ -16,6 +16,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # VU_LIB_PATH: a measurement build of the same sources (tools/build_variant.sh: -D switches of csrc/vu_flash.hip etc.); the product
 # and the tests load the in-tree library
 LIB_PATH = os.environ.get("VU_LIB_PATH") or os.path.join(_HERE, "libvitunet_amd.so")
+if os.environ.get("VU_LIB_PATH"):      # never silently: a measurement build is not the product
+    import sys as _sys
+    print(f"vit_unet: loading the HIP library from VU_LIB_PATH={LIB_PATH} (a measurement build, not the in-tree library)", file=_sys.stderr)
 
 VU_OK = 0
 ABI_VERSION = 200        # include/vit_unet_amd.h: vu_version()
@@ -62,10 +65,13 @@ SIGNATURES = {
     "vu_model_param_table": (_i, [_cfgp, C.POINTER(vu_param_entry), _i]),
     "vu_model_num_attn": (_i, [_cfgp]),
     "vu_model_workspace_bytes": (_sz, [_cfgp, _i]),
+    "vu_model_workspace_bytes_ex": (_sz, [_cfgp, _i, _i]),
+    "vu_model_pcache_bytes": (_sz, [_cfgp, _i]),
     "vu_model_workspace_describe": (_i, [_cfgp, _i, C.c_char_p, _i]),
     "vu_model_prefers_eager": (_i, [_cfgp, _i]),
     "vu_set_flash_key_split": (_i, [_i]),
     "vu_set_flash_pcache": (_i, [_i]),
+    "vu_set_flash_pcache_budget": (_i, [C.c_ulonglong]),
     "vu_model_forward": (_i, [_cfgp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _u64, _vp, _vp]),
     "vu_model_backward": (_i, [_cfgp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _u64, _vp, _i, _vp]),
     "vu_model_num_backward_units": (_i, [_cfgp]),

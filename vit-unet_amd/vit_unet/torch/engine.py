@@ -19,7 +19,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import check, lib, ptr, stream_ptr
+from ._lib import VuError, check, lib, ptr, stream_ptr
 
 
 def dp_buckets(table, total: int):
@@ -80,6 +80,12 @@ def _sum_over_ranks(t: torch.Tensor, group, collective: str):
         torch.distributed.all_reduce(t, group=group)
         return
     if collective == "c_abi":       # the library's own RCCL communicator (include/vit_unet_amd.h: vu_dp_allreduce_bucket), on the current stream
+        if t.dtype not in (torch.float32, torch.bfloat16):
+            raise VuError(f"vu_dp_allreduce_bucket sums fp32 or bf16 buckets, not {t.dtype}")
+        # ONE communicator per process: it cannot stand in for a sub-group of the torch process group
+        if lib().vu_dp_world() != torch.distributed.get_world_size(group):
+            raise VuError(f"collective='c_abi': the library's communicator has {lib().vu_dp_world()} ranks, the group "
+                          f"{torch.distributed.get_world_size(group)} (dp_c_abi_init(group) first; sub-groups are not supported)")
         check(lib().vu_dp_allreduce_bucket(ptr(t), t.numel(), 0 if t.dtype == torch.float32 else 1, stream_ptr(t.device)),
               "vu_dp_allreduce_bucket")
         return
@@ -124,6 +130,10 @@ def dp_c_abi_init(group=None) -> int:
     box = [bytes(buf)]
     torch.distributed.broadcast_object_list(box, src=0, group=group)
     raw = (C.c_ubyte * 128).from_buffer_copy(box[0])
+    # vu_dp_init creates the communicator on the CURRENT HIP device: make that the rank's device (LOCAL_RANK under torchrun) rather
+    # than assuming the caller has done so
+    if "LOCAL_RANK" in os.environ and torch.cuda.is_available():
+        torch.cuda.set_device(int(os.environ["LOCAL_RANK"]))
     check(L.vu_dp_init(rank, world, raw), "vu_dp_init")
     return world
 

@@ -598,13 +598,36 @@ class HViT_UNet(nn.Module):
                         gv.copy_(p.grad)
                     p.grad = gv
 
-    def _workspace(self, B: int) -> torch.Tensor:
-        need = lib().vu_model_workspace_bytes(C.byref(self._cfg), B)
+    def _workspace(self, B: int, training: bool = True) -> torch.Tensor:
+        """The caller-owned workspace of vu_model_forward / _backward.  An eval forward is sized without the probability caches of
+        the recompute attention (vu_model_workspace_bytes_ex(training=0)); a buffer that is already large enough is kept either way.
+        If the training size cannot be allocated, the caches are switched off for the process (vu_set_flash_pcache(0): the sweeps
+        recompute, bit-identical results) and the smaller layout is tried before the error is raised."""
+        L = lib()
+        need = L.vu_model_workspace_bytes_ex(C.byref(self._cfg), B, 1 if training else 0)
         if need == 0:
-            check(lib().vu_model_validate(C.byref(self._cfg)), "vu_model_validate")
+            check(L.vu_model_validate(C.byref(self._cfg)), "vu_model_validate")
         if self._ws is None or self._ws.numel() < need or self._ws.device != self._arena.device:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self._arena.device)
+            self._ws = None
+            try:
+                self._ws = torch.empty(need, dtype=torch.uint8, device=self._arena.device)
+            except torch.OutOfMemoryError:
+                if not training or L.vu_model_pcache_bytes(C.byref(self._cfg), B) == 0:
+                    raise
+                import warnings
+                warnings.warn(f"vit_unet: {need / 2 ** 30:.1f} GiB of workspace do not fit; the probability cache of the recompute "
+                              f"attention is switched off for this process (VU_FLASH_PCACHE=0)")
+                check(L.vu_set_flash_pcache(0), "vu_set_flash_pcache")
+                need = L.vu_model_workspace_bytes_ex(C.byref(self._cfg), B, 1)
+                self._ws = torch.empty(need, dtype=torch.uint8, device=self._arena.device)
         return self._ws
+
+    def workspace_report(self, B: int) -> dict:
+        """Bytes of the training workspace at B images and how much of it is probability cache (bench.py prints it)."""
+        L = lib()
+        return {"train_bytes": int(L.vu_model_workspace_bytes_ex(C.byref(self._cfg), B, 1)),
+                "eval_bytes": int(L.vu_model_workspace_bytes_ex(C.byref(self._cfg), B, 0)),
+                "pcache_bytes": int(L.vu_model_pcache_bytes(C.byref(self._cfg), B))}
 
     def refresh_shadow(self):
         """bf16 copy of the weights for the GEMMs.  A TrainStep keeps it in sync from inside AdamW and vouches for it
@@ -623,7 +646,7 @@ class HViT_UNet(nn.Module):
         B = x.shape[0]
         xc = x.detach().float().contiguous()
         y = torch.empty_like(xc)
-        ws = self._workspace(B)
+        ws = self._workspace(B, training)
         self.refresh_shadow()
         self._gen += 1
         check(lib().vu_model_forward(C.byref(self._cfg), ptr(self._arena), ptr(self._shadow), ptr(self._bn), ptr(xc),
