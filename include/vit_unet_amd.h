@@ -138,6 +138,11 @@ int vu_conv3x3_qkv_fwd(int dtype, const void* xq, const void* xkv, const float* 
 int vu_conv3x3_qkv_dgrad(int dtype, const void* dq, const void* dk, const void* dv, const float* wq, const float* wk,
                          const float* wv, const void* add_q, const void* add_kv, void* dxq, void* dxkv,
                          long long npatch, int C, int s, void* stream);
+/* ... and their weight gradients (autograd of model.py:152-154): dwq += d(q)/d(wq) etc., fp32 (C, C, 3, 3).  `scratch` (optional, at
+ * least 1 MiB, device memory): with it the per-workgroup partial sums are added in a fixed order (bit-reproducible; the model executor
+ * always lends one), without it the sums end in float atomics. */
+int vu_conv3x3_qkv_wgrad(int dtype, const void* dq, const void* dk, const void* dv, const void* xq, const void* xkv, float* dwq,
+                         float* dwk, float* dwv, void* scratch, size_t scratch_bytes, long long npatch, int C, int s, void* stream);
 
 /* ReAttention.forward / SkipConnection.forward (model.py:150-164, 244-259) on token maps
  * xq, xkv (B,N,D); prm = pointers into the arenas.  ws from vu_attn_workspace_bytes. */

@@ -72,6 +72,22 @@ def test_conv3x3_qkv_forms(dt, cross, C_, s, npatch):
     assert serr(dxq, xqr.grad + adds[0].float()) < tol
     if cross:
         assert serr(dxkv, xkr.grad + adds[1].float()) < tol
+    # the three weight gradients (round 6: vu_conv3x3_qkv_wgrad; bf16, C = 3, s = 16 / 8 take the Gram form of csrc/vu_conv_tz.hip when
+    # a scratch slab is lent, and then two runs must agree bit for bit); they ACCUMULATE into dw
+    wsr = [w.clone().requires_grad_(True) for w in ws]
+    wref = torch.autograd.grad(sum((torch.nn.functional.conv2d(xq.float() if t == 0 else xkv.float(), wr, None, padding=1) * dys[t].float()).sum()
+                                   for t, wr in enumerate(wsr)), wsr)
+    scratch = torch.empty(4 << 20, dtype=torch.uint8, device=DEV)
+    got = []
+    for rep in range(2):
+        dws = [torch.full((C_, C_, 3, 3), 0.5, device=DEV) for _ in range(3)]
+        check(lib().vu_conv3x3_qkv_wgrad(code, ptr(dyd[0]), ptr(dyd[1]), ptr(dyd[2]), ptr(xqd), ptr(xkd), ptr(dws[0]), ptr(dws[1]), ptr(dws[2]),
+                                         ptr(scratch), scratch.numel(), npatch, C_, s, st()))
+        got.append([d.cpu() - 0.5 for d in dws])
+    for t in range(3):
+        assert serr(got[0][t], wref[t]) < (2e-4 if dt == torch.float32 else 2e-3), t       # (bf16 operands are exact; fp32 sums over npatch s^2 pixels)
+        if C_ == 3:                # (other channel counts: float atomics, csrc/vu_conv.hip)
+            assert torch.equal(got[0][t], got[1][t]), t
 
 
 # ------------------------------------------------------------------------------------------------

@@ -21,9 +21,15 @@ ap.add_argument("--B", type=int, default=20)
 ap.add_argument("--attn", default="h8", choices=["none", "h8", "all"],
                 help="also run the recompute attention op forward + backward: h8 = Base level 2 (8 heads), all = + the 4-head Lite levels "
                      "(known, DESIGN 2a: their dq / dk sweeps are NOT reproducible under GPU sharing)")
+ap.add_argument("--load-mode", default="process", choices=["process", "thread"],
+                help="process: the load is a second PROCESS on the GPU (its queues are time-sliced against ours: waves can be saved / "
+                     "restored); thread: the SAME train-step loop on a second stream of THIS process (concurrent kernels, one process: "
+                     "no time-slicing between processes).  Round 6, review item 6: do the two sharing faults need a second process?")
+ap.add_argument("--only", default="", help="comma list of op families to run: conv,dgrad,ln,retile,gemm (default: all of them)")
 args = ap.parse_args()
+only = set(x for x in args.only.split(",") if x)
 child = None
-if args.load > 0:
+if args.load > 0 and args.load_mode == "process":
     child = subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "nondet_check.py"), "--as-load", str(args.load), "--B", str(args.B)])
 sys.path.insert(0, os.path.join(ROOT, "vit-unet_amd"))
 import torch  # noqa: E402
@@ -39,6 +45,36 @@ if child is not None:
     while not glob.glob(f"/tmp/nondet_load_{child.pid}") and time.time() - t0 < 180:
         time.sleep(0.2)
     print(f"load process running after {time.time() - t0:.1f} s", flush=True)
+load_thread = None
+if args.load > 0 and args.load_mode == "thread":
+    import threading
+    from vit_unet.torch import model as M_
+    from vit_unet.torch.engine import TrainStep
+    started, nsteps = threading.Event(), [0]
+
+    def load_loop():       # what tools/nondet_check.py --as-load does, on a stream of its own inside this process
+        torch.cuda.set_device(0)
+        s2 = torch.cuda.Stream()
+        with torch.cuda.stream(s2):
+            torch.manual_seed(0)
+            m_ = M_.get_vit_unet("base", dtype=torch.bfloat16).to("cuda").train()
+            ts_ = TrainStep(m_, lr=1e-4, seed=7)
+            g_ = torch.Generator().manual_seed(1000)
+            y_ = torch.rand(args.B, 3, 224, 224, generator=g_)
+            x_ = (y_ + 0.1 * torch.randn(y_.shape, generator=g_)).clamp(0, 1).cuda()
+            y_ = y_.cuda()
+            t0_ = time.time()
+            while time.time() - t0_ < args.load:
+                ts_.step(x_, y_)
+                s2.synchronize()
+                nsteps[0] += 1
+                started.set()
+        print(f"[load thread] {nsteps[0]} steps", flush=True)
+    load_thread = threading.Thread(target=load_loop, daemon=True)
+    load_thread.start()
+    t0 = time.time()
+    started.wait(180)
+    print(f"load thread running after {time.time() - t0:.1f} s (second stream of this process)", flush=True)
 st = _lib.stream_ptr()
 B = args.B
 g = torch.Generator(device="cpu").manual_seed(3)
@@ -105,11 +141,13 @@ for s, N in (() if ap_only else ((32, 49), (16, 196), (8, 784), (4, 3136))):    
     x = torch.randn(B, N, D, generator=g).to(bf).to(dev)
     w = [(torch.randn(3, 3, 3, 3, generator=g) / 5).to(dev) for _ in range(3)]
     q, k, v = (torch.empty_like(x) for _ in range(3))
-    repeat(f"conv3x3_qkv_fwd s={s} npatch={npatch}",
+    if not only or "conv" in only:
+      repeat(f"conv3x3_qkv_fwd s={s} npatch={npatch}",
            lambda: check(L.vu_conv3x3_qkv_fwd(1, ptr(x), ptr(x), ptr(w[0]), ptr(w[1]), ptr(w[2]), ptr(q), ptr(k), ptr(v), npatch, 3, s, st)), [q, k, v], detail=conv_detail(s))
     dq, dk, dv = (torch.randn(B, N, D, generator=g).to(bf).to(dev) for _ in range(3))
     dx = torch.empty_like(x)
-    repeat(f"conv3x3_qkv_dgrad s={s}",
+    if not only or "dgrad" in only:
+      repeat(f"conv3x3_qkv_dgrad s={s}",
            lambda: check(L.vu_conv3x3_qkv_dgrad(1, ptr(dq), ptr(dk), ptr(dv), ptr(w[0]), ptr(w[1]), ptr(w[2]), None, None, ptr(dx), None, npatch, 3, s, st)), [dx])
     # residual add + LayerNorm over (N, D)
     P = N * D
@@ -118,16 +156,18 @@ for s, N in (() if ap_only else ((32, 49), (16, 196), (8, 784), (4, 3136))):    
     z, y = torch.empty_like(a), torch.empty_like(a)
     lws = torch.empty(L.vu_layernorm_workspace_floats(B, P), dtype=torch.float32, device=dev)
     stats = torch.empty(2 * B, dtype=torch.float32, device=dev)
-    repeat(f"add_layernorm_fwd P={P}", lambda: check(L.vu_add_layernorm_fwd(1, ptr(a), ptr(x), ptr(z), ptr(lw), ptr(lb), ptr(y), ptr(lws), ptr(stats), B, P, st)), [z, y, stats])
+    if not only or "ln" in only:
+      repeat(f"add_layernorm_fwd P={P}", lambda: check(L.vu_add_layernorm_fwd(1, ptr(a), ptr(x), ptr(z), ptr(lw), ptr(lb), ptr(y), ptr(lws), ptr(stats), B, P, st)), [z, y, stats])
     # re-tiling to the next level
-    if s > 8:
+    if s > 8 and (not only or "retile" in only):
         o = torch.empty_like(x)
         repeat(f"retile s={s}->{s // 2}", lambda: check(L.vu_retile(1, 0, 0, ptr(x), ptr(o), None, B, 3, 224, s, s // 2, st)), [o])
     # the level's projection: y = x W^T + b
     M = B * N
     wt = (torch.randn(D, D, generator=g) / D ** 0.5).to(bf).to(dev)
     yo = torch.empty(M, D, dtype=bf, device=dev)
-    repeat(f"gemm M={M} N={D} K={D}", lambda: check(L.vu_gemm(1, 0, ptr(x), ptr(wt), ptr(yo), M, D, D, D, 1, 1, D, D, 1, 1, 0, 0, 0, 0, 0, 0, 1.0, None, 0, st)), [yo])
+    if not only or "gemm" in only:
+      repeat(f"gemm M={M} N={D} K={D}", lambda: check(L.vu_gemm(1, 0, ptr(x), ptr(wt), ptr(yo), M, D, D, D, 1, 1, D, D, 1, 1, 0, 0, 0, 0, 0, 0, 1.0, None, 0, st)), [yo])
 # the recompute attention of the Lite levels (4 heads; d = 12 padded to 16, d = 48) and of Base level 2 (8 heads, d = 24): forward +
 # backward through the stand-alone op (its conv / projection WEIGHT gradients end in float atomics: compared are y, dx and the
 # head-mix / BatchNorm gradients, which do not)
@@ -170,5 +210,7 @@ for (N, Cn, s, H) in attn_cases:
 L.vu_set_attn_form(-1, 0)
 if child is not None:
     child.wait()
+if load_thread is not None:
+    load_thread.join(args.load + 60)
 print("CONTENTION_OPS", "CLEAN" if total_bad == 0 else f"{total_bad} bad repetitions", flush=True)
 sys.exit(0 if total_bad == 0 else 1)

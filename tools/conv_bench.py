@@ -43,5 +43,8 @@ for C_, s, N in ((3, 8, 784), (3, 16, 196), (3, 32, 49), (1, 8, 4096)):
     fc = timed(lambda: check(L.vu_conv3x3_qkv_fwd(1, ptr(x), ptr(x2), ptr(w[0]), ptr(w[1]), ptr(w[2]), ptr(o[0]), ptr(o[1]), ptr(o[2]), npatch, C_, s, st)), a.reps)
     d = timed(lambda: check(L.vu_conv3x3_qkv_dgrad(1, ptr(o[0]), ptr(o[1]), ptr(o[2]), ptr(w[0]), ptr(w[1]), ptr(w[2]), ptr(x), None, ptr(o[3]), None, npatch, C_, s, st)), a.reps)
     dc = timed(lambda: check(L.vu_conv3x3_qkv_dgrad(1, ptr(o[0]), ptr(o[1]), ptr(o[2]), ptr(w[0]), ptr(w[1]), ptr(w[2]), ptr(x), ptr(x2), ptr(o[3]), ptr(o[4]), npatch, C_, s, st)), a.reps)
+    dw = [torch.zeros(C_, C_, 3, 3, device="cuda") for _ in range(3)]
+    scr = torch.empty(4 << 20, dtype=torch.uint8, device="cuda")
+    wg = timed(lambda: check(L.vu_conv3x3_qkv_wgrad(1, ptr(o[0]), ptr(o[1]), ptr(o[2]), ptr(x), ptr(x), ptr(dw[0]), ptr(dw[1]), ptr(dw[2]), ptr(scr), scr.numel(), npatch, C_, s, st)), a.reps)
     print(f"C={C_} s={s:2d} npatch={npatch:7d} ({mb:5.1f} MB per tensor)  fwd {f:6.1f} us ({4 * mb / f:5.2f} TB/s)  fwd cross {fc:6.1f}  "
-          f"dgrad {d:6.1f} us ({5 * mb / d:5.2f} TB/s)  dgrad cross {dc:6.1f}   mm={os.environ.get('VU_CONV_MM', '1')}")
+          f"dgrad {d:6.1f} us ({5 * mb / d:5.2f} TB/s)  dgrad cross {dc:6.1f}  wgrad(+reduce) {wg:6.1f} us ({4 * mb / wg:5.2f} TB/s)  tz={os.environ.get('VU_CONV_TZ', '1')}")

@@ -558,6 +558,11 @@ int vu_k_conv3x3_qkv_fwd(int dtype, const void* xq, const void* xkv, const float
   VU_REQUIRE(npatch * s * s / 4 < 4294967295LL, "conv3x3: more than 2^32 pixel quads");
   const long long nq = npatch * s * s / 4;
   if (nq == 0) return VU_OK;
+  if (vu_conv_tz_ok(dtype, C, s, npatch)) {
+    if (int e = vu_k_conv_tz_qkv_fwd(xq, xkv, wq, wk, wv, q, k, v, npatch, s, st)) return e;
+    if (vu_prof_on()) vu_prof_note("conv_tz_fwd_kernel", 2.0 * 243.0 / 9.0 * C * C * nq * 4, (double)nq * 4 * C * 2.0 * (xq == xkv ? 4 : 5));
+    return vu_check_launch("vu_conv3x3_qkv_fwd (Toeplitz form)");
+  }
   if (vu_conv_mm_ok(dtype, C, s, 0) && npatch < 2147483647LL) {
     if (int e = vu_k_conv_mm_qkv_fwd(xq, xkv, wq, wk, wv, q, k, v, npatch, C, s, st)) return e;
     if (vu_prof_on()) vu_prof_note("conv_qkv_mm_kernel", 2.0 * 243.0 / 9.0 * C * C * nq * 4, (double)nq * 4 * C * 2.0 * (xq == xkv ? 4 : 5));
@@ -600,6 +605,11 @@ int vu_k_conv3x3_qkv_dgrad(int dtype, const void* dq, const void* dk, const void
   VU_REQUIRE(npatch * s * s / 4 < 4294967295LL, "conv3x3: more than 2^32 pixel quads");
   const long long nq = npatch * s * s / 4;
   if (nq == 0) return VU_OK;
+  if (vu_conv_tz_ok(dtype, C, s, npatch)) {
+    if (int e = vu_k_conv_tz_qkv_dgrad(dq, dk, dv, wq, wk, wv, add_q, add_kv, dxq, dxkv, npatch, s, st)) return e;
+    if (vu_prof_on()) vu_prof_note("conv_tz_dgrad_kernel", 2.0 * 243.0 / 9.0 * C * C * nq * 4, (double)nq * 4 * C * 2.0 * (dxkv ? 5 + (add_q ? 1 : 0) + (add_kv ? 1 : 0) : 4 + (add_q ? 1 : 0)));
+    return vu_check_launch("vu_conv3x3_qkv_dgrad (Toeplitz form)");
+  }
   if (vu_conv_mm_ok(dtype, C, s, 1) && npatch < 2147483647LL) {
     if (int e = vu_k_conv_mm_qkv_dgrad(dq, dk, dv, wq, wk, wv, add_q, add_kv, dxq, dxkv, npatch, C, s, st)) return e;
     if (vu_prof_on()) vu_prof_note("conv_qkv_dgrad_mm_kernel", 2.0 * 243.0 / 9.0 * C * C * nq * 4, (double)nq * 4 * C * 2.0 * (dxkv ? 5 + (add_q ? 1 : 0) + (add_kv ? 1 : 0) : 4 + (add_q ? 1 : 0)));
@@ -626,6 +636,16 @@ static int wgrad_launch(int dtype, int dout_f32, const WgradSet& set, int nconv,
   VU_REQUIRE(npatch * s * s / 4 < 4294967295LL, "conv3x3: more than 2^32 pixel quads");
   const long long nq = npatch * s * s / 4;
   if (nq == 0) return VU_OK;
+  if (!dout_f32 && nconv == 3 && vu_conv_tz_ok(dtype, C, s, npatch) && !wgrad_valu_forced()) {      // Gram form (vu_conv_tz.hip): needs the lent slab
+    void* scr = nullptr; size_t scr_bytes = 0;
+    vu_gemm_get_scratch(&scr, &scr_bytes);
+    if (scr && scr_bytes >= vu_conv_tz_wgrad_scratch_floats() * sizeof(float)) {
+      if (int e = vu_k_conv_tz_qkv_wgrad(set.dout[0], set.dout[1], set.dout[2], set.in[0], set.in[1], set.dw[0], set.dw[1], set.dw[2], (float*)scr,
+                                         npatch, s, st)) return e;
+      if (vu_prof_on()) vu_prof_note("conv_tzw_kernel(+reduce)", 2.0 * 243.0 / 9.0 * C * C * nq * 4, (double)nq * 4 * C * (set.in[0] == set.in[1] ? 4 : 5) * 2.0);
+      return vu_check_launch("vu_conv3x3_wgrad (Gram form)");
+    }
+  }
   if (dtype == 1 && !dout_f32 && nconv == 3 && C == 3 && s % 8 == 0 && !wgrad_valu_forced()) {
     const long long nunits = npatch * s * s / 32;
     // many waves, few blocks: every block ends in 243 float atomics on the same addresses (measured: 2048 blocks of

@@ -895,11 +895,13 @@ int vu_k_add_ln_fwd(int dtype, const void* a, const void* x, void* z, const floa
 // ts: sample slice b = ts, ts+8, ...): the affine gradients of the chunk are summed over the batch
 // inside the block (registers, then one LDS exchange across the 8 slices - no atomics), and the
 // per-(sample,chunk) partial sums c1 = sum dy*w, c2 = sum dy*w*xhat go to partials2.
-template <typename T>
-__global__ __launch_bounds__(256) void ln_bwd_stats_kernel(const T* __restrict__ dy, const T* __restrict__ z,
+// SL sample slices per block (8: 256 threads, the default; 16: 512 threads, VU_LN_BSL=16 - built in round 6 to put more loads in
+// flight per chunk (588 blocks of 4 waves at 2.9 TB/s) and measured slower: 21.9 vs 19.5 us at 32 images, 31.9 vs 28.8 at 64)
+template <typename T, int SL = 8>
+__global__ __launch_bounds__(32 * SL) void ln_bwd_stats_kernel(const T* __restrict__ dy, const T* __restrict__ z,
                                                            const float* __restrict__ w, const float* __restrict__ stats,
                                                            float* dw, float* db, float* partials2, int B, long long P) {
-  __shared__ float red[2][8][8][33];     // [gw|gb][slice][q][tx]
+  __shared__ float red[2][SL][8][33];     // [gw|gb][slice][q][tx]
   const int tx = threadIdx.x & 31, ts = threadIdx.x >> 5;
   const int c = blockIdx.x, nch = gridDim.x;
   const long long e = (long long)c * VU_LN_BCHUNK + tx * 8;
@@ -909,11 +911,11 @@ __global__ __launch_bounds__(256) void ln_bwd_stats_kernel(const T* __restrict__
   if (ok1) { const float4 t = *reinterpret_cast<const float4*>(w + e + 4); wv[4] = t.x; wv[5] = t.y; wv[6] = t.z; wv[7] = t.w; }
   float gw[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const vu_f4 zero = {{0.f, 0.f, 0.f, 0.f}};
-  for (int bb = ts; bb < B; bb += 32) {        // 4 samples (16 loads) in flight per thread
+  for (int bb = ts; bb < B; bb += 4 * SL) {        // 4 samples (16 loads) in flight per thread
     vu_f4 d0[4], d1[4], z0[4], z1[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int b = bb + 8 * k;
+      const int b = bb + SL * k;
       const long long o = (long long)b * P + e;
       const bool v0 = ok0 && b < B, v1 = ok1 && b < B;
       if (v0 && v1 && (P & 7) == 0) {        // whole 8-element chunk, 16-byte aligned rows: one load per operand
@@ -925,7 +927,7 @@ __global__ __launch_bounds__(256) void ln_bwd_stats_kernel(const T* __restrict__
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int b = bb + 8 * k;
+      const int b = bb + SL * k;
       if (b < B) {
         const float mean = stats[2 * b], rstd = stats[2 * b + 1];
         float c1 = 0.f, c2 = 0.f;
@@ -946,11 +948,11 @@ __global__ __launch_bounds__(256) void ln_bwd_stats_kernel(const T* __restrict__
 #pragma unroll
   for (int q = 0; q < 8; ++q) { red[0][ts][q][tx] = gw[q]; red[1][ts][q][tx] = gb[q]; }
   __syncthreads();
-  {
+  if (threadIdx.x < 256) {
     const int t = threadIdx.x, q = t & 7, x = t >> 3;       // chunk element t = x*8 + q
     float sw = 0.f, sb2 = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { sw += red[0][k][q][x]; sb2 += red[1][k][q][x]; }
+    for (int k = 0; k < SL; ++k) { sw += red[0][k][q][x]; sb2 += red[1][k][q][x]; }
     const long long et = (long long)c * VU_LN_BCHUNK + t;
     if (et < P) { dw[et] += sw; db[et] += sb2; }
   }
@@ -1061,6 +1063,10 @@ int vu_k_ln_bwd(int dtype, const void* dy, const void* z, const float* w, const 
   VU_REQUIRE(P % 4 == 0, "layernorm: P %% 4");
   const int nbch = vu_ln_nbchunks(P), nch = vu_ln_nchunks(P);
   if (ln_wide_ok(dtype, P, dy, z, dz, dz_drop) && !((uintptr_t)w & 15)) {
+    static const int bsl = [] { const char* e = getenv("VU_LN_BSL"); return e ? atoi(e) : 8; }();      // A/B switch: 8 / 16 slices (measured round 6: 16 is SLOWER, 31.9 vs 28.8 us per LayerNorm backward at 64 images)
+    if (bsl == 16 && B >= 32)
+      hipLaunchKernelGGL((ln_bwd_stats_kernel<bf16_t, 16>), dim3(nbch), dim3(512), 0, st, (const bf16_t*)dy, (const bf16_t*)z, w, stats, dw, db, partials2, B, P);
+    else
     hipLaunchKernelGGL((ln_bwd_stats_kernel<bf16_t>), dim3(nbch), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)z, w, stats, dw, db, partials2, B, P);
     if (ln_big_chunk(B, P))
       hipLaunchKernelGGL(ln_bwd_apply8_kernel<4>, dim3((unsigned)((P + 8191) / 8192), B), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)z, w, stats, partials2, nbch, (bf16_t*)dz, (bf16_t*)dz_drop, rng, P);

@@ -1127,6 +1127,14 @@ int vu_conv3x3_qkv_dgrad(int dtype, const void* dq, const void* dk, const void* 
   VU_REQUIRE(dq && dk && dv && wq && wk && wv && dxq, "vu_conv3x3_qkv_dgrad: null argument");
   return vu_k_conv3x3_qkv_dgrad(dtype, dq, dk, dv, wq, wk, wv, add_q, add_kv, dxq, dxkv, npatch, C, s, (hipStream_t)stream);
 }
+int vu_conv3x3_qkv_wgrad(int dtype, const void* dq, const void* dk, const void* dv, const void* xq, const void* xkv, float* dwq, float* dwk,
+                         float* dwv, void* scratch, size_t scratch_bytes, long long npatch, int C, int s, void* stream) {
+  VU_REQUIRE(dq && dk && dv && xq && xkv && dwq && dwk && dwv, "vu_conv3x3_qkv_wgrad: null argument");
+  if (scratch) vu_gemm_set_scratch(scratch, scratch_bytes);       // lent for this call: per-block partial sums, added in a fixed order
+  const int rc = vu_k_conv3x3_qkv_wgrad(dtype, dq, dk, dv, xq, xkv, dwq, dwk, dwv, npatch, C, s, (hipStream_t)stream);
+  if (scratch) vu_gemm_set_scratch(nullptr, 0);
+  return rc;
+}
 
 static void carve_attn_ws(Bump& bp, const AttnDims& d, AttnBuf& a, AttnScratch& sc, void** dzbuf) {
   carve_attn(bp, d, a);

@@ -82,6 +82,7 @@ SIGNATURES = {
     "vu_conv3x3_bwd": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp]),
     "vu_conv3x3_qkv_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp]),
     "vu_conv3x3_qkv_dgrad": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp]),
+    "vu_conv3x3_qkv_wgrad": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _ll, _i, _i, _vp]),
     "vu_attn_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "vu_attn_forward": (_i, [_i, C.POINTER(vu_attn_params), _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i,
                              _f, _f, _i, _u64, _u64, _vp]),
