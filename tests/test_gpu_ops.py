@@ -300,7 +300,8 @@ def test_attention_fwd_bwd(dt, N, Cn, s, H, mode, cross):
     _attention_fwd_bwd(dt, N, Cn, s, H, mode, cross, centered=False)
 
 
-@pytest.mark.parametrize("N,Cn,s,H", [(784, 3, 8, 8), (289, 3, 8, 8)])
+@pytest.mark.parametrize("N,Cn,s,H", [(784, 3, 8, 8), (289, 3, 8, 8),
+                                      (196, 3, 16, 8), (49, 3, 32, 8), (64, 3, 8, 8), (225, 3, 8, 8)])      # round 6: short rows (mix_center_small_kernel): Base / Large levels 1 and 0, a ragged row
 @pytest.mark.parametrize("mode", ["train", "train_drop"])
 def test_attention_centred_map_form(N, Cn, s, H, mode, attn_form):
     """The model path's centred-map form (mix + statistics in one pass, BatchNorm's affine part inside the PV / dv

@@ -1073,12 +1073,93 @@ int vu_k_map_bwd(int dtype, const void* Ps, void* dAhat_dS, const float* W, cons
   return VU_EUNSUPPORTED;
 }
 
+// ---------------------------------------------------------------------------------------------
+// mix_center_small_kernel (bf16 storage, H = 8, short rows: ld <= 256 - Base / Large level 1, N = 196, and level 0, N = 49): the
+// same two results as mix_stats_mm_kernel<., true> - shifted batch moments and the centred mixed map Ac - for rows too short to
+// fill a 256-thread block.  One thread owns a quad of 4 keys of one map row in all 8 heads (8 x 8 bytes in, 8 x 8 bytes out) and
+// mixes them on the VALU (64 multiply-adds per map position: 0.3 GFLOP per launch at 64 images - the kernel is its two map
+// passes); threads run over (row, quad) pairs, consecutive threads over the consecutive quads of a row.  Round 6: with it levels
+// 1 / 0 take the centred-map form too (one pass that reads P and writes Ac instead of mix_stats + mix_apply: two reads, one write).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mix_center_small_kernel(const bf16_t* __restrict__ Ps, const float* __restrict__ W,
+                                                               float* __restrict__ partials, bf16_t* __restrict__ Ac,
+                                                               long long rows, int N, int ld, float inv_keep) {
+  constexpr int H = 8;
+  __shared__ float red[4][2 * H];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // The 64 coefficients live in VECTOR registers, fetched once through an address the compiler cannot prove uniform: as wave-uniform
+  // data they would be scalar loads that hipcc may re-issue inside the loop under register pressure - the pattern that returned
+  // wrong data beside concurrent kernels in conv_fwd_kernel.
+  int vz;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
+  float Wk[H][H], cin[H];
+#pragma unroll
+  for (int g = 0; g < H; ++g) {
+    float sacc = 0.f;
+#pragma unroll
+    for (int h = 0; h < H; ++h) { const float w = W[g * H + h + vz]; Wk[g][h] = w * inv_keep; sacc += w; }
+    cin[g] = -sacc / (float)N;      // -shift_g, shift_g = sum_h W[g,h] / N (the exact mean without dropout; the bias cancels)
+  }
+  const int nq = ld >> 2;
+  const unsigned hs = (unsigned)N * (unsigned)ld;
+  const long long total = rows * nq;
+  float s1[H], s2[H];
+#pragma unroll
+  for (int g = 0; g < H; ++g) { s1[g] = 0.f; s2[g] = 0.f; }
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+    const long long row = t / nq;
+    const int qd = (int)(t - row * nq);
+    const long long b = row / N;
+    const int i = (int)(row - b * N);
+    const long long base = (b * H * N + i) * (long long)ld + 4 * qd;
+    uint2 p[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) p[h] = *reinterpret_cast<const uint2*>(Ps + base + (long long)h * hs);
+    float pv[H][4];
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      const unsigned x = keep_pos(p[h].x), y = keep_pos(p[h].y);
+      pv[h][0] = half_f(x, 0); pv[h][1] = half_f(x, 1); pv[h][2] = half_f(y, 0); pv[h][3] = half_f(y, 1);
+    }
+#pragma unroll
+    for (int g = 0; g < H; ++g) {
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float a = cin[g];
+#pragma unroll
+        for (int h = 0; h < H; ++h) a = fmaf(Wk[g][h], pv[h][e], a);
+        a = (4 * qd + e < N) ? a : 0.f;            // padding columns: zeros in the map, nothing in the sums
+        o[e] = a;
+        s1[g] += a; s2[g] = fmaf(a, a, s2[g]);
+      }
+      *reinterpret_cast<uint2*>(Ac + base + (long long)g * hs) = make_uint2(pk2(o[0], o[1]), pk2(o[2], o[3]));
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < H; ++g) {
+    float v1 = s1[g], v2 = s2[g];
+#pragma unroll
+    for (int m = 1; m <= 32; m <<= 1) { v1 += __shfl_xor(v1, m, 64); v2 += __shfl_xor(v2, m, 64); }
+    if (lane == 0) { red[wave][g] = v1; red[wave][H + g] = v2; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * H)
+    partials[blockIdx.x * 2 * H + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
 // returns VU_OK, a negative error, or 1 when the shape is not covered (the caller uses mix_stats_kernel).
 // Ac != null: also write the centred mixed map (see mix_stats_mm_kernel).
 int vu_k_mix_stats_mm(int dtype, const void* Ps, const float* W, float* partials, void* Ac, int nblocks, int B, int H, int N,
                       int ld, float inv_keep, hipStream_t st) {
-  if (dtype != 1 || H != 8 || ld <= 256 || ld > 1024 || ld % 8 != 0 || (long long)H * N * ld >= 2147483647LL) return 1;
+  if (dtype != 1 || H != 8 || ld > 1024 || ld % 8 != 0 || (long long)H * N * ld >= 2147483647LL) return 1;
   const long long rows = (long long)B * N;
+  if (ld <= 256) {        // short rows: the VALU kernel above (centred map only; the plain statistics stay on mix_stats_kernel)
+    if (!Ac) return 1;
+    hipLaunchKernelGGL(mix_center_small_kernel, dim3(nblocks), dim3(256), 0, st, (const bf16_t*)Ps, W, partials, (bf16_t*)Ac, rows, N, ld, inv_keep);
+    if (vu_prof_on()) vu_prof_note("mix_center_small_kernel", 0.0, (double)B * H * N * N * 4.0);
+    return vu_check_launch("vu_mix_stats_mm");
+  }
   const bool ex = N % 4 == 0;
   auto kern = Ac ? (ex ? mix_stats_mm_kernel<true, true> : mix_stats_mm_kernel<false, true>)
                  : (ex ? mix_stats_mm_kernel<true, false> : mix_stats_mm_kernel<false, false>);

@@ -68,24 +68,34 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
 template <int S, int KIND, int PF>
 __global__ __launch_bounds__(256, 2) void conv_tz_kernel(const tz_args a) {
   constexpr int NB = S == 16 ? 5 : 3;
-  constexpr int NOPS = 3 * NB;                        // (slot, block): slot = output plane (FWD) / input tensor (DG)
+  // Roles.  FORWARD: 9 = (convolution, output channel): a wave owns ONE output plane and holds THREE bf16 terms of its weights
+  // (NB operands x 3 terms = 60 / 36 registers).  hi + lo carry 16 significant bits, and q and k feed a softmax that is saturated in
+  // some blocks (un-normalised skip outputs, logits ~1e4), where a 1e-5 relative change of a logit operand flips one-hot rows: with
+  // two terms the teacher-forced first level-1 decoder block of Base went from 5e-3 to 9e-2 in dx; with three the products are those
+  // of the fp32 weights exactly.  (Three roles of three planes each with the third term in LDS: the 15 dependent ds_read -> MFMA
+  // pairs per tile cost the patch-16 forward its gain, 20 -> 28 us.)  DATA GRADIENT: 3 = the gradient's channel; two terms (a 1e-5
+  // relative error of a gradient is far below its bf16 storage rounding and feeds no softmax).
+  constexpr int NROLE = KIND == TZ_FWD ? 9 : 3;
+  constexpr int NSL = KIND == TZ_FWD ? 1 : 3;         // slots of the operand table: the role's own plane (FWD) / the input tensors (DG)
+  constexpr int NOPS = NSL * NB;
   constexpr int NT = KIND == TZ_FWD ? 1 : 3;          // input tensors a role reads
-  constexpr int NO = KIND == TZ_FWD ? 3 : (KIND == TZ_DG_SAME ? 1 : 2);      // accumulators (output planes) of a role
+  constexpr int NO = KIND == TZ_DG_CROSS ? 2 : 1;     // accumulators (output planes) of a role
   constexpr int PE = 3 * S * S;                       // elements per patch
   __shared__ float wl[3][81];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, g = lane >> 4;
   for (int i = threadIdx.x; i < 243; i += 256) wl[i / 81][i % 81] = a.w[i / 81][i % 81];
   __syncthreads();
   // (wave-uniform by construction; readfirstlane tells the compiler, so that pointers picked by role stay in scalar registers)
-  const int gw = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave), role = gw % 3, stream = gw / 3;
+  const int gw = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave), role = gw % NROLE, stream = gw / NROLE;
+  const int cv = KIND == TZ_FWD ? role / 3 : 0, cch = KIND == TZ_FWD ? role % 3 : role;      // FWD: convolution and output channel
 
   // ---- the role's banded weight operands, built once ----
-  tz_u4 Ahi[NOPS], Alo[NOPS];
+  tz_u4 Ahi[NOPS], Alo[NOPS], A3[KIND == TZ_FWD ? NOPS : 1];
 #pragma unroll
-  for (int sl = 0; sl < 3; ++sl)
+  for (int sl = 0; sl < NSL; ++sl)
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-      unsigned short hi[8], lo[8];
+      unsigned short hi[8], lo[8], l3[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         int plane, ky, kx;
@@ -106,18 +116,22 @@ __global__ __launch_bounds__(256, 2) void conv_tz_kernel(const tz_args a) {
         // FWD: role = convolution, slot = output channel, plane = input channel;  DG: slot = input tensor (= convolution), plane = its
         // channel co, role = the data-gradient channel ci, taps mirrored
         float wv;
-        if constexpr (KIND == TZ_FWD) wv = wl[role][(sl * 3 + plane) * 9 + kyc * 3 + kxc];
+        if constexpr (KIND == TZ_FWD) wv = wl[cv][(cch * 3 + plane) * 9 + kyc * 3 + kxc];
         else wv = wl[sl][(plane * 3 + role) * 9 + (2 - kyc) * 3 + (2 - kxc)];
         wv = ok ? wv : 0.f;
         const bf16_t h = (bf16_t)wv;
         const bf16_t l = (bf16_t)(wv - (float)h);
-        hi[j] = __builtin_bit_cast(unsigned short, h); lo[j] = __builtin_bit_cast(unsigned short, l);
+        const bf16_t l2 = (bf16_t)((wv - (float)h) - (float)l);
+        hi[j] = __builtin_bit_cast(unsigned short, h); lo[j] = __builtin_bit_cast(unsigned short, l); l3[j] = __builtin_bit_cast(unsigned short, l2);
       }
 #pragma unroll
       for (int d = 0; d < 4; ++d) {
         Ahi[sl * NB + b][d] = (unsigned)hi[2 * d] | ((unsigned)hi[2 * d + 1] << 16);
         Alo[sl * NB + b][d] = (unsigned)lo[2 * d] | ((unsigned)lo[2 * d + 1] << 16);
       }
+      if constexpr (KIND == TZ_FWD)
+        A3[sl * NB + b] = tz_u4{(unsigned)l3[0] | ((unsigned)l3[1] << 16), (unsigned)l3[2] | ((unsigned)l3[3] << 16),
+                                (unsigned)l3[4] | ((unsigned)l3[5] << 16), (unsigned)l3[6] | ((unsigned)l3[7] << 16)};
     }
 
   const int ntiles = S == 16 ? a.npatch : (a.npatch + 3) >> 2;
@@ -140,12 +154,12 @@ __global__ __launch_bounds__(256, 2) void conv_tz_kernel(const tz_args a) {
   const bf16_t* tin[NT];
   // (selects, not a.in[role]: indexing the kernel-argument struct with a run-time index is a LOAD from the argument segment -
   // inside the tile loop it drained the whole prefetch ring with s_waitcnt vmcnt(0) once per tile)
-  if constexpr (KIND == TZ_FWD) tin[0] = role == 0 ? a.in[0] : (role == 1 ? a.in[1] : a.in[2]);
+  if constexpr (KIND == TZ_FWD) tin[0] = cv == 0 ? a.in[0] : (cv == 1 ? a.in[1] : a.in[2]);
   else { tin[0] = a.in[0]; tin[1] = a.in[1]; tin[2] = a.in[2]; }
   bf16_t* outp[NO];        // FWD: the role's tensor (channel o added below);  DG: out[o], channel `role`
 #pragma unroll
   for (int o = 0; o < NO; ++o) {
-    if constexpr (KIND == TZ_FWD) outp[o] = (role == 0 ? a.out[0] : (role == 1 ? a.out[1] : a.out[2])) + o * (S * S);
+    if constexpr (KIND == TZ_FWD) outp[o] = (cv == 0 ? a.out[0] : (cv == 1 ? a.out[1] : a.out[2])) + cch * (S * S);
     else outp[o] = (o == 0 ? a.out[0] : a.out[1]) + role * (S * S);
   }
   // residual gradient of output o, channel `role`; without one the quad is still loaded (from the first input: any valid address of
@@ -208,6 +222,7 @@ __global__ __launch_bounds__(256, 2) void conv_tz_kernel(const tz_args a) {
     f32x4 acc[NO], accl[NO];            // (data gradient: the hi and lo products of an output run as two independent chains)
 #pragma unroll
     for (int o = 0; o < NO; ++o) { acc[o] = f32x4{0.f, 0.f, 0.f, 0.f}; accl[o] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    f32x4 acc3 = f32x4{0.f, 0.f, 0.f, 0.f};
     const tz_u4 z4 = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -225,15 +240,15 @@ __global__ __launch_bounds__(256, 2) void conv_tz_kernel(const tz_args a) {
       }
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
-        if constexpr (KIND == TZ_FWD) {
-#pragma unroll
-          for (int o = 0; o < 3; ++o) acc[o] = mma(Ahi[o * NB + b], B[b], acc[o]);
-#pragma unroll
-          for (int o = 0; o < 3; ++o) acc[o] = mma(Alo[o * NB + b], B[b], acc[o]);
+        if constexpr (KIND == TZ_FWD) {      // three independent chains (hi, lo, third term), added at the end
+          acc[0] = mma(Ahi[b], B[b], acc[0]);
+          accl[0] = mma(Alo[b], B[b], accl[0]);
+          acc3 = mma(A3[b], B[b], acc3);
         } else {
           const int o = (KIND == TZ_DG_CROSS && t > 0) ? 1 : 0;
           acc[o] = mma(Ahi[t * NB + b], B[b], acc[o]);
-          accl[o] = mma(Alo[t * NB + b], B[b], accl[o]);
+          if constexpr (KIND == TZ_DG_CROSS && S == 16) acc[o] = mma(Alo[t * NB + b], B[b], acc[o]);      // (one chain: this instantiation sits at 256 registers)
+          else accl[o] = mma(Alo[t * NB + b], B[b], accl[o]);
         }
       }
     }
@@ -242,6 +257,7 @@ __global__ __launch_bounds__(256, 2) void conv_tz_kernel(const tz_args a) {
 #pragma unroll
     for (int o = 0; o < NO; ++o) {
       f32x4 v = acc[o];
+      if constexpr (KIND == TZ_FWD) v += accl[o] + acc3;
       if constexpr (KIND != TZ_FWD) {
         v += accl[o];
         const uint2 r = make_uint2(T.ad[o].x & admask[o], T.ad[o].y & admask[o]);
@@ -471,14 +487,17 @@ int tz_launch(tz_args& a, hipStream_t st) {
   // large launches, 340 (one per CU: half the per-wave set-up) below ~8 tiles per stream; 1020 streams are slower everywhere
   static const int pf_env = tz_env("VU_TZ_PF", 0), ns_env = tz_env("VU_TZ_NS", 0);
   const int pf = pf_env ? pf_env : 2;
-  const int nsc = ns_env ? ns_env : (ntiles >= 5440 ? 680 : 340);
+  // (forward: 9 roles per stream - a third of the streams fill the same wave slots)
+  constexpr int NROLE = KIND == TZ_FWD ? 9 : 3;
+  const int nsc = ns_env ? ns_env : (ntiles >= 5440 ? 680 : 340) * 3 / NROLE;
   int per = ((ntiles + nsc - 1) / nsc + pf - 1) / pf * pf;
   int ns = ((ntiles + per - 1) / per + 3) / 4 * 4;
   a.nstreams = ns; a.per = per;
+  const unsigned grid = (unsigned)(ns * NROLE / 4);
   if (pf == 4) {
-    if constexpr (KIND == TZ_FWD) hipLaunchKernelGGL((conv_tz_kernel<S, KIND, 4>), dim3((unsigned)(ns * 3 / 4)), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((conv_tz_kernel<S, KIND, 2>), dim3((unsigned)(ns * 3 / 4)), dim3(256), 0, st, a);
-  } else hipLaunchKernelGGL((conv_tz_kernel<S, KIND, 2>), dim3((unsigned)(ns * 3 / 4)), dim3(256), 0, st, a);
+    if constexpr (KIND == TZ_FWD) hipLaunchKernelGGL((conv_tz_kernel<S, KIND, 4>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv_tz_kernel<S, KIND, 2>), dim3(grid), dim3(256), 0, st, a);
+  } else hipLaunchKernelGGL((conv_tz_kernel<S, KIND, 2>), dim3(grid), dim3(256), 0, st, a);
   return VU_OK;
 }
 

@@ -193,8 +193,14 @@ inline int flash_switch_op() { return attn_form().flash == 1; }
 // centred-map form (model path only; the stand-alone attention op returns the normalised map itself): the mixed map
 // is stored centred, BatchNorm's affine part is applied inside the two products that consume it.  Needs the MFMA mix
 // kernel and the streaming product kernels to cover the shape.
+// Round 6: short rows too (ld <= 256: mix_center_small_kernel; Base / Large level 1 and level 0, whose 384-wide heads the streaming
+// product kernels take as four 96-wide slices).  VU_ATTN_CENTERED_SMALL=0 keeps the round-1 pair (mix_stats + mix_apply) there.
+inline bool centered_small() { static const bool v = [] { const char* e = getenv("VU_ATTN_CENTERED_SMALL"); return !(e && e[0] == '0'); }(); return v; }
 inline bool centered_ok(const AttnDims& d) {
-  return d.centered && d.dtype == 1 && d.H == 8 && d.ld > 256 && d.ld <= 1024 && d.ld % 8 == 0 && d.D / d.H <= 96 && d.N >= 64;
+  const int dh = d.D / d.H;
+  if (!(d.centered && d.dtype == 1 && d.H == 8 && d.ld <= 1024 && d.ld % 8 == 0)) return false;
+  if (d.ld > 256) return dh <= 96 && d.N >= 64;
+  return centered_small() && d.N >= 32 && (dh <= 96 || (dh % 96 == 0 && d.N <= 256));
 }
 
 inline int stats_blocks(const AttnDims& d) {
