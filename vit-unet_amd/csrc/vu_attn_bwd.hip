@@ -1004,7 +1004,7 @@ int launch_map_bwd_row(const void* Ps, void* dA, const float* W, const float* c,
                        float* dW, float* dc, int B, int N, int ld, float inv_keep, float scale, hipStream_t st) {
   const long long rows = (long long)B * N;
   if constexpr (H == 8 && sizeof(T) == 2) {
-    if (ld <= 256 && ld >= 64 && !map_bwd_valu_forced())
+    if (ld <= 256 && ld >= 64 && !map_bwd_valu_forced())      // (round 6: level 0, ld = 56, measured on this kernel too: 27 vs 34 us per launch, step unchanged within noise - not taken)
       return launch_map_bwd_mm<1>(Ps, dA, W, c, gamma, stats, dW, dc, B, N, ld, inv_keep, scale, st);
   }
   if (ld <= 64) {

@@ -61,6 +61,11 @@ int vu_k_attn_scores(int dtype, const void* q, const void* k, void* Ps, int B, i
 // map x head-slice products for long rows / small head dims (streaming MFMA kernels); 1 = shape not covered
 int vu_k_attn_map_prod(int dtype, int cols, const void* M, const void* X, void* out, const float* sc, const float* kappa,
                        int B, int N, int D, int H, int ld, hipStream_t st);
+// short rows, 8 heads (vu_attn_fused.hip, round 6): scores + softmax + dropout + head mix + shifted moments in ONE launch; Ps and the
+// centred map Ac as vu_k_attn_scores + vu_k_mix_stats_mm(Ac) leave them, *nblocks rows of partials for vu_k_bn_finalize
+bool vu_attn_f1_ok(int dtype, int B, int N, int D, int H, int ld);
+int vu_k_attn_f1(const void* q, const void* k, void* Ps, void* Ac, const float* W, float* partials, int* nblocks, int B, int N, int D, int ld,
+                 float scale, vu_rng rng, hipStream_t st);
 int vu_k_attn_outer(int dtype, const void* a, const void* bmat, void* out, int B, int N, int D, int H, int ld,
                     float scale, hipStream_t st);
 

@@ -269,6 +269,14 @@ int attn_forward(const AttnDims& d, const vu_attn_params& p, const void* xq, con
       VU_TRY(vu_k_head_pad(s2, d2, 1, npatch, H, flash_dh(d), dh, st));
     } else VU_TRY(vu_k_flash_forward(fa, st));
   } else {
+  const double count = (double)B * N * N;
+  const bool cen = centered_ok(d);
+  int nstat = stats_blocks(d);
+  if (cen && vu_attn_f1_ok(dt, B, N, D, H, ld)) {
+    // short rows: logits, softmax, dropout, the head mix and its batch moments in one launch (vu_attn_fused.hip)
+    VU_TRY(vu_k_attn_f1(a.q, a.k, a.Ps, a.Ah, p.mix_w, partials, &nstat, B, N, D, ld, 1.0f / sqrtf((float)dh), ra, st));
+    VU_TRY(vu_check_launch("vu_attn_f1"));
+  } else {
   int fused = vu_k_attn_scores(dt, a.q, a.k, a.Ps, B, N, D, H, ld, 1.0f / sqrtf((float)dh), ra, st);
   if (fused < 0) return fused;
   if (fused == 1) {  // shape outside the fused kernel: S = scale * q k^T (model.py:155), then softmax + dropout
@@ -282,13 +290,12 @@ int attn_forward(const AttnDims& d, const vu_attn_params& p, const void* xq, con
     VU_TRY(vu_gemm_launch(dt, 0, g, st));
     VU_TRY(vu_k_softmax_dropout(dt, a.Ps, (long long)B * H * N, N, ld, ra, st));
   }
-  const double count = (double)B * N * N;
-  const bool cen = centered_ok(d);
   if (cen) {   // one pass over P: batch statistics + the centred mixed map (a.Ah holds Ac, not Ahat)
     const int r = vu_k_mix_stats_mm(dt, a.Ps, p.mix_w, partials, a.Ah, stats_blocks(d), B, H, N, ld, ra.inv_keep, st);
     if (r != 0) { if (r > 0) vu_set_error("attention: centred-map form not available for this shape"); return r < 0 ? r : VU_EUNSUPPORTED; }
   } else if (training) VU_TRY(vu_k_mix_stats(dt, a.Ps, p.mix_w, p.mix_b, partials, stats_blocks(d), B, H, N, ld, ra.inv_keep, st));
-  VU_TRY(vu_k_bn_finalize(partials, stats_blocks(d), p.mix_w, p.mix_b, p.bn_w, p.bn_b, p.run_mean, p.run_var,
+  }
+  VU_TRY(vu_k_bn_finalize(partials, nstat, p.mix_w, p.mix_b, p.bn_w, p.bn_b, p.run_mean, p.run_var,
                           a.stats, H, N, count, training, 0.1f, 1e-5f, st));
   if (!cen) VU_TRY(vu_k_mix_apply(dt, a.Ps, a.Ah, a.stats, B, H, N, ld, ra.inv_keep, st));
   const float* aff_sc = cen ? a.stats + VU_BN_STATS_SC(H) : nullptr;
