@@ -1083,13 +1083,16 @@ __global__ __launch_bounds__(WPB * 64, VU_FLASH_V1_WAVES(H, DH)) void flash_bwd_
 }
 
 // head-mix gradients from the sweep-1 partial sums
-__global__ __launch_bounds__(1024) void flash_bwd_mix_finalize_kernel(const float* __restrict__ partials, int nblocks,
-                                                                       const float* __restrict__ stats, float* dW, float* dc, int H,
-                                                                       float inv_keep) {
-  // one wave per column of the (nblocks x NT) partials, 16 columns per workgroup; fixed order: lane l adds rows l, l + 64, ...
-  // in fp64, then a shuffle tree.  (One workgroup walking all 72 columns took 11.5 us; five run side by side.)
+__global__ __launch_bounds__(256) void flash_bwd_mix_finalize_kernel(const float* __restrict__ partials, int nblocks,
+                                                                      const float* __restrict__ stats, float* dW, float* dc, int H,
+                                                                      float inv_keep) {
+  // one wave per column of the (nblocks x NT) partials, 4 columns per workgroup; fixed order: lane l adds rows l, l + 64, ...
+  // in fp64, then a shuffle tree.  (One workgroup walking all 72 columns took 11.5 us.)  Round 6: 256-thread workgroups instead of
+  // five of 1024 - this launch runs beside the low-priority dv sweep, whose resident workgroups leave no CU with 16 free wave slots:
+  // the 1024-thread form sat 20 us in the dispatcher (28.9 us per launch in the step's trace for a 240 KB reduction) and the dk
+  // sweep behind it waited; the sums and their order are unchanged.
   const int NT = H * H + H;
-  const int c2 = blockIdx.x * 16 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int c2 = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (c2 >= NT) return;          // wave-uniform
   // (eight independent accumulators over loads issued together: as ONE dependent chain the 26 strided rows of a lane at 64 images
   // were 26 memory round trips - 22.9 us per launch)
@@ -3116,7 +3119,7 @@ int launch_backward(const vu_flash_args& a, hipStream_t st) {
     if (vu_prof_on()) vu_prof_note(v1_tag("flash_bwd_delta_kernel", a.N), 4.0 * E * DH + 6.0 * E * H, 4.0 * act);
   }
   VU_TRY(vu_check_launch("flash_bwd_delta"));
-  hipLaunchKernelGGL(flash_bwd_mix_finalize_kernel, dim3((unsigned)((H * H + H + 15) / 16)), dim3(1024), 0, st, a.partials, nblk, a.stats, a.d_mix_w, a.d_mix_b, H, a.rng.inv_keep);
+  hipLaunchKernelGGL(flash_bwd_mix_finalize_kernel, dim3((unsigned)((H * H + H + 3) / 4)), dim3(256), 0, st, a.partials, nblk, a.stats, a.d_mix_w, a.d_mix_b, H, a.rng.inv_keep);
   VU_TRY(vu_check_launch("flash_bwd_mix_finalize"));
   if (!fused) {
     hipLaunchKernelGGL(k2, dim3(nblk), dim3(WPB * 64), lds2, st, q, k, v, dO, a.lse2, a.delta, a.stats, (bf16_t*)a.dq, a.B, a.N, c, a.scale, a.rng);
@@ -3313,7 +3316,7 @@ int launch_backward_v2(const vu_flash_args& a, hipStream_t st) {
     if (vu_prof_on()) vu_prof_note("flash2_bwd_delta_kernel", 4.0 * E * DH + 6.0 * E * H, 4.0 * act);
     VU_TRY(vu_check_launch("flash2_bwd_delta"));
   }
-  hipLaunchKernelGGL(flash_bwd_mix_finalize_kernel, dim3((unsigned)((H * H + H + 15) / 16)), dim3(1024), 0, st, a.partials, nblk, a.stats, a.d_mix_w, a.d_mix_b, H, a.rng.inv_keep);
+  hipLaunchKernelGGL(flash_bwd_mix_finalize_kernel, dim3((unsigned)((H * H + H + 3) / 4)), dim3(256), 0, st, a.partials, nblk, a.stats, a.d_mix_w, a.d_mix_b, H, a.rng.inv_keep);
   VU_TRY(vu_check_launch("flash_bwd_mix_finalize"));
   const bool late_fork = fp && fp->mode == 1;
   if (late_fork) {
