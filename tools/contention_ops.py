@@ -25,7 +25,7 @@ ap.add_argument("--load-mode", default="process", choices=["process", "thread"],
                 help="process: the load is a second PROCESS on the GPU (its queues are time-sliced against ours: waves can be saved / "
                      "restored); thread: the SAME train-step loop on a second stream of THIS process (concurrent kernels, one process: "
                      "no time-slicing between processes).  Round 6, review item 6: do the two sharing faults need a second process?")
-ap.add_argument("--only", default="", help="comma list of op families to run: conv,dgrad,ln,retile,gemm (default: all of them)")
+ap.add_argument("--only", default="", help="comma list of op families to run: conv,dgrad,wgrad,ln,retile,gemm (default: all of them)")
 args = ap.parse_args()
 only = set(x for x in args.only.split(",") if x)
 child = None
@@ -149,6 +149,15 @@ for s, N in (() if ap_only else ((32, 49), (16, 196), (8, 784), (4, 3136))):    
     if not only or "dgrad" in only:
       repeat(f"conv3x3_qkv_dgrad s={s}",
            lambda: check(L.vu_conv3x3_qkv_dgrad(1, ptr(dq), ptr(dk), ptr(dv), ptr(w[0]), ptr(w[1]), ptr(w[2]), None, None, ptr(dx), None, npatch, 3, s, st)), [dx])
+    if (not only or "wgrad" in only) and s % 8 == 0:      # the three weight gradients, partial sums through a lent slab (fixed order)
+        dws = [torch.zeros(3, 3, 3, 3, device=dev) for _ in range(3)]
+        scr = torch.empty(4 << 20, dtype=torch.uint8, device=dev)
+
+        def wg():
+            for t_ in dws:
+                t_.zero_()
+            check(L.vu_conv3x3_qkv_wgrad(1, ptr(dq), ptr(dk), ptr(dv), ptr(x), ptr(x), ptr(dws[0]), ptr(dws[1]), ptr(dws[2]), ptr(scr), scr.numel(), npatch, 3, s, st))
+        repeat(f"conv3x3_qkv_wgrad s={s}", wg, dws)
     # residual add + LayerNorm over (N, D)
     P = N * D
     a = torch.randn(B, N, D, generator=g).to(bf).to(dev)
