@@ -370,7 +370,7 @@ def main():
                 for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))[::-1]:      # newest round first
                     pj = json.load(open(f))
                     wl = pj.get("workload", {"model": "base", "batch": 64})      # (the PMC passes run the default bench.py workload)
-                    if wl.get("model") != a.model or wl.get("batch") != a.batch:
+                    if wl.get("model") != a.model or wl.get("batch") != a.batch or wl.get("dtype", "bf16") != a.dtype:
                         continue          # counters of another workload say nothing about this launch: traffic stays null
                     # several template instances can share the name: the dominant launch is the one with most traffic
                     # (profiler tag -> kernel symbol: the fused delta + dq sweep of the 4-head form is an instantiation of flash_bwd_delta_kernel)
