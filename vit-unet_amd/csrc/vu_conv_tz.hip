@@ -86,7 +86,13 @@ __global__ __launch_bounds__(256, 2) void conv_tz_kernel(const tz_args a) {
   for (int i = threadIdx.x; i < 243; i += 256) wl[i / 81][i % 81] = a.w[i / 81][i % 81];
   __syncthreads();
   // (wave-uniform by construction; readfirstlane tells the compiler, so that pointers picked by role stay in scalar registers)
-  const int gw = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave), role = gw % NROLE, stream = gw / NROLE;
+  // XCD-aware roles.  Workgroups go to the 8 XCDs round-robin and every XCD has its own L2: the NROLE roles of a tile stream must
+  // sit on ONE XCD, or each of them fetches the tile from HBM again (the first mapping - consecutive waves = the roles of a stream -
+  // spread them over 2 - 3 neighbouring workgroups = XCDs: rocprofv3 FETCH + WRITE 118 MB per forward launch for 77 MB, 125 for
+  // the data gradient's 96).  So a whole WORKGROUP has one role, and the workgroups b, b + 8, b + 16, ... of one XCD take the roles
+  // of the same four streams: role = (b / 8) % NROLE, streams 4 ((b / (8 NROLE)) 8 + b % 8) + wave.  (grid: a multiple of 8 NROLE)
+  const int bid = __builtin_amdgcn_readfirstlane((int)blockIdx.x);
+  const int role = (bid >> 3) % NROLE, stream = 4 * ((bid / (8 * NROLE)) * 8 + (bid & 7)) + __builtin_amdgcn_readfirstlane(wave);
   const int cv = KIND == TZ_FWD ? role / 3 : 0, cch = KIND == TZ_FWD ? role % 3 : role;      // FWD: convolution and output channel
 
   // ---- the role's banded weight operands, built once ----
@@ -338,7 +344,8 @@ __global__ __launch_bounds__(256, 2) void conv_tzw_kernel(const tzw_args a) {
   constexpr int PE = 3 * S * S, TP = S == 16 ? 2 : 8, PF = 2, LD = 6;
   __shared__ float red[81][17];          // [weight][wave x 16-lane row] (+1: the 81 final readers walk different rows)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, g = lane >> 4;
-  const int role = blockIdx.x % 3, stream = (blockIdx.x / 3) * 4 + wave;          // (wave-uniform)
+  // (XCD-aware like conv_tz_kernel: the three roles of a stream in workgroups b, b + 8, b + 16 of one XCD - they share x in its L2)
+  const int role = (blockIdx.x >> 3) % 3, stream = 4 * ((blockIdx.x / 24) * 8 + (blockIdx.x & 7)) + wave;          // (wave-uniform)
   const bf16_t* dp = role == 0 ? a.dout[0] : (role == 1 ? a.dout[1] : a.dout[2]);
   const bf16_t* xp = role == 0 ? a.x[0] : (role == 1 ? a.x[1] : a.x[2]);
   const int ntiles = (a.npatch + TP - 1) / TP;
@@ -457,14 +464,19 @@ __global__ __launch_bounds__(256, 2) void conv_tzw_kernel(const tzw_args a) {
   }
 }
 
-// one wave per weight: the partial sums of the role's workgroups (blocks role, role + 3, ...) in a fixed order, then a fixed shuffle tree
+// one wave per weight: the partial sums of the role's workgroups in a fixed order, then a fixed shuffle tree
 __global__ __launch_bounds__(1024) void conv_tzw_reduce_kernel(const float* __restrict__ part, int nblocks, float* dwq, float* dwk, float* dwv) {
   const int o = blockIdx.x * 16 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (o >= 243) return;
   const int role = o / 81, e = o % 81;
   float s4[4] = {0.f, 0.f, 0.f, 0.f};
-  int b = role + 3 * lane, u = 0;
-  for (; b < nblocks; b += 3 * 64, u = (u + 1) & 3) s4[u] += part[(long long)b * 96 + e];
+  // the role's workgroups: b with (b / 8) % 3 == role, i.e. b = 24 i + 8 role + x (x = 0..7); lane l takes the n-th of them, n = l, l + 64, ...
+  const int nrole = nblocks / 3;
+  int u = 0;
+  for (int n = lane; n < nrole; n += 64, u = (u + 1) & 3) {
+    const int b = 24 * (n >> 3) + 8 * role + (n & 7);
+    s4[u] += part[(long long)b * 96 + e];
+  }
   float v = (s4[0] + s4[1]) + (s4[2] + s4[3]);
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
@@ -489,11 +501,11 @@ int tz_launch(tz_args& a, hipStream_t st) {
   const int pf = pf_env ? pf_env : 2;
   // (forward: 9 roles per stream - a third of the streams fill the same wave slots)
   constexpr int NROLE = KIND == TZ_FWD ? 9 : 3;
-  const int nsc = ns_env ? ns_env : (ntiles >= 5440 ? 680 : 340) * 3 / NROLE;
+  const int nsc = ns_env ? ns_env : (KIND == TZ_FWD ? 226 : (ntiles >= 5440 ? 680 : 340));      // (forward, 9 roles: 226 streams fill the wave slots at every size measured)
   int per = ((ntiles + nsc - 1) / nsc + pf - 1) / pf * pf;
-  int ns = ((ntiles + per - 1) / per + 3) / 4 * 4;
+  int ns = ((ntiles + per - 1) / per + 31) / 32 * 32;          // streams in groups of 32 = 8 XCDs x the 4 waves of a workgroup
   a.nstreams = ns; a.per = per;
-  const unsigned grid = (unsigned)(ns * NROLE / 4);
+  const unsigned grid = (unsigned)(ns / 4 * NROLE);
   if (pf == 4) {
     if constexpr (KIND == TZ_FWD) hipLaunchKernelGGL((conv_tz_kernel<S, KIND, 4>), dim3(grid), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((conv_tz_kernel<S, KIND, 2>), dim3(grid), dim3(256), 0, st, a);
@@ -539,7 +551,7 @@ int vu_k_conv_tz_qkv_wgrad(const void* dq, const void* dk, const void* dv, const
   a.part = part; a.npatch = (int)npatch;
   const int tp = s == 16 ? 2 : 8, ntiles = (int)((npatch + tp - 1) / tp);
   // streams PER ROLE (every role walks all tiles): 170 workgroups x 4 waves for large launches, 85 x 4 below ~8 tiles per stream
-  const int wgs = ntiles >= 5440 ? 170 : (ntiles >= 340 ? 85 : (ntiles + 3) / 4);
+  const int wgs = ntiles >= 5440 ? 168 : (ntiles >= 340 ? 88 : ((ntiles + 3) / 4 + 7) / 8 * 8);      // (multiples of 8: one per XCD)
   a.nstreams = wgs * 4;
   a.per = ((ntiles + a.nstreams - 1) / a.nstreams + 1) / 2 * 2;
   if (s == 16) hipLaunchKernelGGL(conv_tzw_kernel<16>, dim3((unsigned)(3 * wgs)), dim3(256), 0, st, a);
