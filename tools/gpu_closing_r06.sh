@@ -10,3 +10,11 @@ for cfg in "base 20" "base 64" "lite 32" "large 16"; do
   timeout -k 10 400 python tools/nondet_check.py --model $1 --B $2 --reps 16 --load 45 2>&1 | grep -v amdgpu.ids | grep "rep 1:\|rep 8:\|rep 15:\|load\|NONDET" >> $O
 done
 cat $O
+T=gpurun_out/r06_train_sanity.txt
+echo "# tools/train_sanity.py on the round-6 build (fused bf16 step on a fixed synthetic batch, lr 1e-3): last two reports of each run" > $T
+timeout -k 10 300 python tools/train_sanity.py base 300 64 2>&1 | grep "step" | tail -2 >> $T
+timeout -k 10 300 python tools/train_sanity.py base 300 16 2>&1 | grep "step" | tail -2 >> $T
+timeout -k 10 300 python tools/train_sanity.py large 150 16 2>&1 | grep "step" | tail -2 >> $T
+timeout -k 10 300 python tools/train_sanity.py seg512 100 32 2>&1 | grep "step" | tail -2 >> $T
+timeout -k 10 300 python tools/train_sanity.py lite 200 32 2>&1 | grep "step" | tail -2 >> $T
+cat $T
