@@ -87,7 +87,7 @@ def test_ops_are_bit_reproducible_while_another_process_uses_the_gpu():
     # (round 4's counts - 45 s of load, 120 repetitions per op - under VU_SHARING_LONG=1; the default keeps the driver's suite inside
     # its 10 minutes.  The ops include the round-6 Toeplitz / Gram convolution kernels: the forward / data gradient at patch 16 and 8
     # take them by default, the weight gradient is in the list with a lent scratch slab.)
-    load, iters = ("45", "120") if os.environ.get("VU_SHARING_LONG") else ("35", "90")
+    load, iters = ("45", "120") if os.environ.get("VU_SHARING_LONG") else ("25", "60")
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "contention_ops.py"), "--load", load, "--iters", iters],
                        capture_output=True, text=True, timeout=420, env=env)
     assert "CONTENTION_OPS CLEAN" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
@@ -106,7 +106,7 @@ def test_four_head_recompute_attention_under_gpu_sharing():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CONTENTION_ATTN_ONLY="1")
     # (VU_SHARING_LONG=1: round 4's 60 s / 30 repetitions.  The 8-head case runs the training forward + backward with the probability
     # cache on - the round-5 cached sweeps, their LDS-DMA rings included - because that is the op's default.)
-    load, iters = ("60", "30") if os.environ.get("VU_SHARING_LONG") else ("45", "20")
+    load, iters = ("60", "30") if os.environ.get("VU_SHARING_LONG") else ("30", "12")
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "contention_ops.py"), "--load", load, "--iters", iters, "--B", "16", "--attn", "all"],
                        capture_output=True, text=True, timeout=420, env=env)
     assert "CONTENTION_OPS CLEAN" in r.stdout, r.stdout[-2000:]
