@@ -2,6 +2,7 @@
 // statistics without a pass over the maps.  (Split from vu_attn.hip to keep the translation units parallel.)
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <type_traits>
 #include "vu_kernels.h"
 // =============================================================================================
@@ -149,13 +150,25 @@ __global__ __launch_bounds__(1024) void map_bwd_partials_reduce_kernel(const flo
   for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m, 64);
   if (lane == 0) { if (i < hh) dW[i] += a; else dc[i - hh] += a; }
 }
-inline float* map_bwd_slab(long long nblocks, int n) {
+// (nblocks rows of h*h + h floats; `defer`: the slab came from the executor's arena and the reduce is queued, vu_gemm.h)
+inline float* map_bwd_slab(long long nblocks, int H, hipStream_t st, bool& defer) {
+  const size_t floats = (size_t)nblocks * (H * H + H);
+  float* p = vu_deferred_take(floats, st);
+  defer = p != nullptr;
+  if (defer) return p;
   void* scr = nullptr; size_t bytes = 0;
   vu_gemm_get_scratch(&scr, &bytes);
-  return (scr && bytes >= (size_t)nblocks * n * sizeof(float)) ? (float*)scr : nullptr;
+  return (scr && bytes >= floats * sizeof(float)) ? (float*)scr : nullptr;
 }
-inline void map_bwd_reduce(float* part, long long nblocks, int H, float* dW, float* dc, hipStream_t st) {
+inline void map_bwd_reduce(float* part, long long nblocks, int H, float* dW, float* dc, hipStream_t st, bool defer) {
   const int n = H * H + H;
+  if (defer) {
+    vu_defred d;
+    memset(&d, 0, sizeof(d));
+    d.kind = VU_DEFRED_MAP; d.nblocks = (int)nblocks; d.n = n; d.hh = H * H; d.part = part; d.dst[0] = dW; d.dst[1] = dc;
+    vu_deferred_push(d);
+    return;
+  }
   hipLaunchKernelGGL(map_bwd_partials_reduce_kernel, dim3((unsigned)((n + 15) / 16)), dim3(1024), 0, st, part, (int)nblocks, n, H * H, dW, dc);
 }
 
@@ -977,10 +990,11 @@ int launch_map_bwd_mm(const void* Ps, void* dA, const float* W, const float* c, 
   static const int cap_env = getenv("VU_MAP_BWD_CAP") ? atoi(getenv("VU_MAP_BWD_CAP")) : 0;     // measurement switch
   if (cap_env > 0 && WPR == 1) { if (grid > cap_env) grid = cap_env; }
   else if (grid > cap) grid = cap;
-  float* part = map_bwd_slab(grid, 8);
+  bool defer = false;
+  float* part = map_bwd_slab(grid, 8, st, defer);
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, (const bf16_t*)Ps, (bf16_t*)dA, W, c, gamma, stats, dW, dc,
                      rows, N, ld, inv_keep, scale, part);
-  if (part) map_bwd_reduce(part, grid, 8, dW, dc, st);
+  if (part) map_bwd_reduce(part, grid, 8, dW, dc, st, defer);
   if (vu_prof_on()) vu_prof_note(WPR == 4 ? "map_bwd_mm_kernel" : "map_bwd_mm_kernel<1 wave/row>", 0.0, (double)B * 8 * N * N * 3 * 2.0);
   return vu_check_launch("vu_map_bwd");
 }
@@ -1011,19 +1025,21 @@ int launch_map_bwd_row(const void* Ps, void* dA, const float* W, const float* c,
     // short rows (level 0: N = 49): 16 threads per row, and few workgroups - every workgroup ends in h*h + h float atomics
     // on the same addresses, ~50 ns each when contended (784 four-row workgroups took 57 us for 2.8 MB of map)
     long long grid = (rows + 15) / 16;
-    float* part = map_bwd_slab(grid > 512 ? 512 : grid, H);
+    bool defer = false;
+    float* part = map_bwd_slab(grid > 512 ? 512 : grid, H, st, defer);
     const long long cap = part ? 512 : 96;
     if (grid > cap) grid = cap;
     hipLaunchKernelGGL((map_bwd_row_kernel<T, H, 16>), dim3((unsigned)grid), dim3(256), 0, st, (const T*)Ps, (T*)dA, W, c, gamma,
                        stats, dW, dc, rows, N, ld, inv_keep, scale, part);
-    if (part) map_bwd_reduce(part, grid, H, dW, dc, st);
+    if (part) map_bwd_reduce(part, grid, H, dW, dc, st, defer);
     if (vu_prof_on()) vu_prof_note("map_bwd_row_kernel", 0.0, (double)B * H * N * N * 3 * sizeof(T));
   } else if (ld <= 256) {
     long long grid = (rows + 3) / 4; if (grid > 2048) grid = 2048;
-    float* part = map_bwd_slab(grid, H);
+    bool defer = false;
+    float* part = map_bwd_slab(grid, H, st, defer);
     hipLaunchKernelGGL((map_bwd_row_kernel<T, H, 64>), dim3((unsigned)grid), dim3(256), 0, st, (const T*)Ps, (T*)dA, W, c, gamma,
                        stats, dW, dc, rows, N, ld, inv_keep, scale, part);
-    if (part) map_bwd_reduce(part, grid, H, dW, dc, st);
+    if (part) map_bwd_reduce(part, grid, H, dW, dc, st, defer);
     if (vu_prof_on()) vu_prof_note("map_bwd_row_kernel", 0.0, (double)B * H * N * N * 3 * sizeof(T));
   } else if (sizeof(T) == 2 && (ld <= 1024 || (ld <= 4096 && H <= 4))) {
     // one block per row: 256 threads (ld <= 1024) or 1024 threads (ld <= 4096; 128-VGPR budget -> H <= 4)

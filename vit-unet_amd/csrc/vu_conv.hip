@@ -5,6 +5,7 @@
 // clamped halo scalars) so all loads of a thread are in flight together; q, k and v are produced
 // from one read of x; their data gradients are summed in one kernel.
 #include <stdlib.h>
+#include <string.h>
 #include "vu_kernels.h"
 
 namespace {
@@ -316,8 +317,18 @@ __global__ __launch_bounds__(1024) void conv_wgrad_reduce_kernel(WgradSet set, c
   const int o = blockIdx.x * 16 + (threadIdx.x >> 6), lane = threadIdx.x & 63;       // o = (conv * C + co) * 32 + i
   const int y = o >> 5, i = o & 31;
   if (y >= nconv * C || i > NW) return;       // wave-uniform
-  float a = 0.f;
-  for (int b = lane; b < nblocks; b += 64) a += part[((long long)y * nblocks + b) * 32 + i];
+  float s[4] = {0.f, 0.f, 0.f, 0.f};      // four chains over loads issued together (the order of the queued form, vu_tsgemm.hip)
+  const float* src = part + (long long)y * nblocks * 32 + i;
+  int b = lane;
+  for (; b + 3 * 64 < nblocks; b += 4 * 64) {
+    float x[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) x[u] = src[(long long)(b + 64 * u) * 32];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s[u] += x[u];
+  }
+  for (; b < nblocks; b += 64) s[0] += src[(long long)b * 32];
+  float a = (s[0] + s[1]) + (s[2] + s[3]);
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m, 64);
   if (lane == 0) {
@@ -637,11 +648,13 @@ static int wgrad_launch(int dtype, int dout_f32, const WgradSet& set, int nconv,
   const long long nq = npatch * s * s / 4;
   if (nq == 0) return VU_OK;
   if (!dout_f32 && nconv == 3 && vu_conv_tz_ok(dtype, C, s, npatch) && !wgrad_valu_forced()) {      // Gram form (vu_conv_tz.hip): needs the lent slab
-    void* scr = nullptr; size_t scr_bytes = 0;
-    vu_gemm_get_scratch(&scr, &scr_bytes);
+    void* scr = vu_deferred_take(vu_conv_tz_wgrad_scratch_floats(), st);      // the partials stay until the executor's flush: the reduce is queued
+    const int defer = scr != nullptr;
+    size_t scr_bytes = defer ? vu_conv_tz_wgrad_scratch_floats() * sizeof(float) : 0;
+    if (!defer) vu_gemm_get_scratch(&scr, &scr_bytes);
     if (scr && scr_bytes >= vu_conv_tz_wgrad_scratch_floats() * sizeof(float)) {
       if (int e = vu_k_conv_tz_qkv_wgrad(set.dout[0], set.dout[1], set.dout[2], set.in[0], set.in[1], set.dw[0], set.dw[1], set.dw[2], (float*)scr,
-                                         npatch, s, st)) return e;
+                                         npatch, s, st, defer)) return e;
       if (vu_prof_on()) vu_prof_note("conv_tzw_kernel(+reduce)", 2.0 * 243.0 / 9.0 * C * C * nq * 4, (double)nq * 4 * C * (set.in[0] == set.in[1] ? 4 : 5) * 2.0);
       return vu_check_launch("vu_conv3x3_wgrad (Gram form)");
     }
@@ -652,28 +665,48 @@ static int wgrad_launch(int dtype, int dout_f32, const WgradSet& set, int nconv,
     // 4 waves 131 us, 512 x 4: 93 us, 256 x 4: 141 us per launch)
     constexpr int WV = 16;
     long long g = (nunits + WV - 1) / WV; if (g > 256) g = 256;
-    void* scr = nullptr; size_t scr_bytes = 0;
-    vu_gemm_get_scratch(&scr, &scr_bytes);            // lent by the model executor: deterministic sum instead of float atomics
-    float* part = (scr && scr_bytes >= (size_t)g * 1024 * 4) ? (float*)scr : nullptr;
+    float* part = vu_deferred_take((size_t)g * 1024, st);      // queued reduce (vu_gemm.h) when the executor has lent its arena
+    const bool defer = part != nullptr;
+    if (!defer) {
+      void* scr = nullptr; size_t scr_bytes = 0;
+      vu_gemm_get_scratch(&scr, &scr_bytes);            // lent by the model executor: deterministic sum instead of float atomics
+      part = (scr && scr_bytes >= (size_t)g * 1024 * 4) ? (float*)scr : nullptr;
+    }
     auto kern = set.in[0] == set.in[1] ? conv_wgrad_mm_kernel<WV, true> : conv_wgrad_mm_kernel<WV, false>;
     hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(WV * 64), 0, st, (const bf16_t*)set.dout[0], (const bf16_t*)set.dout[1],
                        (const bf16_t*)set.dout[2], (const bf16_t*)set.in[0], (const bf16_t*)set.in[1], set.dw[0], set.dw[1], set.dw[2], nunits, s, part);
-    if (part) hipLaunchKernelGGL(conv_wgrad_mm_reduce_kernel, dim3(64), dim3(1024), 0, st, part, (int)g, set.dw[0], set.dw[1], set.dw[2]);
+    if (defer) {
+      vu_defred d;
+      memset(&d, 0, sizeof(d));
+      d.kind = VU_DEFRED_WGRAD_MM; d.nblocks = (int)g; d.part = part; d.dst[0] = set.dw[0]; d.dst[1] = set.dw[1]; d.dst[2] = set.dw[2];
+      vu_deferred_push(d);
+    } else if (part) hipLaunchKernelGGL(conv_wgrad_mm_reduce_kernel, dim3(64), dim3(1024), 0, st, part, (int)g, set.dw[0], set.dw[1], set.dw[2]);
     if (vu_prof_on()) vu_prof_note("conv_wgrad_mm_kernel", 0.0, (double)nq * 4 * C * 5 * 2.0);
     return vu_check_launch("vu_conv3x3_wgrad");
   }
   const int gx = grid_for(nq, nconv == 1 ? 512 : 256);
   float* part = nullptr;
+  bool defer = false;
   if (C == 3) {        // (the reduce kernel's 32-float rows hold 27 weights + the bias sum)
-    void* scr = nullptr; size_t scr_bytes = 0;
-    vu_gemm_get_scratch(&scr, &scr_bytes);            // lent by the model executor
-    if (scr && scr_bytes >= (size_t)gx * nconv * C * 32 * sizeof(float)) part = (float*)scr;
+    part = vu_deferred_take((size_t)gx * nconv * C * 32, st);
+    defer = part != nullptr;
+    if (!defer) {
+      void* scr = nullptr; size_t scr_bytes = 0;
+      vu_gemm_get_scratch(&scr, &scr_bytes);            // lent by the model executor
+      if (scr && scr_bytes >= (size_t)gx * nconv * C * 32 * sizeof(float)) part = (float*)scr;
+    }
   }
   VU_CONV_C(C,
     if (dtype == 0) hipLaunchKernelGGL((conv_wgrad_kernel<float, float, CC>), dim3(gx, nconv * CC), dim3(256), 0, st, set, nq, s, part);
     else if (dout_f32) hipLaunchKernelGGL((conv_wgrad_kernel<float, bf16_t, CC>), dim3(gx, nconv * CC), dim3(256), 0, st, set, nq, s, part);
     else hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, bf16_t, CC>), dim3(gx, nconv * CC), dim3(256), 0, st, set, nq, s, part);)
-  if (part) hipLaunchKernelGGL(conv_wgrad_reduce_kernel<3>, dim3((unsigned)((nconv * 3 * 32 + 15) / 16)), dim3(1024), 0, st, set, part, gx, nconv);
+  if (defer) {
+    vu_defred d;
+    memset(&d, 0, sizeof(d));
+    d.kind = VU_DEFRED_WGRAD3; d.nblocks = gx; d.nconv = nconv; d.part = part;
+    for (int cv = 0; cv < nconv; ++cv) { d.dst[cv] = set.dw[cv]; d.dst[3 + cv] = set.dbias[cv]; }
+    vu_deferred_push(d);
+  } else if (part) hipLaunchKernelGGL(conv_wgrad_reduce_kernel<3>, dim3((unsigned)((nconv * 3 * 32 + 15) / 16)), dim3(1024), 0, st, set, part, gx, nconv);
   if (vu_prof_on()) vu_prof_note(nconv == 1 ? "conv_wgrad_kernel<1>" : "conv_wgrad_kernel<3>", 0.0,
                                  (double)nq * 4 * C * nconv * ((dout_f32 || dtype == 0 ? 4.0 : 2.0) + (dtype == 0 ? 4.0 : 2.0)));
   return vu_check_launch("vu_conv3x3_wgrad");

@@ -27,6 +27,7 @@
 //
 // Weights reach the waves through LDS (vector loads, then ds_read): never through scalar loads inside a loop.
 #include <stdlib.h>
+#include <string.h>
 #include "vu_kernels.h"
 
 namespace {
@@ -544,7 +545,7 @@ int vu_k_conv_tz_qkv_dgrad(const void* dq, const void* dk, const void* dv, const
 
 size_t vu_conv_tz_wgrad_scratch_floats() { return (size_t)510 * 96; }
 int vu_k_conv_tz_qkv_wgrad(const void* dq, const void* dk, const void* dv, const void* xq, const void* xkv, float* dwq, float* dwk, float* dwv,
-                           float* part, long long npatch, int s, hipStream_t st) {
+                           float* part, long long npatch, int s, hipStream_t st, int defer) {
   tzw_args a;
   a.dout[0] = (const bf16_t*)dq; a.dout[1] = (const bf16_t*)dk; a.dout[2] = (const bf16_t*)dv;
   a.x[0] = (const bf16_t*)xq; a.x[1] = a.x[2] = (const bf16_t*)xkv;
@@ -556,6 +557,12 @@ int vu_k_conv_tz_qkv_wgrad(const void* dq, const void* dk, const void* dv, const
   a.per = ((ntiles + a.nstreams - 1) / a.nstreams + 1) / 2 * 2;
   if (s == 16) hipLaunchKernelGGL(conv_tzw_kernel<16>, dim3((unsigned)(3 * wgs)), dim3(256), 0, st, a);
   else hipLaunchKernelGGL(conv_tzw_kernel<8>, dim3((unsigned)(3 * wgs)), dim3(256), 0, st, a);
+  if (defer) {
+    vu_defred d;
+    memset(&d, 0, sizeof(d));
+    d.kind = VU_DEFRED_TZW; d.nblocks = 3 * wgs; d.part = part; d.dst[0] = dwq; d.dst[1] = dwk; d.dst[2] = dwv;
+    vu_deferred_push(d);
+  } else
   hipLaunchKernelGGL(conv_tzw_reduce_kernel, dim3(16), dim3(1024), 0, st, (const float*)part, 3 * wgs, dwq, dwk, dwv);
   return VU_OK;
 }

@@ -27,6 +27,20 @@ void vu_gemm_get_scratch(void** p, size_t* bytes);
 // lends the arena flushes before anything outside its call reads the outputs, and before taking the arena back.
 void vu_tsgemm_set_arena(void* p, size_t bytes);
 int vu_tsgemm_flush(hipStream_t st);
+// The same arena also takes the per-workgroup partial sums of OTHER weight-gradient kernels (the q / k / v convolutions' Gram and
+// stencil forms, the head-mix gradients of the map-backward kernels): their fixed-order tails - one wave per output element over
+// the workgroups' partials - were 21 launches of 5 - 6 us each per Base backward; queued here they are ONE launch at the flush.
+// vu_deferred_take returns nullptr when no arena is lent (stand-alone op calls: the kernel's own reduce launch runs at once);
+// the summation order of a queued reduction is the one of its stand-alone kernel (bit-identical results).
+enum { VU_DEFRED_TZW = 0, VU_DEFRED_WGRAD_MM = 1, VU_DEFRED_WGRAD3 = 2, VU_DEFRED_MAP = 3 };
+struct vu_defred {
+  int kind, blk0;                // blk0: set by the queue
+  int nblocks, n, hh, nconv;     // partial rows; MAP: outputs n = hh + h; WGRAD3: convolutions in the set
+  const float* part;
+  float* dst[6];                 // TZW / WGRAD_MM: dwq, dwk, dwv; WGRAD3: dw[3], dbias[3]; MAP: dW, dc
+};
+float* vu_deferred_take(size_t floats, hipStream_t st);
+void vu_deferred_push(const vu_defred& d);
 
 struct vu_gemm_args {
   const void* A; const void* B; void* C;

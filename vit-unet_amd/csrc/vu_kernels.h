@@ -38,7 +38,7 @@ int vu_k_conv_tz_qkv_dgrad(const void* dq, const void* dk, const void* dv, const
                            const void* add_q, const void* add_kv, void* dxq, void* dxkv, long long npatch, int s, hipStream_t st);
 size_t vu_conv_tz_wgrad_scratch_floats();       // per-workgroup partial sums of the weight-gradient form below
 int vu_k_conv_tz_qkv_wgrad(const void* dq, const void* dk, const void* dv, const void* xq, const void* xkv, float* dwq, float* dwk, float* dwv,
-                           float* part, long long npatch, int s, hipStream_t st);
+                           float* part, long long npatch, int s, hipStream_t st, int defer = 0);      // defer: `part` came from vu_deferred_take, queue the reduce
 // the same two on the matrix cores (vu_conv_mm.hip): bf16, C in {1, 3}, patch size 8 / 16 / 32 - taken by the two launchers above
 bool vu_conv_mm_ok(int dtype, int C, int s, int backward);
 int vu_k_conv_mm_qkv_fwd(const void* xq, const void* xkv, const float* wq, const float* wk, const float* wv, void* q, void* k, void* v,

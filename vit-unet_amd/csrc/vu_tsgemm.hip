@@ -246,19 +246,77 @@ __global__ __launch_bounds__(256) void tsgemm_reduce_batch_kernel(const RedBatch
 // vu_tsgemm_set_arena lends a region for the K-slice partial tiles of MANY products; each product takes the next piece of it
 // and queues its reduction; vu_tsgemm_flush launches them all (the model executor: once per backward call, before anything
 // outside the call reads the gradients).  A product that does not fit flushes first.  Per-thread state, like the scratch.
-struct Arena { char* base = nullptr; size_t bytes = 0, off = 0; RedBatch batch; int blocks = 0; };
+// Queued reductions of other kernels' per-workgroup partials (vu_gemm.h: vu_defred): one wave per output element, lane l adds the
+// partial rows l, l + 64, ... in order over four chains whose loads are issued together, then a fixed shuffle tree - exactly the
+// order of the stand-alone reduce kernels (conv_tzw_reduce_kernel, conv_wgrad_mm_reduce_kernel, conv_wgrad_reduce_kernel,
+// map_bwd_partials_reduce_kernel).
+constexpr int DEF_MAX = 32;
+struct DefBatch { int n; vu_defred d[DEF_MAX]; };
+__global__ __launch_bounds__(1024) void deferred_reduce_batch_kernel(const DefBatch b) {
+  int i = 0;
+  while (i + 1 < b.n && (int)blockIdx.x >= b.d[i + 1].blk0) ++i;          // (workgroup-uniform)
+  const vu_defred& r = b.d[i];
+  const int o = ((int)blockIdx.x - r.blk0) * 16 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const float* src = nullptr; float* dst = nullptr;
+  long long stride = 0; int cnt = r.nblocks, role = -1;
+  if (r.kind == VU_DEFRED_TZW) {
+    if (o >= 243) return;
+    role = o / 81; const int e = o - role * 81;
+    src = r.part + e; stride = 96; cnt = r.nblocks / 3; dst = r.dst[role] + e;
+  } else if (r.kind == VU_DEFRED_WGRAD_MM) {
+    const int which = o >> 9, tt = (o >> 8) & 1, e = o & 255, n = e >> 4, t = tt * 16 + (e & 15);
+    if (o >= 1024 || t >= 27 || n >= (which == 0 ? 3 : 6)) return;
+    src = r.part + o; stride = 1024;
+    dst = which == 0 ? r.dst[0] + n * 27 + t : (n < 3 ? r.dst[1] + n * 27 + t : r.dst[2] + (n - 3) * 27 + t);
+  } else if (r.kind == VU_DEFRED_WGRAD3) {
+    const int y = o >> 5, e = o & 31;
+    if (y >= r.nconv * 3 || e > 27) return;
+    const int cv = y / 3, co = y - cv * 3;
+    src = r.part + (long long)y * r.nblocks * 32 + e; stride = 32;
+    if (e < 27) dst = r.dst[cv] + co * 27 + e; else if (r.dst[3 + cv]) dst = r.dst[3 + cv] + co; else return;
+  } else {
+    if (o >= r.n) return;
+    src = r.part + o; stride = r.n; dst = o < r.hh ? r.dst[0] + o : r.dst[1] + (o - r.hh);
+  }
+  // (TZW: the role's workgroups are b = 24 i + 8 role + x, x = 0..7 - the XCD-aware placement of conv_tzw_kernel)
+  auto row = [&](int n) -> long long { return role >= 0 ? (long long)(24 * (n >> 3) + 8 * role + (n & 7)) : (long long)n; };
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  int n = lane;
+  for (; n + 3 * 64 < cnt; n += 4 * 64) {
+    float x[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) x[u] = src[row(n + 64 * u) * stride];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s[u] += x[u];
+  }
+  for (int u = 0; n < cnt; n += 64, ++u) s[role >= 0 ? u : 0] += src[row(n) * stride];      // (the tails as the stand-alone kernels have them)
+  float a = (s[0] + s[1]) + (s[2] + s[3]);
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m, 64);
+  if (lane == 0) *dst += a;
+}
+
+struct Arena { char* base = nullptr; size_t bytes = 0, off = 0; RedBatch batch; int blocks = 0; DefBatch def; int def_blocks = 0; };
 thread_local Arena g_arena;
 int arena_flush(hipStream_t st) {
   Arena& a = g_arena;
-  if (a.batch.n == 0) { a.off = 0; return VU_OK; }
-  hipLaunchKernelGGL(tsgemm_reduce_batch_kernel, dim3((unsigned)a.blocks), dim3(256), 0, st, a.batch);
-  if (vu_prof_on()) {
-    double bytes = 0.0;
-    for (int i = 0; i < a.batch.n; ++i) bytes += (double)(a.batch.d[i].nsplit + 2) * a.batch.d[i].M * a.batch.d[i].N * 4.0;
-    vu_prof_note("tsgemm_reduce_batch_kernel", 0.0, bytes);
+  int rc = VU_OK;
+  if (a.batch.n) {
+    hipLaunchKernelGGL(tsgemm_reduce_batch_kernel, dim3((unsigned)a.blocks), dim3(256), 0, st, a.batch);
+    if (vu_prof_on()) {
+      double bytes = 0.0;
+      for (int i = 0; i < a.batch.n; ++i) bytes += (double)(a.batch.d[i].nsplit + 2) * a.batch.d[i].M * a.batch.d[i].N * 4.0;
+      vu_prof_note("tsgemm_reduce_batch_kernel", 0.0, bytes);
+    }
+    rc = vu_check_launch("vu_tsgemm_reduce (batched)");
   }
-  a.batch.n = 0; a.blocks = 0; a.off = 0;
-  return vu_check_launch("vu_tsgemm_reduce (batched)");
+  if (a.def.n && rc == VU_OK) {
+    hipLaunchKernelGGL(deferred_reduce_batch_kernel, dim3((unsigned)a.def_blocks), dim3(1024), 0, st, a.def);
+    if (vu_prof_on()) vu_prof_note("deferred_reduce_batch_kernel", 0.0, 0.0);
+    rc = vu_check_launch("vu_deferred_reduce (batched)");
+  }
+  a.batch.n = 0; a.blocks = 0; a.def.n = 0; a.def_blocks = 0; a.off = 0;
+  return rc;
 }
 
 inline bool ldc_ok(const vu_gemm_args& g) { return g.ldc % 4 == 0 && ((uintptr_t)g.C & 15) == 0; }
@@ -337,8 +395,30 @@ inline int side_class(int n) { return n <= 32 ? 32 : (n <= 64 ? 64 : (n <= 128 ?
 
 }  // namespace
 
-void vu_tsgemm_set_arena(void* p, size_t bytes) { g_arena.base = (char*)p; g_arena.bytes = p ? bytes : 0; g_arena.off = 0; g_arena.batch.n = 0; g_arena.blocks = 0; }
+void vu_tsgemm_set_arena(void* p, size_t bytes) {
+  Arena& a = g_arena;
+  a.base = (char*)p; a.bytes = p ? bytes : 0; a.off = 0; a.batch.n = 0; a.blocks = 0; a.def.n = 0; a.def_blocks = 0;
+}
 int vu_tsgemm_flush(hipStream_t st) { return arena_flush(st); }
+
+float* vu_deferred_take(size_t floats, hipStream_t st) {
+  static const bool off = [] { const char* e = getenv("VU_DEFER_RED"); return e && e[0] == '0'; }();     // A/B switch
+  Arena& a = g_arena;
+  const size_t need = (floats * sizeof(float) + 255) / 256 * 256;
+  if (off || !a.base || need > a.bytes) return nullptr;
+  if (a.off + need > a.bytes || a.def.n == DEF_MAX) { if (arena_flush(st) != VU_OK) return nullptr; }
+  float* p = (float*)(a.base + a.off);
+  a.off += need;
+  return p;
+}
+void vu_deferred_push(const vu_defred& d) {      // (after a successful vu_deferred_take: there is a free entry)
+  Arena& a = g_arena;
+  vu_defred& e = a.def.d[a.def.n++];
+  e = d;
+  e.blk0 = a.def_blocks;
+  const int nout = d.kind == VU_DEFRED_TZW ? 243 : (d.kind == VU_DEFRED_WGRAD_MM ? 1024 : (d.kind == VU_DEFRED_WGRAD3 ? d.nconv * 96 : d.n));
+  a.def_blocks += (nout + 15) / 16;
+}
 
 // 1 = launched, 0 = shape not covered (the caller falls through to the tiled GEMM), < 0 = error
 int vu_tsgemm_try(const vu_gemm_args& g, hipStream_t st) {
