@@ -897,7 +897,7 @@ int vu_k_add_ln_fwd(int dtype, const void* a, const void* x, void* z, const floa
 // per-(sample,chunk) partial sums c1 = sum dy*w, c2 = sum dy*w*xhat go to partials2.
 // SL sample slices per block (8: 256 threads, the default; 16: 512 threads, VU_LN_BSL=16 - built in round 6 to put more loads in
 // flight per chunk (588 blocks of 4 waves at 2.9 TB/s) and measured slower: 21.9 vs 19.5 us at 32 images, 31.9 vs 28.8 at 64)
-template <typename T, int SL = 8>
+template <typename T, int SL = 8, int KU = 4>
 __global__ __launch_bounds__(32 * SL) void ln_bwd_stats_kernel(const T* __restrict__ dy, const T* __restrict__ z,
                                                            const float* __restrict__ w, const float* __restrict__ stats,
                                                            float* dw, float* db, float* partials2, int B, long long P) {
@@ -911,10 +911,14 @@ __global__ __launch_bounds__(32 * SL) void ln_bwd_stats_kernel(const T* __restri
   if (ok1) { const float4 t = *reinterpret_cast<const float4*>(w + e + 4); wv[4] = t.x; wv[5] = t.y; wv[6] = t.z; wv[7] = t.w; }
   float gw[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const vu_f4 zero = {{0.f, 0.f, 0.f, 0.f}};
-  for (int bb = ts; bb < B; bb += 4 * SL) {        // 4 samples (16 loads) in flight per thread
-    vu_f4 d0[4], d1[4], z0[4], z1[4];
+  // (the accumulators this thread adds into at the end: fetched now, not behind the exchange)
+  const long long et0 = (long long)c * VU_LN_BCHUNK + threadIdx.x;
+  float dw0 = 0.f, db0 = 0.f;
+  if (threadIdx.x < 256 && et0 < P) { dw0 = dw[et0]; db0 = db[et0]; }
+  for (int bb = ts; bb < B; bb += KU * SL) {        // KU samples (4 KU loads) in flight per thread
+    vu_f4 d0[KU], d1[KU], z0[KU], z1[KU];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < KU; ++k) {
       const int b = bb + SL * k;
       const long long o = (long long)b * P + e;
       const bool v0 = ok0 && b < B, v1 = ok1 && b < B;
@@ -926,7 +930,7 @@ __global__ __launch_bounds__(32 * SL) void ln_bwd_stats_kernel(const T* __restri
       }
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < KU; ++k) {
       const int b = bb + SL * k;
       if (b < B) {
         const float mean = stats[2 * b], rstd = stats[2 * b + 1];
@@ -954,7 +958,7 @@ __global__ __launch_bounds__(32 * SL) void ln_bwd_stats_kernel(const T* __restri
 #pragma unroll
     for (int k = 0; k < SL; ++k) { sw += red[0][k][q][x]; sb2 += red[1][k][q][x]; }
     const long long et = (long long)c * VU_LN_BCHUNK + t;
-    if (et < P) { dw[et] += sw; db[et] += sb2; }
+    if (et < P) { dw[et] = dw0 + sw; db[et] = db0 + sb2; }
   }
 }
 
@@ -1064,8 +1068,11 @@ int vu_k_ln_bwd(int dtype, const void* dy, const void* z, const float* w, const 
   const int nbch = vu_ln_nbchunks(P), nch = vu_ln_nchunks(P);
   if (ln_wide_ok(dtype, P, dy, z, dz, dz_drop) && !((uintptr_t)w & 15)) {
     static const int bsl = [] { const char* e = getenv("VU_LN_BSL"); return e ? atoi(e) : 8; }();      // A/B switch: 8 / 16 slices (measured round 6: 16 is SLOWER, 31.9 vs 28.8 us per LayerNorm backward at 64 images)
+    static const int bku = [] { const char* e = getenv("VU_LN_KU"); return e ? atoi(e) : 4; }();      // A/B switch: samples in flight per thread (measured round 6: 8 is SLOWER at 64 images, 33.4 vs 27.9 us per LayerNorm backward, equal at 32 / 16)
     if (bsl == 16 && B >= 32)
       hipLaunchKernelGGL((ln_bwd_stats_kernel<bf16_t, 16>), dim3(nbch), dim3(512), 0, st, (const bf16_t*)dy, (const bf16_t*)z, w, stats, dw, db, partials2, B, P);
+    else if (bku == 8 && B > 32)
+      hipLaunchKernelGGL((ln_bwd_stats_kernel<bf16_t, 8, 8>), dim3(nbch), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)z, w, stats, dw, db, partials2, B, P);
     else
     hipLaunchKernelGGL((ln_bwd_stats_kernel<bf16_t>), dim3(nbch), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)z, w, stats, dw, db, partials2, B, P);
     if (ln_big_chunk(B, P))
