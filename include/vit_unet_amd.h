@@ -310,6 +310,11 @@ int vu_set_flash_pcache(int on);
  * the sum fits, the others recompute (bit-identical).  Default 96 GiB; initial value VU_FLASH_PCACHE_BUDGET_MB, read once.  Same rule
  * as vu_set_flash_pcache: set it before sizing a workspace, never between a forward and its backward. */
 int vu_set_flash_pcache_budget(unsigned long long bytes);
+/* Weight-gradient tails (csrc/vu_gemm.h: vu_defred).  1 (default): inside vu_model_backward / _backward_units the fixed-order sums over
+ * per-workgroup partial rows that end the q / k / v convolutions' weight gradients and the head-mix gradients of the materialised map
+ * backward are queued and run as ONE launch at the end of the call (before anything outside it reads the gradients); 0: every kernel
+ * launches its own reduce at once.  Same sums in the same order: bit-identical gradients.  Initial value VU_DEFER_RED, read once. */
+int vu_set_deferred_reductions(int on);
 
 /* Data-parallel gradient exchange over RCCL (csrc/vu_dp.cpp).  The reference has no collective
  * (/root/reference/run_denoising.py:79,87: one 'cuda' device); the default exchange of this build is torch.distributed (backend

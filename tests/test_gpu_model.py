@@ -15,6 +15,7 @@ import pytest
 import torch
 
 import vit_unet_oracle as O
+from vit_unet.torch import _lib
 from vit_unet.torch import model as M
 from vit_unet.torch.engine import TrainStep
 
@@ -267,6 +268,36 @@ def test_size_independent_properties_base_bf16():
     assert torch.equal(M.upsampling(M.downsampling(t, 3), 3), t)
     assert M.patch(x, 32).shape == (4, 49, 3, 32, 32)
     assert torch.equal(M.unpatch(M.patch(x, 32), 3).reshape(x.shape), x)
+
+
+@pytest.mark.parametrize("name,B", [("base", 4), ("large", 2), ("lite", 32)])      # (Lite at 2 images takes map kernels that end in float atomics: not reproducible run to run with or without the queue)
+def test_queued_weight_gradient_reductions_are_bit_identical(name, B):
+    """Round 6 (csrc/vu_gemm.h: vu_defred): inside a backward call the fixed-order reduce tails of the q / k / v convolutions' weight
+    gradients (Gram form at patch 16 / 8, stencil form at patch 32, the output convolution) and of the head-mix gradients of the map
+    backward are queued and run as one launch at the end of the call.  Same sums in the same order: every parameter gradient of a
+    full-size bf16 train step equals, bit for bit, the one of the build that launches each reduce at once."""
+    torch.manual_seed(0)
+    m = M.get_vit_unet(name, dtype=torch.bfloat16).to(DEV).train()
+    cfg = O.Config(**O.PRESETS[name])
+    x, y = O.make_batch(cfg, B=B, seed=5)
+    x, y = x.to(DEV), y.to(DEV)
+    ts = TrainStep(m, lr=1e-3, seed=3)
+    grads = []
+    try:
+        for on in (1, 0, 1):
+            _lib.check(_lib.lib().vu_set_deferred_reductions(on), "vu_set_deferred_reductions")
+            ts.step_count.zero_()
+            out, dout = torch.empty_like(x), torch.empty_like(x)
+            ts._enqueue_head(x, y, out, dout)
+            ts._enqueue_units(dout, 0, ts._nunits - 1)
+            torch.cuda.synchronize()
+            grads.append((out.clone(), m._garena.detach().clone()))
+    finally:
+        _lib.check(_lib.lib().vu_set_deferred_reductions(1), "vu_set_deferred_reductions")
+    assert torch.isfinite(grads[0][1]).all() and grads[0][1].abs().max() > 0
+    for o, g in grads[1:]:
+        assert torch.equal(o, grads[0][0])
+        assert torch.equal(g, grads[0][1])
 
 
 def test_train_step_fused_matches_autograd_path(golden_dir):

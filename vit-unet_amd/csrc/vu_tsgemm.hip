@@ -401,11 +401,17 @@ void vu_tsgemm_set_arena(void* p, size_t bytes) {
 }
 int vu_tsgemm_flush(hipStream_t st) { return arena_flush(st); }
 
+// process-level switch (include/vit_unet_amd.h: vu_set_deferred_reductions; initial value VU_DEFER_RED, read once)
+static int g_defer_red = [] { const char* e = getenv("VU_DEFER_RED"); return (e && e[0] == '0') ? 0 : 1; }();
+extern "C" int vu_set_deferred_reductions(int on) {
+  if (on < 0 || on > 1) { vu_set_error("vu_set_deferred_reductions: 0 or 1"); return VU_EINVAL; }
+  g_defer_red = on;
+  return VU_OK;
+}
 float* vu_deferred_take(size_t floats, hipStream_t st) {
-  static const bool off = [] { const char* e = getenv("VU_DEFER_RED"); return e && e[0] == '0'; }();     // A/B switch
   Arena& a = g_arena;
   const size_t need = (floats * sizeof(float) + 255) / 256 * 256;
-  if (off || !a.base || need > a.bytes) return nullptr;
+  if (!g_defer_red || !a.base || need > a.bytes) return nullptr;
   if (a.off + need > a.bytes || a.def.n == DEF_MAX) { if (arena_flush(st) != VU_OK) return nullptr; }
   float* p = (float*)(a.base + a.off);
   a.off += need;

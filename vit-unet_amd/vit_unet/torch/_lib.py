@@ -72,6 +72,7 @@ SIGNATURES = {
     "vu_set_flash_key_split": (_i, [_i]),
     "vu_set_flash_pcache": (_i, [_i]),
     "vu_set_flash_pcache_budget": (_i, [C.c_ulonglong]),
+    "vu_set_deferred_reductions": (_i, [_i]),
     "vu_model_forward": (_i, [_cfgp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _u64, _vp, _vp]),
     "vu_model_backward": (_i, [_cfgp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _u64, _vp, _i, _vp]),
     "vu_model_num_backward_units": (_i, [_cfgp]),
