@@ -565,7 +565,9 @@ void carve_model(const Plan& pl, int B, char* base, ModelWS& w, int training) {
   w.lnp2 = bp.takef((size_t)B * vu_ln_nbchunks(P) * 2);
   w.wgs_bytes = dt == 1 ? (size_t)40 << 20 : 0;      // (16 K slices of a 768 x 768 output)
   w.wgs = w.wgs_bytes ? bp.take(w.wgs_bytes) : nullptr;
-  w.wga_bytes = dt == 1 ? (size_t)160 << 20 : 0;     // (a Base backward queues ~100 MB of partial tiles: one reduce launch per call)
+  // (a Base backward queues ~100 MB of partial tiles at 16 images and ~490 MB at 64 - the K slices grow with the token count: sized
+  // for ONE flush per call, 10 MB per image within [160 MB, 1 GB])
+  w.wga_bytes = dt == 1 ? std::min((size_t)1 << 30, std::max((size_t)160 << 20, (size_t)B * ((size_t)10 << 20))) : 0;
   w.wga = w.wga_bytes ? bp.take(w.wga_bytes) : nullptr;
   w.bytes = vu_align_up(bp.off, 256);
   w.pcache_bytes = bp.pc_total;

@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void tsgemm_reduce_batch_kernel(const RedBatch
 // partial rows l, l + 64, ... in order over four chains whose loads are issued together, then a fixed shuffle tree - exactly the
 // order of the stand-alone reduce kernels (conv_tzw_reduce_kernel, conv_wgrad_mm_reduce_kernel, conv_wgrad_reduce_kernel,
 // map_bwd_partials_reduce_kernel).
-constexpr int DEF_MAX = 32;
+constexpr int DEF_MAX = 40;      // (40 x 80 bytes of kernel arguments)
 struct DefBatch { int n; vu_defred d[DEF_MAX]; };
 __global__ __launch_bounds__(1024) void deferred_reduce_batch_kernel(const DefBatch b) {
   int i = 0;
