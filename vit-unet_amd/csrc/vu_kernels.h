@@ -12,7 +12,7 @@ int vu_gemm_launch(int dtype, int c_float, vu_gemm_args g, hipStream_t st);
 // that are multiples of 4).  n <= 4 tensors in one launch.  The recompute attention's zero-padded operands (vu_model.hip, flash_padded).
 int vu_k_head_pad(const void* const* src, void* const* dst, int n, long long rows, int H, int dh_src, int dh_dst, hipStream_t st);
 int vu_k_retile(int dtype, int in_f32, int out_f32, const void* in, void* out, const float* pos,
-                int B, int C, int im, int s_in, int s_out, hipStream_t st);
+                int B, int C, int im, int s_in, int s_out, hipStream_t st, const void* add = nullptr);      // add: storage type, OUTPUT tiling, out = retile(in) + add
 // out[r] += sum_b in[b*P + r]   (positional-embedding gradient)
 int vu_k_batch_sum(int dtype, const void* in, float* out, int B, long long P, hipStream_t st);
 

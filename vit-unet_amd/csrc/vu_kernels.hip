@@ -48,8 +48,11 @@ __global__ void retile_kernel(const TI* __restrict__ in, TO* __restrict__ out,
 
 // pure permutation of 16-byte pieces (bf16 -> bf16, no positional add, both patch sizes multiples of 8): half the
 // instructions and index divisions per byte of the 4-element form
+// ADD: out = retile(in) + add (add in the OUTPUT tiling; the sum in fp32, rounded once - what vu_k_add would leave): the gradient
+// of a down-sampling meets the gradient that arrives through the skip connection in the same pass (round 6: two launches less).
+template <bool ADD>
 __global__ __launch_bounds__(256) void retile_copy16_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, long long total8, int P,
-                                                             int C, int im, int s_in, int s_out) {
+                                                             int C, int im, int s_in, int s_out, const uint4* __restrict__ add) {
   const int e_in = im / s_in, e_out = im / s_out;
   const int ss_in = s_in * s_in, ss_out = s_out * s_out;
   const int D_in = C * ss_in, D_out = C * ss_out;
@@ -64,12 +67,24 @@ __global__ __launch_bounds__(256) void retile_copy16_kernel(const uint4* __restr
     const int y = (n_out / e_out) * s_out + i, x = (n_out % e_out) * s_out + j;
     const int n_in = (y / s_in) * e_in + x / s_in;
     const int f_in = ch * ss_in + (y % s_in) * s_in + (x % s_in);
-    out[((long long)b * P + r) >> 3] = in[((long long)b * P + (long long)n_in * D_in + f_in) >> 3];
+    uint4 v = in[((long long)b * P + (long long)n_in * D_in + f_in) >> 3];
+    if constexpr (ADD) {
+      const uint4 a = add[((long long)b * P + r) >> 3];
+      const unsigned vw[4] = {v.x, v.y, v.z, v.w}, aw[4] = {a.x, a.y, a.z, a.w};
+      union { uint4 u; bf16_t h[8]; } o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o.h[2 * e] = (bf16_t)(__uint_as_float(vw[e] << 16) + __uint_as_float(aw[e] << 16));
+        o.h[2 * e + 1] = (bf16_t)(__uint_as_float(vw[e] & 0xffff0000u) + __uint_as_float(aw[e] & 0xffff0000u));
+      }
+      v = o.u;
+    }
+    out[((long long)b * P + r) >> 3] = v;
   }
 }
 
 int vu_k_retile(int dtype, int in_f32, int out_f32, const void* in, void* out, const float* pos,
-                int B, int C, int im, int s_in, int s_out, hipStream_t st) {
+                int B, int C, int im, int s_in, int s_out, hipStream_t st, const void* add) {
   VU_REQUIRE(s_in % 4 == 0 && s_out % 4 == 0 && im % s_in == 0 && im % s_out == 0,
              "vu_retile: patch sizes must be multiples of 4 that divide im (im=%d s_in=%d s_out=%d)", im, s_in, s_out);
   const int P = C * im * im;
@@ -78,10 +93,16 @@ int vu_k_retile(int dtype, int in_f32, int out_f32, const void* in, void* out, c
   VU_REQUIRE(total4 < 4294967295LL, "vu_retile: more than 2^32 element quads");
   const int grid = grid_for(total4);
   const bool fi = in_f32 || dtype == 0, fo = out_f32 || dtype == 0;
-  if (!fi && !fo && !pos && s_in % 8 == 0 && s_out % 8 == 0 && ((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 15) == 0) {
-    hipLaunchKernelGGL(retile_copy16_kernel, dim3(grid_for(total4 / 2)), dim3(256), 0, st, (const uint4*)in, (uint4*)out, total4 / 2, P, C, im, s_in, s_out);
-    if (vu_prof_on()) vu_prof_note("retile_kernel", 0.0, (double)total4 * 4 * 2 * 2.0);
+  if (!fi && !fo && !pos && s_in % 8 == 0 && s_out % 8 == 0 && ((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)add & 15) == 0) {
+    if (add) hipLaunchKernelGGL(retile_copy16_kernel<true>, dim3(grid_for(total4 / 2)), dim3(256), 0, st, (const uint4*)in, (uint4*)out, total4 / 2, P, C, im, s_in, s_out, (const uint4*)add);
+    else hipLaunchKernelGGL(retile_copy16_kernel<false>, dim3(grid_for(total4 / 2)), dim3(256), 0, st, (const uint4*)in, (uint4*)out, total4 / 2, P, C, im, s_in, s_out, (const uint4*)nullptr);
+    if (vu_prof_on()) vu_prof_note("retile_kernel", 0.0, (double)total4 * 4 * (add ? 3 : 2) * 2.0);
     return vu_check_launch("vu_retile");
+  }
+  if (add) {      // (no fused form for this layout: the permutation, then the sum in place)
+    if (int e = vu_k_retile(dtype, in_f32, out_f32, in, out, pos, B, C, im, s_in, s_out, st, nullptr)) return e;
+    VU_REQUIRE(!fo || dtype == 0, "vu_retile: an addend needs the output in the storage type");
+    return vu_k_add(dtype, out, add, out, (long long)B * P, st);
   }
   if (fi && fo) hipLaunchKernelGGL((retile_kernel<float, float>), dim3(grid), dim3(256), 0, st, (const float*)in, (float*)out, pos, total4, P, C, im, s_in, s_out);
   else if (fi) hipLaunchKernelGGL((retile_kernel<float, bf16_t>), dim3(grid), dim3(256), 0, st, (const float*)in, (bf16_t*)out, pos, total4, P, C, im, s_in, s_out);

@@ -911,8 +911,9 @@ int model_backward(Ctx& cx, const float* dy, float* dx, int first, int last) {
         if ((i + 1) % c.depth_te == 0) {
           if (run) {   // gradient of downsampling (retile back) + gradient arriving through the skip connection
             const int l = pl.enc[i].level;
-            VU_TRY(vu_k_retile(dt, 0, 0, cur, oth, nullptr, B, C, im, pl.lv[l + 1].s, pl.lv[l].s, cx.st));
-            VU_TRY(vu_k_add(dt, oth, w.dskip[l], oth, (long long)B * P, cx.st));
+            static const bool sep = [] { const char* e = getenv("VU_RETILE_ADD"); return e && e[0] == '0'; }();      // A/B switch: the sum as its own launch
+            VU_TRY(vu_k_retile(dt, 0, 0, cur, oth, nullptr, B, C, im, pl.lv[l + 1].s, pl.lv[l].s, cx.st, sep ? nullptr : w.dskip[l]));
+            if (sep) VU_TRY(vu_k_add(dt, oth, w.dskip[l], oth, (long long)B * P, cx.st));
           }
           swap();
         }
