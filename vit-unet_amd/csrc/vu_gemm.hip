@@ -103,6 +103,15 @@ static int launch_tiles(const vu_gemm_args& g, hipStream_t st) {
     }
     return launch_one<T, TC, TA, TB, 64, 64>(g, st);
   }
+  // float outputs (weight gradients the skinny and the big-tile kernels do not take: the 3072 x 128 feed-forward layers of level 0 at
+  // 16 images per GPU, K = 784): 24 tiles of 128 x 128 leave most CUs idle.  Measured per launch (round 6, tools/ab_r06/gpu_r06_f32q.sh):
+  // 128 x 64 tiles 27.1 - 28.7 us, 64 x 64 20.4, 32 x 64 17.7 - 18.2, the skinny kernel with K slices 17.8 - 19.7 + its reduce; the step
+  // at 16 images +0.4 % (Base), +0.35 % (Large).  VU_GEMM_F32_QUARTER=0: off; =1: 64 x 64; default 32 x 64
+  if constexpr (sizeof(TC) == 4 && sizeof(T) == 2) {
+    static const int f32q = [] { const char* e = getenv("VU_GEMM_F32_QUARTER"); return e ? atoi(e) : 32; }();
+    if (f32q && g.K >= 256 && (long long)vu_cdiv(g.M, 128) * vu_cdiv(g.N, 128) * g.Z1 * g.Z2 < 64 && g.N >= 128 && g.M >= 128)
+      return f32q == 32 ? launch_bk<T, TC, TA, TB, 32, 64, 64, 4>(g, st) : launch_one<T, TC, TA, TB, 64, 64>(g, st);
+  }
   // between one and ~1.5 big tiles per CU (the level-0 / level-1 linears at 16 - 32 images per GPU: 150 - 312 tiles): half-width
   // tiles balance the chip (measured: M1568 N3072 K3072 107 -> 85 us, M3136 N768 K768 26 -> 20 us; tools/gemm_small_batch.py)
   if constexpr (sizeof(T) == 2) {

@@ -433,7 +433,8 @@ int vu_tsgemm_try(const vu_gemm_args& g, hipStream_t st) {
   if (!g.accumulate || g.act || g.dropout || g.addend || g.bias || g.alpha != 1.f || g.Z1 * g.Z2 != 1) return 0;
   if (g.sAm != 1 || g.sBn != 1 || g.colsum_side == 2) return 0;
   if (g.M % 8 || g.N % 8 || g.sAk % 8 || g.sBk % 8 || ((uintptr_t)g.A & 15) || ((uintptr_t)g.B & 15)) return 0;
-  if (g.K < 1024) return 0;                                         // long K; at most 16 tiles of 192 x 192 (below)
+  static const int mink = [] { const char* e = getenv("VU_TSGEMM_MINK"); return e ? atoi(e) : 1024; }();      // measurement switch
+  if (g.K < mink) return 0;                                         // long K; at most 16 tiles of 192 x 192 (below)
   if (g.M > 192 && g.N > 192) {
     // 768-class square outputs: no faster than the tiled kernel with float atomics (53 + 7 us against 61), but with a slab
     // the sum is deterministic - taken only when the executor has lent one
