@@ -442,7 +442,18 @@ int launch(const bg_args& a, hipStream_t st) {
     const long long big_tiles = (long long)vu_cdiv(a.M, 2 * TM * 16) * vu_cdiv(a.N, 4 * TN * 16);
     if constexpr (TN == 3) {
       const long long half_tiles = (long long)vu_cdiv(a.M, TM * 16) * vu_cdiv(a.N, 4 * TN * 16);
-      if (force == 3 || (force < 0 && half_tiles < 144)) return launch_tile<TA, TB, CF, TM, 2, 1, 2>(a, st);
+      // Up to 32 images per GPU: 112 x 64 tiles (44 KB of LDS: three workgroups per CU) while they fit ONE round of 768 slots, i.e. up
+      // to 256 tiles of 112 x 192.  Round 6, in the step (same-box A/B, images/s): 16 images 2954 -> 3010 (Large 1592 -> 1620), 24 images
+      // 3475 -> 3600, 32 images 4362 -> 4467; 64 images (448 such tiles, 1.75 rounds) 5736 -> 5604: not there.  Stand-alone with warm
+      // operands the same launches measure EQUAL or slower (tools/gemm_small_batch.py: M 784 35.6 -> 32.7 us, M 1568 46.7 -> 47.6,
+      // M 3136 N 768 10.7 -> 12.8) - in the step the operands come from HBM and three times the workgroups keep more loads in flight.
+      // VU_BGEMM_T64 = 0 / 2 / 3: off / two / three stages; VU_BGEMM_T64_MAX: the tile-count limit
+      static const int t64 = [] { const char* e = getenv("VU_BGEMM_T64"); return e ? atoi(e) : 2; }();
+      static const int t64max = [] { const char* e = getenv("VU_BGEMM_T64_MAX"); return e ? atoi(e) : 257; }();
+      if (t64 == 2 && half_tiles < t64max) return launch_tile<TA, TB, CF, TM, 1, 1, 2>(a, st);
+      if (t64 == 3 && half_tiles < t64max) return launch_tile<TA, TB, CF, TM, 1, 1, 3>(a, st);
+      // ... and 112 x 128 (60 KB: two per CU) while THOSE fit one round of 512 slots (40 - 48 images: 4437 -> 4539, 4958 -> 5013)
+      if (force == 3 || (force < 0 && half_tiles * 3 <= 1024)) return launch_tile<TA, TB, CF, TM, 2, 1, 2>(a, st);
     }
     if (force == 1 || (force < 0 && big_tiles < 160)) return launch_tile<TA, TB, CF, TM, TN, 1, 2>(a, st);
     if (force == 2) return launch_tile<TA, TB, CF, TM, TN, 1, 3>(a, st);
