@@ -338,7 +338,8 @@ int launch_ts(const vu_gemm_args& g, hipStream_t st) {
   // K slices: enough workgroups to put a stream on every CU and at least 8 k-steps (256 rows) per slice.  With a slab the
   // partial tiles cost a plain write and a read (bounded by half the operand bytes and by the slab); without one they are
   // float atomics on a small, contended output (measured 0.3 TB/s): no more of those than a third of the operand bytes
-  int want = (256 + mt * nt - 1) / (mt * nt);
+  static const int want_wgs = [] { const char* e = getenv("VU_TSGEMM_WGS"); return e ? atoi(e) : 256; }();      // measurement switch: workgroups a product aims at
+  int want = (want_wgs + mt * nt - 1) / (mt * nt);
   int by_out = (int)(in_bytes / ((use_slab ? 2.0 : 3.0) * out_bytes));
   // (few workgroups even so - the 3072 x 128 outputs of level 0: 16 tiles x 6 slices - : let the slab traffic reach the
   // operand bytes; one CU sustains ~20 GB/s, the stream wants every CU)
