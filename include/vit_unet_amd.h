@@ -119,6 +119,11 @@ int vu_model_backward_units(const vu_config* cfg, const float* params, const voi
  * layout, one sample) is added when non-NULL (PatchEncoder, model.py:84-91). */
 int vu_retile(int dtype, int in_f32, int out_f32, const void* in, void* out, const float* pos,
               int B, int C, int im, int s_in, int s_out, void* stream);
+/* out = retile(in) + add: the backward of a level change where a second gradient arrives in the output tiling - the gradient of
+ * downsampling (model.py:40-53 run backwards) meets the one that comes through the skip connection (model.py:407-410, 420-423).  All
+ * three tensors in the storage type, `add` and `out` in the s_out tiling, three distinct buffers; the sum is formed in fp32 and
+ * rounded once, as a separate add would leave it. */
+int vu_retile_add(int dtype, const void* in, const void* add, void* out, int B, int C, int im, int s_in, int s_out, void* stream);
 
 /* Conv2d(C,C,3,padding='same') applied per patch (model.py:137-139,152-154) or on the whole
  * image (model.py:370,428: npatch = B, s = im). */

@@ -105,6 +105,24 @@ def test_retile_bit_exact(dt, C_, im, s_in, s_out):
     assert torch.equal(out.cpu(), ref)
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C_,im,s_in,s_out", [(3, 224, 16, 8), (3, 224, 32, 16), (3, 32, 8, 4), (1, 64, 16, 32)])
+def test_retile_with_addend_equals_retile_then_add(dt, C_, im, s_in, s_out):
+    """Round 6: the gradient of a down-sampling and the gradient that arrives through the skip connection meet inside the re-tiling
+    (vu_retile_add; bf16 with patch sizes that are multiples of 8: one 16-byte pass; anything else: the permutation, then the sum) -
+    bit for bit what the permutation followed by a separate sum in the storage type gives."""
+    B = 3
+    img = torch.randn(B, C_, im, im)
+    tin = O.patchify(img, s_in).to(dt)
+    add = torch.randn(O.retile(tin.float(), C_, s_out).shape).to(dt)
+    ref = (O.retile(tin.float(), C_, s_out).to(dt).float() + add.float()).to(dt)
+    x, a = dev(tin), dev(add)
+    out = torch.empty(ref.shape, dtype=dt, device=DEV)
+    check(lib().vu_retile_add(_lib.DTYPE_CODE[dt], ptr(x), ptr(a), ptr(out), B, C_, im, s_in, s_out, st()))
+    assert torch.equal(out.cpu(), ref)
+    assert lib().vu_retile_add(_lib.DTYPE_CODE[dt], ptr(x), ptr(a), ptr(a), B, C_, im, s_in, s_out, st()) != 0      # (no aliasing)
+
+
 def test_retile_patch_encoder_posemb():
     B, C_, im, s = 3, 3, 56, 8
     img = torch.rand(B, C_, im, im)
@@ -237,6 +255,20 @@ def test_gemm_tall_skinny_weight_gradient_form(M, N, K):
     _gemm(torch.bfloat16, dev(a), dev(b), M, N, K, 1, M, N, 1, c_float=1, accumulate=1, out=out)
     ref = a.double().t() @ b.double() + base.double()
     assert serr(out.view(M, N), ref) < 2e-3
+
+
+@pytest.mark.parametrize("M,N,K", [(3072, 128, 784), (128, 3072, 784), (768, 128, 392)])
+def test_gemm_float_output_with_few_big_tiles(M, N, K):
+    """Round 6: weight-gradient products neither the skinny kernel (K < 1024) nor the big-tile kernel takes - the level-0 FeedForward
+    layers at 16 images per GPU - run on 32 x 64 tiles of vu_gemm.h instead of 24 tiles of 128 x 64 (csrc/vu_gemm.hip: launch_tiles)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(K, M, generator=g).to(torch.bfloat16)
+    b = torch.randn(K, N, generator=g).to(torch.bfloat16)
+    base = torch.randn(M, N, generator=g)
+    out = dev(base.clone())
+    _gemm(torch.bfloat16, dev(a), dev(b), M, N, K, 1, M, N, 1, c_float=1, accumulate=1, out=out)
+    ref = a.double().t() @ b.double() + base.double()
+    assert serr(out.view(M, N), ref) < 2e-5
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])

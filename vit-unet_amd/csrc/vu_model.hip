@@ -1121,6 +1121,11 @@ int vu_retile(int dtype, int in_f32, int out_f32, const void* in, void* out, con
               int s_in, int s_out, void* stream) {
   return vu_k_retile(dtype, in_f32, out_f32, in, out, pos, B, C, im, s_in, s_out, (hipStream_t)stream);
 }
+int vu_retile_add(int dtype, const void* in, const void* add, void* out, int B, int C, int im, int s_in, int s_out, void* stream) {
+  VU_REQUIRE(in && add && out, "vu_retile_add: null argument");
+  VU_REQUIRE(add != out && in != out, "vu_retile_add: the output must not alias an input");
+  return vu_k_retile(dtype, 0, 0, in, out, nullptr, B, C, im, s_in, s_out, (hipStream_t)stream, add);
+}
 int vu_conv3x3_fwd(int dtype, int out_f32, const void* in, const float* w, const float* bias, void* out, long long npatch,
                    int C, int s, void* stream) {
   return vu_k_conv3x3_fwd(dtype, out_f32, in, w, bias, out, npatch, C, s, (hipStream_t)stream);

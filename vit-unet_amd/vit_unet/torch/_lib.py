@@ -79,6 +79,7 @@ SIGNATURES = {
     "vu_model_backward_unit_ranges": (_i, [_cfgp, C.POINTER(C.c_longlong), _i]),
     "vu_model_backward_units": (_i, [_cfgp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _u64, _vp, _i, _i, _vp]),
     "vu_retile": (_i, [_i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "vu_retile_add": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "vu_conv3x3_fwd": (_i, [_i, _i, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp]),
     "vu_conv3x3_bwd": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp]),
     "vu_conv3x3_qkv_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp]),
